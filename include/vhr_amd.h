@@ -1,0 +1,234 @@
+/*
+ * vhr_amd.h -- C ABI of libvhr_amd.so: the MI355X-native (HIP / gfx950) implementation of the
+ * ray-traced shadow / AO / mirror-reflection pass and the SVGF denoiser of
+ * RMichelsen/VulkanHybridRenderer, behind the reference's render-graph pass API.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  All functions return 0 on success and a negative code on failure unless noted;
+ * vhr_last_error() returns the message.  The reference has no error returns (VK_CHECK asserts,
+ * vulkan_common.h:4-7); pool exhaustion returns -1 like resource_manager.cpp:847-848,876-877.
+ *
+ * Threading: like the reference (renderer.cpp:184-235) one host thread drives one context; all device
+ * work of a context is issued in order on ONE HIP stream (the one given at creation, or an internal
+ * one).  One context per GPU / per process for multi-GPU (row strips, vhr_set_strip).
+ */
+#ifndef VHR_AMD_H
+#define VHR_AMD_H
+
+#include "vhr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vhr_context vhr_context;
+typedef struct vhr_raytracing_execution_context vhr_raytracing_execution_context;
+typedef struct vhr_compute_execution_context vhr_compute_execution_context;
+
+enum {
+    VHR_OK = 0,
+    VHR_ERROR_INVALID_ARGUMENT = -1,
+    VHR_ERROR_DEVICE = -2,
+    VHR_ERROR_NOT_FOUND = -3,
+    VHR_ERROR_OUT_OF_SLOTS = -4,
+    VHR_ERROR_GRAPH = -5,
+    VHR_ERROR_NO_DEVICE = -6
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * Context (replaces VulkanContext + the device half of ResourceManager:
+ * src/rendering_backend/vulkan_context.cpp:44-89, resource_manager.cpp:15-70)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vhr_create_info {
+    int32_t  device;          /* HIP device ordinal */
+    uint32_t width;           /* display ("swapchain") size: context.swapchain.extent */
+    uint32_t height;
+    void    *stream;          /* hipStream_t to issue all work on; NULL = create an internal stream */
+    uint32_t flags;           /* reserved, 0 */
+} vhr_create_info;
+
+int  vhr_create(const vhr_create_info *info, vhr_context **out);
+void vhr_destroy(vhr_context *ctx);
+const char *vhr_last_error(const vhr_context *ctx);   /* ctx may be NULL: error of the last failed vhr_create */
+int  vhr_synchronize(vhr_context *ctx);               /* hipStreamSynchronize on the context stream */
+const char *vhr_version(void);
+int  vhr_abi_struct_sizes(uint32_t out[8]);            /* vertex, material, primitive, light, per-frame, push constants, trace params, 0 */
+void vhr_default_trace_params(vhr_trace_params *out); /* raygen.rgen:29-65 constants */
+
+/* ---------------------------------------------------------------------------------------------
+ * ResourceManager (src/rendering_backend/resource_manager.h:16-78)
+ * ------------------------------------------------------------------------------------------- */
+/* UpdateGeometry (resource_manager.h:34, .cpp:291-360) + UpdateBLAS (.cpp:593-701) + UpdateTLAS
+ * (.cpp:703-801): uploads the flat vertex / index / primitive arrays and builds the acceleration
+ * structure -- here a host-built binned-SAH BVH2 over the world-space (transform-baked), two-sided,
+ * all-opaque triangle soup.  gl_GeometryIndexEXT == primitive index, gl_PrimitiveID == triangle index
+ * within the primitive. */
+int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t vertex_count,
+                        const uint32_t *indices, uint32_t index_count,
+                        const vhr_primitive *primitives, uint32_t primitive_count);
+/* UploadTextureFromData (resource_manager.h:26, .cpp:152-196): RGBA8 texels, format
+ * VHR_FORMAT_R8G8B8A8_{SRGB,UNORM}, sampler NULL = default sampler (LINEAR / REPEAT, .cpp:58-69).
+ * Returns the bindless texture index (>= 0) or a negative error. */
+int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t height, const uint8_t *data,
+                                     int32_t format, const vhr_sampler_info *sampler_info);
+/* UploadNewStorageImage (resource_manager.h:28, .cpp:230-263): returns the first free slot index
+ * (< 2048) of the bindless storage-image pool, or -1 when exhausted.  Contents are zero-initialised
+ * (the reference leaves them undefined). */
+int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t height, int32_t format);
+/* DestroyStorageImage (resource_manager.h:29, .cpp:265-269) */
+int vhr_destroy_storage_image(vhr_context *ctx, int32_t id);
+/* UpdatePerFrameUBO (resource_manager.h:35, .cpp:362-364); resource_idx < 3 (MAX_FRAMES_IN_FLIGHT) */
+int vhr_update_per_frame_ubo(vhr_context *ctx, uint32_t resource_idx, const vhr_per_frame_data *per_frame_data);
+/* extension: the constants raygen.rgen hard-codes */
+int vhr_set_trace_params(vhr_context *ctx, const vhr_trace_params *params);
+
+/* ---------------------------------------------------------------------------------------------
+ * RenderGraph (src/render_graph/render_graph.h:10-21)
+ * ------------------------------------------------------------------------------------------- */
+typedef void (*vhr_external_pass_callback)(void *user, vhr_context *ctx);
+typedef void (*vhr_raytracing_pass_callback)(void *user, vhr_raytracing_execution_context *exec);
+typedef void (*vhr_compute_pass_callback)(void *user, vhr_compute_execution_context *exec);
+
+/* DestroyResources (render_graph.h:8, .cpp:16-68): drops passes, pipelines and transient images */
+int vhr_graph_destroy_resources(vhr_context *ctx);
+/* AddGraphicsPass (render_graph.h:10-12, .cpp:70-85).  Raster passes (G-buffer, composition) stay with
+ * the integrator: the callback runs at the pass's place in the execution order and is expected to
+ * produce / consume the named transient images (through imported memory, vhr_graph_bind_external_image,
+ * or vhr_upload_image).  `callback` may be NULL. */
+int vhr_graph_add_graphics_pass(vhr_context *ctx, const char *render_pass_name,
+                                const vhr_transient_resource *dependencies, uint32_t dependency_count,
+                                const vhr_transient_resource *outputs, uint32_t output_count,
+                                vhr_external_pass_callback callback, void *user);
+/* AddRaytracingPass (render_graph.h:13-15, .cpp:87-101).  The shader names select HIP kernels:
+ * raygen "hybrid_render_path/raygen.rgen", miss[0] "hybrid_render_path/miss.rmiss", miss[1]
+ * "hybrid_render_path/reflection_miss.rmiss", hit[0].closest_hit
+ * "hybrid_render_path/reflection_hit.rchit" (hybrid_render_path.cpp:112-124). */
+int vhr_graph_add_raytracing_pass(vhr_context *ctx, const char *render_pass_name,
+                                  const vhr_transient_resource *dependencies, uint32_t dependency_count,
+                                  const vhr_transient_resource *outputs, uint32_t output_count,
+                                  const vhr_raytracing_pipeline_description *pipeline,
+                                  vhr_raytracing_pass_callback callback, void *user);
+/* AddComputePass (render_graph.h:16-18, .cpp:103-116).  Known kernels:
+ * "hybrid_render_path/svgf.comp", "hybrid_render_path/svgf_atrous_filter.comp".  A shader name is a
+ * global key: registering it in two passes fails (render_graph.cpp:677). */
+int vhr_graph_add_compute_pass(vhr_context *ctx, const char *render_pass_name,
+                               const vhr_transient_resource *dependencies, uint32_t dependency_count,
+                               const vhr_transient_resource *outputs, uint32_t output_count,
+                               const vhr_compute_pipeline_description *pipeline,
+                               vhr_compute_pass_callback callback, void *user);
+/* Build (render_graph.h:20, .cpp:118-149): creates every named transient image, derives the execution
+ * order by BFS from the single writer of "RENDER_OUTPUT" (.cpp:686-720) and runs SanityCheck
+ * (.cpp:980-1021). */
+int vhr_graph_build(vhr_context *ctx);
+/* Execute (render_graph.h:21, .cpp:151-187): runs the pass callbacks in order on the context stream,
+ * bracketing each pass with a pair of timing events (the reference's timestamp queries). */
+int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_idx);
+/* GatherPerformanceStatistics (render_graph.h:22, .cpp:189-201): blocks on the last Execute and folds
+ * the per-pass times into the reference's EMA (0.95 * old + 0.05 * new). */
+int vhr_graph_gather_performance_statistics(vhr_context *ctx);
+/* pass_timestamps[name] (render_graph.cpp:199): EMA and last sample, milliseconds */
+int vhr_graph_get_pass_time_ms(vhr_context *ctx, const char *render_pass_name, double *ema_ms, double *last_ms);
+/* execution_order (render_graph.h:47): pass names joined by '\n' into buf; returns the pass count */
+int vhr_graph_get_execution_order(vhr_context *ctx, char *buf, uint32_t buf_size);
+/* ContainsImage / GetImageFormat (render_graph.h:25-26) */
+int vhr_graph_contains_image(vhr_context *ctx, const char *image_name);
+int32_t vhr_graph_get_image_format(vhr_context *ctx, const char *image_name);
+
+/* extension (multi-GPU / interop hook): called right after the named pass's callback returns, on the
+ * host thread, with the pass's work already enqueued on the context stream */
+int vhr_graph_set_pass_epilogue(vhr_context *ctx, const char *render_pass_name,
+                                vhr_external_pass_callback callback, void *user);
+/* extension (interop): point a transient image at externally owned device memory of the same extent and
+ * format (what VK_KHR_external_memory import would provide).  NULL restores the context-owned memory. */
+int vhr_graph_bind_external_image(vhr_context *ctx, const char *image_name, void *device_ptr);
+
+/* ---------------------------------------------------------------------------------------------
+ * RaytracingExecutionContext (src/render_graph/raytracing_execution_context.h:13)
+ * ------------------------------------------------------------------------------------------- */
+/* TraceRays(width, height) -> vkCmdTraceRaysKHR(w, h, 1) (raytracing_execution_context.cpp:4-13) */
+int vhr_trace_rays(vhr_raytracing_execution_context *exec, uint32_t width, uint32_t height);
+
+/* ---------------------------------------------------------------------------------------------
+ * ComputeExecutionContext (src/render_graph/compute_execution_context.h:17-31)
+ * ------------------------------------------------------------------------------------------- */
+/* GetDisplaySize (:17) */
+int vhr_compute_get_display_size(vhr_compute_execution_context *exec, uint32_t *width, uint32_t *height);
+/* Dispatch (:18) and Dispatch<T> (:20-27): push constants are copied at call time (vkCmdPushConstants),
+ * push_constants_size must equal the size declared at registration (assert at :23). */
+int vhr_compute_dispatch(vhr_compute_execution_context *exec, const char *shader, uint32_t x_groups,
+                         uint32_t y_groups, uint32_t z_groups, const void *push_constants,
+                         uint32_t push_constants_size);
+/* BlitImageStorageToTransient / TransientToStorage / StorageToStorage (:29-31, .cpp:31-176): same-extent
+ * VK_FILTER_NEAREST blits == copies */
+int vhr_compute_blit_image_storage_to_transient(vhr_compute_execution_context *exec, int32_t src, const char *dst);
+int vhr_compute_blit_image_transient_to_storage(vhr_compute_execution_context *exec, const char *src, int32_t dst);
+int vhr_compute_blit_image_storage_to_storage(vhr_compute_execution_context *exec, int32_t src, int32_t dst);
+
+/* ---------------------------------------------------------------------------------------------
+ * HybridRenderPath (src/render_paths/hybrid_render_path.{h,cpp}, render_path.{h,cpp}) re-hosted on the
+ * API above; these entry points expose the C++ re-host (csrc/hybrid_render_path.cpp) to C callers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vhr_hybrid_render_path vhr_hybrid_render_path;
+typedef struct vhr_hybrid_settings {
+    int32_t shadow_mode;             /* 0 raytraced, 1 rasterized, 2 off   (hybrid_render_path.h:4-8)  */
+    int32_t ambient_occlusion_mode;  /* 0 raytraced, 1 ssao, 2 off        (hybrid_render_path.h:10-14) */
+    int32_t reflection_mode;         /* 0 raytraced, 1 ssr, 2 off         (hybrid_render_path.h:16-20) */
+    int32_t denoise_shadow_and_ao;   /* bool                              (hybrid_render_path.h:35)    */
+    int32_t atrous_steps;            /* 5 in the reference (hybrid_render_path.cpp:299)               */
+} vhr_hybrid_settings;
+/* g-buffer / composition are external passes: callbacks may be NULL */
+int  vhr_hybrid_create(vhr_context *ctx, const vhr_hybrid_settings *settings,
+                       vhr_external_pass_callback gbuffer_pass, void *gbuffer_user,
+                       vhr_external_pass_callback composition_pass, void *composition_user,
+                       vhr_hybrid_render_path **out);
+void vhr_hybrid_destroy(vhr_hybrid_render_path *path);      /* DeregisterPath + free */
+int  vhr_hybrid_build(vhr_hybrid_render_path *path);        /* RenderPath::Build   (render_path.cpp:14-20) */
+int  vhr_hybrid_rebuild(vhr_hybrid_render_path *path, const vhr_hybrid_settings *settings); /* Rebuild (:22-27) */
+int  vhr_hybrid_get_push_constants(vhr_hybrid_render_path *path, vhr_svgf_push_constants *out);
+const char *vhr_hybrid_last_error(vhr_hybrid_render_path *path);
+
+/* ---------------------------------------------------------------------------------------------
+ * Harness / test access (no reference counterpart: the reference inspects images through its ImGui
+ * debug-texture viewer, renderer.cpp:215-224)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vhr_image_info {
+    void    *device_ptr;      /* linear, row-major, tightly packed */
+    uint32_t width, height;
+    int32_t  format;
+    uint32_t bytes_per_pixel;
+} vhr_image_info;
+int vhr_get_display_size(vhr_context *ctx, uint32_t *width, uint32_t *height);   /* context.swapchain.extent */
+int vhr_get_transient_image(vhr_context *ctx, const char *name, vhr_image_info *out);
+int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out);
+/* synchronous copies (stream-ordered, then waited) */
+int vhr_upload_transient_image(vhr_context *ctx, const char *name, const void *host_data, uint64_t bytes);
+int vhr_download_transient_image(vhr_context *ctx, const char *name, void *host_data, uint64_t bytes);
+int vhr_upload_storage_image(vhr_context *ctx, int32_t id, const void *host_data, uint64_t bytes);
+int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, uint64_t bytes);
+
+/* Stand-in producer for the untouched G-buffer stage (gbuf.vert:19-28, gbuf.frag:17-59): casts primary
+ * rays through the same BVH and writes the three named transient images with gbuf.frag's encodings
+ * (normals+object id RGBA16F, motion+metallic/roughness RGBA16F, reverse-Z depth D32F) and the clears of
+ * hybrid_render_path.cpp:16-19.  Uses the per-frame data of resource_idx. */
+int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image,
+                        const char *motion_image, const char *depth_image);
+
+/* Multi-GPU row strips: this context owns rows [row_begin, row_end) of the
+ * display; ray tracing runs on the owned rows, the SVGF kernels and copies on the owned rows extended by
+ * `overlap` rows on each side (clamped to the image).  Default: whole image, overlap 0. */
+int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap);
+
+/* Statistics of the last vhr_trace_rays: out[0] = unique rays traced, out[1] = rays the reference would
+ * issue (4x duplicate shadow ray, raygen.rgen:38-40), out[2] = covered (non-sky) pixels, out[3] = traversal
+ * stack overflows (must be 0).  Requires vhr_set_ray_statistics(ctx, 1) (costs one counter flush per pass). */
+int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable);
+int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
+
+/* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
+ * out[3] = node bytes, out[4] = triangle bytes */
+int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VHR_AMD_H */

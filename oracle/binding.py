@@ -1,0 +1,216 @@
+"""ctypes binding of oracle/libvhr_oracle.so (TEST INFRASTRUCTURE ONLY -- see oracle/vhr_oracle.h).
+
+PARITY UNPINNED: the oracle is pinned only by hand-derived known-answer values (tests/golden/) and an
+independent numpy restatement (tests/numpy_restatement.py), because the reference ships no tests and
+cannot be built in this image.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libvhr_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("vhr_oracle.c", "vhr_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libvhr_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u32, f32, vp, i32 = C.c_uint32, C.c_float, C.c_void_p, C.c_int
+        L.orc_seed_thread.restype = u32
+        L.orc_seed_thread.argtypes = [u32]
+        L.orc_random.restype = u32
+        L.orc_random.argtypes = [C.POINTER(u32)]
+        L.orc_random01.restype = f32
+        L.orc_random01.argtypes = [C.POINTER(u32)]
+        L.orc_random_range.restype = u32
+        L.orc_random_range.argtypes = [C.POINTER(u32), u32, u32]
+        L.orc_f32_to_f16.restype = C.c_uint16
+        L.orc_f32_to_f16.argtypes = [f32]
+        L.orc_f16_to_f32.restype = f32
+        L.orc_f16_to_f32.argtypes = [C.c_uint16]
+        L.orc_sincos.argtypes = [f32, C.POINTER(f32), C.POINTER(f32)]
+        L.orc_uniform_sample_cone.argtypes = [f32, f32, f32, vp]
+        L.orc_cosine_hemisphere.argtypes = [f32, f32, vp]
+        L.orc_onb.argtypes = [vp, vp]
+        L.orc_ray_triangle.restype = i32
+        L.orc_ray_triangle.argtypes = [vp, vp, vp, vp, vp, f32, f32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
+        L.orc_infinite_reverse_depth_projection.argtypes = [f32, f32, f32, vp]
+        L.orc_mat4_inverse.argtypes = [vp, vp]
+        L.orc_mat4_mul.argtypes = [vp, vp, vp]
+        L.orc_default_trace_params.argtypes = [vp]
+        L.orc_struct_sizes.restype = i32
+        L.orc_struct_sizes.argtypes = [vp]
+        L.orc_scene_create.restype = vp
+        L.orc_scene_create.argtypes = [vp, u32, vp, u32, vp, u32]
+        L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_add_texture.restype = i32
+        L.orc_scene_add_texture.argtypes = [vp, u32, u32, vp, i32, i32, i32, i32, i32]
+        L.orc_scene_triangle_count.restype = u32
+        L.orc_scene_triangle_count.argtypes = [vp]
+        L.orc_scene_occluded.restype = i32
+        L.orc_scene_occluded.argtypes = [vp, vp, vp, f32, f32, i32]
+        L.orc_scene_closest.restype = i32
+        L.orc_scene_closest.argtypes = [vp, vp, vp, f32, f32, i32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32),
+                                        C.POINTER(u32), C.POINTER(u32)]
+        L.orc_gbuffer.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+        L.orc_raygen.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, i32]
+        L.orc_svgf_temporal.argtypes = [vp, u32, u32] + [vp] * 8
+        L.orc_svgf_atrous.argtypes = [vp, u32, u32, vp, vp, vp, C.c_int32]
+        L.orc_svgf_create.restype = vp
+        L.orc_svgf_create.argtypes = [u32, u32]
+        L.orc_svgf_destroy.argtypes = [vp]
+        L.orc_svgf_frame.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_svgf_image.restype = vp
+        L.orc_svgf_image.argtypes = [vp, i32]
+        L.orc_max_threads.restype = i32
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype=None):
+    a = np.ascontiguousarray(a) if dtype is None else np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def f32_to_f16_bits(x):
+    L = lib()
+    return np.array([L.orc_f32_to_f16(float(np.float32(v))) for v in np.ravel(x)], np.uint16).reshape(np.shape(x))
+
+
+def rng_sequence(seed_input, n):
+    """seed_thread(seed_input) followed by n random01 draws -> (seed, states, floats)."""
+    L = lib()
+    st = C.c_uint32(L.orc_seed_thread(seed_input))
+    seed = st.value
+    states, vals = [], []
+    for _ in range(n):
+        vals.append(np.float32(L.orc_random01(C.byref(st))))
+        states.append(st.value)
+    return seed, states, vals
+
+
+def sincos(phi):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos(float(np.float32(phi)), C.byref(s), C.byref(c))
+    return np.float32(s.value), np.float32(c.value)
+
+
+class Scene:
+    def __init__(self, scene):
+        L = lib()
+        self._v = _c(scene.vertices)
+        self._i = _c(scene.indices, np.uint32)
+        self._p = _c(scene.primitives)
+        self.handle = L.orc_scene_create(_p(self._v), len(self._v), _p(self._i), len(self._i), _p(self._p), len(self._p))
+        for t in scene.textures:
+            img = _c(t["rgba8"], np.uint8)
+            L.orc_scene_add_texture(self.handle, img.shape[1], img.shape[0], _p(img), t["format"], t["mag"], t["min"],
+                                    t["address_u"], t["address_v"])
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().orc_scene_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def triangle_count(self):
+        return lib().orc_scene_triangle_count(self.handle)
+
+    def occluded(self, o, d, tmin, tmax, use_bvh=True):
+        o, d = _c(o, np.float32), _c(d, np.float32)
+        return bool(lib().orc_scene_occluded(self.handle, _p(o), _p(d), tmin, tmax, int(use_bvh)))
+
+    def closest(self, o, d, tmin, tmax, use_bvh=True):
+        o, d = _c(o, np.float32), _c(d, np.float32)
+        t, u, v = C.c_float(), C.c_float(), C.c_float()
+        pr, tr = C.c_uint32(), C.c_uint32()
+        hit = lib().orc_scene_closest(self.handle, _p(o), _p(d), tmin, tmax, int(use_bvh), C.byref(t), C.byref(u),
+                                      C.byref(v), C.byref(pr), C.byref(tr))
+        return (np.float32(t.value), np.float32(u.value), np.float32(v.value), pr.value, tr.value) if hit else None
+
+    def gbuffer(self, pfd, W, H):
+        normals = np.zeros((H, W, 4), np.uint16)
+        motion = np.zeros((H, W, 4), np.uint16)
+        depth = np.zeros((H, W), np.float32)
+        pfd = _c(pfd)
+        lib().orc_gbuffer(self.handle, _p(pfd), W, H, _p(normals), _p(motion), _p(depth))
+        return normals, motion, depth
+
+    def raygen(self, pfd, tp, normals, depth, rows=None, use_bvh=True, want_reflections=True):
+        H, W = depth.shape
+        r0, r1 = rows if rows is not None else (0, H)
+        shadow_ao = np.zeros((H, W, 2), np.uint16)
+        refl = np.zeros((H, W, 4), np.uint16) if want_reflections else None
+        mask = np.zeros((H, W), np.uint8)
+        rays = C.c_uint64()
+        pfd, tp = _c(pfd), _c(tp)
+        normals, depth = _c(normals, np.uint16), _c(depth, np.float32)
+        lib().orc_raygen(self.handle, _p(pfd), _p(tp), W, H, r0, r1, _p(normals), _p(depth), _p(shadow_ao), _p(refl),
+                         _p(mask), C.byref(rays), int(use_bvh))
+        return shadow_ao, refl, mask, rays.value
+
+
+def svgf_temporal(pfd, normals, motion, raytraced, prev_normals, history, moments_in):
+    H, W = normals.shape[:2]
+    integrated = np.zeros((H, W, 4), np.uint16)
+    moments = np.zeros((H, W, 2), np.uint16)
+    a = [_c(x, np.uint16) for x in (normals, motion, raytraced, prev_normals, history, moments_in)]
+    pfd = _c(pfd)
+    lib().orc_svgf_temporal(_p(pfd), W, H, *[_p(x) for x in a], _p(integrated), _p(moments))
+    return integrated, moments
+
+
+def svgf_atrous(pfd, normals, integrated_in, step):
+    H, W = normals.shape[:2]
+    out = np.zeros((H, W, 4), np.uint16)
+    normals, integrated_in, pfd = _c(normals, np.uint16), _c(integrated_in, np.uint16), _c(pfd)
+    lib().orc_svgf_atrous(_p(pfd), W, H, _p(normals), _p(integrated_in), _p(out), int(step))
+    return out
+
+
+class SVGF:
+    """Host schedule of hybrid_render_path.cpp:245-331 with its five persistent images."""
+
+    def __init__(self, W, H):
+        self.W, self.H = W, H
+        self.handle = lib().orc_svgf_create(W, H)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().orc_svgf_destroy(self.handle)
+            self.handle = None
+
+    def frame(self, pfd, normals, motion, raytraced):
+        out = np.zeros((self.H, self.W, 4), np.uint16)
+        a = [_c(x, np.uint16) for x in (normals, motion, raytraced)]
+        pfd = _c(pfd)
+        lib().orc_svgf_frame(self.handle, _p(pfd), *[_p(x) for x in a], _p(out))
+        return out
+
+    def image(self, which):
+        ch = 2 if which == 4 else 4
+        ptr = lib().orc_svgf_image(self.handle, which)
+        buf = (C.c_uint16 * (self.W * self.H * ch)).from_address(ptr)
+        return np.frombuffer(buf, np.uint16).reshape(self.H, self.W, ch).copy()
+
+
+def max_threads():
+    return lib().orc_max_threads()

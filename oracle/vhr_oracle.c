@@ -1,0 +1,1044 @@
+/*
+ * vhr_oracle.c -- TEST INFRASTRUCTURE ONLY (see vhr_oracle.h for the contract).
+ *
+ * Plain-C restatement of the reference's GLSL hot path.  PARITY UNPINNED (no reference
+ * tests / fixtures exist; the reference cannot be built in this image).
+ *
+ * Decisions the reference leaves open, fixed here and mirrored,
+ * independently re-implemented, by the HIP product:
+ *   (i)   dispatches execute sequentially with full visibility;
+ *   (ii)  svgf.comp reads the moments history from a pre-dispatch snapshot;
+ *   (iii) image stores round fp32->fp16 round-to-nearest-even, loads widen exactly;
+ *   (iv)  an RG16F image read as vec4 yields (r, g, 0, 1);
+ *   (v)   pow(x, 128) = x^128 by seven squarings for x > 0, 0 for x <= 0;
+ *   (vi)  triangle hit iff tmin < t < tmax, two-sided, Moeller-Trumbore in the op order
+ *         written below, no FMA contraction (build with -ffp-contract=off), det == 0 -> miss;
+ *         closest hit = min t, ties broken by the smaller flat triangle index;
+ *   (vii) sin/cos come from the 3-term Cody-Waite + Cephes-polynomial routine below,
+ *         normalize(v) = v * (1 / sqrt(dot(v, v))), dot = (x*x' + y*y') + z*z';
+ *   (viii) storage images are zero-initialised; int(NaN) = 0.
+ */
+#include "vhr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * small vector helpers (explicit op order; never contracted)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v3mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v3neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline v3 normalize3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return v3scale(a, inv); }
+
+/* GLSL mat4 * vec4, column-major storage m[c*4+r]; sum accumulated left to right */
+static inline v4 mat4_mul_v4(const float *m, v4 v) {
+    v4 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+/* transform a point by the upper 3x4 of a column-major mat4 (w = 1) */
+static inline v3 mat4_mul_point(const float *m, v3 p) {
+    v3 r;
+    r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12];
+    r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13];
+    r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14];
+    return r;
+}
+
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]) {
+    float r[16];
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 4; ++i)
+            r[c * 4 + i] = ((a[0 * 4 + i] * b[c * 4 + 0] + a[1 * 4 + i] * b[c * 4 + 1]) + a[2 * 4 + i] * b[c * 4 + 2]) +
+                           a[3 * 4 + i] * b[c * 4 + 3];
+    memcpy(out, r, sizeof r);
+}
+
+/* general 4x4 inverse by cofactors, evaluated in double and rounded once (glm::inverse stand-in,
+ * renderer.cpp:195-196) */
+void orc_mat4_inverse(const float m[16], float out[16]) {
+    double a[16], inv[16];
+    for (int i = 0; i < 16; ++i) a[i] = m[i];
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    double id = (det != 0.0) ? 1.0 / det : 0.0;
+    for (int i = 0; i < 16; ++i) out[i] = (float)(inv[i] * id);
+}
+
+/* src/rendering_backend/vulkan_utils.h:494-503 (column-major initialiser order) */
+void orc_infinite_reverse_depth_projection(float yfov, float aspect, float znear, float out[16]) {
+    float scale = 1.0f / tanf(yfov * 0.5f);
+    float m[16] = { scale / aspect, 0, 0, 0, 0, scale, 0, 0, 0, 0, 0, -1.0f, 0, 0, znear, 0 };
+    memcpy(out, m, sizeof m);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * fp16 storage semantics (decision iii)
+ * ---------------------------------------------------------------------------------------- */
+uint16_t orc_f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) {                       /* inf / nan */
+        if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u | ((ax >> 13) & 0x1ffu));
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);   /* >= 65520 rounds to inf */
+    if (ax < 0x33000001u) return (uint16_t)sign;                 /* <= 2^-25 rounds to zero */
+    int32_t e = (int32_t)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    uint32_t shift, half;
+    if (e < -14) {                                  /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));
+        half = 0;
+    } else {
+        shift = 13;
+        half = (uint32_t)(e + 15) << 10;
+    }
+    uint32_t mant = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t halfway = 1u << (shift - 1);
+    if (e >= -14) mant &= 0x3ffu;                   /* drop implicit bit for normals */
+    uint32_t h = half + mant;
+    if (rem > halfway || (rem == halfway && (h & 1u))) h += 1u;  /* RTNE; carry into exponent is correct */
+    return (uint16_t)(sign | h);
+}
+
+float orc_f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            m &= 0x3ffu;
+            x = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+        }
+    } else if (e == 31) {
+        x = sign | 0x7f800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+static inline v4 load_rgba16f(const uint16_t *img, uint32_t W, int x, int y) {
+    const uint16_t *p = img + ((size_t)y * W + (size_t)x) * 4;
+    v4 r = { orc_f16_to_f32(p[0]), orc_f16_to_f32(p[1]), orc_f16_to_f32(p[2]), orc_f16_to_f32(p[3]) };
+    return r;
+}
+/* decision (iv): RG16F read as vec4 = (r, g, 0, 1) */
+static inline v4 load_rg16f(const uint16_t *img, uint32_t W, int x, int y) {
+    const uint16_t *p = img + ((size_t)y * W + (size_t)x) * 2;
+    v4 r = { orc_f16_to_f32(p[0]), orc_f16_to_f32(p[1]), 0.0f, 1.0f };
+    return r;
+}
+static inline void store_rgba16f(uint16_t *img, uint32_t W, int x, int y, float a, float b, float c, float d) {
+    uint16_t *p = img + ((size_t)y * W + (size_t)x) * 4;
+    p[0] = orc_f32_to_f16(a); p[1] = orc_f32_to_f16(b); p[2] = orc_f32_to_f16(c); p[3] = orc_f32_to_f16(d);
+}
+static inline void store_rg16f(uint16_t *img, uint32_t W, int x, int y, float a, float b) {
+    uint16_t *p = img + ((size_t)y * W + (size_t)x) * 2;
+    p[0] = orc_f32_to_f16(a); p[1] = orc_f32_to_f16(b);
+}
+/* decision (viii): GLSL int(float) truncates toward zero; NaN -> 0; saturating */
+static inline int f2i(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * data/shaders/common.glsl
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_TWO_PI 6.28318530717958647692528f
+#define ORC_PI 3.14159265358979323846264f
+#define ORC_PI_INVERSE 0.31830988618379067153776f
+#define ORC_COS_PI_4 0.70710678118654752440084f
+
+/* common.glsl:47-56 Thomas Wang hash */
+uint32_t orc_seed_thread(uint32_t seed) {
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+/* common.glsl:58-64 xorshift32 */
+uint32_t orc_random(uint32_t *state) {
+    uint32_t s = *state;
+    s ^= (s << 13);
+    s ^= (s >> 17);
+    s ^= (s << 5);
+    *state = s;
+    return s;
+}
+/* common.glsl:66-68 */
+float orc_random01(uint32_t *state) {
+    uint32_t bits = 0x3f800000u | (orc_random(state) >> 9);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f - 1.0f;
+}
+/* common.glsl:74-76 */
+uint32_t orc_random_range(uint32_t *state, uint32_t lower, uint32_t upper) {
+    return lower + (uint32_t)((float)(upper - lower + 1u) * orc_random01(state));
+}
+
+/* decision (vii): sin/cos shared definition. phi in [0, 2*pi]; quadrant reduction with a 3-term
+ * Cody-Waite split of pi/2 and the Cephes sinf/cosf minimax polynomials on [-pi/4, pi/4]. */
+void orc_sincos(float phi, float *s_out, float *c_out) {
+    float k = rintf(phi * 0.636619772367581343f);
+    float r = ((phi - k * 1.5703125f) - k * 4.837512969970703125e-4f) - k * 7.54978995489188e-8f;
+    float z = r * r;
+    float s = ((((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z) * r) + r;
+    float c = ((((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z) * z) + (1.0f - 0.5f * z);
+    int q = ((int)k) & 3;
+    float ss, cc;
+    if (q == 0) { ss = s; cc = c; }
+    else if (q == 1) { ss = c; cc = -s; }
+    else if (q == 2) { ss = -s; cc = -c; }
+    else { ss = -c; cc = s; }
+    *s_out = ss;
+    *c_out = cc;
+}
+
+/* common.glsl:29-34 */
+static v3 uniform_sample_cone(float ux, float uy, float cos_theta_max) {
+    float cos_theta = (1.0f - ux) + ux * cos_theta_max;
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float phi = uy * ORC_TWO_PI;
+    float s, c;
+    orc_sincos(phi, &s, &c);
+    return V3(c * sin_theta, s * sin_theta, cos_theta);
+}
+void orc_uniform_sample_cone(float u0, float u1, float cos_theta_max, float out[3]) {
+    v3 r = uniform_sample_cone(u0, u1, cos_theta_max);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* common.glsl:37-42 */
+static v3 cosine_hemisphere(float ux, float uy) {
+    float s, c;
+    orc_sincos(ORC_TWO_PI * uy, &s, &c);
+    float sq = sqrtf(ux);
+    return V3(sq * c, sq * s, sqrtf(1.0f - ux));
+}
+void orc_cosine_hemisphere(float u0, float u1, float out[3]) {
+    v3 r = cosine_hemisphere(u0, u1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* common.glsl:80-93 Frisvad ONB; M = three columns */
+typedef struct { v3 c0, c1, c2; } m3;
+static m3 onb_from_unit_vector(v3 n) {
+    m3 M;
+    M.c2 = n;
+    if (n.z < -0.9999999f) {
+        M.c0 = V3(0.0f, -1.0f, 0.0f);
+        M.c1 = V3(-1.0f, 0.0f, 0.0f);
+        return M;
+    }
+    float a = 1.0f / (1.0f + n.z);
+    float b = ((-n.x) * n.y) * a;
+    M.c0 = V3(1.0f - (n.x * n.x) * a, b, -n.x);
+    M.c1 = V3(b, 1.0f - (n.y * n.y) * a, -n.y);
+    return M;
+}
+void orc_onb(const float n[3], float M[9]) {
+    m3 r = onb_from_unit_vector(V3(n[0], n[1], n[2]));
+    M[0] = r.c0.x; M[1] = r.c0.y; M[2] = r.c0.z;
+    M[3] = r.c1.x; M[4] = r.c1.y; M[5] = r.c1.z;
+    M[6] = r.c2.x; M[7] = r.c2.y; M[8] = r.c2.z;
+}
+/* GLSL mat3 * vec3 */
+static inline v3 m3_mul(m3 M, v3 v) {
+    return V3((M.c0.x * v.x + M.c1.x * v.y) + M.c2.x * v.z,
+              (M.c0.y * v.x + M.c1.y * v.y) + M.c2.y * v.z,
+              (M.c0.z * v.x + M.c1.z * v.y) + M.c2.z * v.z);
+}
+
+/* common.glsl:116-150 BRDF helpers */
+static v3 fresnel_schlick(v3 f0, v3 H, v3 V) {
+    float hv = fmaxf(dot3(H, V), 0.0f);
+    float om = 1.0f - hv;
+    float p5 = om * om * om * om * om;
+    return V3(f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5);
+}
+static float D_GGX(float roughness, v3 N, v3 H) {
+    float a2 = roughness * roughness;
+    float nh = fmaxf(dot3(N, H), 0.0f);
+    float f = nh * nh * (a2 - 1.0f) + 1.0f;
+    return a2 / (ORC_PI * f * f);
+}
+static float G_GGX(float roughness, v3 N, v3 V, v3 L) {
+    float k = ((roughness + 1.0f) * (roughness + 1.0f)) * 0.125f;
+    float nv = fmaxf(dot3(N, V), 0.0f);
+    float nl = fmaxf(dot3(N, L), 0.0f);
+    float gv = nv / (nv * (1.0f - k) + k);
+    float gl = nl / (nl * (1.0f - k) + k);
+    return gv * gl;
+}
+static v3 specular_brdf(float roughness, v3 F, v3 V, v3 L, v3 N, v3 H) {
+    float dg = D_GGX(roughness, N, H) * G_GGX(roughness, N, V, L);
+    float denom = 4.0f * fmaxf(dot3(N, V), 0.0f) * fmaxf(dot3(N, L), 0.0f);
+    float inv = 1.0f / fmaxf(denom, 1e-6f);
+    return V3(dg * F.x * inv, dg * F.y * inv, dg * F.z * inv);
+}
+static v3 diffuse_brdf(float metallic, v3 albedo, v3 F) {
+    v3 dp = V3((1.0f - F.x) * (1.0f - metallic), (1.0f - F.y) * (1.0f - metallic), (1.0f - F.z) * (1.0f - metallic));
+    return V3(dp.x * albedo.x / ORC_PI, dp.y * albedo.y / ORC_PI, dp.z * albedo.z / ORC_PI);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ray / triangle (decision vi)
+ * ---------------------------------------------------------------------------------------- */
+static inline int ray_triangle(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, float tmax, float *t, float *u, float *v) {
+    v3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (det == 0.0f) return 0;
+    float inv = 1.0f / det;
+    v3 tvec = v3sub(o, v0);
+    float uu = dot3(tvec, pvec) * inv;
+    if (!(uu >= 0.0f) || uu > 1.0f) return 0;
+    v3 qvec = cross3(tvec, e1);
+    float vv = dot3(d, qvec) * inv;
+    if (!(vv >= 0.0f) || uu + vv > 1.0f) return 0;
+    float tt = dot3(e2, qvec) * inv;
+    if (!(tt > tmin && tt < tmax)) return 0;
+    *t = tt; *u = uu; *v = vv;
+    return 1;
+}
+int orc_ray_triangle(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3],
+                     float tmin, float tmax, float *t, float *u, float *v) {
+    return ray_triangle(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), V3(v0[0], v0[1], v0[2]), V3(e1[0], e1[1], e1[2]),
+                        V3(e2[0], e2[1], e2[2]), tmin, tmax, t, u, v);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scene: world-space triangle soup + the oracle's own (median-split) BVH
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { v3 v0, e1, e2; uint32_t prim, tri; } orc_tri;
+typedef struct { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; } orc_node;
+typedef struct { uint32_t w, h; int format, mag, min, au, av; uint8_t *data; } orc_texture;
+
+struct orc_scene {
+    orc_vertex *vertices; uint32_t nv;
+    uint32_t *indices; uint32_t ni;
+    orc_primitive *prims; uint32_t np;
+    orc_tri *tris; uint32_t ntris;     /* flat order: primitive-major, triangle-minor */
+    uint32_t *order;                   /* BVH leaf order -> flat triangle index */
+    orc_node *nodes; uint32_t nnodes, cap_nodes;
+    orc_texture *textures; uint32_t ntex;
+    float srgb_lut[256];
+};
+
+static void tri_bounds(const orc_tri *t, float lo[3], float hi[3]) {
+    v3 a = t->v0, b = v3add(t->v0, t->e1), c = v3add(t->v0, t->e2);
+    float xs[3] = { a.x, b.x, c.x }, ys[3] = { a.y, b.y, c.y }, zs[3] = { a.z, b.z, c.z };
+    lo[0] = fminf(xs[0], fminf(xs[1], xs[2])); hi[0] = fmaxf(xs[0], fmaxf(xs[1], xs[2]));
+    lo[1] = fminf(ys[0], fminf(ys[1], ys[2])); hi[1] = fmaxf(ys[0], fmaxf(ys[1], ys[2]));
+    lo[2] = fminf(zs[0], fminf(zs[1], zs[2])); hi[2] = fmaxf(zs[0], fmaxf(zs[1], zs[2]));
+}
+
+static int32_t build_node(orc_scene *s, float *cent, uint32_t first, uint32_t count) {
+    if (s->nnodes == s->cap_nodes) {
+        s->cap_nodes = s->cap_nodes ? s->cap_nodes * 2 : 1024;
+        s->nodes = (orc_node *)realloc(s->nodes, sizeof(orc_node) * s->cap_nodes);
+    }
+    int32_t id = (int32_t)s->nnodes++;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = first; i < first + count; ++i) {
+        float tl[3], th[3];
+        tri_bounds(&s->tris[s->order[i]], tl, th);
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], tl[a]); hi[a] = fmaxf(hi[a], th[a]);
+            float c = cent[(size_t)s->order[i] * 3 + a];
+            clo[a] = fminf(clo[a], c); chi[a] = fmaxf(chi[a], c);
+        }
+    }
+    for (int a = 0; a < 3; ++a) {        /* conservative padding so box culling can never change a hit */
+        float pad = 1e-3f + 1e-5f * fmaxf(fabsf(lo[a]), fabsf(hi[a]));
+        lo[a] -= pad; hi[a] += pad;
+    }
+    int axis = 0;
+    float ext = chi[0] - clo[0];
+    if (chi[1] - clo[1] > ext) { axis = 1; ext = chi[1] - clo[1]; }
+    if (chi[2] - clo[2] > ext) { axis = 2; ext = chi[2] - clo[2]; }
+    orc_node n;
+    memcpy(n.lo, lo, sizeof lo); memcpy(n.hi, hi, sizeof hi);
+    n.left = n.right = -1; n.first = first; n.count = count;
+    if (count > 4 && ext > 0.0f) {
+        float split = 0.5f * (clo[axis] + chi[axis]);
+        uint32_t i = first, j = first + count;
+        while (i < j) {
+            if (cent[(size_t)s->order[i] * 3 + axis] < split) ++i;
+            else { --j; uint32_t t = s->order[i]; s->order[i] = s->order[j]; s->order[j] = t; }
+        }
+        uint32_t mid = i;
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        n.count = 0;
+        s->nodes[id] = n;
+        int32_t l = build_node(s, cent, first, mid - first);
+        int32_t r = build_node(s, cent, mid, first + count - mid);
+        s->nodes[id].left = l; s->nodes[id].right = r;
+    } else {
+        s->nodes[id] = n;
+    }
+    return id;
+}
+
+orc_scene *orc_scene_create(const orc_vertex *vertices, uint32_t nv, const uint32_t *indices, uint32_t ni,
+                            const orc_primitive *primitives, uint32_t np) {
+    orc_scene *s = (orc_scene *)calloc(1, sizeof *s);
+    s->vertices = (orc_vertex *)malloc(sizeof(orc_vertex) * (nv ? nv : 1)); memcpy(s->vertices, vertices, sizeof(orc_vertex) * nv); s->nv = nv;
+    s->indices = (uint32_t *)malloc(sizeof(uint32_t) * (ni ? ni : 1)); memcpy(s->indices, indices, sizeof(uint32_t) * ni); s->ni = ni;
+    s->prims = (orc_primitive *)malloc(sizeof(orc_primitive) * (np ? np : 1)); memcpy(s->prims, primitives, sizeof(orc_primitive) * np); s->np = np;
+    uint32_t nt = 0;
+    for (uint32_t p = 0; p < np; ++p) nt += primitives[p].index_count / 3;   /* resource_manager.cpp:637 */
+    s->ntris = nt;
+    s->tris = (orc_tri *)malloc(sizeof(orc_tri) * (nt ? nt : 1));
+    uint32_t k = 0;
+    for (uint32_t p = 0; p < np; ++p) {
+        const orc_primitive *pr = &primitives[p];
+        for (uint32_t t = 0; t < pr->index_count / 3; ++t) {
+            /* resource_manager.cpp:638-639: indices offset by index_offset, vertices by vertex_offset;
+             * :608-617: the primitive transform is baked into the geometry */
+            v3 w[3];
+            for (int c = 0; c < 3; ++c) {
+                uint32_t vi = pr->vertex_offset + indices[pr->index_offset + 3 * t + c];
+                const float *pp = vertices[vi].pos;
+                w[c] = mat4_mul_point(pr->transform, V3(pp[0], pp[1], pp[2]));
+            }
+            s->tris[k].v0 = w[0];
+            s->tris[k].e1 = v3sub(w[1], w[0]);
+            s->tris[k].e2 = v3sub(w[2], w[0]);
+            s->tris[k].prim = p;
+            s->tris[k].tri = t;
+            ++k;
+        }
+    }
+    s->order = (uint32_t *)malloc(sizeof(uint32_t) * (nt ? nt : 1));
+    float *cent = (float *)malloc(sizeof(float) * 3 * (nt ? nt : 1));
+    for (uint32_t i = 0; i < nt; ++i) {
+        s->order[i] = i;
+        float lo[3], hi[3];
+        tri_bounds(&s->tris[i], lo, hi);
+        for (int a = 0; a < 3; ++a) cent[(size_t)i * 3 + a] = 0.5f * (lo[a] + hi[a]);
+    }
+    if (nt) build_node(s, cent, 0, nt);
+    free(cent);
+    for (int i = 0; i < 256; ++i) {     /* sRGB EOTF */
+        double c = i / 255.0;
+        s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    return s;
+}
+
+void orc_scene_destroy(orc_scene *s) {
+    if (!s) return;
+    for (uint32_t i = 0; i < s->ntex; ++i) free(s->textures[i].data);
+    free(s->textures); free(s->vertices); free(s->indices); free(s->prims); free(s->tris); free(s->order); free(s->nodes);
+    free(s);
+}
+
+int orc_scene_add_texture(orc_scene *s, uint32_t w, uint32_t h, const uint8_t *rgba8, int format, int mag_filter,
+                          int min_filter, int address_u, int address_v) {
+    s->textures = (orc_texture *)realloc(s->textures, sizeof(orc_texture) * (s->ntex + 1));
+    orc_texture *t = &s->textures[s->ntex];
+    t->w = w; t->h = h; t->format = format; t->mag = mag_filter; t->min = min_filter; t->au = address_u; t->av = address_v;
+    t->data = (uint8_t *)malloc((size_t)w * h * 4);
+    memcpy(t->data, rgba8, (size_t)w * h * 4);
+    return (int)s->ntex++;
+}
+
+uint32_t orc_scene_triangle_count(const orc_scene *s) { return s->ntris; }
+
+static inline int box_hit(const orc_node *n, v3 o, v3 inv, float tmin, float tmax) {
+    float t0, t1, tn = tmin, tf = tmax;
+    t0 = (n->lo[0] - o.x) * inv.x; t1 = (n->hi[0] - o.x) * inv.x;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (n->lo[1] - o.y) * inv.y; t1 = (n->hi[1] - o.y) * inv.y;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (n->lo[2] - o.z) * inv.z; t1 = (n->hi[2] - o.z) * inv.z;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    return tn <= tf;
+}
+
+typedef struct { int hit; float t, u, v; uint32_t flat; } orc_hit;
+
+/* any_hit != 0: return on the first accepted triangle (gl_RayFlagsTerminateOnFirstHitEXT,
+ * raygen.rgen:39); otherwise closest hit with the flat-index tie break (decision vi) */
+static orc_hit trace(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit, int use_bvh) {
+    orc_hit best = { 0, tmax, 0, 0, 0xffffffffu };
+    if (s->ntris == 0) return best;
+    if (!use_bvh) {
+        for (uint32_t i = 0; i < s->ntris; ++i) {
+            const orc_tri *tr = &s->tris[i];
+            float t, u, v;
+            if (ray_triangle(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t, &u, &v)) {
+                if (any_hit) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = i; return best; }
+                if (!best.hit || t < best.t || (t == best.t && i < best.flat)) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = i; }
+            }
+        }
+        return best;
+    }
+    v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const orc_node *n = &s->nodes[stack[--sp]];
+        /* closest hit keeps the full [tmin, tmax] interval on purpose: pruning by best.t would be an
+         * optimisation whose only effect must be none */
+        if (!box_hit(n, o, inv, tmin, tmax)) continue;
+        if (n->left >= 0) { stack[sp++] = n->left; stack[sp++] = n->right; continue; }
+        for (uint32_t i = n->first; i < n->first + n->count; ++i) {
+            uint32_t flat = s->order[i];
+            const orc_tri *tr = &s->tris[flat];
+            float t, u, v;
+            if (ray_triangle(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t, &u, &v)) {
+                if (any_hit) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = flat; return best; }
+                if (!best.hit || t < best.t || (t == best.t && flat < best.flat)) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = flat; }
+            }
+        }
+    }
+    return best;
+}
+
+int orc_scene_occluded(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh) {
+    return trace(s, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, 1, use_bvh).hit;
+}
+int orc_scene_closest(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
+                      float *t, float *u, float *v, uint32_t *prim, uint32_t *tri_in_prim) {
+    orc_hit h = trace(s, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, 0, use_bvh);
+    if (!h.hit) return 0;
+    *t = h.t; *u = h.u; *v = h.v; *prim = s->tris[h.flat].prim; *tri_in_prim = s->tris[h.flat].tri;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * texture(): LOD 0, per-texture sampler (resource_manager.cpp:58-69,152-196; scene_loader.cpp:241-300)
+ * ---------------------------------------------------------------------------------------- */
+static inline int wrap_coord(int i, int n, int mode) {
+    if (mode == 2) return i < 0 ? 0 : (i >= n ? n - 1 : i);              /* CLAMP_TO_EDGE */
+    if (mode == 1) {                                                       /* MIRRORED_REPEAT */
+        int p = 2 * n;
+        int m = i % p; if (m < 0) m += p;
+        return m < n ? m : p - 1 - m;
+    }
+    int m = i % n; if (m < 0) m += n;                                      /* REPEAT */
+    return m;
+}
+static inline v4 texel(const orc_scene *s, const orc_texture *t, int x, int y) {
+    const uint8_t *p = t->data + ((size_t)y * t->w + (size_t)x) * 4;
+    v4 r;
+    if (t->format == 43) { r.x = s->srgb_lut[p[0]]; r.y = s->srgb_lut[p[1]]; r.z = s->srgb_lut[p[2]]; }
+    else { r.x = p[0] * (1.0f / 255.0f); r.y = p[1] * (1.0f / 255.0f); r.z = p[2] * (1.0f / 255.0f); }
+    r.w = p[3] * (1.0f / 255.0f);
+    return r;
+}
+static v4 sample_texture(const orc_scene *s, int idx, float u, float v) {
+    v4 zero = { 0, 0, 0, 0 };
+    if (idx < 0 || (uint32_t)idx >= s->ntex) return zero;
+    const orc_texture *t = &s->textures[idx];
+    float x = u * (float)t->w, y = v * (float)t->h;
+    if (t->mag == 0) {
+        int ix = wrap_coord((int)floorf(x), (int)t->w, t->au), iy = wrap_coord((int)floorf(y), (int)t->h, t->av);
+        return texel(s, t, ix, iy);
+    }
+    x -= 0.5f; y -= 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = wrap_coord((int)fx0, (int)t->w, t->au), x1 = wrap_coord((int)fx0 + 1, (int)t->w, t->au);
+    int y0 = wrap_coord((int)fy0, (int)t->h, t->av), y1 = wrap_coord((int)fy0 + 1, (int)t->h, t->av);
+    v4 a = texel(s, t, x0, y0), b = texel(s, t, x1, y0), c = texel(s, t, x0, y1), d = texel(s, t, x1, y1);
+    v4 r;
+    r.x = (a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy;
+    r.y = (a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy;
+    r.z = (a.z * (1.0f - fx) + b.z * fx) * (1.0f - fy) + (c.z * (1.0f - fx) + d.z * fx) * fy;
+    r.w = (a.w * (1.0f - fx) + b.w * fx) * (1.0f - fy) + (c.w * (1.0f - fx) + d.w * fx) * fy;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * reflection_hit.rchit:10-72 (closest-hit shading); returns the payload rgb, a = 1
+ * ---------------------------------------------------------------------------------------- */
+static v4 reflection_hit(const orc_scene *s, const orc_per_frame_data *pfd, const orc_hit *h) {
+    const orc_tri *tr = &s->tris[h->flat];
+    const orc_primitive *prim = &s->prims[tr->prim];                               /* :11 gl_GeometryIndexEXT */
+    uint32_t i0 = s->indices[prim->index_offset + 3 * tr->tri + 0];               /* :13-15 gl_PrimitiveID */
+    uint32_t i1 = s->indices[prim->index_offset + 3 * tr->tri + 1];
+    uint32_t i2 = s->indices[prim->index_offset + 3 * tr->tri + 2];
+    const orc_vertex *a = &s->vertices[prim->vertex_offset + i0];                 /* :17-19 */
+    const orc_vertex *b = &s->vertices[prim->vertex_offset + i1];
+    const orc_vertex *c = &s->vertices[prim->vertex_offset + i2];
+    float bx = 1.0f - h->u - h->v, by = h->u, bz = h->v;                          /* :21 */
+    float uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;                 /* :22 */
+    float uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
+    v3 normal = V3(a->normal[0] * bx + b->normal[0] * by + c->normal[0] * bz,     /* :23 object space, unnormalised */
+                   a->normal[1] * bx + b->normal[1] * by + c->normal[1] * bz,
+                   a->normal[2] * bx + b->normal[2] * by + c->normal[2] * bz);
+    v3 opos = V3(a->pos[0] * bx + b->pos[0] * by + c->pos[0] * bz,
+                 a->pos[1] * bx + b->pos[1] * by + c->pos[1] * bz,
+                 a->pos[2] * bx + b->pos[2] * by + c->pos[2] * bz);
+    v3 position = mat4_mul_point(prim->transform, opos);                           /* :24 */
+
+    v3 albedo;
+    if (prim->material.base_color_texture == -1)                                   /* :27-32 */
+        albedo = V3(prim->material.base_color[0], prim->material.base_color[1], prim->material.base_color[2]);
+    else { v4 t = sample_texture(s, prim->material.base_color_texture, uvx, uvy); albedo = V3(t.x, t.y, t.z); }
+    float metallic = prim->material.metallic_factor;                               /* :33-39 */
+    float roughness = prim->material.roughness_factor;
+    if (prim->material.metallic_roughness_texture != -1) {
+        v4 mr = sample_texture(s, prim->material.metallic_roughness_texture, uvx, uvy);
+        metallic *= mr.y;
+        roughness *= mr.z;
+    }
+    v3 cam = V3(pfd->camera_view_inverse[12], pfd->camera_view_inverse[13], pfd->camera_view_inverse[14]);   /* :41 */
+    v3 V = normalize3(v3sub(cam, position));
+    v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
+    v3 N = normal;
+    v3 H = normalize3(v3add(L, V));
+    roughness = fminf(fmaxf(roughness, 0.04f), 1.0f);                              /* :53-55 */
+    metallic = fminf(fmaxf(metallic, 0.0f), 1.0f);
+    float ambient_factor = ORC_PI_INVERSE * 0.2f;                                  /* :59 */
+    v3 li = V3(pfd->directional_light.intensity[0], pfd->directional_light.intensity[1], pfd->directional_light.intensity[2]);
+    v3 lc = V3(pfd->directional_light.color[0], pfd->directional_light.color[1], pfd->directional_light.color[2]);
+    v3 f0 = V3(0.04f * (1.0f - metallic) + albedo.x * metallic, 0.04f * (1.0f - metallic) + albedo.y * metallic,
+               0.04f * (1.0f - metallic) + albedo.z * metallic);                   /* :63-64 mix */
+    v3 F = fresnel_schlick(f0, H, V);
+    v3 ambient = v3scale(albedo, ambient_factor);                                  /* :67 */
+    v3 diffuse = diffuse_brdf(metallic, albedo, F);
+    v3 specular = specular_brdf(roughness, F, V, L, N, H);
+    float nl = fmaxf(dot3(N, L), 0.0f);
+    v3 lit = v3mul(v3mul(v3scale(v3add(diffuse, specular), nl), li), lc);          /* :70 */
+    v3 lighting = v3add(ambient, lit);
+    v4 r = { lighting.x, lighting.y, lighting.z, 1.0f };
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * raygen.rgen:14-66 (+ miss.rmiss:6-8, reflection_miss.rmiss:6-8)
+ * ---------------------------------------------------------------------------------------- */
+void orc_default_trace_params(orc_trace_params *p) {
+    p->shadow_enable = 1; p->ao_spp = 2; p->ao_tmax = 5.0f; p->reflections = 1;
+    p->cone_cos_max = 0.999995f; p->normal_bias = 0.1f; p->tmin = 0.01f; p->tmax = 10000.0f;
+}
+
+/* glsl_common.h:118-122 */
+static v3 get_world_space_position(const orc_per_frame_data *pfd, float depth, float u, float v) {
+    v4 ndc = { u * 2.0f - 1.0f, v * 2.0f - 1.0f, depth, 1.0f };
+    v4 r = mat4_mul_v4(pfd->camera_viewproj_inverse, ndc);
+    return V3(r.x / r.w, r.y / r.w, r.z / r.w);
+}
+
+void orc_raygen(const orc_scene *s, const orc_per_frame_data *pfd, const orc_trace_params *tp, uint32_t W, uint32_t H,
+                uint32_t row_begin, uint32_t row_end, const uint16_t *normals_ids, const float *depth,
+                uint16_t *shadow_ao, uint16_t *reflections, uint8_t *vis_mask, uint64_t *rays_out, int use_bvh) {
+    uint64_t rays = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays)
+    for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; ++yy) {
+        uint32_t y = (uint32_t)yy;
+        for (uint32_t x = 0; x < W; ++x) {
+            float u = ((float)x + 0.5f) / (float)W;                                       /* :15-16 */
+            float v = ((float)y + 0.5f) / (float)H;
+            uint32_t rng = orc_seed_thread((y * H + x) * pfd->frame_index);               /* :17 LaunchSize.y quirk */
+            float d = depth[(size_t)y * W + x];                                           /* :19 texel-centre fetch */
+            uint8_t mask = 0;
+            if (d == 0.0f) {                                                              /* :20-24 */
+                store_rg16f(shadow_ao, W, (int)x, (int)y, 1.0f, 1.0f);
+                if (reflections) store_rgba16f(reflections, W, (int)x, (int)y, 0, 0, 0, 0);
+                if (vis_mask) vis_mask[(size_t)y * W + x] = 0x40;
+                continue;
+            }
+            v3 P = get_world_space_position(pfd, d, u, v);                                /* :26 */
+            v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1],
+                            pfd->directional_light.direction[2]));                        /* :27 */
+            v4 nid = load_rgba16f(normals_ids, W, (int)x, (int)y);                        /* :28 */
+            v3 N = V3(nid.x, nid.y, nid.z);
+            v3 origin = v3add(P, v3scale(N, tp->normal_bias));                            /* :29 */
+
+            float rnd1 = orc_random01(&rng);                                              /* :32-33 */
+            float rnd2 = orc_random01(&rng);
+            float shadow_payload = 1.0f;
+            if (tp->shadow_enable) {
+                v3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, tp->cone_cos_max));   /* :34 */
+                m3 R = onb_from_unit_vector(L);                                           /* :35 */
+                v3 dir = m3_mul(R, cone_dir);
+                /* :37-41 four identical traces; the payload of the last one survives == one trace */
+                int occluded = trace(s, origin, dir, tp->tmin, tp->tmax, 1, use_bvh).hit;
+                shadow_payload = occluded ? 0.0f : 1.0f;                                  /* miss.rmiss:7 */
+                ++rays;
+            }
+            if (shadow_payload != 0.0f) mask |= 1;
+
+            float ao_payload = 0.0f;                                                      /* :44-55 */
+            for (uint32_t i = 0; i < tp->ao_spp; ++i) {
+                rnd1 = orc_random01(&rng);
+                rnd2 = orc_random01(&rng);
+                v3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
+                m3 R = onb_from_unit_vector(N);
+                v3 dir = m3_mul(R, rnd_dir);
+                int occluded = trace(s, origin, dir, tp->tmin, tp->ao_tmax, 1, use_bvh).hit;
+                ao_payload += occluded ? 0.0f : 1.0f;
+                if (!occluded && i < 5) mask |= (uint8_t)(2u << i);
+                ++rays;
+            }
+            if (tp->ao_spp) ao_payload /= (float)tp->ao_spp; else ao_payload = 1.0f;
+            store_rg16f(shadow_ao, W, (int)x, (int)y, shadow_payload, ao_payload);       /* :57 (RG16F target) */
+
+            if (reflections) {
+                v4 payload = { 0, 0, 0, 0 };
+                if (tp->reflections) {                                                    /* :60-65 */
+                    v3 cam = V3(pfd->camera_view_inverse[12], pfd->camera_view_inverse[13], pfd->camera_view_inverse[14]);
+                    v3 I = normalize3(v3sub(P, cam));
+                    float ni2 = 2.0f * dot3(N, I);
+                    v3 rdir = v3sub(I, v3scale(N, ni2));                                   /* reflect(I, N) */
+                    orc_hit h = trace(s, origin, rdir, tp->tmin, tp->tmax, 0, use_bvh);
+                    ++rays;
+                    if (h.hit) { payload = reflection_hit(s, pfd, &h); mask |= 0x80; }     /* else reflection_miss.rmiss:7 */
+                }
+                store_rgba16f(reflections, W, (int)x, (int)y, payload.x, payload.y, payload.z, payload.w);
+            }
+            if (vis_mask) vis_mask[(size_t)y * W + x] = mask;
+        }
+    }
+    if (rays_out) *rays_out = rays;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * stand-in G-buffer producer: primary rays, gbuf.frag encodings
+ * ---------------------------------------------------------------------------------------- */
+static void normal_matrix3(const float *m, float out[9]) {  /* inverseTranspose(mat3(transform)), hybrid_render_path.cpp:44 */
+    double a = m[0], b = m[4], c = m[8], d = m[1], e = m[5], f = m[9], g = m[2], h = m[6], i = m[10];
+    /* rows of M: (a b c), (d e f), (g h i); cofactor matrix / det == inverse transpose */
+    double c00 = e * i - f * h, c01 = -(d * i - f * g), c02 = d * h - e * g;
+    double c10 = -(b * i - c * h), c11 = a * i - c * g, c12 = -(a * h - b * g);
+    double c20 = b * f - c * e, c21 = -(a * f - c * d), c22 = a * e - b * d;
+    double det = a * c00 + b * c01 + c * c02;
+    double id = det != 0.0 ? 1.0 / det : 0.0;
+    /* out is column-major: out[col*3+row]; element (row r, col c) = cofactor(r,c)/det */
+    out[0] = (float)(c00 * id); out[3] = (float)(c01 * id); out[6] = (float)(c02 * id);
+    out[1] = (float)(c10 * id); out[4] = (float)(c11 * id); out[7] = (float)(c12 * id);
+    out[2] = (float)(c20 * id); out[5] = (float)(c21 * id); out[8] = (float)(c22 * id);
+}
+
+void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint16_t *normals_ids,
+                 uint16_t *motion_mr, float *depth) {
+    float *nm = (float *)malloc(sizeof(float) * 9 * (s->np ? s->np : 1));
+    for (uint32_t p = 0; p < s->np; ++p) normal_matrix3(s->prims[p].transform, nm + 9 * p);
+    float projview[16], prev_projview[16];
+    orc_mat4_mul(pfd->camera_proj, pfd->camera_view, projview);
+    orc_mat4_mul(pfd->camera_proj_prev_frame, pfd->camera_view_prev_frame, prev_projview);
+    v3 cam = V3(pfd->camera_view_inverse[12], pfd->camera_view_inverse[13], pfd->camera_view_inverse[14]);
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int64_t yy = 0; yy < (int64_t)H; ++yy) {
+        int y = (int)yy;
+        for (int x = 0; x < (int)W; ++x) {
+            float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+            v3 pnear = get_world_space_position(pfd, 1.0f, u, v);     /* reverse-Z: depth 1 == near plane */
+            v3 dir = v3sub(pnear, cam);
+            orc_hit h = trace(s, cam, dir, 1.0f, 3.0e38f, 0, 1);
+            size_t px = (size_t)y * W + (size_t)x;
+            if (!h.hit) {                                              /* clears: hybrid_render_path.cpp:16-19 */
+                store_rgba16f(normals_ids, W, x, y, 0, 0, 0, 0);
+                store_rgba16f(motion_mr, W, x, y, 0, 0, -1.0f, -1.0f);
+                depth[px] = 0.0f;
+                continue;
+            }
+            const orc_tri *tr = &s->tris[h.flat];
+            const orc_primitive *prim = &s->prims[tr->prim];
+            v3 P = v3add(cam, v3scale(dir, h.t));
+            v4 clip = mat4_mul_v4(projview, (v4){ P.x, P.y, P.z, 1.0f });
+            depth[px] = clip.z / clip.w;
+            uint32_t i0 = s->indices[prim->index_offset + 3 * tr->tri + 0];
+            uint32_t i1 = s->indices[prim->index_offset + 3 * tr->tri + 1];
+            uint32_t i2 = s->indices[prim->index_offset + 3 * tr->tri + 2];
+            const orc_vertex *a = &s->vertices[prim->vertex_offset + i0];
+            const orc_vertex *b = &s->vertices[prim->vertex_offset + i1];
+            const orc_vertex *c = &s->vertices[prim->vertex_offset + i2];
+            float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
+            v3 n = V3(a->normal[0] * bx + b->normal[0] * by + c->normal[0] * bz,
+                      a->normal[1] * bx + b->normal[1] * by + c->normal[1] * bz,
+                      a->normal[2] * bx + b->normal[2] * by + c->normal[2] * bz);
+            const float *M = nm + 9 * tr->prim;
+            v3 wn = V3((M[0] * n.x + M[3] * n.y) + M[6] * n.z, (M[1] * n.x + M[4] * n.y) + M[7] * n.z,
+                       (M[2] * n.x + M[5] * n.y) + M[8] * n.z);
+            wn = normalize3(wn);                                        /* gbuf.frag:43 */
+            store_rgba16f(normals_ids, W, x, y, wn.x, wn.y, wn.z, (float)tr->prim);
+            /* gbuf.frag:46-47: current = gl_FragCoord.xy * display_size_inverse, prev = reprojected ndc*0.5+0.5 */
+            float cx = ((float)x + 0.5f) * pfd->display_size_inverse[0];
+            float cy = ((float)y + 0.5f) * pfd->display_size_inverse[1];
+            v4 rp = mat4_mul_v4(prev_projview, (v4){ P.x, P.y, P.z, 1.0f });
+            float px_ = (rp.x / rp.w) * 0.5f + 0.5f, py_ = (rp.y / rp.w) * 0.5f + 0.5f;
+            float metallic = prim->material.metallic_factor, roughness = prim->material.roughness_factor;
+            if (prim->material.metallic_roughness_texture != -1) {    /* gbuf.frag:50-56 */
+                float uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;
+                float uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
+                v4 mr = sample_texture(s, prim->material.metallic_roughness_texture, uvx, uvy);
+                metallic *= mr.y; roughness *= mr.z;
+            }
+            store_rgba16f(motion_mr, W, x, y, cx - px_, cy - py_, metallic, roughness);   /* gbuf.frag:58 */
+        }
+    }
+    free(nm);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * svgf.comp
+ * ---------------------------------------------------------------------------------------- */
+/* svgf.comp:16-39 */
+static int is_valid_reprojection(const orc_per_frame_data *pfd, const uint16_t *prev_normals, uint32_t W, int px, int py,
+                                 int current_object_id, v3 current_normal) {
+    if (px < 0 || py < 0 || (float)px >= pfd->display_size[0] || (float)py >= pfd->display_size[1]) return 0;
+    v4 pn = load_rgba16f(prev_normals, W, px, py);
+    int prev_id = f2i(pn.w);
+    if (current_object_id != prev_id) return 0;
+    if (dot3(current_normal, V3(pn.x, pn.y, pn.z)) < ORC_COS_PI_4) return 0;
+    return 1;
+}
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+/* svgf.comp:41-145 */
+void orc_svgf_temporal(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, const uint16_t *normals_ids,
+                       const uint16_t *motion_mr, const uint16_t *raytraced, const uint16_t *prev_normals_ids,
+                       const uint16_t *history, const uint16_t *moments_in, uint16_t *integrated_out, uint16_t *moments_out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t yy = 0; yy < (int64_t)H; ++yy) {
+        int cy = (int)yy;
+        for (int cx = 0; cx < (int)W; ++cx) {
+            v4 nid = load_rgba16f(normals_ids, W, cx, cy);                                 /* :43-45 */
+            v3 current_normal = V3(nid.x, nid.y, nid.z);
+            int current_object_id = f2i(nid.w);
+            v4 mv = load_rgba16f(motion_mr, W, cx, cy);                                    /* :46 */
+            v4 cur = load_rg16f(raytraced, W, cx, cy);                                     /* :47-49 */
+            float current_shadow = cur.x, current_ao = cur.y;
+
+            float pcx = ((float)cx - mv.x * pfd->display_size[0]) + 0.5f;                  /* :52 */
+            float pcy = ((float)cy - mv.y * pfd->display_size[1]) + 0.5f;
+            float x = pcx - floorf(pcx);                                                    /* :53-54 fract */
+            float y = pcy - floorf(pcy);
+            int ax = f2i(pcx), ay = f2i(pcy);                                               /* :55 truncation */
+            float bw[4] = { (1.0f - x) * (1.0f - y), x * (1.0f - y), (1.0f - x) * y, x * y };  /* :57 */
+            static const int off[4][2] = { { 0, 0 }, { 1, 0 }, { 0, 1 }, { 1, 1 } };
+
+            float prev_shadow = 0.0f, prev_ao = 0.0f, sum = 0.0f;
+            float psm0 = 0.0f, psm1 = 0.0f, pam0 = 0.0f, pam1 = 0.0f;
+            for (int i = 0; i < 4; ++i) {                                                   /* :65-77 */
+                int sx = ax + off[i][0], sy = ay + off[i][1];
+                if (is_valid_reprojection(pfd, prev_normals_ids, W, sx, sy, current_object_id, current_normal)) {
+                    v4 hs = load_rgba16f(history, W, sx, sy);
+                    prev_shadow += bw[i] * hs.x;
+                    prev_ao += bw[i] * hs.y;
+                    v4 m = load_rg16f(moments_in, W, sx, sy);
+                    psm0 += bw[i] * m.x; psm1 += bw[i] * m.y;
+                    pam0 += bw[i] * m.z; pam1 += bw[i] * m.w;
+                    sum += bw[i];
+                }
+            }
+            int valid = sum > 1e-6f;                                                        /* :78 */
+            if (!valid) {                                                                   /* :81-97 (accumulators not reset) */
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int sx = ax + dx, sy = ay + dy;
+                        if (is_valid_reprojection(pfd, prev_normals_ids, W, sx, sy, current_object_id, current_normal)) {
+                            v4 hs = load_rgba16f(history, W, sx, sy);
+                            v4 m = load_rg16f(moments_in, W, sx, sy);
+                            prev_shadow += hs.x; prev_ao += hs.y;
+                            psm0 += m.x; psm1 += m.y; pam0 += m.z; pam1 += m.w;
+                            sum += 1.0f;
+                        }
+                    }
+                valid = sum > 1e-6f;
+            }
+            float sm0 = current_shadow, sm1 = current_shadow * current_shadow;              /* :99-102 */
+            float am0 = current_ao, am1 = current_ao * current_ao;
+            if (valid) {                                                                    /* :106-126 */
+                const float alpha = 0.2f, moments_alpha = 0.2f;
+                prev_shadow /= sum; psm0 /= sum; psm1 /= sum;
+                prev_ao /= sum; pam0 /= sum; pam1 /= sum;
+                sm0 = mixf(psm0, sm0, moments_alpha); sm1 = mixf(psm1, sm1, moments_alpha);
+                am0 = mixf(pam0, am0, moments_alpha); am1 = mixf(pam1, am1, moments_alpha);
+                float sv = fmaxf(0.0f, sm1 - sm0 * sm0);
+                float av = fmaxf(0.0f, am1 - am0 * am0);
+                store_rgba16f(integrated_out, W, cx, cy, mixf(prev_shadow, current_shadow, alpha),
+                              mixf(prev_ao, current_ao, alpha), sv, av);
+            } else {                                                                        /* :127-135 */
+                float sv = fmaxf(0.0f, sm1 - sm0 * sm0);
+                float av = fmaxf(0.0f, am1 - am0 * am0);
+                store_rgba16f(integrated_out, W, cx, cy, current_shadow, current_ao, sv, av);
+            }
+            store_rg16f(moments_out, W, cx, cy, sm0, sm1);                                  /* :138-144 into an RG16F image */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * svgf_atrous_filter.comp
+ * ---------------------------------------------------------------------------------------- */
+static inline float pow128(float x) {   /* decision (v) */
+    if (!(x > 0.0f)) return 0.0f;
+    x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+    return x;
+}
+/* :48-51 */
+static inline float edge_stopping_luminance(float variance_p, float lp, float lq) {
+    float e = fabsf(lp - lq) / (4.0f * sqrtf(variance_p) + 1e-6f);
+    return expf(-e);
+}
+
+void orc_svgf_atrous(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, const uint16_t *normals_ids,
+                     const uint16_t *in, uint16_t *out, int32_t step) {
+    static const float gauss[9] = { 1.0f / 16, 1.0f / 8, 1.0f / 16, 1.0f / 8, 1.0f / 4, 1.0f / 8, 1.0f / 16, 1.0f / 8, 1.0f / 16 };
+    static const float k5[25] = { 1.0f / 256, 1.0f / 64, 3.0f / 128, 1.0f / 64, 1.0f / 256,
+                                  1.0f / 64,  1.0f / 16, 3.0f / 32,  1.0f / 16, 1.0f / 64,
+                                  3.0f / 128, 3.0f / 32, 9.0f / 64,  3.0f / 32, 3.0f / 128,
+                                  1.0f / 64,  1.0f / 16, 3.0f / 32,  1.0f / 16, 1.0f / 64,
+                                  1.0f / 256, 1.0f / 64, 3.0f / 128, 1.0f / 64, 1.0f / 256 };
+    const float dsx = pfd->display_size[0], dsy = pfd->display_size[1];
+#pragma omp parallel for schedule(static)
+    for (int64_t yy = 0; yy < (int64_t)H; ++yy) {
+        int cy = (int)yy;
+        for (int cx = 0; cx < (int)W; ++cx) {
+            v4 np = load_rgba16f(normals_ids, W, cx, cy);                                   /* :55-57 */
+            v3 normal_p = V3(np.x, np.y, np.z);
+            int id_p = f2i(np.w);
+            v4 p = load_rgba16f(in, W, cx, cy);                                             /* :59 */
+            float var_s = 0.0f, var_a = 0.0f;                                               /* :17-38 gauss_3x3_filter */
+            for (int y = -1; y <= 1; ++y)
+                for (int x = -1; x <= 1; ++x) {
+                    int sx = cx + x, sy = cy + y;
+                    if (sx < 0 || (float)sx >= dsx || sy < 0 || (float)sy >= dsy) continue;
+                    float w = gauss[3 * (y + 1) + (x + 1)];
+                    v4 q = load_rgba16f(in, W, sx, sy);
+                    var_s += w * q.z;
+                    var_a += w * q.w;
+                }
+            float sw_s = 1.0f, sw_a = 1.0f;                                                 /* :70-71 */
+            float s0 = p.x, s1 = p.y, s2 = p.z, s3 = p.w;
+            for (int y = -2; y <= 2; ++y)
+                for (int x = -2; x <= 2; ++x) {                                             /* :72-94 */
+                    int sx = cx + x * step, sy = cy + y * step;
+                    if (sx < 0 || (float)sx >= dsx || sy < 0 || (float)sy >= dsy || (x == 0 && y == 0)) continue;
+                    v4 q = load_rgba16f(in, W, sx, sy);
+                    float kernel = k5[5 * (y + 2) + (x + 2)];
+                    v4 nq = load_rgba16f(normals_ids, W, sx, sy);
+                    float wn = fmaxf(0.0f, pow128(dot3(normal_p, V3(nq.x, nq.y, nq.z))));  /* :44-46 */
+                    float wid = (id_p == f2i(nq.w)) ? 1.0f : 0.0f;                          /* :40-42 */
+                    float w = kernel * wn * wid;
+                    float wx = w * edge_stopping_luminance(var_s, p.x, q.x);
+                    float wy = w * edge_stopping_luminance(var_a, p.y, q.y);
+                    sw_s += wx; sw_a += wy;
+                    s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;
+                }
+            store_rgba16f(out, W, cx, cy, s0 / sw_s, s1 / sw_a, s2 / (sw_s * sw_s), s3 / (sw_a * sw_a));  /* :97-101 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host schedule: hybrid_render_path.cpp:245-331
+ * ---------------------------------------------------------------------------------------- */
+struct orc_svgf_state {
+    uint32_t W, H;
+    uint16_t *img[5];          /* 0,1 integrated ping-pong; 2 prev normals; 3 history; 4 moments (RG16F) */
+    uint16_t *moments_snapshot;
+    int x, y;                  /* svgf_push_constants.integrated_shadow_and_ao.{x,y} */
+};
+
+orc_svgf_state *orc_svgf_create(uint32_t W, uint32_t H) {
+    orc_svgf_state *st = (orc_svgf_state *)calloc(1, sizeof *st);
+    st->W = W; st->H = H;
+    size_t px = (size_t)W * H;
+    for (int i = 0; i < 4; ++i) st->img[i] = (uint16_t *)calloc(px * 4, 2);     /* :247-258 (decision viii: zeroed) */
+    st->img[4] = (uint16_t *)calloc(px * 2, 2);                                   /* :259-261 R16G16 */
+    st->moments_snapshot = (uint16_t *)calloc(px * 2, 2);
+    st->x = 0; st->y = 1;
+    return st;
+}
+void orc_svgf_destroy(orc_svgf_state *st) {
+    if (!st) return;
+    for (int i = 0; i < 5; ++i) free(st->img[i]);
+    free(st->moments_snapshot);
+    free(st);
+}
+const uint16_t *orc_svgf_image(const orc_svgf_state *st, int which) {
+    if (which == 0) return st->img[st->x];
+    if (which == 1) return st->img[st->y];
+    return st->img[which];
+}
+
+void orc_svgf_frame(orc_svgf_state *st, const orc_per_frame_data *pfd, const uint16_t *normals_ids, const uint16_t *motion_mr,
+                    const uint16_t *raytraced, uint16_t *denoised_out) {
+    const uint32_t W = st->W, H = st->H;
+    const size_t px = (size_t)W * H;
+    /* :291-297 svgf.comp (decision ii: moments read from a snapshot) */
+    memcpy(st->moments_snapshot, st->img[4], px * 2 * 2);
+    orc_svgf_temporal(pfd, W, H, normals_ids, motion_mr, raytraced, st->img[2], st->img[3], st->moments_snapshot,
+                      st->img[st->x], st->img[4]);
+    for (int i = 0; i < 5; ++i) {                                                 /* :299-319 */
+        orc_svgf_atrous(pfd, W, H, normals_ids, st->img[st->x], st->img[st->y], 1 << i);
+        if (i == 0) memcpy(st->img[3], st->img[st->y], px * 4 * 2);               /* :310-315 */
+        int t = st->x; st->x = st->y; st->y = t;                                  /* :318 */
+    }
+    memcpy(st->img[2], normals_ids, px * 4 * 2);                                  /* :321 */
+    memcpy(denoised_out, st->img[st->y], px * 4 * 2);                             /* :322-325 */
+    { int t = st->x; st->x = st->y; st->y = t; }                                  /* :328 */
+}
+
+int orc_struct_sizes(uint32_t out[8]) {
+    out[0] = sizeof(orc_vertex); out[1] = sizeof(orc_material); out[2] = sizeof(orc_primitive);
+    out[3] = sizeof(orc_directional_light); out[4] = sizeof(orc_per_frame_data); out[5] = sizeof(orc_trace_params);
+    out[6] = 0; out[7] = 0;
+    return 6;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

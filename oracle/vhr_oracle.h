@@ -1,0 +1,134 @@
+/*
+ * vhr_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C11 + OpenMP) of the hybrid ray-tracing hot path of
+ * RMichelsen/VulkanHybridRenderer.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product
+ * (vulkanhybridrenderer_amd/) never links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures and
+ * cannot be built here (Win32 + Vulkan SDK + GLSL->SPIR-V toolchain absent; its
+ * ray/triangle + BVH arithmetic lives in the Vulkan driver).  The restatement is
+ * pinned only by known-answer values derived by hand from the reference's
+ * formulas (tests/golden/kat_*.json) and by an independent numpy restatement.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef VHR_ORACLE_H
+#define VHR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data ABI: src/rendering_backend/glsl_common.h:22-99 (scalar layout) ---- */
+typedef struct { float pos[3]; float normal[3]; float tangent[4]; float uv0[2]; float uv1[2]; } orc_vertex;      /* 56 B */
+typedef struct {
+    float base_color[4];
+    int32_t base_color_texture, metallic_roughness_texture, normal_map;
+    float metallic_factor, roughness_factor;
+    int32_t alpha_mask;
+    float alpha_cutoff;
+} orc_material;                                                                                                  /* 44 B */
+typedef struct { float transform[16]; orc_material material; uint32_t vertex_offset, index_offset, index_count; } orc_primitive; /* 120 B */
+typedef struct { float projview[16]; float direction[4]; float color[4]; float intensity[4]; } orc_directional_light;      /* 112 B */
+typedef struct {
+    float camera_view[16], camera_proj[16], camera_view_inverse[16], camera_proj_inverse[16];
+    float camera_viewproj_inverse[16], camera_view_prev_frame[16], camera_proj_prev_frame[16];
+    orc_directional_light directional_light;
+    float display_size[2], display_size_inverse[2];
+    uint32_t frame_index;
+    int32_t blue_noise_texture_index;
+} orc_per_frame_data;                                                                                            /* 584 B */
+
+/* Parameters the reference hard-codes inside raygen.rgen (spp, tmax, ...). The
+ * defaults reproduce the shader; other values are documented extensions. */
+typedef struct {
+    uint32_t shadow_enable;   /* raygen.rgen:31-41 (1) */
+    uint32_t ao_spp;          /* raygen.rgen:45 (2) */
+    float    ao_tmax;         /* raygen.rgen:52 (5.0) */
+    uint32_t reflections;     /* raygen.rgen:59-65 (1 = one bounce, 0 = off) */
+    float    cone_cos_max;    /* raygen.rgen:34 (0.999995) */
+    float    normal_bias;     /* raygen.rgen:29 (0.1) */
+    float    tmin;            /* raygen.rgen:40 (0.01) */
+    float    tmax;            /* raygen.rgen:40 (10000.0) */
+} orc_trace_params;
+
+typedef struct orc_scene orc_scene;
+
+/* ---- known-answer level entry points ---- */
+uint32_t orc_seed_thread(uint32_t seed);
+uint32_t orc_random(uint32_t *state);
+float    orc_random01(uint32_t *state);
+uint32_t orc_random_range(uint32_t *state, uint32_t lower, uint32_t upper);
+uint16_t orc_f32_to_f16(float f);
+float    orc_f16_to_f32(uint16_t h);
+void     orc_sincos(float phi, float *s, float *c);
+void     orc_uniform_sample_cone(float u0, float u1, float cos_theta_max, float out[3]);
+void     orc_cosine_hemisphere(float u0, float u1, float out[3]);
+void     orc_onb(const float n[3], float M[9]);
+int      orc_ray_triangle(const float o[3], const float d[3], const float v0[3], const float e1[3],
+                          const float e2[3], float tmin, float tmax, float *t, float *u, float *v);
+void     orc_infinite_reverse_depth_projection(float yfov, float aspect, float znear, float out[16]);
+void     orc_mat4_inverse(const float m[16], float out[16]);
+void     orc_mat4_mul(const float a[16], const float b[16], float out[16]);
+void     orc_default_trace_params(orc_trace_params *p);
+int      orc_struct_sizes(uint32_t out[8]);
+
+/* ---- scene (resource_manager.cpp:593-718 semantics: world-space two-sided opaque soup) ---- */
+orc_scene *orc_scene_create(const orc_vertex *vertices, uint32_t nv, const uint32_t *indices, uint32_t ni,
+                            const orc_primitive *primitives, uint32_t np);
+void     orc_scene_destroy(orc_scene *s);
+/* format: 43 = R8G8B8A8_SRGB, 37 = R8G8B8A8_UNORM; filters 0 nearest / 1 linear;
+ * address modes 0 repeat / 1 mirrored repeat / 2 clamp to edge (Vk enum values). */
+int      orc_scene_add_texture(orc_scene *s, uint32_t w, uint32_t h, const uint8_t *rgba8, int format,
+                               int mag_filter, int min_filter, int address_u, int address_v);
+uint32_t orc_scene_triangle_count(const orc_scene *s);
+
+/* any-hit / closest-hit queries for tests: use_bvh = 0 brute force, 1 oracle BVH */
+int      orc_scene_occluded(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh);
+int      orc_scene_closest(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
+                           float *t, float *u, float *v, uint32_t *prim, uint32_t *tri_in_prim);
+
+/* ---- stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 encodings; primary rays) ---- */
+void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
+                 uint16_t *normals_ids /*RGBA16F*/, uint16_t *motion_mr /*RGBA16F*/, float *depth /*D32F*/);
+
+/* ---- K1 + K2: raygen.rgen:14-66, miss.rmiss, reflection_miss.rmiss, reflection_hit.rchit ---- */
+/* vis_mask (optional, may be NULL): per pixel bit0 = shadow ray missed (lit), bit(1+i) = AO ray i missed,
+ * bit7 = reflection ray hit, 0x40 = sky pixel. rays_out (optional): [0] unique rays traced. */
+void orc_raygen(const orc_scene *s, const orc_per_frame_data *pfd, const orc_trace_params *tp,
+                uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                const uint16_t *normals_ids, const float *depth,
+                uint16_t *shadow_ao /*RG16F*/, uint16_t *reflections /*RGBA16F*/,
+                uint8_t *vis_mask, uint64_t *rays_out, int use_bvh);
+
+/* ---- K3: svgf.comp:41-145 ---- */
+void orc_svgf_temporal(const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
+                       const uint16_t *normals_ids, const uint16_t *motion_mr, const uint16_t *raytraced /*RG16F*/,
+                       const uint16_t *prev_normals_ids, const uint16_t *history /*RGBA16F*/,
+                       const uint16_t *moments_in /*RG16F snapshot*/,
+                       uint16_t *integrated_out /*RGBA16F*/, uint16_t *moments_out /*RG16F*/);
+
+/* ---- K4: svgf_atrous_filter.comp:53-103 ---- */
+void orc_svgf_atrous(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, const uint16_t *normals_ids,
+                     const uint16_t *integrated_in, uint16_t *integrated_out, int32_t step);
+
+/* ---- host schedule: hybrid_render_path.cpp:245-331 (persistent images + per-frame dispatch order) ---- */
+typedef struct orc_svgf_state orc_svgf_state;
+orc_svgf_state *orc_svgf_create(uint32_t W, uint32_t H);
+void orc_svgf_destroy(orc_svgf_state *st);
+void orc_svgf_frame(orc_svgf_state *st, const orc_per_frame_data *pfd, const uint16_t *normals_ids,
+                    const uint16_t *motion_mr, const uint16_t *raytraced, uint16_t *denoised_out /*RGBA16F*/);
+/* which: 0 integrated.x, 1 integrated.y, 2 prev normals, 3 history (RGBA16F each), 4 moments (RG16F) */
+const uint16_t *orc_svgf_image(const orc_svgf_state *st, int which);
+
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,272 @@
+// K0: acceleration-structure build.  Replaces ResourceManager::UpdateBLAS / UpdateTLAS
+// (/root/reference/src/rendering_backend/resource_manager.cpp:593-801): one geometry per Primitive with
+// its transform baked in (:608-617), all opaque (:633), triangle count index_count / 3 (:637), indices
+// offset by index_offset and vertices by vertex_offset (:638-639), one identity instance with face
+// culling disabled (:704-718)  ==>  a world-space, two-sided triangle soup.
+//
+// Output: a binned-SAH BVH2 laid out for the CDNA4 traversal kernel -- 64-byte nodes holding BOTH child
+// boxes (one node fetch = 4 dwordx4 loads decides both children), emitted in breadth-first order so the
+// first K nodes are the top of the tree (the part the traversal kernel stages in LDS), leaves of <= 4
+// triangles stored contiguously as 48-byte Moeller-Trumbore records.  Depth is bounded by kMaxBvhDepth,
+// which is also the capacity of the traversal stack.
+//
+// Built with -ffp-contract=off: the world-space vertex transform and the edge subtraction below are part
+// of the bit-exact visibility contract ("exact arithmetic").
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+#include "vhr_internal.hpp"
+
+namespace vhr {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -std::numeric_limits<float>::infinity(); }
+    }
+    void grow(const Box &b) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+    }
+    void grow(const float p[3]) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct TmpNode {
+    Box box;
+    int32_t left = -1, right = -1;
+    uint32_t first = 0, count = 0;     // leaf range in `order`
+    uint32_t depth = 0;
+};
+
+struct Builder {
+    std::vector<BvhTri> tris;          // flat order
+    std::vector<Box> tri_box;
+    std::vector<float> centroid;       // 3 per tri
+    std::vector<uint32_t> order;
+    std::vector<TmpNode> nodes;
+    uint32_t max_depth = 0;
+
+    static uint32_t levels_needed(uint32_t count) {
+        uint32_t leaves = (count + kMaxLeafTris - 1) / kMaxLeafTris;
+        uint32_t l = 0;
+        while ((1u << l) < leaves) ++l;
+        return l;
+    }
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+        int32_t id = int32_t(nodes.size());
+        nodes.emplace_back();
+        TmpNode n;
+        n.box.reset();
+        Box cb;
+        cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            n.box.grow(tri_box[order[i]]);
+            cb.grow(&centroid[size_t(order[i]) * 3]);
+        }
+        n.first = first;
+        n.count = count;
+        n.depth = depth;
+        max_depth = std::max(max_depth, depth);
+        if (count <= uint32_t(kMaxLeafTris)) {
+            nodes[id] = n;
+            return id;
+        }
+        uint32_t mid = 0;
+        bool force_median = depth + levels_needed(count) + 1 >= uint32_t(kMaxBvhDepth);
+        if (!force_median) {
+            constexpr int kBins = 16;
+            float best_cost = std::numeric_limits<float>::infinity();
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                float ext = cb.hi[axis] - cb.lo[axis];
+                if (!(ext > 0.0f)) continue;
+                Box bin_box[kBins];
+                uint32_t bin_count[kBins] = {};
+                for (auto &b : bin_box) b.reset();
+                float scale = float(kBins) / ext;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    uint32_t t = order[i];
+                    int b = std::min(kBins - 1, std::max(0, int((centroid[size_t(t) * 3 + axis] - cb.lo[axis]) * scale)));
+                    bin_box[b].grow(tri_box[t]);
+                    ++bin_count[b];
+                }
+                float right_area[kBins];
+                uint32_t right_count[kBins];
+                Box acc;
+                acc.reset();
+                uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bin_box[b]);
+                    c += bin_count[b];
+                    right_area[b] = acc.half_area();
+                    right_count[b] = c;
+                }
+                acc.reset();
+                c = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bin_box[b]);
+                    c += bin_count[b];
+                    if (c == 0 || right_count[b + 1] == 0) continue;
+                    float cost = acc.half_area() * float(c) + right_area[b + 1] * float(right_count[b + 1]);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float ext = cb.hi[best_axis] - cb.lo[best_axis];
+                float scale = 16.0f / ext;
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                    int b = std::min(15, std::max(0, int((centroid[size_t(t) * 3 + best_axis] - cb.lo[best_axis]) * scale)));
+                    return b <= best_bin;
+                });
+                mid = uint32_t(it - order.begin());
+            }
+        }
+        if (mid <= first || mid >= first + count) {      // forced or degenerate: split by count along the widest axis
+            int axis = 0;
+            float ext = cb.hi[0] - cb.lo[0];
+            if (cb.hi[1] - cb.lo[1] > ext) { axis = 1; ext = cb.hi[1] - cb.lo[1]; }
+            if (cb.hi[2] - cb.lo[2] > ext) { axis = 2; }
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) {
+                                 float ca = centroid[size_t(a) * 3 + axis], cb2 = centroid[size_t(b) * 3 + axis];
+                                 return ca < cb2 || (ca == cb2 && a < b);
+                             });
+        }
+        n.count = 0;
+        nodes[id] = n;
+        int32_t l = build(first, mid - first, depth + 1);
+        int32_t r = build(mid, first + count - mid, depth + 1);
+        nodes[id].left = l;
+        nodes[id].right = r;
+        return id;
+    }
+};
+
+inline void padded(const Box &b, float lo[3], float hi[3]) {
+    // Conservative padding: box culling must never change which triangles are accepted.
+    for (int a = 0; a < 3; ++a) {
+        float pad = 1e-3f + 1e-5f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+        lo[a] = b.lo[a] - pad;
+        hi[a] = b.hi[a] + pad;
+    }
+}
+
+inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((first << 2) | (count - 1)); }
+
+}  // namespace
+
+void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
+               uint32_t primitive_count, HostBvh &out) {
+    Builder b;
+    size_t total = 0;
+    for (uint32_t p = 0; p < primitive_count; ++p) total += primitives[p].index_count / 3;
+    b.tris.reserve(total);
+    for (uint32_t p = 0; p < primitive_count; ++p) {
+        const vhr_primitive &pr = primitives[p];
+        const float *m = pr.transform;
+        for (uint32_t t = 0; t < pr.index_count / 3; ++t) {
+            float w[3][3];
+            for (int c = 0; c < 3; ++c) {
+                const float *v = vertices[pr.vertex_offset + indices[pr.index_offset + 3 * t + c]].pos;
+                // transform * vec4(pos, 1), columns accumulated left to right, no contraction
+                w[c][0] = ((m[0] * v[0] + m[4] * v[1]) + m[8] * v[2]) + m[12];
+                w[c][1] = ((m[1] * v[0] + m[5] * v[1]) + m[9] * v[2]) + m[13];
+                w[c][2] = ((m[2] * v[0] + m[6] * v[1]) + m[10] * v[2]) + m[14];
+            }
+            BvhTri tri;
+            for (int a = 0; a < 3; ++a) {
+                tri.v0[a] = w[0][a];
+                tri.e1[a] = w[1][a] - w[0][a];
+                tri.e2[a] = w[2][a] - w[0][a];
+            }
+            tri.prim = p;
+            tri.tri = t;
+            tri.flat = uint32_t(b.tris.size());
+            b.tris.push_back(tri);
+        }
+    }
+    const uint32_t n = uint32_t(b.tris.size());
+    out.nodes.clear();
+    out.tris.clear();
+    out.max_depth = 0;
+    if (n == 0) return;
+
+    b.tri_box.resize(n);
+    b.centroid.resize(size_t(n) * 3);
+    b.order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const BvhTri &t = b.tris[i];
+        Box bx;
+        bx.reset();
+        float p1[3], p2[3];
+        for (int a = 0; a < 3; ++a) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
+        bx.grow(t.v0);
+        bx.grow(p1);
+        bx.grow(p2);
+        b.tri_box[i] = bx;
+        for (int a = 0; a < 3; ++a) b.centroid[size_t(i) * 3 + a] = 0.5f * (bx.lo[a] + bx.hi[a]);
+        b.order[i] = i;
+    }
+    b.nodes.reserve(size_t(n));
+    b.build(0, n, 0);
+    out.max_depth = b.max_depth;
+
+    out.tris.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out.tris[i] = b.tris[b.order[i]];
+
+    const float inf = std::numeric_limits<float>::infinity();
+    auto set_child = [&](BvhNode &node, int which, const TmpNode &child, int32_t link) {
+        float lo[3], hi[3];
+        padded(child.box, lo, hi);
+        std::memcpy(which == 0 ? node.lo0 : node.lo1, lo, sizeof lo);
+        std::memcpy(which == 0 ? node.hi0 : node.hi1, hi, sizeof hi);
+        (which == 0 ? node.child0 : node.child1) = link;
+    };
+
+    const TmpNode &root = b.nodes[0];
+    if (root.left < 0) {                       // whole scene fits one leaf
+        BvhNode node{};
+        set_child(node, 0, root, leaf_link(root.first, root.count));
+        for (int a = 0; a < 3; ++a) { node.lo1[a] = inf; node.hi1[a] = -inf; }
+        node.child1 = node.child0;
+        out.nodes.push_back(node);
+        return;
+    }
+    // breadth-first numbering of the inner nodes
+    std::vector<int32_t> bfs_index(b.nodes.size(), -1);
+    std::vector<int32_t> bfs_order;
+    std::queue<int32_t> q;
+    q.push(0);
+    while (!q.empty()) {
+        int32_t id = q.front();
+        q.pop();
+        bfs_index[id] = int32_t(bfs_order.size());
+        bfs_order.push_back(id);
+        const TmpNode &t = b.nodes[id];
+        if (b.nodes[t.left].left >= 0) q.push(t.left);
+        if (b.nodes[t.right].left >= 0) q.push(t.right);
+    }
+    out.nodes.resize(bfs_order.size());
+    for (size_t k = 0; k < bfs_order.size(); ++k) {
+        const TmpNode &t = b.nodes[bfs_order[k]];
+        BvhNode node{};
+        const TmpNode &l = b.nodes[t.left], &r = b.nodes[t.right];
+        set_child(node, 0, l, l.left >= 0 ? bfs_index[t.left] : leaf_link(l.first, l.count));
+        set_child(node, 1, r, r.left >= 0 ? bfs_index[t.right] : leaf_link(r.first, r.count));
+        out.nodes[k] = node;
+    }
+}
+
+}  // namespace vhr

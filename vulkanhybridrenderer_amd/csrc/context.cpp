@@ -1,0 +1,394 @@
+// Context + ResourceManager half of the C ABI (include/vhr_amd.h): device memory for the global scene
+// buffers, the bindless texture table, the storage-image pool and the per-frame uniform data.
+// Reference: src/rendering_backend/resource_manager.{h,cpp}, vulkan_context.cpp.
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "vhr_internal.hpp"
+
+namespace vhr {
+int upload_srgb_lut(const float *lut);
+
+uint32_t format_stride(int32_t format) {      // VkUtils::FormatStride, vulkan_utils.h:128-148
+    switch (format) {
+        case VHR_FORMAT_R8G8B8A8_UNORM:
+        case VHR_FORMAT_R8G8B8A8_SRGB:
+        case VHR_FORMAT_B8G8R8A8_UNORM:
+        case VHR_FORMAT_R16G16_SFLOAT:
+        case VHR_FORMAT_D32_SFLOAT: return 4;
+        case VHR_FORMAT_R16G16B16A16_SFLOAT: return 8;
+        default: return 0;
+    }
+}
+}  // namespace vhr
+
+using namespace vhr;
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return (ctx)->fail(VHR_ERROR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+vhr::DeviceScene vhr_context::device_scene() const {
+    DeviceScene s;
+    s.nodes = d_nodes;
+    s.tris = d_tris;
+    s.vertices = d_vertices;
+    s.indices = d_indices;
+    s.primitives = d_primitives;
+    s.normal_matrices = d_normal_matrices;
+    s.textures = d_textures;
+    s.node_count = node_count;
+    s.tri_count = tri_count;
+    s.primitive_count = primitive_count;
+    s.texture_count = uint32_t(textures.size());
+    return s;
+}
+
+extern "C" {
+
+const char *vhr_version(void) { return "vhr_amd 0.1.0 (gfx950)"; }
+
+int vhr_abi_struct_sizes(uint32_t out[8]) {
+    out[0] = sizeof(vhr_vertex); out[1] = sizeof(vhr_material); out[2] = sizeof(vhr_primitive);
+    out[3] = sizeof(vhr_directional_light); out[4] = sizeof(vhr_per_frame_data); out[5] = sizeof(vhr_svgf_push_constants);
+    out[6] = sizeof(vhr_trace_params); out[7] = 0;
+    return 7;
+}
+
+void vhr_default_trace_params(vhr_trace_params *p) {
+    p->shadow_enable = 1;          // raygen.rgen:31-41
+    p->ao_spp = 2;                 // raygen.rgen:45
+    p->ao_tmax = 5.0f;             // raygen.rgen:52
+    p->reflections = 1;            // raygen.rgen:59-65
+    p->cone_cos_max = 0.999995f;   // raygen.rgen:34
+    p->normal_bias = 0.1f;         // raygen.rgen:29
+    p->tmin = 0.01f;               // raygen.rgen:40
+    p->tmax = 10000.0f;
+}
+
+int vhr_create(const vhr_create_info *info, vhr_context **out) {
+    if (!info || !out || info->width == 0 || info->height == 0) { g_create_error = "vhr_create: invalid arguments"; return VHR_ERROR_INVALID_ARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        // the product path never falls back to the CPU
+        g_create_error = "vhr_create: no HIP device available (this library has no CPU path)";
+        return VHR_ERROR_NO_DEVICE;
+    }
+    if (info->device < 0 || info->device >= count) { g_create_error = "vhr_create: device ordinal out of range"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (hipSetDevice(info->device) != hipSuccess) { g_create_error = "vhr_create: hipSetDevice failed"; return VHR_ERROR_DEVICE; }
+    vhr_context *ctx = new vhr_context();
+    ctx->device = info->device;
+    ctx->width = info->width;
+    ctx->height = info->height;
+    ctx->row_begin = 0;
+    ctx->row_end = info->height;
+    if (info->stream) {
+        ctx->stream = static_cast<hipStream_t>(info->stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            g_create_error = "vhr_create: hipStreamCreate failed";
+            delete ctx;
+            return VHR_ERROR_DEVICE;
+        }
+        ctx->own_stream = true;
+    }
+    ctx->storage_images.resize(vhr_context::kMaxGlobalResources);
+    vhr_default_trace_params(&ctx->trace_params);
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        double c = i / 255.0;
+        lut[i] = float(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), sizeof(RayStats)) != hipSuccess) {
+        g_create_error = "vhr_create: device initialisation failed";
+        vhr_destroy(ctx);
+        return VHR_ERROR_DEVICE;
+    }
+    *out = ctx;
+    return VHR_OK;
+}
+
+static void free_scene(vhr_context *ctx) {
+    hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_tris);
+    ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_tris = nullptr;
+    ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
+}
+
+void vhr_destroy(vhr_context *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    vhr_graph_destroy_resources(ctx);
+    for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
+        if (!im.used) continue;
+        hipFree(im.ptr);
+        if (im.alt && im.alt != im.ptr) hipFree(im.alt);
+    }
+    for (auto &t : ctx->textures) hipFree(t.texels);
+    hipFree(ctx->d_textures);
+    free_scene(ctx);
+    hipFree(ctx->d_ray_stats);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int vhr_synchronize(vhr_context *ctx) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VHR_OK;
+}
+
+// inverseTranspose(mat3(transform)) -- hybrid_render_path.cpp:44 (used by the stand-in G-buffer only)
+static void normal_matrix3(const float *m, float out[9]) {
+    double a = m[0], b = m[4], c = m[8], d = m[1], e = m[5], f = m[9], g = m[2], h = m[6], i = m[10];
+    double c00 = e * i - f * h, c01 = -(d * i - f * g), c02 = d * h - e * g;
+    double c10 = -(b * i - c * h), c11 = a * i - c * g, c12 = -(a * h - b * g);
+    double c20 = b * f - c * e, c21 = -(a * f - c * d), c22 = a * e - b * d;
+    double det = a * c00 + b * c01 + c * c02;
+    double id = det != 0.0 ? 1.0 / det : 0.0;
+    out[0] = float(c00 * id); out[3] = float(c01 * id); out[6] = float(c02 * id);
+    out[1] = float(c10 * id); out[4] = float(c11 * id); out[7] = float(c12 * id);
+    out[2] = float(c20 * id); out[5] = float(c21 * id); out[8] = float(c22 * id);
+}
+
+int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t vertex_count, const uint32_t *indices,
+                        uint32_t index_count, const vhr_primitive *primitives, uint32_t primitive_count) {
+    if (!ctx || (!vertices && vertex_count) || (!indices && index_count) || (!primitives && primitive_count))
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: null array") : VHR_ERROR_INVALID_ARGUMENT;
+    // Validate every offset the kernels will dereference (an out-of-range index would fault the GPU).
+    for (uint32_t p = 0; p < primitive_count; ++p) {
+        const vhr_primitive &pr = primitives[p];
+        if (uint64_t(pr.index_offset) + pr.index_count > index_count)
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: primitive " + std::to_string(p) + " index range exceeds the index buffer");
+        for (uint32_t k = 0; k < pr.index_count; ++k)
+            if (uint64_t(pr.vertex_offset) + indices[pr.index_offset + k] >= vertex_count)
+                return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: primitive " + std::to_string(p) + " references a vertex beyond the vertex buffer");
+        const int32_t tex[2] = { pr.material.base_color_texture, pr.material.metallic_roughness_texture };
+        for (int32_t t : tex)
+            if (t < -1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: negative texture index other than -1");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    HostBvh bvh;
+    build_bvh(vertices, indices, primitives, primitive_count, bvh);          // UpdateBLAS + UpdateTLAS
+    std::vector<float> nm(size_t(primitive_count) * 9);
+    for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
+
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        *dst = nullptr;
+        if (bytes == 0) return hipSuccess;
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_vertices), vertices, sizeof(vhr_vertex) * vertex_count));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_indices), indices, sizeof(uint32_t) * index_count));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_primitives), primitives, sizeof(vhr_primitive) * primitive_count));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_normal_matrices), nm.data(), sizeof(float) * nm.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
+    ctx->vertex_count = vertex_count;
+    ctx->index_count = index_count;
+    ctx->primitive_count = primitive_count;
+    ctx->node_count = uint32_t(bvh.nodes.size());
+    ctx->tri_count = uint32_t(bvh.tris.size());
+    ctx->bvh_depth = bvh.max_depth;
+    return VHR_OK;
+}
+
+int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t height, const uint8_t *data, int32_t format,
+                                     const vhr_sampler_info *sampler_info) {
+    if (!ctx || !data || !width || !height) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
+    if (format != VHR_FORMAT_R8G8B8A8_SRGB && format != VHR_FORMAT_R8G8B8A8_UNORM)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: format must be R8G8B8A8_SRGB or R8G8B8A8_UNORM");
+    if (ctx->textures.size() >= vhr_context::kMaxGlobalResources) { ctx->error = "texture table exhausted"; return -1; }   // resource_manager.cpp:847-848
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    vhr_context::Texture t{};
+    const size_t bytes = size_t(width) * height * 4;
+    HIP_TRY(ctx, hipMalloc(&t.texels, bytes));
+    HIP_TRY(ctx, hipMemcpy(t.texels, data, bytes, hipMemcpyHostToDevice));
+    t.w = width; t.h = height; t.format = format;
+    // default sampler: LINEAR / REPEAT (resource_manager.cpp:58-69)
+    t.sampler = sampler_info ? *sampler_info : vhr_sampler_info{ 1, 1, 0, 0 };
+    ctx->textures.push_back(t);
+    // rebuild the device-side descriptor table (set 0, binding 4: textures[])
+    std::vector<DeviceTexture> table(ctx->textures.size());
+    for (size_t i = 0; i < table.size(); ++i) {
+        const auto &s = ctx->textures[i];
+        table[i] = DeviceTexture{ static_cast<const uint8_t *>(s.texels), s.w, s.h, s.format, s.sampler.mag_filter, s.sampler.address_mode_u, s.sampler.address_mode_v, 0 };
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->d_textures);
+    ctx->d_textures = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_textures), sizeof(DeviceTexture) * table.size()));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_textures, table.data(), sizeof(DeviceTexture) * table.size(), hipMemcpyHostToDevice));
+    return int32_t(ctx->textures.size() - 1);
+}
+
+int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t height, int32_t format) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    const uint32_t bpp = format_stride(format);
+    if (!bpp || !width || !height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadNewStorageImage: unsupported format or empty extent");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < vhr_context::kMaxGlobalResources; ++i) {         // first free slot, resource_manager.cpp:866-878
+        Image &im = ctx->storage_images[i];
+        if (im.used) continue;
+        im = Image{};
+        im.width = width; im.height = height; im.format = format; im.bpp = bpp;
+        HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
+        HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
+        im.ptr = im.owned;
+        if (format == VHR_FORMAT_R16G16_SFLOAT) {
+            // svgf.comp reads neighbours of, and rewrites, the moments history in one dispatch
+            // (svgf.comp:72,140-144): keep a second buffer so the dispatch reads a snapshot
+            HIP_TRY(ctx, hipMalloc(&im.alt, im.bytes()));
+            HIP_TRY(ctx, hipMemsetAsync(im.alt, 0, im.bytes(), ctx->stream));
+        }
+        im.used = true;
+        return int32_t(i);
+    }
+    ctx->error = "storage image pool exhausted";
+    return -1;
+}
+
+int vhr_destroy_storage_image(vhr_context *ctx, int32_t id) {
+    if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
+        return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "DestroyStorageImage: no such image") : VHR_ERROR_INVALID_ARGUMENT;   // assert at resource_manager.cpp:266
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    Image &im = ctx->storage_images[id];
+    // ptr/alt may have been flipped: free both distinct allocations
+    void *a = im.ptr, *b = im.alt;
+    hipFree(a);
+    if (b && b != a) hipFree(b);
+    im = Image{};
+    return VHR_OK;
+}
+
+int vhr_update_per_frame_ubo(vhr_context *ctx, uint32_t resource_idx, const vhr_per_frame_data *pfd) {
+    if (!ctx || !pfd || resource_idx >= 3) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdatePerFrameUBO: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
+    std::memcpy(&ctx->per_frame[resource_idx], pfd, sizeof *pfd);            // resource_manager.cpp:362-364
+    return VHR_OK;
+}
+
+int vhr_set_trace_params(vhr_context *ctx, const vhr_trace_params *p) {
+    if (!ctx || !p) return VHR_ERROR_INVALID_ARGUMENT;
+    if (p->ao_spp > 64) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "trace params: ao_spp > 64");
+    ctx->trace_params = *p;
+    return VHR_OK;
+}
+
+int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap) {
+    if (!ctx || row_begin > row_end || row_end > ctx->height)
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "set_strip: need row_begin <= row_end <= height") : VHR_ERROR_INVALID_ARGUMENT;
+    ctx->row_begin = row_begin;
+    ctx->row_end = row_end;
+    ctx->overlap = overlap;
+    return VHR_OK;
+}
+
+int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    ctx->ray_stats_enabled = enable != 0;
+    return VHR_OK;
+}
+
+int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const vhr_trace_params &tp = ctx->trace_params;
+    const uint64_t covered = ctx->h_ray_stats.covered_pixels;
+    out[0] = covered * (uint64_t(tp.shadow_enable ? 1 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));
+    out[1] = covered * (uint64_t(tp.shadow_enable ? 4 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));   // raygen.rgen:38-40 duplicates
+    out[2] = covered;
+    out[3] = ctx->h_ray_stats.stack_overflows;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    out[0] = ctx->node_count; out[1] = ctx->tri_count; out[2] = ctx->bvh_depth;
+    out[3] = uint64_t(ctx->node_count) * sizeof(BvhNode); out[4] = uint64_t(ctx->tri_count) * sizeof(BvhTri);
+    return VHR_OK;
+}
+
+int vhr_get_display_size(vhr_context *ctx, uint32_t *width, uint32_t *height) {
+    if (!ctx || !width || !height) return VHR_ERROR_INVALID_ARGUMENT;
+    *width = ctx->width;
+    *height = ctx->height;
+    return VHR_OK;
+}
+
+static int image_info(vhr_context *ctx, const Image &im, vhr_image_info *out) {
+    out->device_ptr = im.ptr; out->width = im.width; out->height = im.height; out->format = im.format; out->bytes_per_pixel = im.bpp;
+    (void)ctx;
+    return VHR_OK;
+}
+
+int vhr_get_transient_image(vhr_context *ctx, const char *name, vhr_image_info *out) {
+    if (!ctx || !name || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->images.find(name);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + name + "'");
+    return image_info(ctx, it->second, out);
+}
+
+int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out) {
+    if (!ctx || !out || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
+        return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    return image_info(ctx, ctx->storage_images[id], out);
+}
+
+static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t bytes, bool to_device) {
+    if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VHR_OK;
+}
+
+int vhr_upload_transient_image(vhr_context *ctx, const char *name, const void *host_data, uint64_t bytes) {
+    if (!ctx || !name) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->images.find(name);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + name + "'");
+    return copy_image(ctx, it->second, const_cast<void *>(host_data), bytes, true);
+}
+int vhr_download_transient_image(vhr_context *ctx, const char *name, void *host_data, uint64_t bytes) {
+    if (!ctx || !name) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->images.find(name);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + name + "'");
+    return copy_image(ctx, it->second, host_data, bytes, false);
+}
+int vhr_upload_storage_image(vhr_context *ctx, int32_t id, const void *host_data, uint64_t bytes) {
+    if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
+        return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    return copy_image(ctx, ctx->storage_images[id], const_cast<void *>(host_data), bytes, true);
+}
+int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, uint64_t bytes) {
+    if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
+        return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    return copy_image(ctx, ctx->storage_images[id], host_data, bytes, false);
+}
+
+int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image, const char *motion_image, const char *depth_image) {
+    if (!ctx || !normals_image || !motion_image || !depth_image || resource_idx >= 3) return VHR_ERROR_INVALID_ARGUMENT;
+    auto n = ctx->images.find(normals_image), m = ctx->images.find(motion_image), d = ctx->images.find(depth_image);
+    if (n == ctx->images.end() || m == ctx->images.end() || d == ctx->images.end())
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "standin_gbuffer: unknown transient image");
+    if (n->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || m->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || d->second.format != VHR_FORMAT_D32_SFLOAT)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: formats must be RGBA16F, RGBA16F, D32F (hybrid_render_path.cpp:16-19)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_standin_gbuffer(ctx, ctx->per_frame[resource_idx], n->second, m->second, d->second);
+}
+
+}  // extern "C"

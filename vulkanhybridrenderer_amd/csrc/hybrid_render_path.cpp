@@ -1,0 +1,230 @@
+// Host side of the hot path: which passes the hybrid path registers, what they read and
+// write, which persistent SVGF images it owns, and the per-frame SVGF dispatch schedule.
+// Reference: src/render_paths/hybrid_render_path.cpp -- RT pass :101-136, SVGF images :245-262, SVGF pass and
+// schedule :264-331, composition inputs :333-351, DeregisterPath :383-392.
+//
+// Written against the vhr:: facade only (no access to library internals), i.e. exactly what a maintainer of
+// the reference would compile after swapping the Vulkan render graph for this one.
+#include "hybrid_render_path.hpp"
+
+#include <utility>
+
+namespace vhr {
+
+namespace {
+constexpr const char *kNormals = "World Space Normals and Object IDs";
+constexpr const char *kMotion = "Motion Vectors and Metallic Roughness";
+constexpr const char *kDepth = "Depth";
+constexpr const char *kAlbedo = "Albedo";
+constexpr const char *kRaytraced = "Raytraced Shadows and Ambient Occlusion";
+constexpr const char *kReflections = "Raytraced Reflections";
+constexpr const char *kDenoised = "Denoised Raytraced Shadows and Ambient Occlusion";
+constexpr const char *kSvgfShader = "hybrid_render_path/svgf.comp";
+constexpr const char *kAtrousShader = "hybrid_render_path/svgf_atrous_filter.comp";
+
+inline uint32_t groups_of_8(uint32_t n) { return n / 8 + (n % 8 != 0); }
+}  // namespace
+
+void HybridRenderPath::RegisterPath(DeviceContext &context, RenderGraph &render_graph, ResourceManager &resource_manager) {
+    const uint32_t display_w = context.swapchain.extent.width, display_h = context.swapchain.extent.height;
+    const bool any_raytraced = shadow_mode == SHADOW_MODE_RAYTRACED || ambient_occlusion_mode == AMBIENT_OCCLUSION_MODE_RAYTRACED ||
+                               reflection_mode == REFLECTION_MODE_RAYTRACED;
+
+    // G-buffer stage (hybrid_render_path.cpp:13-56): untouched raster pass, declared so the graph knows who
+    // produces the hot path's inputs and with which formats / clears.
+    render_graph.AddGraphicsPass("G-Buffer Pass", {},
+                                 { VkUtils::CreateTransientAttachmentImage(kAlbedo, VHR_FORMAT_B8G8R8A8_UNORM, 0, VkUtils::ClearColor(0, 0, 0, 0)),
+                                   VkUtils::CreateTransientAttachmentImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 1, VkUtils::ClearColor(0, 0, 0, 0)),
+                                   VkUtils::CreateTransientAttachmentImage(kMotion, VHR_FORMAT_R16G16B16A16_SFLOAT, 2, VkUtils::ClearColor(0, 0, -1, -1)),
+                                   VkUtils::CreateTransientAttachmentImage(kDepth, VHR_FORMAT_D32_SFLOAT, 3, VkUtils::ClearDepth(0)) },
+                                 gbuffer_pass);
+
+    if (shadow_mode == SHADOW_MODE_RASTERIZED) {
+        // :58-100 -- a rasterised shadow map suppresses the ray-tracing pass even when AO / reflections are
+        // ray traced (the reference's if / else-if); the shadow-map pass itself is raster work and stays outside.
+        render_graph.AddGraphicsPass("Shadow Map Pass", {},
+                                     { VkUtils::CreateTransientAttachmentImage("Shadow Map", 4096, 4096, VHR_FORMAT_D32_SFLOAT, 0, VkUtils::ClearDepth(0)) },
+                                     nullptr);
+    } else if (any_raytraced) {
+        RaytracingPipelineDescription pipeline;                               // :112-124
+        pipeline.name = "Raytrace Pipeline";
+        pipeline.raygen_shader = "hybrid_render_path/raygen.rgen";
+        pipeline.miss_shaders = { "hybrid_render_path/miss.rmiss", "hybrid_render_path/reflection_miss.rmiss" };
+        pipeline.hit_shaders = { HitShader{ "hybrid_render_path/reflection_hit.rchit", nullptr } };
+        render_graph.AddRaytracingPass(
+            "Raytrace Pass",
+            { VkUtils::CreateTransientSampledImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 0),
+              VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 1) },
+            { VkUtils::CreateTransientStorageImage(kRaytraced, VHR_FORMAT_R16G16_SFLOAT, 2),
+              VkUtils::CreateTransientStorageImage(kReflections, VHR_FORMAT_R16G16B16A16_SFLOAT, 3) },
+            pipeline,
+            [display_w, display_h](ExecuteRaytracingCallback execute_pipeline) {
+                execute_pipeline("Raytrace Pipeline", [=](RaytracingExecutionContext &execution_context) {
+                    execution_context.TraceRays(display_w, display_h);        // :128-131
+                });
+            });
+    }
+
+    if (ambient_occlusion_mode == AMBIENT_OCCLUSION_MODE_SSAO || reflection_mode == REFLECTION_MODE_SSR)
+        throw std::runtime_error("HybridRenderPath: SSAO / SSR are raster-side alternatives outside the ray-traced hot path (SURVEY.md row 27)");
+
+    if (denoise_shadow_and_ao && any_raytraced) {
+        // five persistent images, :247-262 (the moments history really is allocated R16G16)
+        svgf_push_constants.integrated_shadow_and_ao[0] = int32_t(resource_manager.UploadNewStorageImage(display_w, display_h, VHR_FORMAT_R16G16B16A16_SFLOAT));
+        svgf_push_constants.integrated_shadow_and_ao[1] = int32_t(resource_manager.UploadNewStorageImage(display_w, display_h, VHR_FORMAT_R16G16B16A16_SFLOAT));
+        svgf_push_constants.prev_frame_normals_and_object_ids = int32_t(resource_manager.UploadNewStorageImage(display_w, display_h, VHR_FORMAT_R16G16B16A16_SFLOAT));
+        svgf_push_constants.shadow_and_ao_history = int32_t(resource_manager.UploadNewStorageImage(display_w, display_h, VHR_FORMAT_R16G16B16A16_SFLOAT));
+        svgf_push_constants.shadow_and_ao_moments_history = int32_t(resource_manager.UploadNewStorageImage(display_w, display_h, VHR_FORMAT_R16G16_SFLOAT));
+        svgf_push_constants.atrous_step = 1;
+        svgf_textures_created = true;
+
+        ComputePipelineDescription pipeline;                                  // :275-286
+        pipeline.kernels = { ComputeKernel{ kSvgfShader }, ComputeKernel{ kAtrousShader } };
+        pipeline.push_constant_description.size = sizeof(SVGFPushConstants);
+        render_graph.AddComputePass(
+            "SVGF Denoise Pass",
+            { VkUtils::CreateTransientStorageImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 0),
+              VkUtils::CreateTransientStorageImage(kMotion, VHR_FORMAT_R16G16B16A16_SFLOAT, 1),
+              VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 2),
+              VkUtils::CreateTransientStorageImage(kRaytraced, VHR_FORMAT_R16G16_SFLOAT, 3) },
+            { VkUtils::CreateTransientStorageImage(kDenoised, VHR_FORMAT_R16G16B16A16_SFLOAT, 4) },
+            pipeline,
+            [this](ComputeExecutionContext &execution_context) {
+                // Per-frame schedule, :288-329.  With (x, y) = the ping-pong pair at frame start:
+                //   svgf.comp writes x; iteration i filters x -> y with step 2^i, then the pair swaps;
+                //   after iteration 0 its output becomes the temporal history; after the loop the current
+                //   normals become next frame's "previous" normals and image y -- which after an odd number
+                //   of swaps is the output of the SECOND-TO-LAST iteration -- is what gets published as the
+                //   denoised result (the reference's off-by-one: with 5 steps the step-16 pass is dead work).
+                SVGFPushConstants &pc = svgf_push_constants;
+                const uvec2 display_size = execution_context.GetDisplaySize();
+                const uint32_t gx = groups_of_8(display_size.x), gy = groups_of_8(display_size.y);
+                execution_context.Dispatch(kSvgfShader, gx, gy, 1, pc);
+                for (int i = 0; i < atrous_steps; ++i) {
+                    pc.atrous_step = 1 << i;
+                    execution_context.Dispatch(kAtrousShader, gx, gy, 1, pc);
+                    if (i == 0) execution_context.BlitImageStorageToStorage(pc.integrated_shadow_and_ao[1], pc.shadow_and_ao_history);
+                    std::swap(pc.integrated_shadow_and_ao[0], pc.integrated_shadow_and_ao[1]);
+                }
+                execution_context.BlitImageTransientToStorage(kNormals, pc.prev_frame_normals_and_object_ids);
+                execution_context.BlitImageStorageToTransient(pc.integrated_shadow_and_ao[1], kDenoised);
+                std::swap(pc.integrated_shadow_and_ao[0], pc.integrated_shadow_and_ao[1]);   // ready for the next frame
+            });
+    }
+
+    // Composition stage (:333-379): untouched raster pass; its dependency list is what pulls the passes above
+    // into the execution order (FindExecutionOrder walks back from RENDER_OUTPUT).
+    render_graph.AddGraphicsPass(
+        "Composition Pass",
+        { VkUtils::CreateTransientSampledImage(kAlbedo, VHR_FORMAT_B8G8R8A8_UNORM, 0),
+          VkUtils::CreateTransientSampledImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 1),
+          VkUtils::CreateTransientSampledImage(kMotion, VHR_FORMAT_R16G16B16A16_SFLOAT, 2),
+          VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 3),
+          VkUtils::CreateTransientSampledImage("Shadow Map", 4096, 4096, VHR_FORMAT_D32_SFLOAT, 4),
+          VkUtils::CreateTransientSampledImage("Screen Space Ambient Occlusion", VHR_FORMAT_R16G16B16A16_SFLOAT, 5),
+          VkUtils::CreateTransientSampledImage("Screen Space Reflections", VHR_FORMAT_R16G16B16A16_SFLOAT, 6),
+          denoise_shadow_and_ao ? VkUtils::CreateTransientSampledImage(kDenoised, VHR_FORMAT_R16G16B16A16_SFLOAT, 7)
+                                : VkUtils::CreateTransientSampledImage(kRaytraced, VHR_FORMAT_R16G16_SFLOAT, 7),
+          VkUtils::CreateTransientSampledImage(kReflections, VHR_FORMAT_R16G16B16A16_SFLOAT, 8) },
+        { VkUtils::CreateTransientRenderOutput(0) }, composition_pass);
+}
+
+void HybridRenderPath::DeregisterPath(DeviceContext &, RenderGraph &, ResourceManager &resource_manager) {   // :383-392
+    if (!svgf_textures_created) return;
+    resource_manager.DestroyStorageImage(uint32_t(svgf_push_constants.integrated_shadow_and_ao[0]));
+    resource_manager.DestroyStorageImage(uint32_t(svgf_push_constants.integrated_shadow_and_ao[1]));
+    resource_manager.DestroyStorageImage(uint32_t(svgf_push_constants.prev_frame_normals_and_object_ids));
+    resource_manager.DestroyStorageImage(uint32_t(svgf_push_constants.shadow_and_ao_history));
+    resource_manager.DestroyStorageImage(uint32_t(svgf_push_constants.shadow_and_ao_moments_history));
+    svgf_textures_created = false;
+}
+
+}  // namespace vhr
+
+// ---------------------------------------------------------------------------------------------------------
+// C entry points (vhr_amd.h, "HybridRenderPath" section) for callers without a C++ toolchain
+// ---------------------------------------------------------------------------------------------------------
+struct vhr_hybrid_render_path {
+    vhr::DeviceContext context;
+    vhr::ResourceManager resource_manager;
+    vhr::RenderGraph render_graph;
+    vhr::HybridRenderPath path;
+    vhr_external_pass_callback gbuffer_cb = nullptr, composition_cb = nullptr;
+    void *gbuffer_user = nullptr, *composition_user = nullptr;
+    std::string error;
+    vhr_hybrid_render_path(vhr_context *ctx, uint32_t w, uint32_t h)
+        : context(ctx), resource_manager(context), render_graph(context, resource_manager), path(context, render_graph, resource_manager) {
+        context.swapchain.extent = { w, h };
+    }
+};
+
+static void apply_settings(vhr_hybrid_render_path *p, const vhr_hybrid_settings *s) {
+    p->path.shadow_mode = s->shadow_mode;
+    p->path.ambient_occlusion_mode = s->ambient_occlusion_mode;
+    p->path.reflection_mode = s->reflection_mode;
+    p->path.denoise_shadow_and_ao = s->denoise_shadow_and_ao != 0;
+    p->path.atrous_steps = s->atrous_steps > 0 ? s->atrous_steps : 5;
+}
+
+template <typename F>
+static int guarded(vhr_hybrid_render_path *p, F &&f) {
+    try {
+        f();
+        return VHR_OK;
+    } catch (const std::exception &e) {
+        p->error = e.what();
+        return VHR_ERROR_GRAPH;
+    }
+}
+
+extern "C" {
+
+int vhr_hybrid_create(vhr_context *ctx, const vhr_hybrid_settings *settings, vhr_external_pass_callback gbuffer_pass, void *gbuffer_user,
+                      vhr_external_pass_callback composition_pass, void *composition_user, vhr_hybrid_render_path **out) {
+    if (!ctx || !settings || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    uint32_t w = 0, h = 0;
+    if (vhr_get_display_size(ctx, &w, &h) < 0) return VHR_ERROR_INVALID_ARGUMENT;
+    auto *p = new vhr_hybrid_render_path(ctx, w, h);
+    apply_settings(p, settings);
+    p->gbuffer_cb = gbuffer_pass; p->gbuffer_user = gbuffer_user;
+    p->composition_cb = composition_pass; p->composition_user = composition_user;
+    if (gbuffer_pass) p->path.gbuffer_pass = [p](vhr::DeviceContext &c) { p->gbuffer_cb(p->gbuffer_user, c.handle); };
+    if (composition_pass) p->path.composition_pass = [p](vhr::DeviceContext &c) { p->composition_cb(p->composition_user, c.handle); };
+    *out = p;
+    return VHR_OK;
+}
+
+void vhr_hybrid_destroy(vhr_hybrid_render_path *p) {
+    if (!p) return;
+    try {
+        p->path.DeregisterPath(p->context, p->render_graph, p->resource_manager);
+        p->render_graph.DestroyResources();
+    } catch (...) {
+    }
+    delete p;
+}
+
+int vhr_hybrid_build(vhr_hybrid_render_path *p) {
+    if (!p) return VHR_ERROR_INVALID_ARGUMENT;
+    return guarded(p, [&] { p->path.Build(); });
+}
+
+int vhr_hybrid_rebuild(vhr_hybrid_render_path *p, const vhr_hybrid_settings *settings) {
+    if (!p) return VHR_ERROR_INVALID_ARGUMENT;
+    return guarded(p, [&] {
+        // the UI applies the new modes, then calls Rebuild() (hybrid_render_path.cpp:394-441)
+        p->path.DeregisterPath(p->context, p->render_graph, p->resource_manager);
+        if (settings) apply_settings(p, settings);
+        p->path.Build();
+    });
+}
+
+int vhr_hybrid_get_push_constants(vhr_hybrid_render_path *p, vhr_svgf_push_constants *out) {
+    if (!p || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    *out = p->path.svgf_push_constants;
+    return VHR_OK;
+}
+
+const char *vhr_hybrid_last_error(vhr_hybrid_render_path *p) { return p ? p->error.c_str() : ""; }
+
+}  // extern "C"

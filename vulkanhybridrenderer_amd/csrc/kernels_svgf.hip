@@ -1,0 +1,294 @@
+// K3 / K4 / K5: the SVGF denoiser of the hybrid render path for gfx950.
+//
+//   data/shaders/hybrid_render_path/svgf.comp:16-145               -> svgf_temporal_kernel
+//   data/shaders/hybrid_render_path/svgf_atrous_filter.comp:17-103 -> svgf_atrous_kernel
+//   ComputeExecutionContext::BlitImage (compute_execution_context.cpp:178-211) -> copy_image_rows
+//
+// Numerics: fp32 compute, fp16 storage (stores round to nearest even), the same operation order as the
+// shaders; exp / reciprocal use the hardware approximations, so agreement with the CPU oracle is within the
+// float tolerance stated in tests/test_svgf_gpu.py, not bit-exact.  Images are linear row-major buffers:
+// RGBA16F = one 8-byte uint2 per pixel, RG16F = one 4-byte word per pixel, so a 64-lane wave reading 64
+// consecutive pixels of a row moves 512 contiguous bytes (dwordx2 per lane).
+#include "device_math.hpp"
+#include "vhr_internal.hpp"
+
+namespace vhr {
+
+constexpr int kSvgfBlockX = 64;    // one wave per image row segment: fully coalesced 512-byte row reads
+constexpr int kSvgfBlockY = 4;
+
+__device__ __forceinline__ f4 unpack_rgba16f(uint2 raw) {
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
+    const float2 hi = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));
+    return f4{ lo.x, lo.y, hi.x, hi.y };
+}
+__device__ __forceinline__ uint2 pack_rgba16f(float a, float b, float c, float d) {
+    const __half2 lo = __floats2half2_rn(a, b), hi = __floats2half2_rn(c, d);
+    uint2 r;
+    r.x = *reinterpret_cast<const uint32_t *>(&lo);
+    r.y = *reinterpret_cast<const uint32_t *>(&hi);
+    return r;
+}
+__device__ __forceinline__ float2 unpack_rg16f(uint32_t raw) { return __half22float2(*reinterpret_cast<const __half2 *>(&raw)); }
+__device__ __forceinline__ uint32_t pack_rg16f(float a, float b) {
+    const __half2 h = __floats2half2_rn(a, b);
+    return *reinterpret_cast<const uint32_t *>(&h);
+}
+// GLSL int(float): truncation toward zero; v_cvt_i32_f32 maps NaN to 0 and saturates
+__device__ __forceinline__ int f2i(float f) { return int(f); }
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+// ---------------------------------------------------------------------------------------------
+// K3: svgf.comp
+// ---------------------------------------------------------------------------------------------
+struct TemporalArgs {
+    const uint2 *normals, *motion, *prev_normals, *history;   // RGBA16F
+    const uint32_t *raytraced, *moments_in;                   // RG16F
+    uint2 *integrated_out;                                     // RGBA16F
+    uint32_t *moments_out;                                     // RG16F
+    uint32_t width, height;       // image extent
+    uint32_t limit_x, limit_y;    // pixels covered by the dispatch (groups * 8, clamped)
+    uint32_t row_begin, row_end;  // rows this context computes
+    float display_w, display_h;   // pfd.display_size
+};
+
+// svgf.comp:16-39
+__device__ __forceinline__ bool is_valid_reprojection(const TemporalArgs &a, int px, int py, int current_object_id, f3 current_normal) {
+    if (px < 0 || py < 0 || float(px) >= a.display_w || float(py) >= a.display_h) return false;
+    if (uint32_t(px) >= a.width || uint32_t(py) >= a.height) return false;     // imageLoad outside the image returns 0
+    const f4 pn = unpack_rgba16f(a.prev_normals[size_t(py) * a.width + px]);
+    if (current_object_id != f2i(pn.w)) return false;
+    if (dot3(current_normal, f3{ pn.x, pn.y, pn.z }) < 0.70710678118654752440084f) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel(const TemporalArgs a) {
+    const uint32_t cx = blockIdx.x * kSvgfBlockX + threadIdx.x;
+    const uint32_t cy = a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y;
+    if (cx >= a.limit_x || cy >= a.row_end || cy >= a.limit_y) return;
+    const size_t idx = size_t(cy) * a.width + cx;
+    const f4 nid = unpack_rgba16f(a.normals[idx]);                                          // :43-45
+    const f3 current_normal = f3{ nid.x, nid.y, nid.z };
+    const int current_object_id = f2i(nid.w);
+    const f4 mv = unpack_rgba16f(a.motion[idx]);                                            // :46
+    const float2 cur = unpack_rg16f(a.raytraced[idx]);                                      // :47-49
+    const float current_shadow = cur.x, current_ao = cur.y;
+
+    const float pcx = (float(cx) - mv.x * a.display_w) + 0.5f;                              // :52
+    const float pcy = (float(cy) - mv.y * a.display_h) + 0.5f;
+    const float x = pcx - floorf(pcx), y = pcy - floorf(pcy);                               // :53-54
+    const int ax = f2i(pcx), ay = f2i(pcy);                                                 // :55
+    const float bw[4] = { (1.0f - x) * (1.0f - y), x * (1.0f - y), (1.0f - x) * y, x * y };  // :57
+
+    float prev_shadow = 0.0f, prev_ao = 0.0f, sum = 0.0f;
+    float psm0 = 0.0f, psm1 = 0.0f, pam0 = 0.0f, pam1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                                           // :65-77
+        const int sx = ax + (i & 1), sy = ay + (i >> 1);
+        if (is_valid_reprojection(a, sx, sy, current_object_id, current_normal)) {
+            const size_t sidx = size_t(sy) * a.width + sx;
+            const f4 hs = unpack_rgba16f(a.history[sidx]);
+            prev_shadow += bw[i] * hs.x;
+            prev_ao += bw[i] * hs.y;
+            const float2 m = unpack_rg16f(a.moments_in[sidx]);       // RG16F read as vec4 = (r, g, 0, 1)
+            psm0 += bw[i] * m.x; psm1 += bw[i] * m.y;
+            pam0 += bw[i] * 0.0f; pam1 += bw[i] * 1.0f;
+            sum += bw[i];
+        }
+    }
+    bool valid = sum > 1e-6f;                                                               // :78
+    if (!valid) {                                                                           // :81-97
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int sx = ax + dx, sy = ay + dy;
+                if (is_valid_reprojection(a, sx, sy, current_object_id, current_normal)) {
+                    const size_t sidx = size_t(sy) * a.width + sx;
+                    const f4 hs = unpack_rgba16f(a.history[sidx]);
+                    const float2 m = unpack_rg16f(a.moments_in[sidx]);
+                    prev_shadow += hs.x; prev_ao += hs.y;
+                    psm0 += m.x; psm1 += m.y; pam0 += 0.0f; pam1 += 1.0f;
+                    sum += 1.0f;
+                }
+            }
+        valid = sum > 1e-6f;
+    }
+    float sm0 = current_shadow, sm1 = current_shadow * current_shadow;                      // :99-102
+    float am0 = current_ao, am1 = current_ao * current_ao;
+    float out_s = current_shadow, out_a = current_ao;
+    if (valid) {                                                                            // :106-126
+        prev_shadow /= sum; psm0 /= sum; psm1 /= sum;
+        prev_ao /= sum; pam0 /= sum; pam1 /= sum;
+        sm0 = mixf(psm0, sm0, 0.2f); sm1 = mixf(psm1, sm1, 0.2f);
+        am0 = mixf(pam0, am0, 0.2f); am1 = mixf(pam1, am1, 0.2f);
+        out_s = mixf(prev_shadow, current_shadow, 0.2f);
+        out_a = mixf(prev_ao, current_ao, 0.2f);
+    }
+    const float sv = fmaxf(0.0f, sm1 - sm0 * sm0);
+    const float av = fmaxf(0.0f, am1 - am0 * am0);
+    a.integrated_out[idx] = pack_rgba16f(out_s, out_a, sv, av);                             // :118-135
+    a.moments_out[idx] = pack_rg16f(sm0, sm1);                                              // :138-144 (RG16F image keeps .xy)
+}
+
+static void strip_rows(const vhr_context *ctx, uint32_t height, uint32_t &r0, uint32_t &r1) {
+    const uint32_t b = std::min(ctx->row_begin, height), e = std::min(ctx->row_end, height);
+    r0 = b > ctx->overlap ? b - ctx->overlap : 0;
+    r1 = std::min(height, e + ctx->overlap);
+    if (e <= b) { r0 = r1 = 0; }
+}
+
+int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
+                         const Image &raytraced, const Image &prev_normals, const Image &history, Image &moments,
+                         Image &integrated_out, uint32_t x_groups, uint32_t y_groups) {
+    const uint32_t W = normals.width, H = normals.height;
+    const Image *all[] = { &motion, &raytraced, &prev_normals, &history, &moments, &integrated_out };
+    for (const Image *im : all)
+        if (im->width != W || im->height != H) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf.comp: image extents differ");
+    if (normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || motion.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
+        prev_normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || history.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
+        integrated_out.format != VHR_FORMAT_R16G16B16A16_SFLOAT || raytraced.format != VHR_FORMAT_R16G16_SFLOAT ||
+        moments.format != VHR_FORMAT_R16G16_SFLOAT)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf.comp: unexpected image format (moments / raytraced must be R16G16, the rest R16G16B16A16)");
+    if (!moments.alt) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf.comp: moments history must be a storage image");
+    TemporalArgs a;
+    a.normals = static_cast<const uint2 *>(normals.ptr);
+    a.motion = static_cast<const uint2 *>(motion.ptr);
+    a.prev_normals = static_cast<const uint2 *>(prev_normals.ptr);
+    a.history = static_cast<const uint2 *>(history.ptr);
+    a.raytraced = static_cast<const uint32_t *>(raytraced.ptr);
+    a.moments_in = static_cast<const uint32_t *>(moments.ptr);
+    a.integrated_out = static_cast<uint2 *>(integrated_out.ptr);
+    a.moments_out = static_cast<uint32_t *>(moments.alt);
+    a.width = W; a.height = H;
+    a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
+    a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
+    strip_rows(ctx, H, a.row_begin, a.row_end);
+    a.display_w = pfd.display_size[0];
+    a.display_h = pfd.display_size[1];
+    if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
+        const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+        hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+        if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
+    }
+    // the dispatch read a snapshot (ptr) and wrote the new moments (alt): flip (oracle decision ii)
+    std::swap(moments.ptr, moments.alt);
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: svgf_atrous_filter.comp
+// ---------------------------------------------------------------------------------------------
+struct AtrousArgs {
+    const uint2 *normals, *in;
+    uint2 *out;
+    uint32_t width, height, limit_x, limit_y, row_begin, row_end;
+    int32_t step;
+    float display_w, display_h;
+};
+
+__device__ __forceinline__ float pow128(float x) {      // max(0, pow(x, 128)); pow of x <= 0 defined as 0
+    x = fmaxf(x, 0.0f);
+    x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+    return x;
+}
+
+__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(const AtrousArgs a) {
+    const int cx = int(blockIdx.x * kSvgfBlockX + threadIdx.x);
+    const int cy = int(a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y);
+    if (uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) return;
+    const int W = int(a.width), H = int(a.height);
+    // bounds as the shader writes them (float compare against display_size), plus the image extent
+    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
+    const size_t idx = size_t(cy) * W + cx;
+    const f4 np = unpack_rgba16f(a.normals[idx]);                                           // :55-57
+    const f3 normal_p = f3{ np.x, np.y, np.z };
+    const int id_p = f2i(np.w);
+    const f4 p = unpack_rgba16f(a.in[idx]);                                                 // :59
+
+    float var_s = 0.0f, var_a = 0.0f;                                                       // :17-38
+#pragma unroll
+    for (int y = -1; y <= 1; ++y)
+#pragma unroll
+        for (int x = -1; x <= 1; ++x) {
+            const int sx = cx + x, sy = cy + y;
+            if (sx < 0 || sx >= max_x || sy < 0 || sy >= max_y) continue;
+            const float w = (x == 0 ? 0.5f : 0.25f) * (y == 0 ? 0.5f : 0.25f);
+            const f4 q = unpack_rgba16f(a.in[size_t(sy) * W + sx]);
+            var_s += w * q.z;
+            var_a += w * q.w;
+        }
+    const float inv_s = __frcp_rn(4.0f * sqrtf(var_s) + 1e-6f);                             // :48-50 denominators
+    const float inv_a = __frcp_rn(4.0f * sqrtf(var_a) + 1e-6f);
+
+    float sw_s = 1.0f, sw_a = 1.0f;                                                         // :70-71
+    float s0 = p.x, s1 = p.y, s2 = p.z, s3 = p.w;
+    const int step = a.step;
+#pragma unroll
+    for (int y = -2; y <= 2; ++y)
+#pragma unroll
+        for (int x = -2; x <= 2; ++x) {                                                     // :72-94
+            if (x == 0 && y == 0) continue;
+            const int sx = cx + x * step, sy = cy + y * step;
+            if (sx < 0 || sx >= max_x || sy < 0 || sy >= max_y) continue;
+            const size_t sidx = size_t(sy) * W + sx;
+            const f4 q = unpack_rgba16f(a.in[sidx]);
+            const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
+            const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
+            const float kernel = kx * ky;                                                   // :62-68 (exact products)
+            const f4 nq = unpack_rgba16f(a.normals[sidx]);
+            const float wn = pow128(dot3(normal_p, f3{ nq.x, nq.y, nq.z }));                // :44-46
+            const float w = (id_p == f2i(nq.w)) ? kernel * wn : 0.0f;                       // :40-42, :87
+            const float wx = w * __expf(-(fabsf(p.x - q.x) * inv_s));                       // :88
+            const float wy = w * __expf(-(fabsf(p.y - q.y) * inv_a));                       // :89
+            sw_s += wx; sw_a += wy;                                                         // :91
+            s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;   // :92
+        }
+    const float rs = __frcp_rn(sw_s), ra = __frcp_rn(sw_a);
+    a.out[idx] = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
+}
+
+int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in, Image &out,
+                       int32_t step, uint32_t x_groups, uint32_t y_groups) {
+    const uint32_t W = normals.width, H = normals.height;
+    if (in.width != W || in.height != H || out.width != W || out.height != H)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf_atrous_filter.comp: image extents differ");
+    if (normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || in.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
+        out.format != VHR_FORMAT_R16G16B16A16_SFLOAT)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf_atrous_filter.comp: images must be R16G16B16A16_SFLOAT");
+    if (in.ptr == out.ptr) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf_atrous_filter.comp: ping-pong images alias");
+    if (step < 1 || step > 4096) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "svgf_atrous_filter.comp: atrous_step out of range");
+    AtrousArgs a;
+    a.normals = static_cast<const uint2 *>(normals.ptr);
+    a.in = static_cast<const uint2 *>(in.ptr);
+    a.out = static_cast<uint2 *>(out.ptr);
+    a.width = W; a.height = H;
+    a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
+    a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
+    strip_rows(ctx, H, a.row_begin, a.row_end);
+    a.step = step;
+    a.display_w = pfd.display_size[0];
+    a.display_h = pfd.display_size[1];
+    if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
+    const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+    hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: same-extent, same-format VK_FILTER_NEAREST blit == copy (compute_execution_context.cpp:178-211)
+// ---------------------------------------------------------------------------------------------
+int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
+    if (src.width != dst.width || src.height != dst.height)          // asserts at compute_execution_context.cpp:179-180
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: extents differ");
+    if (src.bpp != dst.bpp) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: formats of different texel size are not supported");
+    uint32_t r0, r1;
+    strip_rows(ctx, src.height, r0, r1);
+    if (r1 <= r0 || src.ptr == dst.ptr) return VHR_OK;
+    const size_t row = size_t(src.width) * src.bpp;
+    if (hipMemcpyAsync(static_cast<char *>(dst.ptr) + r0 * row, static_cast<const char *>(src.ptr) + r0 * row, (r1 - r0) * row,
+                       hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: hipMemcpyAsync failed");
+    return VHR_OK;
+}
+
+}  // namespace vhr

@@ -1,0 +1,484 @@
+// K1 + K2 + stand-in G-buffer producer: software BVH2 ray tracing for gfx950.
+//
+// Replaces, for the hybrid render path's "Raytrace Pass" (hybrid_render_path.cpp:101-136):
+//   data/shaders/hybrid_render_path/raygen.rgen:14-66        -> raygen_kernel
+//   data/shaders/hybrid_render_path/miss.rmiss:6-8            -> payload 1.0 when the any-hit walk finds nothing
+//   data/shaders/hybrid_render_path/reflection_miss.rmiss:6-8 -> payload 0 when the closest-hit walk finds nothing
+//   data/shaders/hybrid_render_path/reflection_hit.rchit:10-72 -> shade_reflection_hit
+//   vkCmdTraceRaysKHR (raytracing_execution_context.cpp:4-13) -> launch_raygen
+// and the driver's acceleration-structure traversal (traceRayEXT) by traverse<>() below.
+//
+// Compiled with -ffp-contract=off: ray setup and Moeller-Trumbore follow the exact-arithmetic contract of
+// device_math.hpp so visibility results are bit-reproducible.
+#include "device_math.hpp"
+#include "vhr_internal.hpp"
+
+namespace vhr {
+
+__constant__ float c_srgb_lut[256];
+
+constexpr int kTraceBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile of a 16x16 block tile
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri_index;    // index into DeviceScene::tris
+    uint32_t flat;
+};
+
+// Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax (decision vi in DESIGN.md)
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax,
+                                             float &t, float &u, float &v) {
+    f3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    f3 tvec = o - v0;
+    float uu = dot3(tvec, pvec) * inv;
+    if (!(uu >= 0.0f) || uu > 1.0f) return false;
+    f3 qvec = cross3(tvec, e1);
+    float vv = dot3(d, qvec) * inv;
+    if (!(vv >= 0.0f) || uu + vv > 1.0f) return false;
+    float tt = dot3(e2, qvec) * inv;
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+// Slab test of one child box against [tmin, tlimit]; NaNs from 0 * inf drop out of fminf/fmaxf
+// (IEEE minNum/maxNum), which can only enlarge the interval, i.e. stays conservative.
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv,
+                                         float tmin, float tlimit, float &tnear) {
+    float t0 = (lox - o.x) * inv.x, t1 = (hix - o.x) * inv.x;
+    float tn = fmaxf(tmin, fminf(t0, t1)), tf = fminf(tlimit, fmaxf(t0, t1));
+    t0 = (loy - o.y) * inv.y; t1 = (hiy - o.y) * inv.y;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (loz - o.z) * inv.z; t1 = (hiz - o.z) * inv.z;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// Per-lane BVH2 walk with the traversal stack in LDS (stack[level * kTraceBlock + thread]: conflict free).
+// ANY_HIT: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (raygen.rgen:39,51) -- returns at the
+// first accepted triangle; the boolean result does not depend on the visiting order.
+// !ANY_HIT: closest hit = min t, ties broken by the smaller flat triangle index; subtrees are pruned with
+// tnear > best t only (strict), so equal-t candidates are always examined.
+template <bool ANY_HIT>
+__device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, int *stack, Hit &best,
+                                         uint32_t &overflow) {
+    if (sc.node_count == 0) return false;
+    const f3 inv = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    bool found = false;
+    float tbest = tmax;
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int4 q3 = reinterpret_cast<const int4 *>(np)[3];
+            float tn0, tn1;
+            const bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, tbest, tn0);
+            const bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, tbest, tn1);
+            if (h0 && h1) {
+                const bool first0 = tn0 <= tn1;
+                const int nearc = first0 ? q3.x : q3.y, farc = first0 ? q3.y : q3.x;
+                if (sp < kTraceStack) { stack[sp * kTraceBlock] = farc; ++sp; } else { overflow = 1; }
+                cur = nearc;
+                continue;
+            }
+            if (h0) { cur = q3.x; continue; }
+            if (h1) { cur = q3.y; continue; }
+        } else {
+            const uint32_t v = ~uint32_t(cur);
+            const uint32_t first = v >> 2, count = (v & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
+                const float4 a = tp[0], b = tp[1];
+                const float4 c = tp[2];
+                float t, u, w;
+                if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, tmin, tmax, t, u, w)) {
+                    if (ANY_HIT) return true;
+                    const uint32_t flat = __float_as_uint(c.w);
+                    if (!found || t < best.t || (t == best.t && flat < best.flat)) {
+                        found = true;
+                        best.t = t; best.u = u; best.v = w; best.tri_index = first + i; best.flat = flat;
+                        tbest = t;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * kTraceBlock];
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// image helpers (linear, row-major, tightly packed)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f4 load_rgba16f(const void *img, uint32_t W, uint32_t x, uint32_t y) {
+    const uint2 raw = reinterpret_cast<const uint2 *>(img)[size_t(y) * W + x];
+    return f4{ half_bits_to_float(uint16_t(raw.x & 0xffffu)), half_bits_to_float(uint16_t(raw.x >> 16)),
+               half_bits_to_float(uint16_t(raw.y & 0xffffu)), half_bits_to_float(uint16_t(raw.y >> 16)) };
+}
+__device__ __forceinline__ void store_rgba16f(void *img, uint32_t W, uint32_t x, uint32_t y, float a, float b, float c, float d) {
+    uint2 raw;
+    raw.x = uint32_t(float_to_half_bits(a)) | (uint32_t(float_to_half_bits(b)) << 16);
+    raw.y = uint32_t(float_to_half_bits(c)) | (uint32_t(float_to_half_bits(d)) << 16);
+    reinterpret_cast<uint2 *>(img)[size_t(y) * W + x] = raw;
+}
+__device__ __forceinline__ void store_rg16f(void *img, uint32_t W, uint32_t x, uint32_t y, float a, float b) {
+    reinterpret_cast<uint32_t *>(img)[size_t(y) * W + x] =
+        uint32_t(float_to_half_bits(a)) | (uint32_t(float_to_half_bits(b)) << 16);
+}
+
+// glsl_common.h:118-122
+__device__ __forceinline__ f3 get_world_space_position(const vhr_per_frame_data &pfd, float depth, float u, float v) {
+    const f4 r = mat4_mul(pfd.camera_viewproj_inverse, f4{ u * 2.0f - 1.0f, v * 2.0f - 1.0f, depth, 1.0f });
+    return f3{ r.x / r.w, r.y / r.w, r.z / r.w };
+}
+
+// ---------------------------------------------------------------------------------------------
+// texture(): LOD 0, per-texture sampler, software bilinear (float tolerance, not bit-exact)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap_coord(int i, int n, int mode) {
+    if (mode == 2) return min(max(i, 0), n - 1);
+    if (mode == 1) {
+        const int p = 2 * n;
+        int m = i % p;
+        if (m < 0) m += p;
+        return m < n ? m : p - 1 - m;
+    }
+    int m = i % n;
+    if (m < 0) m += n;
+    return m;
+}
+__device__ __forceinline__ f4 fetch_texel(const DeviceTexture &t, int x, int y) {
+    const uchar4 p = reinterpret_cast<const uchar4 *>(t.texels)[size_t(y) * t.width + x];
+    f4 r;
+    if (t.format == VHR_FORMAT_R8G8B8A8_SRGB) { r.x = c_srgb_lut[p.x]; r.y = c_srgb_lut[p.y]; r.z = c_srgb_lut[p.z]; }
+    else { r.x = p.x * (1.0f / 255.0f); r.y = p.y * (1.0f / 255.0f); r.z = p.z * (1.0f / 255.0f); }
+    r.w = p.w * (1.0f / 255.0f);
+    return r;
+}
+__device__ f4 sample_texture(const DeviceScene &sc, int idx, float u, float v) {
+    if (idx < 0 || uint32_t(idx) >= sc.texture_count) return f4{ 0, 0, 0, 0 };
+    const DeviceTexture t = sc.textures[idx];
+    float x = u * float(t.width), y = v * float(t.height);
+    if (t.mag_filter == 0)
+        return fetch_texel(t, wrap_coord(int(floorf(x)), int(t.width), t.address_u), wrap_coord(int(floorf(y)), int(t.height), t.address_v));
+    x -= 0.5f; y -= 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int x0 = wrap_coord(int(fx0), int(t.width), t.address_u), x1 = wrap_coord(int(fx0) + 1, int(t.width), t.address_u);
+    const int y0 = wrap_coord(int(fy0), int(t.height), t.address_v), y1 = wrap_coord(int(fy0) + 1, int(t.height), t.address_v);
+    const f4 a = fetch_texel(t, x0, y0), b = fetch_texel(t, x1, y0), c = fetch_texel(t, x0, y1), d = fetch_texel(t, x1, y1);
+    f4 r;
+    r.x = (a.x * (1.0f - fx) + b.x * fx) * (1.0f - fy) + (c.x * (1.0f - fx) + d.x * fx) * fy;
+    r.y = (a.y * (1.0f - fx) + b.y * fx) * (1.0f - fy) + (c.y * (1.0f - fx) + d.y * fx) * fy;
+    r.z = (a.z * (1.0f - fx) + b.z * fx) * (1.0f - fy) + (c.z * (1.0f - fx) + d.z * fx) * fy;
+    r.w = (a.w * (1.0f - fx) + b.w * fx) * (1.0f - fy) + (c.w * (1.0f - fx) + d.w * fx) * fy;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: reflection_hit.rchit:10-72
+// ---------------------------------------------------------------------------------------------
+// common.glsl:116-150
+__device__ __forceinline__ f3 fresnel_schlick(f3 f0, f3 H, f3 V) {
+    const float hv = fmaxf(dot3(H, V), 0.0f);
+    const float om = 1.0f - hv;
+    const float p5 = om * om * om * om * om;
+    return f3{ f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5 };
+}
+__device__ __forceinline__ float D_GGX(float roughness, f3 N, f3 H) {
+    const float a2 = roughness * roughness;
+    const float nh = fmaxf(dot3(N, H), 0.0f);
+    const float f = nh * nh * (a2 - 1.0f) + 1.0f;
+    return a2 / (VHR_PI * f * f);
+}
+__device__ __forceinline__ float G_GGX(float roughness, f3 N, f3 V, f3 L) {
+    const float k = ((roughness + 1.0f) * (roughness + 1.0f)) * 0.125f;
+    const float nv = fmaxf(dot3(N, V), 0.0f), nl = fmaxf(dot3(N, L), 0.0f);
+    return (nv / (nv * (1.0f - k) + k)) * (nl / (nl * (1.0f - k) + k));
+}
+
+struct TriAttributes { float uvx, uvy; f3 normal; f3 object_pos; };
+
+__device__ __forceinline__ TriAttributes interpolate(const DeviceScene &sc, const vhr_primitive &prim, uint32_t tri, float u, float v) {
+    const uint32_t i0 = sc.indices[prim.index_offset + 3 * tri + 0];
+    const uint32_t i1 = sc.indices[prim.index_offset + 3 * tri + 1];
+    const uint32_t i2 = sc.indices[prim.index_offset + 3 * tri + 2];
+    const vhr_vertex &a = sc.vertices[prim.vertex_offset + i0];
+    const vhr_vertex &b = sc.vertices[prim.vertex_offset + i1];
+    const vhr_vertex &c = sc.vertices[prim.vertex_offset + i2];
+    const float bx = 1.0f - u - v, by = u, bz = v;                                     // rchit:21
+    TriAttributes r;
+    r.uvx = a.uv0[0] * bx + b.uv0[0] * by + c.uv0[0] * bz;                             // rchit:22
+    r.uvy = a.uv0[1] * bx + b.uv0[1] * by + c.uv0[1] * bz;
+    r.normal = f3{ a.normal[0] * bx + b.normal[0] * by + c.normal[0] * bz,            // rchit:23 (object space)
+                   a.normal[1] * bx + b.normal[1] * by + c.normal[1] * bz,
+                   a.normal[2] * bx + b.normal[2] * by + c.normal[2] * bz };
+    r.object_pos = f3{ a.pos[0] * bx + b.pos[0] * by + c.pos[0] * bz, a.pos[1] * bx + b.pos[1] * by + c.pos[1] * bz,
+                       a.pos[2] * bx + b.pos[2] * by + c.pos[2] * bz };
+    return r;
+}
+
+__device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_data &pfd, const Hit &h) {
+    const BvhTri &bt = sc.tris[h.tri_index];
+    const vhr_primitive &prim = sc.primitives[bt.prim];                                 // rchit:11
+    const TriAttributes at = interpolate(sc, prim, bt.tri, h.u, h.v);
+    const f3 position = mat4_mul_point(prim.transform, at.object_pos);                  // rchit:24
+    f3 albedo;
+    if (prim.material.base_color_texture == -1) {                                       // rchit:27-32
+        albedo = f3{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2] };
+    } else {
+        const f4 t = sample_texture(sc, prim.material.base_color_texture, at.uvx, at.uvy);
+        albedo = f3{ t.x, t.y, t.z };
+    }
+    float metallic = prim.material.metallic_factor, roughness = prim.material.roughness_factor;
+    if (prim.material.metallic_roughness_texture != -1) {                               // rchit:35-39
+        const f4 mr = sample_texture(sc, prim.material.metallic_roughness_texture, at.uvx, at.uvy);
+        metallic *= mr.y;
+        roughness *= mr.z;
+    }
+    const f3 cam = f3{ pfd.camera_view_inverse[12], pfd.camera_view_inverse[13], pfd.camera_view_inverse[14] };
+    const f3 V = normalize3(cam - position);                                            // rchit:42
+    const f3 L = -f3{ pfd.directional_light.direction[0], pfd.directional_light.direction[1], pfd.directional_light.direction[2] };
+    const f3 N = at.normal;                                                             // rchit:44 (not normalised)
+    const f3 H = normalize3(L + V);
+    roughness = fminf(fmaxf(roughness, 0.04f), 1.0f);                                   // rchit:53-55
+    metallic = fminf(fmaxf(metallic, 0.0f), 1.0f);
+    const float ambient_factor = VHR_PI_INVERSE * 0.2f;                                 // rchit:59
+    const f3 li = f3{ pfd.directional_light.intensity[0], pfd.directional_light.intensity[1], pfd.directional_light.intensity[2] };
+    const f3 lc = f3{ pfd.directional_light.color[0], pfd.directional_light.color[1], pfd.directional_light.color[2] };
+    const f3 f0 = f3{ 0.04f * (1.0f - metallic) + albedo.x * metallic, 0.04f * (1.0f - metallic) + albedo.y * metallic,
+                      0.04f * (1.0f - metallic) + albedo.z * metallic };                // rchit:63-64
+    const f3 F = fresnel_schlick(f0, H, V);
+    const f3 ambient = albedo * ambient_factor;                                         // rchit:67
+    const f3 dp = f3{ (1.0f - F.x) * (1.0f - metallic), (1.0f - F.y) * (1.0f - metallic), (1.0f - F.z) * (1.0f - metallic) };
+    const f3 diffuse = f3{ dp.x * albedo.x / VHR_PI, dp.y * albedo.y / VHR_PI, dp.z * albedo.z / VHR_PI };
+    const float dg = D_GGX(roughness, N, H) * G_GGX(roughness, N, V, L);
+    const float denom = 4.0f * fmaxf(dot3(N, V), 0.0f) * fmaxf(dot3(N, L), 0.0f);
+    const float invd = 1.0f / fmaxf(denom, 1e-6f);
+    const f3 specular = f3{ dg * F.x * invd, dg * F.y * invd, dg * F.z * invd };
+    const float nl = fmaxf(dot3(N, L), 0.0f);
+    const f3 lit = mul3(mul3((diffuse + specular) * nl, li), lc);                       // rchit:70
+    const f3 lighting = ambient + lit;
+    return f4{ lighting.x, lighting.y, lighting.z, 1.0f };
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: raygen.rgen:14-66
+// ---------------------------------------------------------------------------------------------
+struct RaygenArgs {
+    DeviceScene scene;
+    vhr_per_frame_data pfd;
+    vhr_trace_params tp;
+    const void *normals;     // RGBA16F
+    const float *depth;      // D32F
+    void *shadow_ao;         // RG16F
+    void *reflections;       // RGBA16F or nullptr
+    uint32_t width, height;  // launch size == image size
+    uint32_t row_begin, row_end;
+    RayStats *stats;         // nullptr = off
+};
+
+__device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
+    // 16x16 pixel tile per block; wave w covers the 8x8 sub-tile (w & 1, w >> 1)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    y = row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+__global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a) {
+    __shared__ int s_stack[kTraceStack * kTraceBlock];
+    int *stack = s_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, a.row_begin);
+    uint32_t overflow = 0;
+    bool covered = false;
+    if (x < a.width && y < a.row_end) {
+        const uint32_t W = a.width, H = a.height;
+        const float u = (float(x) + 0.5f) / float(W);                                        // rgen:15-16
+        const float v = (float(y) + 0.5f) / float(H);
+        uint32_t rng = seed_thread((y * H + x) * a.pfd.frame_index);                         // rgen:17 (LaunchSize.y)
+        const float depth = a.depth[size_t(y) * W + x];                                      // rgen:19
+        if (depth == 0.0f) {                                                                 // rgen:20-24
+            store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);
+            if (a.reflections) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            covered = true;
+            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
+            const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1],
+                              a.pfd.directional_light.direction[2] };                        // rgen:27
+            const f4 nid = load_rgba16f(a.normals, W, x, y);                                 // rgen:28
+            const f3 N = f3{ nid.x, nid.y, nid.z };
+            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
+            Hit hit;
+
+            float rnd1 = random01(rng);                                                      // rgen:32-33
+            float rnd2 = random01(rng);
+            float shadow_payload = 1.0f;
+            if (a.tp.shadow_enable) {
+                const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));   // rgen:34
+                const f3 dir = onb_transform(L, cone_dir);                                   // rgen:35,40
+                // rgen:37-41 issues this trace four times with identical arguments; once is equivalent
+                const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.tmax, stack, hit, overflow);
+                shadow_payload = occluded ? 0.0f : 1.0f;                                     // miss.rmiss:7
+            }
+            float ao_payload = 0.0f;                                                         // rgen:44-55
+            for (uint32_t i = 0; i < a.tp.ao_spp; ++i) {
+                rnd1 = random01(rng);
+                rnd2 = random01(rng);
+                const f3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
+                const f3 dir = onb_transform(N, rnd_dir);
+                const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.ao_tmax, stack, hit, overflow);
+                ao_payload += occluded ? 0.0f : 1.0f;
+            }
+            if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
+            store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                   // rgen:57
+
+            if (a.reflections) {
+                f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                if (a.tp.reflections) {                                                      // rgen:60-65
+                    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+                    const f3 I = normalize3(P - cam);
+                    const float ni2 = 2.0f * dot3(N, I);
+                    const f3 rdir = I - N * ni2;                                             // reflect(I, N)
+                    if (traverse<false>(a.scene, origin, rdir, a.tp.tmin, a.tp.tmax, stack, hit, overflow))
+                        payload = shade_reflection_hit(a.scene, a.pfd, hit);                 // else reflection_miss.rmiss:7
+                }
+                store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+            }
+        }
+    }
+    if (a.stats) {
+        const unsigned long long cov = __ballot(covered), ovf = __ballot(overflow != 0);
+        if ((threadIdx.x & 63u) == 0) {
+            if (cov) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov));
+            if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
+        }
+    }
+}
+
+int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
+                  const Image &depth, Image &shadow_ao, Image *reflections) {
+    if (width != normals.width || height != normals.height || width != depth.width || height != depth.height ||
+        width != shadow_ao.width || height != shadow_ao.height || (reflections && (reflections->width != width || reflections->height != height)))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "TraceRays: launch size must equal the extent of the pass images");
+    RaygenArgs a;
+    a.scene = ctx->device_scene();
+    a.pfd = pfd;
+    a.tp = ctx->trace_params;
+    a.normals = normals.ptr;
+    a.depth = static_cast<const float *>(depth.ptr);
+    a.shadow_ao = shadow_ao.ptr;
+    a.reflections = reflections ? reflections->ptr : nullptr;
+    a.width = width;
+    a.height = height;
+    a.row_begin = std::min(ctx->row_begin, height);
+    a.row_end = std::min(ctx->row_end, height);
+    a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
+    if (a.row_end <= a.row_begin) return VHR_OK;
+    if (a.stats) {
+        if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
+            return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
+    }
+    const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
+    hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
+    if (a.stats) {
+        if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+            return ctx->fail(VHR_ERROR_DEVICE, "hipMemcpyAsync(ray stats) failed");
+    }
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 encodings) -- primary rays
+// ---------------------------------------------------------------------------------------------
+struct GbufferArgs {
+    DeviceScene scene;
+    vhr_per_frame_data pfd;
+    float projview[16], prev_projview[16];
+    void *normals, *motion;
+    float *depth;
+    uint32_t width, height;
+};
+
+__global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs a) {
+    __shared__ int s_stack[kTraceStack * kTraceBlock];
+    int *stack = s_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, 0);
+    if (x >= a.width || y >= a.height) return;
+    const uint32_t W = a.width, H = a.height;
+    const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
+    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+    const f3 pnear = get_world_space_position(a.pfd, 1.0f, u, v);      // reverse-Z: depth 1 is the near plane
+    const f3 dir = pnear - cam;
+    Hit h;
+    uint32_t overflow = 0;
+    if (!traverse<false>(a.scene, cam, dir, 1.0f, 3.0e38f, stack, h, overflow)) {   // clears: hybrid_render_path.cpp:16-19
+        store_rgba16f(a.normals, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
+        store_rgba16f(a.motion, W, x, y, 0.0f, 0.0f, -1.0f, -1.0f);
+        a.depth[size_t(y) * W + x] = 0.0f;
+        return;
+    }
+    const BvhTri &bt = a.scene.tris[h.tri_index];
+    const vhr_primitive &prim = a.scene.primitives[bt.prim];
+    const f3 P = cam + dir * h.t;
+    const f4 clip = mat4_mul(a.projview, f4{ P.x, P.y, P.z, 1.0f });
+    a.depth[size_t(y) * W + x] = clip.z / clip.w;
+    const TriAttributes at = interpolate(a.scene, prim, bt.tri, h.u, h.v);
+    const float *M = a.scene.normal_matrices + 9 * size_t(bt.prim);
+    const f3 n = at.normal;
+    const f3 wn = normalize3(f3{ (M[0] * n.x + M[3] * n.y) + M[6] * n.z, (M[1] * n.x + M[4] * n.y) + M[7] * n.z,
+                                 (M[2] * n.x + M[5] * n.y) + M[8] * n.z });                  // gbuf.frag:43
+    store_rgba16f(a.normals, W, x, y, wn.x, wn.y, wn.z, float(bt.prim));
+    const float cx = (float(x) + 0.5f) * a.pfd.display_size_inverse[0];                      // gbuf.frag:46
+    const float cy = (float(y) + 0.5f) * a.pfd.display_size_inverse[1];
+    const f4 rp = mat4_mul(a.prev_projview, f4{ P.x, P.y, P.z, 1.0f });
+    const float px = (rp.x / rp.w) * 0.5f + 0.5f, py = (rp.y / rp.w) * 0.5f + 0.5f;          // gbuf.frag:47
+    float metallic = prim.material.metallic_factor, roughness = prim.material.roughness_factor;
+    if (prim.material.metallic_roughness_texture != -1) {                                    // gbuf.frag:50-56
+        const f4 mr = sample_texture(a.scene, prim.material.metallic_roughness_texture, at.uvx, at.uvy);
+        metallic *= mr.y;
+        roughness *= mr.z;
+    }
+    store_rgba16f(a.motion, W, x, y, cx - px, cy - py, metallic, roughness);                 // gbuf.frag:58
+}
+
+static void host_mat4_mul(const float *a, const float *b, float *out) {
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 4; ++i)
+            out[c * 4 + i] = ((a[0 * 4 + i] * b[c * 4 + 0] + a[1 * 4 + i] * b[c * 4 + 1]) + a[2 * 4 + i] * b[c * 4 + 2]) + a[3 * 4 + i] * b[c * 4 + 3];
+}
+
+int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth) {
+    if (normals.width != depth.width || normals.height != depth.height || motion.width != depth.width || motion.height != depth.height)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: image extents differ");
+    GbufferArgs a;
+    a.scene = ctx->device_scene();
+    a.pfd = pfd;
+    host_mat4_mul(pfd.camera_proj, pfd.camera_view, a.projview);
+    host_mat4_mul(pfd.camera_proj_prev_frame, pfd.camera_view_prev_frame, a.prev_projview);
+    a.normals = normals.ptr;
+    a.motion = motion.ptr;
+    a.depth = static_cast<float *>(depth.ptr);
+    a.width = depth.width;
+    a.height = depth.height;
+    const dim3 grid((a.width + 15) / 16, (a.height + 15) / 16);
+    hipLaunchKernelGGL(gbuffer_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "gbuffer kernel launch failed");
+    return VHR_OK;
+}
+
+int upload_srgb_lut(const float *lut) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_lut), lut, 256 * sizeof(float)) == hipSuccess ? 0 : -1;
+}
+
+}  // namespace vhr

@@ -1,0 +1,435 @@
+// RenderGraph half of the C ABI: pass registry, transient images, execution order, per-pass timing, and the
+// two execution contexts the pass callbacks drive.  Reference: src/render_graph/render_graph.{h,cpp},
+// raytracing_execution_context.{h,cpp}, compute_execution_context.{h,cpp}.
+//
+// Where the reference records Vulkan commands and submits once per frame (renderer.cpp:135), callbacks here
+// enqueue HIP work directly on the context's single in-order stream: the order of enqueue is the order of
+// execution, which gives the sequential semantics the reference intends (it omits the compute->compute
+// barriers between its SVGF dispatches, compute_execution_context.cpp:12-29).
+#include <algorithm>
+#include <cstring>
+#include <deque>
+
+#include "vhr_internal.hpp"
+
+using namespace vhr;
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return (ctx)->fail(VHR_ERROR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static const char *kRenderOutput = "RENDER_OUTPUT";
+static const char *kRaygen = "hybrid_render_path/raygen.rgen";
+static const char *kMiss = "hybrid_render_path/miss.rmiss";
+static const char *kReflectionMiss = "hybrid_render_path/reflection_miss.rmiss";
+static const char *kReflectionHit = "hybrid_render_path/reflection_hit.rchit";
+static const char *kSvgf = "hybrid_render_path/svgf.comp";
+static const char *kAtrous = "hybrid_render_path/svgf_atrous_filter.comp";
+
+static void free_pass_events(PassDescription &p) {
+    if (p.ev_begin) hipEventDestroy(p.ev_begin);
+    if (p.ev_end) hipEventDestroy(p.ev_end);
+    p.ev_begin = p.ev_end = nullptr;
+}
+
+static int add_pass_common(vhr_context *ctx, PassDescription &p, const char *name, const vhr_transient_resource *deps, uint32_t ndeps,
+                           const vhr_transient_resource *outs, uint32_t nouts) {
+    if (!name || (!deps && ndeps) || (!outs && nouts)) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Add*Pass: null argument");
+    if (ctx->pass_descriptions.count(name))        // assert(!pass_descriptions.contains(name)), render_graph.cpp:84,99,114
+        return ctx->fail(VHR_ERROR_GRAPH, std::string("render pass '") + name + "' is already registered");
+    p.name = name;
+    p.resource_names.reserve(ndeps + nouts);
+    auto take = [&](const vhr_transient_resource *src, uint32_t n, std::vector<vhr_transient_resource> &dst) -> int {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!src[i].name) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Add*Pass: transient resource without a name");
+            if (src[i].type != VHR_TRANSIENT_RESOURCE_IMAGE) return ctx->fail(VHR_ERROR_GRAPH, "transient buffers are not supported (render_graph.cpp:1015-1018)");
+            p.resource_names.emplace_back(src[i].name);   // the reference stores the caller's pointer; we own a copy
+            dst.push_back(src[i]);
+        }
+        return VHR_OK;
+    };
+    int rc = take(deps, ndeps, p.dependencies);
+    if (rc) return rc;
+    rc = take(outs, nouts, p.outputs);
+    if (rc) return rc;
+    size_t k = 0;
+    for (auto &r : p.dependencies) r.name = p.resource_names[k++].c_str();
+    for (auto &r : p.outputs) r.name = p.resource_names[k++].c_str();
+    return VHR_OK;
+}
+
+static void commit_pass(vhr_context *ctx, PassDescription &&p) {
+    const std::string name = p.name;
+    auto &slot = ctx->pass_descriptions[name];
+    slot = std::move(p);
+    // resource name pointers must follow the moved strings
+    size_t k = 0;
+    for (auto &r : slot.dependencies) r.name = slot.resource_names[k++].c_str();
+    for (auto &r : slot.outputs) r.name = slot.resource_names[k++].c_str();
+    ctx->registration_order.push_back(name);
+    ctx->built = false;
+}
+
+static const vhr_transient_resource *find_binding(const PassDescription &p, uint32_t binding) {
+    for (auto &r : p.dependencies) if (r.image.binding == binding) return &r;
+    for (auto &r : p.outputs) if (r.image.binding == binding) return &r;
+    return nullptr;
+}
+
+static Image *pass_image(vhr_context *ctx, const PassDescription &p, uint32_t binding, int32_t expect_format, const char *what) {
+    const vhr_transient_resource *r = find_binding(p, binding);
+    if (!r) { ctx->fail(VHR_ERROR_GRAPH, std::string("pass '") + p.name + "' declares no resource at binding " + std::to_string(binding) + " (" + what + ")"); return nullptr; }
+    auto it = ctx->images.find(r->name);
+    if (it == ctx->images.end()) { ctx->fail(VHR_ERROR_GRAPH, std::string("transient image '") + r->name + "' was not created (graph not built?)"); return nullptr; }
+    if (expect_format && it->second.format != expect_format) {
+        ctx->fail(VHR_ERROR_GRAPH, std::string("transient image '") + r->name + "' has an unexpected format for " + what);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+extern "C" {
+
+int vhr_graph_destroy_resources(vhr_context *ctx) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pass_descriptions) free_pass_events(kv.second);
+    for (auto &kv : ctx->images) hipFree(kv.second.owned);
+    ctx->pass_descriptions.clear();
+    ctx->registration_order.clear();
+    ctx->execution_order.clear();
+    ctx->images.clear();
+    ctx->compute_kernel_owner.clear();
+    ctx->built = false;
+    return VHR_OK;
+}
+
+int vhr_graph_add_graphics_pass(vhr_context *ctx, const char *name, const vhr_transient_resource *deps, uint32_t ndeps,
+                                const vhr_transient_resource *outs, uint32_t nouts, vhr_external_pass_callback cb, void *user) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    PassDescription p;
+    p.kind = PassKind::Graphics;
+    int rc = add_pass_common(ctx, p, name, deps, ndeps, outs, nouts);
+    if (rc) return rc;
+    p.external_cb = cb;
+    p.user = user;
+    commit_pass(ctx, std::move(p));
+    return VHR_OK;
+}
+
+int vhr_graph_add_raytracing_pass(vhr_context *ctx, const char *name, const vhr_transient_resource *deps, uint32_t ndeps,
+                                  const vhr_transient_resource *outs, uint32_t nouts,
+                                  const vhr_raytracing_pipeline_description *pipeline, vhr_raytracing_pass_callback cb, void *user) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!pipeline || !pipeline->raygen_shader || !cb) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "AddRaytracingPass: pipeline description and callback are required");
+    // Shader names select the HIP kernels.  Only the hybrid path's shader set exists here.
+    if (std::strcmp(pipeline->raygen_shader, kRaygen) != 0)
+        return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no HIP kernel for raygen shader '") + pipeline->raygen_shader + "'");
+    PassDescription p;
+    p.kind = PassKind::Raytracing;
+    int rc = add_pass_common(ctx, p, name, deps, ndeps, outs, nouts);
+    if (rc) return rc;
+    p.pipeline_name = pipeline->name ? pipeline->name : "";
+    p.raygen = pipeline->raygen_shader;
+    for (uint32_t i = 0; i < pipeline->miss_shader_count; ++i) p.miss.emplace_back(pipeline->miss_shaders[i] ? pipeline->miss_shaders[i] : "");
+    for (uint32_t i = 0; i < pipeline->hit_shader_count; ++i) {
+        if (pipeline->hit_shaders[i].any_hit) return ctx->fail(VHR_ERROR_NOT_FOUND, "any-hit shaders are not part of the hybrid path (all geometry is opaque, resource_manager.cpp:633)");
+        p.closest_hit.emplace_back(pipeline->hit_shaders[i].closest_hit ? pipeline->hit_shaders[i].closest_hit : "");
+    }
+    // miss index 0 = visibility, 1 = reflection (raygen.rgen:39,64); hit group 0 = reflection closest hit
+    if (p.miss.size() < 2 || p.miss[0] != kMiss || p.miss[1] != kReflectionMiss || p.closest_hit.empty() || p.closest_hit[0] != kReflectionHit)
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "raytracing pipeline must name miss.rmiss, reflection_miss.rmiss and reflection_hit.rchit (hybrid_render_path.cpp:112-124)");
+    p.rt_cb = cb;
+    p.user = user;
+    commit_pass(ctx, std::move(p));
+    return VHR_OK;
+}
+
+int vhr_graph_add_compute_pass(vhr_context *ctx, const char *name, const vhr_transient_resource *deps, uint32_t ndeps,
+                               const vhr_transient_resource *outs, uint32_t nouts, const vhr_compute_pipeline_description *pipeline,
+                               vhr_compute_pass_callback cb, void *user) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!pipeline || !cb || (!pipeline->kernels && pipeline->kernel_count)) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "AddComputePass: pipeline description and callback are required");
+    PassDescription p;
+    p.kind = PassKind::Compute;
+    int rc = add_pass_common(ctx, p, name, deps, ndeps, outs, nouts);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < pipeline->kernel_count; ++i) {
+        const char *k = pipeline->kernels[i];
+        if (!k || (std::strcmp(k, kSvgf) != 0 && std::strcmp(k, kAtrous) != 0))
+            return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no HIP kernel for compute shader '") + (k ? k : "(null)") + "'");
+        if (ctx->compute_kernel_owner.count(k))       // assert(!compute_pipelines.contains(kernel.shader)), render_graph.cpp:677
+            return ctx->fail(VHR_ERROR_GRAPH, std::string("compute shader '") + k + "' is already registered by pass '" + ctx->compute_kernel_owner[k] + "'");
+        p.kernels.emplace_back(k);
+    }
+    for (auto &k : p.kernels) ctx->compute_kernel_owner[k] = name;
+    p.push_constant_size = pipeline->push_constant_size;
+    p.compute_cb = cb;
+    p.user = user;
+    commit_pass(ctx, std::move(p));
+    return VHR_OK;
+}
+
+// ActualizeResource, render_graph.cpp:921-977
+static int actualize(vhr_context *ctx, const vhr_transient_resource &r) {
+    if (!std::strcmp(r.name, kRenderOutput)) return VHR_OK;
+    if (ctx->images.count(r.name)) return VHR_OK;
+    Image im;
+    im.width = (r.image.width == 0 && r.image.height == 0) ? ctx->width : r.image.width;      // swapchain sized, :960-964
+    im.height = (r.image.width == 0 && r.image.height == 0) ? ctx->height : r.image.height;
+    im.format = r.image.format;
+    im.bpp = format_stride(r.image.format);
+    if (!im.bpp || !im.width || !im.height) return ctx->fail(VHR_ERROR_GRAPH, std::string("transient image '") + r.name + "': unsupported format or empty extent");
+    HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
+    HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
+    im.ptr = im.owned;
+    im.used = true;
+    ctx->images[r.name] = im;
+    return VHR_OK;
+}
+
+// FindExecutionOrder, render_graph.cpp:686-720: BFS from the single writer of RENDER_OUTPUT through
+// writers[dependency], reversed, duplicates pruned keeping the first occurrence.
+static int find_execution_order(vhr_context *ctx, std::map<std::string, std::vector<std::string>> &writers) {
+    auto &w = writers[kRenderOutput];
+    if (w.size() != 1) return ctx->fail(VHR_ERROR_GRAPH, "exactly one pass must write RENDER_OUTPUT (render_graph.cpp:687)");
+    std::vector<std::string> order{ w[0] };
+    std::deque<std::string> stack{ w[0] };
+    size_t guard = 0;
+    while (!stack.empty()) {
+        const PassDescription &pass = ctx->pass_descriptions[stack.front()];
+        stack.pop_front();
+        for (const auto &dep : pass.dependencies)
+            for (const auto &writer : writers[dep.name]) {
+                order.push_back(writer);
+                stack.push_back(writer);
+            }
+        if (++guard > 1000000) return ctx->fail(VHR_ERROR_GRAPH, "cyclic render graph");
+    }
+    std::reverse(order.begin(), order.end());
+    std::vector<std::string> found;
+    for (auto &n : order)
+        if (std::find(found.begin(), found.end(), n) == found.end()) found.push_back(n);
+    ctx->execution_order = found;
+    return VHR_OK;
+}
+
+// SanityCheck, render_graph.cpp:980-1021
+static int sanity_check(vhr_context *ctx) {
+    std::map<std::string, std::vector<vhr_transient_resource>> participating;
+    for (auto &name : ctx->execution_order) {
+        const PassDescription &p = ctx->pass_descriptions[name];
+        for (auto &r : p.dependencies) participating[r.name].push_back(r);
+        for (auto &r : p.outputs) participating[r.name].push_back(r);
+    }
+    for (auto &kv : participating) {
+        if (kv.first == kRenderOutput) continue;
+        const auto &f = kv.second.front();
+        for (auto &r : kv.second)
+            if (r.image.width != f.image.width || r.image.height != f.image.height || r.image.format != f.image.format)
+                return ctx->fail(VHR_ERROR_GRAPH, "SanityCheck: resource '" + kv.first + "' is declared with different extent/format by different passes");
+    }
+    return VHR_OK;
+}
+
+int vhr_graph_build(vhr_context *ctx) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::map<std::string, std::vector<std::string>> writers;
+    // the reference iterates an unordered_map; registration order is the deterministic choice here
+    for (auto &name : ctx->registration_order) {
+        PassDescription &p = ctx->pass_descriptions[name];
+        for (auto &r : p.dependencies) { int rc = actualize(ctx, r); if (rc) return rc; }
+        for (auto &r : p.outputs) { writers[r.name].push_back(p.name); int rc = actualize(ctx, r); if (rc) return rc; }
+        if (!p.ev_begin) {
+            HIP_TRY(ctx, hipEventCreate(&p.ev_begin));
+            HIP_TRY(ctx, hipEventCreate(&p.ev_end));
+        }
+    }
+    int rc = find_execution_order(ctx, writers);
+    if (rc) return rc;
+    rc = sanity_check(ctx);
+    if (rc) return rc;
+    ctx->built = true;
+    return VHR_OK;
+}
+
+int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_idx) {
+    (void)image_idx;
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->built) return ctx->fail(VHR_ERROR_GRAPH, "Execute before Build");
+    if (resource_idx >= 3) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "resource_idx >= MAX_FRAMES_IN_FLIGHT");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->error.clear();
+    for (auto &name : ctx->execution_order) {
+        PassDescription &p = ctx->pass_descriptions[name];
+        HIP_TRY(ctx, hipEventRecord(p.ev_begin, ctx->stream));                 // vkCmdWriteTimestamp, render_graph.cpp:167-182
+        if (p.kind == PassKind::Graphics) {
+            if (p.external_cb) p.external_cb(p.user, ctx);
+        } else if (p.kind == PassKind::Raytracing) {
+            vhr_raytracing_execution_context ec{ ctx, &p, resource_idx };      // ExecuteRaytracingPass, :889-912
+            p.rt_cb(p.user, &ec);
+        } else {
+            vhr_compute_execution_context ec{ ctx, &p, resource_idx };         // ExecuteComputePass, :914-919
+            p.compute_cb(p.user, &ec);
+        }
+        HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
+        p.timed = true;
+        if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
+        if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
+    }
+    return VHR_OK;
+}
+
+int vhr_graph_gather_performance_statistics(vhr_context *ctx) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           // VK_QUERY_RESULT_WAIT_BIT, render_graph.cpp:192-193
+    for (auto &name : ctx->execution_order) {
+        PassDescription &p = ctx->pass_descriptions[name];
+        if (!p.timed) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.ev_begin, p.ev_end) != hipSuccess) continue;
+        p.last_ms = ms;
+        p.ema_ms = p.ema_ms * 0.95 + double(ms) * 0.05;                        // render_graph.cpp:199
+    }
+    return VHR_OK;
+}
+
+int vhr_graph_get_pass_time_ms(vhr_context *ctx, const char *name, double *ema_ms, double *last_ms) {
+    if (!ctx || !name) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->pass_descriptions.find(name);
+    if (it == ctx->pass_descriptions.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no pass named '") + name + "'");
+    if (ema_ms) *ema_ms = it->second.ema_ms;
+    if (last_ms) *last_ms = it->second.last_ms;
+    return VHR_OK;
+}
+
+int vhr_graph_get_execution_order(vhr_context *ctx, char *buf, uint32_t buf_size) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    std::string s;
+    for (size_t i = 0; i < ctx->execution_order.size(); ++i) { if (i) s += '\n'; s += ctx->execution_order[i]; }
+    if (buf && buf_size) { std::strncpy(buf, s.c_str(), buf_size - 1); buf[buf_size - 1] = 0; }
+    return int(ctx->execution_order.size());
+}
+
+int vhr_graph_contains_image(vhr_context *ctx, const char *image_name) {
+    return (ctx && image_name && ctx->images.count(image_name)) ? 1 : 0;
+}
+int32_t vhr_graph_get_image_format(vhr_context *ctx, const char *image_name) {
+    if (!ctx || !image_name) return 0;
+    auto it = ctx->images.find(image_name);
+    return it == ctx->images.end() ? 0 : it->second.format;
+}
+
+int vhr_graph_set_pass_epilogue(vhr_context *ctx, const char *name, vhr_external_pass_callback cb, void *user) {
+    if (!ctx || !name) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->pass_descriptions.find(name);
+    if (it == ctx->pass_descriptions.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no pass named '") + name + "'");
+    it->second.epilogue_cb = cb;
+    it->second.epilogue_user = user;
+    return VHR_OK;
+}
+
+int vhr_graph_bind_external_image(vhr_context *ctx, const char *image_name, void *device_ptr) {
+    if (!ctx || !image_name) return VHR_ERROR_INVALID_ARGUMENT;
+    auto it = ctx->images.find(image_name);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + image_name + "'");
+    it->second.ptr = device_ptr ? device_ptr : it->second.owned;
+    return VHR_OK;
+}
+
+// ---- RaytracingExecutionContext::TraceRays (raytracing_execution_context.cpp:4-13) ----
+int vhr_trace_rays(vhr_raytracing_execution_context *exec, uint32_t width, uint32_t height) {
+    if (!exec) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = exec->ctx;
+    const PassDescription &p = *exec->pass;
+    // set 3 bindings of raygen.rgen:6-9
+    Image *normals = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
+    Image *depth = pass_image(ctx, p, 1, VHR_FORMAT_D32_SFLOAT, "depth");
+    Image *shadow_ao = pass_image(ctx, p, 2, VHR_FORMAT_R16G16_SFLOAT, "raytraced_shadow_and_ambient_occlusion");
+    if (!normals || !depth || !shadow_ao) return VHR_ERROR_GRAPH;
+    Image *reflections = find_binding(p, 3) ? pass_image(ctx, p, 3, VHR_FORMAT_R16G16B16A16_SFLOAT, "raytraced_reflections") : nullptr;
+    if (find_binding(p, 3) && !reflections) return VHR_ERROR_GRAPH;
+    return launch_raygen(ctx, ctx->per_frame[exec->resource_idx], width, height, *normals, *depth, *shadow_ao, reflections);
+}
+
+// ---- ComputeExecutionContext (compute_execution_context.{h,cpp}) ----
+int vhr_compute_get_display_size(vhr_compute_execution_context *exec, uint32_t *width, uint32_t *height) {
+    if (!exec || !width || !height) return VHR_ERROR_INVALID_ARGUMENT;
+    *width = exec->ctx->width;              // context.swapchain.extent, compute_execution_context.cpp:8-10
+    *height = exec->ctx->height;
+    return VHR_OK;
+}
+
+static Image *storage_image(vhr_context *ctx, int32_t id, const char *what) {
+    if (id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used) {
+        ctx->fail(VHR_ERROR_NOT_FOUND, std::string("storage image index ") + std::to_string(id) + " (" + what + ") is not allocated");
+        return nullptr;
+    }
+    return &ctx->storage_images[id];
+}
+
+int vhr_compute_dispatch(vhr_compute_execution_context *exec, const char *shader, uint32_t x_groups, uint32_t y_groups,
+                         uint32_t z_groups, const void *push_constants, uint32_t push_constants_size) {
+    if (!exec || !shader) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = exec->ctx;
+    const PassDescription &p = *exec->pass;
+    if (std::find(p.kernels.begin(), p.kernels.end(), shader) == p.kernels.end())
+        return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("compute shader '") + shader + "' is not part of pass '" + p.name + "'");
+    if (push_constants_size != p.push_constant_size || (push_constants_size && !push_constants))     // assert, compute_execution_context.h:23
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: push constant size differs from the pipeline's declaration");
+    if (push_constants_size != sizeof(vhr_svgf_push_constants))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: the SVGF kernels take SVGFPushConstants (24 bytes)");
+    if (z_groups != 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: z_groups must be 1");
+    vhr_svgf_push_constants pc;
+    std::memcpy(&pc, push_constants, sizeof pc);              // copied at call time, like vkCmdPushConstants
+    const vhr_per_frame_data &pfd = ctx->per_frame[exec->resource_idx];
+    // set 3 bindings of svgf.comp:8-12 / svgf_atrous_filter.comp:8-12
+    Image *normals = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
+    if (!normals) return VHR_ERROR_GRAPH;
+    if (!std::strcmp(shader, kSvgf)) {
+        Image *motion = pass_image(ctx, p, 1, VHR_FORMAT_R16G16B16A16_SFLOAT, "motion_vectors_and_metallic_roughness");
+        Image *raytraced = pass_image(ctx, p, 3, VHR_FORMAT_R16G16_SFLOAT, "raytraced_shadow_and_ao_texture");
+        Image *integrated = storage_image(ctx, pc.integrated_shadow_and_ao[0], "integrated_shadow_and_ao[0]");
+        Image *prev_normals = storage_image(ctx, pc.prev_frame_normals_and_object_ids, "prev_frame_normals_and_object_ids");
+        Image *history = storage_image(ctx, pc.shadow_and_ao_history, "shadow_and_ao_history");
+        Image *moments = storage_image(ctx, pc.shadow_and_ao_moments_history, "shadow_and_ao_moments_history");
+        if (!motion || !raytraced || !integrated || !prev_normals || !history || !moments) return VHR_ERROR_GRAPH;
+        return launch_svgf_temporal(ctx, pfd, *normals, *motion, *raytraced, *prev_normals, *history, *moments, *integrated, x_groups, y_groups);
+    }
+    Image *in = storage_image(ctx, pc.integrated_shadow_and_ao[0], "integrated_shadow_and_ao[0]");
+    Image *out = storage_image(ctx, pc.integrated_shadow_and_ao[1], "integrated_shadow_and_ao[1]");
+    if (!in || !out) return VHR_ERROR_GRAPH;
+    return launch_svgf_atrous(ctx, pfd, *normals, *in, *out, pc.atrous_step, x_groups, y_groups);
+}
+
+int vhr_compute_blit_image_storage_to_transient(vhr_compute_execution_context *exec, int32_t src, const char *dst) {
+    if (!exec || !dst) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = exec->ctx;
+    Image *s = storage_image(ctx, src, "blit source");
+    auto it = ctx->images.find(dst);
+    if (!s) return VHR_ERROR_GRAPH;
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + dst + "'");
+    return copy_image_rows(ctx, *s, it->second);
+}
+int vhr_compute_blit_image_transient_to_storage(vhr_compute_execution_context *exec, const char *src, int32_t dst) {
+    if (!exec || !src) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = exec->ctx;
+    Image *d = storage_image(ctx, dst, "blit destination");
+    auto it = ctx->images.find(src);
+    if (!d) return VHR_ERROR_GRAPH;
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + src + "'");
+    return copy_image_rows(ctx, it->second, *d);
+}
+int vhr_compute_blit_image_storage_to_storage(vhr_compute_execution_context *exec, int32_t src, int32_t dst) {
+    if (!exec) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = exec->ctx;
+    Image *s = storage_image(ctx, src, "blit source"), *d = storage_image(ctx, dst, "blit destination");
+    if (!s || !d) return VHR_ERROR_GRAPH;
+    return copy_image_rows(ctx, *s, *d);
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// Internal declarations shared by the host side (context / graph / BVH build) and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "vhr_amd.h"
+
+namespace vhr {
+
+// ---------------------------------------------------------------------------------------------
+// device-visible scene layout
+// ---------------------------------------------------------------------------------------------
+// BVH2 node = the two child boxes + two child links, 64 B = 4 x dwordx4 loads.
+//   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//   q2 = (lo1.z, hi1.x, hi1.y, hi1.z)  q3 = (child0, child1, 0, 0) as int bits
+// child >= 0: inner node index.  child < 0: leaf, v = ~child, first = v >> 2, count = (v & 3) + 1.
+// An absent child (single-leaf scene) has an inverted box (lo = +inf, hi = -inf) and is never entered.
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+
+// Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
+// (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
+struct BvhTri {
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    uint32_t prim;      // gl_GeometryIndexEXT
+    uint32_t tri;       // gl_PrimitiveID
+    uint32_t flat;      // primitive-major flat triangle index (closest-hit tie break)
+};
+static_assert(sizeof(BvhTri) == 48, "BvhTri");
+
+constexpr int kMaxLeafTris = 4;
+constexpr int kMaxBvhDepth = 32;     // builder guarantee == traversal stack capacity
+constexpr int kTraceStack = 32;
+
+struct DeviceTexture {
+    const uint8_t *texels;   // RGBA8
+    uint32_t width, height;
+    int32_t format;          // VHR_FORMAT_R8G8B8A8_{SRGB,UNORM}
+    int32_t mag_filter, address_u, address_v;
+    int32_t pad;
+};
+
+struct DeviceScene {
+    const BvhNode *nodes;
+    const BvhTri *tris;
+    const vhr_vertex *vertices;
+    const uint32_t *indices;
+    const vhr_primitive *primitives;
+    const float *normal_matrices;    // 9 floats per primitive, column-major inverseTranspose(mat3(transform))
+    const DeviceTexture *textures;
+    uint32_t node_count, tri_count, primitive_count, texture_count;
+};
+
+// ---------------------------------------------------------------------------------------------
+// host-side objects
+// ---------------------------------------------------------------------------------------------
+struct Image {
+    void *ptr = nullptr;          // active device pointer (owned or external)
+    void *owned = nullptr;        // context-owned allocation (may differ from ptr when bound externally)
+    void *alt = nullptr;          // second buffer for images a kernel reads and rewrites in one dispatch
+    uint32_t width = 0, height = 0;
+    int32_t format = 0;
+    uint32_t bpp = 0;
+    bool used = false;
+    size_t bytes() const { return size_t(width) * height * bpp; }
+};
+
+struct HostBvh {
+    std::vector<BvhNode> nodes;
+    std::vector<BvhTri> tris;
+    uint32_t max_depth = 0;
+};
+
+// builds the BVH2 (csrc/bvh_build.cpp)
+void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
+               uint32_t primitive_count, HostBvh &out);
+
+enum class PassKind { Graphics, Raytracing, Compute };
+
+struct PassDescription {
+    std::string name;
+    PassKind kind;
+    std::vector<vhr_transient_resource> dependencies, outputs;
+    std::vector<std::string> resource_names;       // storage for the name strings above
+    // raytracing
+    std::string pipeline_name, raygen;
+    std::vector<std::string> miss, closest_hit;
+    // compute
+    std::vector<std::string> kernels;
+    uint32_t push_constant_size = 0;
+    vhr_external_pass_callback external_cb = nullptr;
+    vhr_raytracing_pass_callback rt_cb = nullptr;
+    vhr_compute_pass_callback compute_cb = nullptr;
+    void *user = nullptr;
+    vhr_external_pass_callback epilogue_cb = nullptr;
+    void *epilogue_user = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timed = false;
+    double ema_ms = 0.0, last_ms = 0.0;
+};
+
+struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, pad; };
+
+}  // namespace vhr
+
+struct vhr_raytracing_execution_context {
+    vhr_context *ctx;
+    vhr::PassDescription *pass;
+    uint32_t resource_idx;
+};
+struct vhr_compute_execution_context {
+    vhr_context *ctx;
+    vhr::PassDescription *pass;
+    uint32_t resource_idx;
+};
+
+struct vhr_context {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string error;
+
+    // ResourceManager state
+    static constexpr uint32_t kMaxGlobalResources = 2048;   // resource_manager.h:13
+    std::vector<vhr::Image> storage_images;                 // pool of kMaxGlobalResources
+    struct Texture { void *texels; uint32_t w, h; int32_t format; vhr_sampler_info sampler; };
+    std::vector<Texture> textures;
+    vhr::DeviceTexture *d_textures = nullptr;
+    bool textures_dirty = false;
+    vhr_per_frame_data per_frame[3] = {};
+    vhr_trace_params trace_params = {};
+
+    // scene
+    vhr_vertex *d_vertices = nullptr;
+    uint32_t *d_indices = nullptr;
+    vhr_primitive *d_primitives = nullptr;
+    float *d_normal_matrices = nullptr;
+    vhr::BvhNode *d_nodes = nullptr;
+    vhr::BvhTri *d_tris = nullptr;
+    uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
+
+    // RenderGraph state
+    std::map<std::string, vhr::PassDescription> pass_descriptions;
+    std::vector<std::string> registration_order;
+    std::vector<std::string> execution_order;
+    std::unordered_map<std::string, vhr::Image> images;
+    std::unordered_map<std::string, std::string> compute_kernel_owner;    // shader -> pass (global key)
+    bool built = false;
+
+    // strips
+    uint32_t row_begin = 0, row_end = 0, overlap = 0;
+
+    // statistics
+    bool ray_stats_enabled = false;
+    vhr::RayStats *d_ray_stats = nullptr;
+    vhr::RayStats h_ray_stats = {};
+
+    vhr::DeviceScene device_scene() const;
+    int fail(int code, const std::string &msg) { error = msg; return code; }
+};
+
+namespace vhr {
+
+uint32_t format_stride(int32_t format);   // VkUtils::FormatStride (vulkan_utils.h:128-148)
+
+// kernel launchers (csrc/kernels_trace.hip, csrc/kernels_svgf.hip).  All enqueue on ctx->stream.
+struct ImageView { void *ptr; uint32_t width, height; };
+int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height,
+                  const Image &normals, const Image &depth, Image &shadow_ao, Image *reflections);
+int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth);
+int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
+                         const Image &raytraced, const Image &prev_normals, const Image &history,
+                         Image &moments, Image &integrated_out, uint32_t x_groups, uint32_t y_groups);
+int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in,
+                       Image &out, int32_t step, uint32_t x_groups, uint32_t y_groups);
+int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst);
+
+}  // namespace vhr

@@ -1,0 +1,478 @@
+"""ctypes binding of libvhr_amd.so (the C ABI declared in include/vhr_amd.h).
+
+The shared library is the product; this module only marshals numpy arrays and Python callbacks across the
+boundary, mirroring the reference's class names (ResourceManager / RenderGraph / execution contexts:
+/root/reference/src/rendering_backend/resource_manager.h:16-78, src/render_graph/render_graph.h:5-60,
+compute_execution_context.h:7-43, raytracing_execution_context.h:4-20).  There is no CPU fallback: if the
+library is missing or no HIP device exists, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvhr_amd.so")
+
+# every symbol include/vhr_amd.h declares (tests/test_abi.py checks the .so exports each of them)
+EXPORTS = [
+    "vhr_create", "vhr_destroy", "vhr_last_error", "vhr_synchronize", "vhr_version", "vhr_abi_struct_sizes",
+    "vhr_default_trace_params", "vhr_update_geometry", "vhr_upload_texture_from_data", "vhr_upload_new_storage_image",
+    "vhr_destroy_storage_image", "vhr_update_per_frame_ubo", "vhr_set_trace_params", "vhr_graph_destroy_resources",
+    "vhr_graph_add_graphics_pass", "vhr_graph_add_raytracing_pass", "vhr_graph_add_compute_pass", "vhr_graph_build",
+    "vhr_graph_execute", "vhr_graph_gather_performance_statistics", "vhr_graph_get_pass_time_ms",
+    "vhr_graph_get_execution_order", "vhr_graph_contains_image", "vhr_graph_get_image_format",
+    "vhr_graph_set_pass_epilogue", "vhr_graph_bind_external_image", "vhr_trace_rays", "vhr_compute_get_display_size",
+    "vhr_compute_dispatch", "vhr_compute_blit_image_storage_to_transient", "vhr_compute_blit_image_transient_to_storage",
+    "vhr_compute_blit_image_storage_to_storage", "vhr_hybrid_create", "vhr_hybrid_destroy", "vhr_hybrid_build",
+    "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
+    "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
+    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_set_strip",
+    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics",
+]
+
+
+class VhrError(RuntimeError):
+    pass
+
+
+class CreateInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("stream", C.c_void_p),
+                ("flags", C.c_uint32)]
+
+
+class TransientImage(C.Structure):
+    _fields_ = [("type", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_int32),
+                ("binding", C.c_uint32), ("clear_value", C.c_float * 4), ("multisampled", C.c_int32)]
+
+
+class TransientResource(C.Structure):
+    _fields_ = [("type", C.c_int32), ("name", C.c_char_p), ("image", TransientImage)]
+
+
+class HitShader(C.Structure):
+    _fields_ = [("closest_hit", C.c_char_p), ("any_hit", C.c_char_p)]
+
+
+class RaytracingPipelineDescription(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("raygen_shader", C.c_char_p), ("miss_shaders", C.POINTER(C.c_char_p)),
+                ("miss_shader_count", C.c_uint32), ("hit_shaders", C.POINTER(HitShader)), ("hit_shader_count", C.c_uint32)]
+
+
+class ComputePipelineDescription(C.Structure):
+    _fields_ = [("kernels", C.POINTER(C.c_char_p)), ("kernel_count", C.c_uint32), ("push_constant_size", C.c_uint32)]
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [("device_ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_int32),
+                ("bytes_per_pixel", C.c_uint32)]
+
+
+class HybridSettings(C.Structure):
+    _fields_ = [("shadow_mode", C.c_int32), ("ambient_occlusion_mode", C.c_int32), ("reflection_mode", C.c_int32),
+                ("denoise_shadow_and_ao", C.c_int32), ("atrous_steps", C.c_int32)]
+
+
+EXTERNAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+RAYTRACING_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+COMPUTE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+_lib = None
+
+
+def load():
+    """Load libvhr_amd.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VhrError(f"{LIB_PATH} is missing: build it with `make -C vulkanhybridrenderer_amd/csrc` "
+                       "(there is no CPU or pure-Python fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+    L.vhr_create.argtypes = [C.POINTER(CreateInfo), C.POINTER(vp)]
+    L.vhr_destroy.argtypes = [vp]
+    L.vhr_destroy.restype = None
+    L.vhr_last_error.argtypes = [vp]
+    L.vhr_last_error.restype = C.c_char_p
+    L.vhr_synchronize.argtypes = [vp]
+    L.vhr_version.restype = C.c_char_p
+    L.vhr_abi_struct_sizes.argtypes = [C.POINTER(u32)]
+    L.vhr_default_trace_params.argtypes = [vp]
+    L.vhr_default_trace_params.restype = None
+    L.vhr_update_geometry.argtypes = [vp, vp, u32, vp, u32, vp, u32]
+    L.vhr_upload_texture_from_data.argtypes = [vp, u32, u32, vp, i32, vp]
+    L.vhr_upload_new_storage_image.argtypes = [vp, u32, u32, i32]
+    L.vhr_destroy_storage_image.argtypes = [vp, i32]
+    L.vhr_update_per_frame_ubo.argtypes = [vp, u32, vp]
+    L.vhr_set_trace_params.argtypes = [vp, vp]
+    L.vhr_graph_destroy_resources.argtypes = [vp]
+    L.vhr_graph_add_graphics_pass.argtypes = [vp, C.c_char_p, C.POINTER(TransientResource), u32,
+                                              C.POINTER(TransientResource), u32, EXTERNAL_CB, vp]
+    L.vhr_graph_add_raytracing_pass.argtypes = [vp, C.c_char_p, C.POINTER(TransientResource), u32,
+                                                C.POINTER(TransientResource), u32,
+                                                C.POINTER(RaytracingPipelineDescription), RAYTRACING_CB, vp]
+    L.vhr_graph_add_compute_pass.argtypes = [vp, C.c_char_p, C.POINTER(TransientResource), u32,
+                                             C.POINTER(TransientResource), u32, C.POINTER(ComputePipelineDescription),
+                                             COMPUTE_CB, vp]
+    L.vhr_graph_build.argtypes = [vp]
+    L.vhr_graph_execute.argtypes = [vp, u32, u32]
+    L.vhr_graph_gather_performance_statistics.argtypes = [vp]
+    L.vhr_graph_get_pass_time_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.vhr_graph_get_execution_order.argtypes = [vp, C.c_char_p, u32]
+    L.vhr_graph_contains_image.argtypes = [vp, C.c_char_p]
+    L.vhr_graph_get_image_format.argtypes = [vp, C.c_char_p]
+    L.vhr_graph_set_pass_epilogue.argtypes = [vp, C.c_char_p, EXTERNAL_CB, vp]
+    L.vhr_graph_bind_external_image.argtypes = [vp, C.c_char_p, vp]
+    L.vhr_trace_rays.argtypes = [vp, u32, u32]
+    L.vhr_compute_get_display_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.vhr_compute_dispatch.argtypes = [vp, C.c_char_p, u32, u32, u32, vp, u32]
+    L.vhr_compute_blit_image_storage_to_transient.argtypes = [vp, i32, C.c_char_p]
+    L.vhr_compute_blit_image_transient_to_storage.argtypes = [vp, C.c_char_p, i32]
+    L.vhr_compute_blit_image_storage_to_storage.argtypes = [vp, i32, i32]
+    L.vhr_hybrid_create.argtypes = [vp, C.POINTER(HybridSettings), EXTERNAL_CB, vp, EXTERNAL_CB, vp, C.POINTER(vp)]
+    L.vhr_hybrid_destroy.argtypes = [vp]
+    L.vhr_hybrid_destroy.restype = None
+    L.vhr_hybrid_build.argtypes = [vp]
+    L.vhr_hybrid_rebuild.argtypes = [vp, C.POINTER(HybridSettings)]
+    L.vhr_hybrid_get_push_constants.argtypes = [vp, vp]
+    L.vhr_hybrid_last_error.argtypes = [vp]
+    L.vhr_hybrid_last_error.restype = C.c_char_p
+    L.vhr_get_display_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.vhr_get_transient_image.argtypes = [vp, C.c_char_p, C.POINTER(ImageInfo)]
+    L.vhr_get_storage_image.argtypes = [vp, i32, C.POINTER(ImageInfo)]
+    L.vhr_upload_transient_image.argtypes = [vp, C.c_char_p, vp, u64]
+    L.vhr_download_transient_image.argtypes = [vp, C.c_char_p, vp, u64]
+    L.vhr_upload_storage_image.argtypes = [vp, i32, vp, u64]
+    L.vhr_download_storage_image.argtypes = [vp, i32, vp, u64]
+    L.vhr_standin_gbuffer.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.vhr_set_strip.argtypes = [vp, u32, u32, u32]
+    L.vhr_set_ray_statistics.argtypes = [vp, i32]
+    L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+# image / resource names of the hybrid path (hybrid_render_path.cpp:16-19,104-111,265-273)
+NORMALS = "World Space Normals and Object IDs"
+MOTION = "Motion Vectors and Metallic Roughness"
+DEPTH = "Depth"
+RAYTRACED = "Raytraced Shadows and Ambient Occlusion"
+REFLECTIONS = "Raytraced Reflections"
+DENOISED = "Denoised Raytraced Shadows and Ambient Occlusion"
+SVGF_SHADER = "hybrid_render_path/svgf.comp"
+ATROUS_SHADER = "hybrid_render_path/svgf_atrous_filter.comp"
+
+ATTACHMENT_IMAGE, SAMPLED_IMAGE, STORAGE_IMAGE = 0, 1, 2
+
+
+def transient(name, fmt, binding, kind=STORAGE_IMAGE, width=0, height=0, clear=(0, 0, 0, 0)):
+    """VkUtils::CreateTransient{Attachment,Sampled,Storage}Image (vulkan_utils.h:363-453)."""
+    r = TransientResource()
+    r.type = 0
+    r.name = name.encode()
+    r.image.type = kind
+    r.image.width, r.image.height = width, height
+    r.image.format = fmt
+    r.image.binding = binding
+    r.image.clear_value = (C.c_float * 4)(*clear)
+    return r
+
+
+def render_output(binding=0):
+    return transient("RENDER_OUTPUT", 0, binding, ATTACHMENT_IMAGE)
+
+
+_NP_FORMATS = {abi.FORMAT_R16G16B16A16_SFLOAT: (np.uint16, 4), abi.FORMAT_R16G16_SFLOAT: (np.uint16, 2),
+               abi.FORMAT_D32_SFLOAT: (np.float32, 1), abi.FORMAT_B8G8R8A8_UNORM: (np.uint8, 4),
+               abi.FORMAT_R8G8B8A8_UNORM: (np.uint8, 4), abi.FORMAT_R8G8B8A8_SRGB: (np.uint8, 4)}
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """vhr_context: device + ResourceManager + RenderGraph state for one GPU."""
+
+    def __init__(self, width, height, device=0, stream=None):
+        self.L = load()
+        self.handle = C.c_void_p()
+        info = CreateInfo(device, width, height, stream, 0)
+        rc = self.L.vhr_create(C.byref(info), C.byref(self.handle))
+        if rc < 0:
+            self.handle = None
+            raise VhrError("vhr_create: " + self.L.vhr_last_error(None).decode())
+        self.width, self.height = width, height
+        self._keep = []        # callbacks and strings the C side points at
+        self._callback_error = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.vhr_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc < 0:
+            raise VhrError(f"{what}: {self.L.vhr_last_error(self.handle).decode()}")
+        return rc
+
+    def synchronize(self):
+        self.check(self.L.vhr_synchronize(self.handle), "synchronize")
+
+    # ---- ResourceManager ----
+    def update_geometry(self, vertices, indices, primitives):
+        v = np.ascontiguousarray(vertices)
+        i = np.ascontiguousarray(indices, np.uint32)
+        p = np.ascontiguousarray(primitives)
+        assert v.dtype == abi.vertex_dtype and p.dtype == abi.primitive_dtype
+        self.check(self.L.vhr_update_geometry(self.handle, _p(v), len(v), _p(i), len(i), _p(p), len(p)), "UpdateGeometry")
+
+    def upload_scene(self, scene):
+        for t in scene.textures:
+            self.upload_texture_from_data(t["rgba8"], t["format"], (t["mag"], t["min"], t["address_u"], t["address_v"]))
+        self.update_geometry(scene.vertices, scene.indices, scene.primitives)
+
+    def upload_texture_from_data(self, rgba8, fmt=abi.FORMAT_R8G8B8A8_UNORM, sampler=None):
+        img = np.ascontiguousarray(rgba8, np.uint8)
+        s = (C.c_int32 * 4)(*sampler) if sampler is not None else None
+        return self.check(self.L.vhr_upload_texture_from_data(self.handle, img.shape[1], img.shape[0], _p(img), fmt, s),
+                          "UploadTextureFromData")
+
+    def upload_new_storage_image(self, width, height, fmt):
+        r = self.L.vhr_upload_new_storage_image(self.handle, width, height, fmt)
+        if r < -1:
+            self.check(r, "UploadNewStorageImage")
+        return r
+
+    def destroy_storage_image(self, idx):
+        self.check(self.L.vhr_destroy_storage_image(self.handle, idx), "DestroyStorageImage")
+
+    def update_per_frame_ubo(self, resource_idx, pfd):
+        a = np.ascontiguousarray(pfd)
+        assert a.dtype == abi.per_frame_dtype
+        self.check(self.L.vhr_update_per_frame_ubo(self.handle, resource_idx, _p(a)), "UpdatePerFrameUBO")
+
+    def set_trace_params(self, tp):
+        a = np.ascontiguousarray(tp)
+        assert a.dtype == abi.trace_params_dtype
+        self.check(self.L.vhr_set_trace_params(self.handle, _p(a)), "set_trace_params")
+
+    def set_strip(self, row_begin, row_end, overlap=0):
+        self.check(self.L.vhr_set_strip(self.handle, row_begin, row_end, overlap), "set_strip")
+
+    # ---- RenderGraph ----
+    def destroy_resources(self):
+        self.check(self.L.vhr_graph_destroy_resources(self.handle), "DestroyResources")
+        self._keep.clear()
+
+    @staticmethod
+    def _resources(lst):
+        arr = (TransientResource * max(1, len(lst)))(*lst)
+        return arr, len(lst)
+
+    def add_graphics_pass(self, name, dependencies, outputs, callback=None):
+        cb = EXTERNAL_CB(lambda user, ctx: self._guard(lambda: callback(self))) if callback else EXTERNAL_CB()
+        d, nd = self._resources(dependencies)
+        o, no = self._resources(outputs)
+        self._keep += [cb, d, o, dependencies, outputs]
+        self.check(self.L.vhr_graph_add_graphics_pass(self.handle, name.encode(), d, nd, o, no, cb, None), "AddGraphicsPass")
+
+    def add_raytracing_pass(self, name, dependencies, outputs, callback, raygen="hybrid_render_path/raygen.rgen",
+                            miss=("hybrid_render_path/miss.rmiss", "hybrid_render_path/reflection_miss.rmiss"),
+                            closest_hit=("hybrid_render_path/reflection_hit.rchit",), pipeline_name="Raytrace Pipeline"):
+        cb = RAYTRACING_CB(lambda user, exec_: self._guard(lambda: callback(RaytracingExecutionContext(self, exec_))))
+        d, nd = self._resources(dependencies)
+        o, no = self._resources(outputs)
+        miss_arr = (C.c_char_p * len(miss))(*[m.encode() for m in miss])
+        hits = (HitShader * len(closest_hit))(*[HitShader(h.encode(), None) for h in closest_hit])
+        desc = RaytracingPipelineDescription(pipeline_name.encode(), raygen.encode(), miss_arr, len(miss), hits, len(closest_hit))
+        self._keep += [cb, d, o, dependencies, outputs, miss_arr, hits, desc]
+        self.check(self.L.vhr_graph_add_raytracing_pass(self.handle, name.encode(), d, nd, o, no, C.byref(desc), cb, None),
+                   "AddRaytracingPass")
+
+    def add_compute_pass(self, name, dependencies, outputs, kernels, push_constant_size, callback):
+        cb = COMPUTE_CB(lambda user, exec_: self._guard(lambda: callback(ComputeExecutionContext(self, exec_))))
+        d, nd = self._resources(dependencies)
+        o, no = self._resources(outputs)
+        k = (C.c_char_p * len(kernels))(*[s.encode() for s in kernels])
+        desc = ComputePipelineDescription(k, len(kernels), push_constant_size)
+        self._keep += [cb, d, o, dependencies, outputs, k, desc]
+        self.check(self.L.vhr_graph_add_compute_pass(self.handle, name.encode(), d, nd, o, no, C.byref(desc), cb, None),
+                   "AddComputePass")
+
+    def set_pass_epilogue(self, name, callback):
+        cb = EXTERNAL_CB(lambda user, ctx: self._guard(lambda: callback(self))) if callback else EXTERNAL_CB()
+        self._keep.append(cb)
+        self.check(self.L.vhr_graph_set_pass_epilogue(self.handle, name.encode(), cb, None), "set_pass_epilogue")
+
+    def build(self):
+        self.check(self.L.vhr_graph_build(self.handle), "Build")
+
+    def execute(self, resource_idx=0, image_idx=0):
+        self._callback_error = None
+        rc = self.L.vhr_graph_execute(self.handle, resource_idx, image_idx)
+        if self._callback_error is not None:
+            raise self._callback_error
+        self.check(rc, "Execute")
+
+    def gather_performance_statistics(self):
+        self.check(self.L.vhr_graph_gather_performance_statistics(self.handle), "GatherPerformanceStatistics")
+
+    def pass_time_ms(self, name):
+        ema, last = C.c_double(), C.c_double()
+        self.check(self.L.vhr_graph_get_pass_time_ms(self.handle, name.encode(), C.byref(ema), C.byref(last)), "pass_time_ms")
+        return ema.value, last.value
+
+    def execution_order(self):
+        buf = C.create_string_buffer(4096)
+        n = self.check(self.L.vhr_graph_get_execution_order(self.handle, buf, 4096), "execution_order")
+        return buf.value.decode().split("\n") if n else []
+
+    def contains_image(self, name):
+        return bool(self.L.vhr_graph_contains_image(self.handle, name.encode()))
+
+    def image_format(self, name):
+        return self.L.vhr_graph_get_image_format(self.handle, name.encode())
+
+    def bind_external_image(self, name, device_ptr):
+        self.check(self.L.vhr_graph_bind_external_image(self.handle, name.encode(), device_ptr), "bind_external_image")
+
+    # ---- harness access ----
+    def transient_info(self, name):
+        info = ImageInfo()
+        self.check(self.L.vhr_get_transient_image(self.handle, name.encode(), C.byref(info)), "get_transient_image")
+        return info
+
+    def storage_info(self, idx):
+        info = ImageInfo()
+        self.check(self.L.vhr_get_storage_image(self.handle, idx, C.byref(info)), "get_storage_image")
+        return info
+
+    @staticmethod
+    def _host_array(info):
+        dt, ch = _NP_FORMATS[info.format]
+        shape = (info.height, info.width, ch) if ch > 1 else (info.height, info.width)
+        return np.zeros(shape, dt)
+
+    def download(self, name_or_idx):
+        if isinstance(name_or_idx, str):
+            info = self.transient_info(name_or_idx)
+            out = self._host_array(info)
+            self.check(self.L.vhr_download_transient_image(self.handle, name_or_idx.encode(), _p(out), out.nbytes), "download")
+        else:
+            info = self.storage_info(name_or_idx)
+            out = self._host_array(info)
+            self.check(self.L.vhr_download_storage_image(self.handle, name_or_idx, _p(out), out.nbytes), "download")
+        return out
+
+    def upload(self, name_or_idx, array):
+        a = np.ascontiguousarray(array)
+        if isinstance(name_or_idx, str):
+            self.check(self.L.vhr_upload_transient_image(self.handle, name_or_idx.encode(), _p(a), a.nbytes), "upload")
+        else:
+            self.check(self.L.vhr_upload_storage_image(self.handle, name_or_idx, _p(a), a.nbytes), "upload")
+
+    def standin_gbuffer(self, resource_idx=0, normals=NORMALS, motion=MOTION, depth=DEPTH):
+        self.check(self.L.vhr_standin_gbuffer(self.handle, resource_idx, normals.encode(), motion.encode(), depth.encode()),
+                   "standin_gbuffer")
+
+    def set_ray_statistics(self, enable):
+        self.check(self.L.vhr_set_ray_statistics(self.handle, int(enable)), "set_ray_statistics")
+
+    def ray_statistics(self):
+        out = (C.c_uint64 * 4)()
+        self.check(self.L.vhr_get_ray_statistics(self.handle, out), "ray_statistics")
+        return dict(unique_rays=out[0], reference_issued_rays=out[1], covered_pixels=out[2], stack_overflows=out[3])
+
+    def bvh_statistics(self):
+        out = (C.c_uint64 * 5)()
+        self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
+        return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
+
+    def _guard(self, fn):
+        """Run a Python pass body; park exceptions (they must not unwind through C) for execute() to re-raise."""
+        try:
+            fn()
+        except Exception as e:   # noqa: BLE001
+            self._callback_error = e
+
+
+class RaytracingExecutionContext:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def trace_rays(self, width, height):
+        self.ctx.check(self.ctx.L.vhr_trace_rays(self.handle, width, height), "TraceRays")
+
+
+class ComputeExecutionContext:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def get_display_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self.ctx.check(self.ctx.L.vhr_compute_get_display_size(self.handle, C.byref(w), C.byref(h)), "GetDisplaySize")
+        return w.value, h.value
+
+    def dispatch(self, shader, x_groups, y_groups, z_groups, push_constants=None):
+        if push_constants is None:
+            rc = self.ctx.L.vhr_compute_dispatch(self.handle, shader.encode(), x_groups, y_groups, z_groups, None, 0)
+        else:
+            a = np.ascontiguousarray(push_constants)
+            rc = self.ctx.L.vhr_compute_dispatch(self.handle, shader.encode(), x_groups, y_groups, z_groups, _p(a), a.nbytes)
+        self.ctx.check(rc, "Dispatch")
+
+    def blit_image_storage_to_transient(self, src, dst):
+        self.ctx.check(self.ctx.L.vhr_compute_blit_image_storage_to_transient(self.handle, src, dst.encode()), "BlitImageStorageToTransient")
+
+    def blit_image_transient_to_storage(self, src, dst):
+        self.ctx.check(self.ctx.L.vhr_compute_blit_image_transient_to_storage(self.handle, src.encode(), dst), "BlitImageTransientToStorage")
+
+    def blit_image_storage_to_storage(self, src, dst):
+        self.ctx.check(self.ctx.L.vhr_compute_blit_image_storage_to_storage(self.handle, src, dst), "BlitImageStorageToStorage")
+
+
+class HybridRenderPath:
+    """vhr_hybrid_*: the C++ re-host of HybridRenderPath (csrc/hybrid_render_path.cpp)."""
+
+    def __init__(self, ctx, shadow_mode=0, ambient_occlusion_mode=2, reflection_mode=2, denoise=False, atrous_steps=5,
+                 gbuffer_pass=None, composition_pass=None):
+        self.ctx = ctx
+        self.settings = HybridSettings(shadow_mode, ambient_occlusion_mode, reflection_mode, int(denoise), atrous_steps)
+        self._g = EXTERNAL_CB(lambda user, c: ctx._guard(lambda: gbuffer_pass(ctx))) if gbuffer_pass else EXTERNAL_CB()
+        self._c = EXTERNAL_CB(lambda user, c: ctx._guard(lambda: composition_pass(ctx))) if composition_pass else EXTERNAL_CB()
+        self.handle = C.c_void_p()
+        ctx.check(ctx.L.vhr_hybrid_create(ctx.handle, C.byref(self.settings), self._g, None, self._c, None, C.byref(self.handle)),
+                  "vhr_hybrid_create")
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise VhrError(f"{what}: {self.ctx.L.vhr_hybrid_last_error(self.handle).decode()}")
+
+    def build(self):
+        self._check(self.ctx.L.vhr_hybrid_build(self.handle), "HybridRenderPath::Build")
+
+    def rebuild(self, **changes):
+        for k, v in changes.items():
+            setattr(self.settings, k, int(v))
+        self._check(self.ctx.L.vhr_hybrid_rebuild(self.handle, C.byref(self.settings)), "HybridRenderPath::Rebuild")
+
+    def push_constants(self):
+        pc = np.zeros((), abi.svgf_push_constants_dtype)
+        self.ctx.check(self.ctx.L.vhr_hybrid_get_push_constants(self.handle, _p(pc)), "get_push_constants")
+        return pc
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.L.vhr_hybrid_destroy(self.handle)
+            self.handle = None
