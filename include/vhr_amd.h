@@ -214,15 +214,25 @@ int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *nor
                         const char *motion_image, const char *depth_image);
 
 /* Multi-GPU row strips: this context owns rows [row_begin, row_end) of the
- * display; ray tracing runs on the owned rows, the SVGF kernels and copies on the owned rows extended by
- * `overlap` rows on each side (clamped to the image).  Default: whole image, overlap 0. */
-int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap);
+ * display.  Ray tracing runs on the owned rows; the SVGF kernels on the owned rows extended by `overlap`
+ * rows on each side (recomputed instead of exchanged between a-trous iterations); the blits copy the owned
+ * rows extended by `halo` rows (>= overlap: the rows next frame's temporal pass may read).  All ranges are
+ * clamped to the image.  Default: whole image, overlap 0, halo 0.  The halo rows themselves are filled by
+ * the caller's neighbour exchange (vulkanhybridrenderer_amd/tiling.py over RCCL). */
+int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo);
 
 /* Statistics of the last vhr_trace_rays: out[0] = unique rays traced, out[1] = rays the reference would
  * issue (4x duplicate shadow ray, raygen.rgen:38-40), out[2] = covered (non-sky) pixels, out[3] = traversal
  * stack overflows (must be 0).  Requires vhr_set_ray_statistics(ctx, 1) (costs one counter flush per pass). */
 int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable);
 int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
+
+/* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel
+ * kind: 0 = raygen (K1+K2), 1 = svgf.comp (K3), 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5).
+ * vhr_get_kernel_time synchronises, folds the recorded pairs into (total milliseconds, launch count) and
+ * optionally resets the totals. */
+int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable);
+int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

@@ -49,7 +49,50 @@ vhr::DeviceScene vhr_context::device_scene() const {
     return s;
 }
 
+// ---- optional per-kernel event timing -------------------------------------------------------------
+static constexpr size_t kTimerCapacity = 16384;     // events per kernel kind (8192 launches between drains)
+
+void vhr_context::time_begin(int kind) {
+    if (!kernel_timing) return;
+    KernelTimer &t = kernel_timers[kind];
+    if (t.used + 2 > kTimerCapacity) return;
+    while (t.events.size() < t.used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        t.events.push_back(e);
+    }
+    hipEventRecord(t.events[t.used], stream);
+}
+void vhr_context::time_end(int kind) {
+    if (!kernel_timing) return;
+    KernelTimer &t = kernel_timers[kind];
+    if (t.used + 2 > kTimerCapacity || t.events.size() < t.used + 2) return;
+    hipEventRecord(t.events[t.used + 1], stream);
+    t.used += 2;
+}
+
 extern "C" {
+
+int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    ctx->kernel_timing = enable != 0;
+    return VHR_OK;
+}
+
+int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset) {
+    if (!ctx || kind < 0 || kind >= kKernelKinds) return VHR_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    KernelTimer &t = ctx->kernel_timers[kind];
+    for (size_t i = 0; i + 1 < t.used; i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.events[i], t.events[i + 1]) == hipSuccess) { t.total_ms += ms; ++t.launches; }
+    }
+    t.used = 0;
+    if (total_ms) *total_ms = t.total_ms;
+    if (launches) *launches = t.launches;
+    if (reset) { t.total_ms = 0.0; t.launches = 0; }
+    return VHR_OK;
+}
 
 const char *vhr_version(void) { return "vhr_amd 0.1.0 (gfx950)"; }
 
@@ -135,6 +178,8 @@ void vhr_destroy(vhr_context *ctx) {
     hipFree(ctx->d_textures);
     free_scene(ctx);
     hipFree(ctx->d_ray_stats);
+    for (auto &t : ctx->kernel_timers)
+        for (hipEvent_t e : t.events) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -288,12 +333,13 @@ int vhr_set_trace_params(vhr_context *ctx, const vhr_trace_params *p) {
     return VHR_OK;
 }
 
-int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap) {
-    if (!ctx || row_begin > row_end || row_end > ctx->height)
-        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "set_strip: need row_begin <= row_end <= height") : VHR_ERROR_INVALID_ARGUMENT;
+int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo) {
+    if (!ctx || row_begin > row_end || row_end > ctx->height || halo < overlap)
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "set_strip: need row_begin <= row_end <= height and halo >= overlap") : VHR_ERROR_INVALID_ARGUMENT;
     ctx->row_begin = row_begin;
     ctx->row_end = row_end;
     ctx->overlap = overlap;
+    ctx->halo = halo;
     return VHR_OK;
 }
 

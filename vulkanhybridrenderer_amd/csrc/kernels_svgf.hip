@@ -129,10 +129,11 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel
     a.moments_out[idx] = pack_rg16f(sm0, sm1);                                              // :138-144 (RG16F image keeps .xy)
 }
 
-static void strip_rows(const vhr_context *ctx, uint32_t height, uint32_t &r0, uint32_t &r1) {
+// rows [row_begin - extend, row_end + extend) clamped to the image
+static void strip_rows(const vhr_context *ctx, uint32_t height, uint32_t extend, uint32_t &r0, uint32_t &r1) {
     const uint32_t b = std::min(ctx->row_begin, height), e = std::min(ctx->row_end, height);
-    r0 = b > ctx->overlap ? b - ctx->overlap : 0;
-    r1 = std::min(height, e + ctx->overlap);
+    r0 = b > extend ? b - extend : 0;
+    r1 = uint32_t(std::min<uint64_t>(height, uint64_t(e) + extend));
     if (e <= b) { r0 = r1 = 0; }
 }
 
@@ -161,12 +162,14 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
     a.width = W; a.height = H;
     a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
     a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
-    strip_rows(ctx, H, a.row_begin, a.row_end);
+    strip_rows(ctx, H, ctx->overlap, a.row_begin, a.row_end);
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
     if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
         const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+        ctx->time_begin(kKernelTemporal);
         hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+        ctx->time_end(kKernelTemporal);
         if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
     }
     // the dispatch read a snapshot (ptr) and wrote the new moments (alt): flip (oracle decision ii)
@@ -263,13 +266,15 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     a.width = W; a.height = H;
     a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
     a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
-    strip_rows(ctx, H, a.row_begin, a.row_end);
+    strip_rows(ctx, H, ctx->overlap, a.row_begin, a.row_end);
     a.step = step;
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
     if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
     const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+    ctx->time_begin(kKernelAtrous);
     hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+    ctx->time_end(kKernelAtrous);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
     return VHR_OK;
 }
@@ -282,12 +287,14 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: extents differ");
     if (src.bpp != dst.bpp) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: formats of different texel size are not supported");
     uint32_t r0, r1;
-    strip_rows(ctx, src.height, r0, r1);
+    strip_rows(ctx, src.height, ctx->halo, r0, r1);
     if (r1 <= r0 || src.ptr == dst.ptr) return VHR_OK;
     const size_t row = size_t(src.width) * src.bpp;
-    if (hipMemcpyAsync(static_cast<char *>(dst.ptr) + r0 * row, static_cast<const char *>(src.ptr) + r0 * row, (r1 - r0) * row,
-                       hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-        return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: hipMemcpyAsync failed");
+    ctx->time_begin(kKernelCopy);
+    const hipError_t copy_rc = hipMemcpyAsync(static_cast<char *>(dst.ptr) + r0 * row, static_cast<const char *>(src.ptr) + r0 * row, (r1 - r0) * row,
+                       hipMemcpyDeviceToDevice, ctx->stream);
+    ctx->time_end(kKernelCopy);
+    if (copy_rc != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: hipMemcpyAsync failed");
     return VHR_OK;
 }
 

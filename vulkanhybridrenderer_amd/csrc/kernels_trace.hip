@@ -388,7 +388,9 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
     }
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
+    ctx->time_begin(kKernelRaygen);
     hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    ctx->time_end(kKernelRaygen);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {
         if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

@@ -114,6 +114,15 @@ struct PassDescription {
 
 struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, pad; };
 
+// optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
+enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };
+struct KernelTimer {
+    std::vector<hipEvent_t> events;     // begin/end pairs
+    size_t used = 0;                    // events recorded since the last drain
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
 }  // namespace vhr
 
 struct vhr_raytracing_execution_context {
@@ -162,12 +171,17 @@ struct vhr_context {
     bool built = false;
 
     // strips
-    uint32_t row_begin = 0, row_end = 0, overlap = 0;
+    uint32_t row_begin = 0, row_end = 0, overlap = 0, halo = 0;
 
     // statistics
     bool ray_stats_enabled = false;
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
+
+    bool kernel_timing = false;
+    vhr::KernelTimer kernel_timers[vhr::kKernelKinds];
+    void time_begin(int kind);
+    void time_end(int kind);
 
     vhr::DeviceScene device_scene() const;
     int fail(int code, const std::string &msg) { error = msg; return code; }

@@ -1,0 +1,122 @@
+"""Headless frame loop around the hot path: what Renderer::Render (/root/reference/src/rendering_backend/
+renderer.cpp:184-235) does per frame, minus windowing -- fill PerFrameData, run the render graph -- with the
+untouched raster stages stood in for: the G-buffer of every frame is produced up front by the stand-in
+primary-ray producer and bound as external memory (the route a Vulkan integration would use), so the timed
+loop contains only the hot path (Raytrace Pass + SVGF Denoise Pass) and, for N > 1 GPUs, its halo exchanges.
+
+PyTorch is plumbing here: device memory for the precomputed G-buffers, the HIP stream, and torch.distributed
+(backend "nccl" == RCCL) for the neighbour exchanges.
+"""
+import numpy as np
+
+from . import abi, camera, lib, tiling
+
+_TYPESTR = {abi.FORMAT_R16G16B16A16_SFLOAT: ("<f2", 4), abi.FORMAT_R16G16_SFLOAT: ("<f2", 2), abi.FORMAT_D32_SFLOAT: ("<f4", 1)}
+
+
+class _DeviceArray:
+    """Exposes an image of the context as __cuda_array_interface__ so torch can alias it (no copy)."""
+
+    def __init__(self, info):
+        typestr, ch = _TYPESTR[info.format]
+        shape = (info.height, info.width, ch) if ch > 1 else (info.height, info.width)
+        self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(info.device_ptr), False), version=2)
+
+
+def alias_tensor(info):
+    import torch
+    return torch.as_tensor(_DeviceArray(info), device="cuda")
+
+
+class HybridFrameLoop:
+    def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
+                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0):
+        import torch
+        self.torch = torch
+        self.scene, self.W, self.H = scene, width, height
+        self.rank, self.world, self.dist = rank, world, dist
+        torch.cuda.set_device(device)
+        self.stream = torch.cuda.current_stream()
+        self.ctx = lib.Context(width, height, device=device, stream=self.stream.cuda_stream)
+        self.ctx.upload_scene(scene)
+        self.tp = abi.default_trace_params(shadow=shadow, ao_spp=ao_spp, reflections=reflections)
+        self.ctx.set_trace_params(self.tp)
+        self.rays_per_pixel = int(shadow) + ao_spp + int(reflections)
+        self.reference_rays_per_pixel = 4 * int(shadow) + ao_spp + int(reflections)     # raygen.rgen:38-40 duplicates
+        self.pfds = camera.dolly_frames(scene, width, height, n_frames, start_frame_index)
+        self.current = 0
+        self.path = lib.HybridRenderPath(self.ctx, shadow_mode=0 if shadow else 2, ambient_occlusion_mode=0 if ao_spp else 2,
+                                         reflection_mode=0 if reflections else 2, denoise=denoise, atrous_steps=atrous_steps,
+                                         gbuffer_pass=self._gbuffer_pass)
+        self.path.build()
+        self.denoise = denoise
+        self.atrous_steps = atrous_steps
+        self._precompute_gbuffers()
+        self.plan = tiling.make_plan(height, world, rank, self.max_motion_rows, atrous_steps)
+        if world > 1:
+            self.ctx.set_strip(self.plan.row_begin, self.plan.row_end, self.plan.overlap, self.plan.halo)
+            self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
+            if denoise:
+                self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)
+        self.pc = self.path.push_constants() if denoise else None
+
+    # ---- stand-in for the raster G-buffer stage ----
+    def _precompute_gbuffers(self):
+        torch = self.torch
+        self.gbuffers = []
+        covered = []
+        max_mv = 0.0
+        self._binding = False
+        for i, pfd in enumerate(self.pfds):
+            self.ctx.update_per_frame_ubo(0, pfd)
+            self.ctx.standin_gbuffer(0)
+            n = alias_tensor(self.ctx.transient_info(lib.NORMALS)).clone()
+            m = alias_tensor(self.ctx.transient_info(lib.MOTION)).clone()
+            d = alias_tensor(self.ctx.transient_info(lib.DEPTH)).clone()
+            self.gbuffers.append((n, m, d))
+            covered.append(int(torch.count_nonzero(d).item()))
+            mv = m[..., 1].float()
+            mv = torch.nan_to_num(mv, nan=0.0)[d != 0]
+            if mv.numel():
+                max_mv = max(max_mv, float(mv.abs().max().item()) * self.H)
+        self.covered_pixels = covered
+        self.max_motion_rows = int(np.ceil(max_mv))
+        self._binding = True
+
+    def _gbuffer_pass(self, ctx):
+        if not self._binding:
+            return
+        n, m, d = self.gbuffers[self.current % len(self.gbuffers)]
+        ctx.bind_external_image(lib.NORMALS, n.data_ptr())
+        ctx.bind_external_image(lib.MOTION, m.data_ptr())
+        ctx.bind_external_image(lib.DEPTH, d.data_ptr())
+
+    # ---- multi-GPU halo exchanges (tiling.py) ----
+    def _exchange_raytraced(self, ctx):
+        t = alias_tensor(ctx.transient_info(lib.RAYTRACED))
+        tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)
+
+    def _exchange_history(self, ctx):
+        hist = alias_tensor(ctx.storage_info(int(self.pc["shadow_and_ao_history"])))
+        mom = alias_tensor(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))     # current (just written) buffer
+        tiling.exchange_rows(self.dist, [hist, mom], self.plan, self.plan.halo)
+
+    # ---- one frame of the hot path ----
+    def frame(self, i):
+        self.current = i
+        self.ctx.update_per_frame_ubo(0, self.pfds[i % len(self.pfds)])
+        self.ctx.execute(0, 0)
+
+    def owned_rows(self):
+        return self.plan.row_begin, self.plan.row_end
+
+    def rays_in_frame(self, i, owned_only=True):
+        """Unique rays traced by this rank in frame i."""
+        if self.world == 1 or not owned_only:
+            return self.covered_pixels[i % len(self.gbuffers)] * self.rays_per_pixel
+        d = self.gbuffers[i % len(self.gbuffers)][2][self.plan.row_begin:self.plan.row_end]
+        return int(self.torch.count_nonzero(d).item()) * self.rays_per_pixel
+
+    def close(self):
+        self.path.destroy()
+        self.ctx.close()

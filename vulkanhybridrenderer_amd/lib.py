@@ -30,7 +30,8 @@ EXPORTS = [
     "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_set_strip",
-    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics",
+    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
+    "vhr_get_kernel_time",
 ]
 
 
@@ -148,10 +149,12 @@ def load():
     L.vhr_upload_storage_image.argtypes = [vp, i32, vp, u64]
     L.vhr_download_storage_image.argtypes = [vp, i32, vp, u64]
     L.vhr_standin_gbuffer.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p]
-    L.vhr_set_strip.argtypes = [vp, u32, u32, u32]
+    L.vhr_set_strip.argtypes = [vp, u32, u32, u32, u32]
     L.vhr_set_ray_statistics.argtypes = [vp, i32]
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_set_kernel_timing.argtypes = [vp, i32]
+    L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
     return L
 
@@ -267,8 +270,9 @@ class Context:
         assert a.dtype == abi.trace_params_dtype
         self.check(self.L.vhr_set_trace_params(self.handle, _p(a)), "set_trace_params")
 
-    def set_strip(self, row_begin, row_end, overlap=0):
-        self.check(self.L.vhr_set_strip(self.handle, row_begin, row_end, overlap), "set_strip")
+    def set_strip(self, row_begin, row_end, overlap=0, halo=None):
+        halo = overlap if halo is None else halo
+        self.check(self.L.vhr_set_strip(self.handle, row_begin, row_end, overlap, halo), "set_strip")
 
     # ---- RenderGraph ----
     def destroy_resources(self):
@@ -398,6 +402,17 @@ class Context:
         out = (C.c_uint64 * 5)()
         self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
+
+    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3}
+
+    def set_kernel_timing(self, enable):
+        self.check(self.L.vhr_set_kernel_timing(self.handle, int(enable)), "set_kernel_timing")
+
+    def kernel_time(self, kind, reset=False):
+        """(total_ms, launches) of a kernel kind, measured with HIP events on the context stream."""
+        ms, n = C.c_double(), C.c_uint64()
+        self.check(self.L.vhr_get_kernel_time(self.handle, self.KERNEL_KINDS[kind], C.byref(ms), C.byref(n), int(reset)), "kernel_time")
+        return ms.value, n.value
 
     def _guard(self, fn):
         """Run a Python pass body; park exceptions (they must not unwind through C) for execute() to re-raise."""

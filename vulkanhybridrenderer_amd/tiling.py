@@ -1,0 +1,105 @@
+"""Multi-GPU decomposition of the hot path: the framebuffer is sharded by ROW STRIPS, one process per GPU,
+the scene / BVH / textures / G-buffer replicated (the reference itself is single-GPU).
+
+Per frame and per rank (strip = rows [y0, y1), E = overlap, Hh = history halo):
+
+  Raytrace Pass      rays for the owned rows only                                       (per-pixel independent)
+  exchange #1        E rows of the raw shadow/AO image from each neighbour                      (RCCL send/recv)
+  SVGF Denoise Pass  svgf.comp and every a-trous iteration on rows [y0-E, y1+E): the overlap is RECOMPUTED
+                     from valid inputs, so no exchange is needed between iterations
+  exchange #2        Hh rows of the temporal history and the moments history from each neighbour (their
+                     owners computed them exactly); consumed by NEXT frame's svgf.comp, so it is off the
+                     critical path of this frame's output
+
+Why E: the published image is the output of a-trous iteration n-2 (hybrid_render_path.cpp:322-325 copies the
+image the LAST iteration did not write); iteration i reads +-2*2^i rows (svgf_atrous_filter.comp:72-75; the
+3x3 variance pre-filter's +-1 is inside that), so the rows a strip needs from svgf.comp's output reach
+sum_{i=0}^{n-2} 2*2^i = 2*(2^(n-1)-1) = 30 rows beyond the strip for n = 5.
+Why Hh: next frame's svgf.comp runs on [y0-E, y1+E) and reads history / moments / previous normals at the
+reprojected position, i.e. up to ceil(max |motion.y| * H) + 2 rows further (svgf.comp:52-60,81-84).
+
+Everything here is placement logic shared by the GPU path (bench.py, RCCL via torch.distributed "nccl") and the
+CPU gloo test (tests/test_tiling_gloo.py); results are bit-identical to the single-strip run because the same
+kernels run on the same inputs -- only where the rows live differs.
+"""
+from dataclasses import dataclass
+
+
+def atrous_overlap(atrous_steps=5):
+    """Rows of svgf.comp output a strip needs beyond its own rows (see module docstring)."""
+    if atrous_steps < 2:
+        return 0
+    return 2 * (2 ** (atrous_steps - 1) - 1)
+
+
+@dataclass(frozen=True)
+class StripPlan:
+    rank: int
+    world: int
+    height: int
+    row_begin: int
+    row_end: int
+    overlap: int          # E: rows recomputed beyond the strip by the SVGF kernels
+    halo: int             # Hh: rows of history / moments fetched from each neighbour
+
+    @property
+    def rows(self):
+        return self.row_end - self.row_begin
+
+    def neighbours(self):
+        """[(peer_rank, rows_i_send (a, b), rows_i_receive (a, b))] for a halo of `n` rows -> see exchanges()."""
+        return [r for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
+
+    def exchanges(self, n_rows):
+        """Row ranges for an n_rows-deep halo: list of (peer, send (a, b), recv (a, b)), global row indices.
+        I send rows I own next to the shared boundary and receive the rows the peer owns next to it."""
+        out = []
+        if self.rank > 0:
+            out.append((self.rank - 1, (self.row_begin, min(self.row_end, self.row_begin + n_rows)),
+                        (max(0, self.row_begin - n_rows), self.row_begin)))
+        if self.rank < self.world - 1:
+            out.append((self.rank + 1, (max(self.row_begin, self.row_end - n_rows), self.row_end),
+                        (self.row_end, min(self.height, self.row_end + n_rows))))
+        return out
+
+
+def strip_bounds(height, world, rank):
+    """Rows [g*H/N, (g+1)*H/N) -- 135 rows at 1080p / 8, 270 at 4K / 8."""
+    return (rank * height) // world, ((rank + 1) * height) // world
+
+
+def make_plan(height, world, rank, max_motion_rows, atrous_steps=5):
+    y0, y1 = strip_bounds(height, world, rank)
+    if world == 1:
+        return StripPlan(rank, world, height, 0, height, 0, 0)
+    overlap = atrous_overlap(atrous_steps)
+    halo = overlap + int(max_motion_rows) + 2
+    smallest = min(strip_bounds(height, world, r)[1] - strip_bounds(height, world, r)[0] for r in range(world))
+    if halo > smallest:
+        raise ValueError(f"strips of {smallest} rows are thinner than the {halo}-row history halo "
+                         f"(overlap {overlap} + motion {max_motion_rows} + 2): use fewer GPUs or a taller image")
+    return StripPlan(rank, world, height, y0, y1, overlap, halo)
+
+
+def exchange_rows(dist, tensors, plan, n_rows, group=None):
+    """Neighbour halo exchange of `n_rows` rows of each [H, ...] tensor (device or host), in place.
+
+    One grouped batch of point-to-point ops (ncclGroupStart/End under the "nccl" = RCCL backend): each
+    neighbour pair talks over its direct xGMI link; no collective involves more than two ranks."""
+    if plan.world == 1 or n_rows <= 0:
+        return
+    ops = []
+    recvs = []
+    for peer, (sa, sb), (ra, rb) in plan.exchanges(n_rows):
+        for t in tensors:
+            send = t[sa:sb].contiguous()
+            recv = t[ra:rb]
+            if not recv.is_contiguous():
+                raise ValueError("row slices of a [H, ...] tensor must be contiguous")
+            ops.append(dist.P2POp(dist.isend, send, peer, group=group))
+            ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
+            recvs.append(send)      # keep the send buffers alive until completion
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
