@@ -39,12 +39,19 @@ enum {
  * Context (replaces VulkanContext + the device half of ResourceManager:
  * src/rendering_backend/vulkan_context.cpp:44-89, resource_manager.cpp:15-70)
  * ------------------------------------------------------------------------------------------- */
+/* vhr_create_info.flags */
+enum {
+    /* Pass registry / execution order / SanityCheck only: no HIP call is made, nothing can be uploaded,
+     * executed or downloaded.  Lets the host-side graph logic be checked on a machine without a GPU. */
+    VHR_CREATE_HOST_ONLY = 1
+};
+
 typedef struct vhr_create_info {
     int32_t  device;          /* HIP device ordinal */
     uint32_t width;           /* display ("swapchain") size: context.swapchain.extent */
     uint32_t height;
     void    *stream;          /* hipStream_t to issue all work on; NULL = create an internal stream */
-    uint32_t flags;           /* reserved, 0 */
+    uint32_t flags;           /* 0 or VHR_CREATE_HOST_ONLY */
 } vhr_create_info;
 
 int  vhr_create(const vhr_create_info *info, vhr_context **out);

@@ -1,0 +1,173 @@
+"""Independent numpy restatement of the SVGF kernels and the RNG (TEST INFRASTRUCTURE), written from the GLSL
+(/root/reference/data/shaders/hybrid_render_path/svgf.comp, svgf_atrous_filter.comp, ../common.glsl) without
+looking at oracle/vhr_oracle.c's structure: a second pin for the oracle (SURVEY.md section 8c 'Fixtures policy').
+Vectorised over the image, so the operation order per pixel is the shader's but taps are processed image-wide."""
+import numpy as np
+
+F = np.float32
+
+
+def h2f(bits):
+    return np.asarray(bits, np.uint16).view(np.float16).astype(np.float32)
+
+
+def f2h(x):
+    with np.errstate(over="ignore", invalid="ignore"):
+        return np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+
+
+def seed_thread(seed):
+    m = 0xffffffff
+    seed &= m
+    seed = ((seed ^ 61) ^ (seed >> 16)) & m
+    seed = (seed * 9) & m
+    seed = (seed ^ (seed >> 4)) & m
+    seed = (seed * 0x27d4eb2d) & m
+    seed = (seed ^ (seed >> 15)) & m
+    return seed
+
+
+def xorshift(state):
+    m = 0xffffffff
+    state ^= (state << 13) & m
+    state ^= state >> 17
+    state ^= (state << 5) & m
+    return state & m
+
+
+def random01(state):
+    state = xorshift(state)
+    bits = np.array([0x3f800000 | (state >> 9)], np.uint32)
+    return state, np.float32(bits.view(np.float32)[0] - F(1.0))
+
+
+def _shift(img, dx, dy, fill=0):
+    """out[y, x] = img[y + dy, x + dx] where in range, else `fill`; also returns the in-range mask."""
+    H, W = img.shape[:2]
+    out = np.full_like(img, fill)
+    ys = slice(max(0, -dy), min(H, H - dy))
+    xs = slice(max(0, -dx), min(W, W - dx))
+    yd = slice(max(0, -dy) + dy, min(H, H - dy) + dy)
+    xd = slice(max(0, -dx) + dx, min(W, W - dx) + dx)
+    mask = np.zeros((H, W), bool)
+    if ys.start < ys.stop and xs.start < xs.stop:
+        out[ys, xs] = img[yd, xd]
+        mask[ys, xs] = True
+    return out, mask
+
+
+def atrous(normals_bits, in_bits, step):
+    n = h2f(normals_bits)
+    p = h2f(in_bits)
+    H, W = p.shape[:2]
+    normal_p, id_p = n[..., :3], n[..., 3].astype(np.int32)
+    var = np.zeros((H, W, 2), F)
+    gw = [F(1 / 16), F(1 / 8), F(1 / 16), F(1 / 8), F(1 / 4), F(1 / 8), F(1 / 16), F(1 / 8), F(1 / 16)]
+    for y in (-1, 0, 1):
+        for x in (-1, 0, 1):
+            q, m = _shift(p, x, y)
+            w = gw[3 * (y + 1) + (x + 1)]
+            var = var + np.where(m[..., None], w * q[..., 2:4], F(0)).astype(F)
+    k1 = [F(1 / 16), F(1 / 4), F(3 / 8), F(1 / 4), F(1 / 16)]
+    sum_w = np.ones((H, W, 2), F)
+    acc = p.copy()
+    denom = (F(4.0) * np.sqrt(var) + F(1e-6)).astype(F)
+    for y in range(-2, 3):
+        for x in range(-2, 3):
+            if x == 0 and y == 0:
+                continue
+            q, m = _shift(p, x * step, y * step)
+            nq, _ = _shift(n, x * step, y * step)
+            kernel = F(k1[y + 2] * k1[x + 2])
+            d = ((normal_p[..., 0] * nq[..., 0] + normal_p[..., 1] * nq[..., 1]) + normal_p[..., 2] * nq[..., 2]).astype(F)
+            with np.errstate(over="ignore", under="ignore"):
+                pw = np.where(d > 0, d, F(0)).astype(F)
+                for _ in range(7):
+                    pw = (pw * pw).astype(F)
+            wid = (id_p == nq[..., 3].astype(np.int32)).astype(F)
+            w = ((kernel * pw) * wid).astype(F)
+            e = (np.abs(p[..., 0:2] - q[..., 0:2]) / denom).astype(F)
+            lw = np.exp(-e).astype(F)
+            wxy = (w[..., None] * lw).astype(F)
+            wxy = np.where(m[..., None], wxy, F(0)).astype(F)
+            sum_w = (sum_w + wxy).astype(F)
+            acc[..., 0:2] = (acc[..., 0:2] + wxy * q[..., 0:2]).astype(F)
+            acc[..., 2:4] = (acc[..., 2:4] + (wxy * wxy) * q[..., 2:4]).astype(F)
+    out = np.empty_like(acc)
+    out[..., 0:2] = acc[..., 0:2] / sum_w
+    out[..., 2:4] = acc[..., 2:4] / (sum_w * sum_w)
+    return f2h(out)
+
+
+def temporal(W, H, normals_bits, motion_bits, rt_bits, prev_normals_bits, history_bits, moments_bits):
+    n = h2f(normals_bits)
+    mv = h2f(motion_bits)
+    rt = h2f(rt_bits)
+    pn = h2f(prev_normals_bits)
+    hist = h2f(history_bits)
+    mom = h2f(moments_bits)
+    ys, xs = np.mgrid[0:H, 0:W]
+    cur_n, cur_id = n[..., :3], n[..., 3].astype(np.int32)
+    pcx = ((xs.astype(F) - mv[..., 0] * F(W)) + F(0.5)).astype(F)
+    pcy = ((ys.astype(F) - mv[..., 1] * F(H)) + F(0.5)).astype(F)
+    fx = (pcx - np.floor(pcx)).astype(F)
+    fy = (pcy - np.floor(pcy)).astype(F)
+    with np.errstate(invalid="ignore"):
+        ax = np.where(np.isnan(pcx), 0, np.trunc(pcx)).astype(np.int64)
+        ay = np.where(np.isnan(pcy), 0, np.trunc(pcy)).astype(np.int64)
+    weights = [(1 - fx) * (1 - fy), fx * (1 - fy), (1 - fx) * fy, fx * fy]
+
+    def gather(sx, sy):
+        inb = (sx >= 0) & (sy >= 0) & (sx < W) & (sy < H)
+        cx, cy = np.clip(sx, 0, W - 1), np.clip(sy, 0, H - 1)
+        p = pn[cy, cx]
+        ok = inb & (cur_id == p[..., 3].astype(np.int32))
+        d = ((cur_n[..., 0] * p[..., 0] + cur_n[..., 1] * p[..., 1]) + cur_n[..., 2] * p[..., 2]).astype(F)
+        ok &= ~(d < F(0.70710678118654752440084))
+        return ok, hist[cy, cx], mom[cy, cx]
+
+    z = np.zeros((H, W), F)
+    ps, pa, s = z.copy(), z.copy(), z.copy()
+    m0, m1, a0, a1 = z.copy(), z.copy(), z.copy(), z.copy()
+    for i, (ox, oy) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+        ok, h, m = gather(ax + ox, ay + oy)
+        w = weights[i].astype(F)
+        ps = np.where(ok, ps + w * h[..., 0], ps).astype(F)
+        pa = np.where(ok, pa + w * h[..., 1], pa).astype(F)
+        m0 = np.where(ok, m0 + w * m[..., 0], m0).astype(F)
+        m1 = np.where(ok, m1 + w * m[..., 1], m1).astype(F)
+        a0 = np.where(ok, a0 + w * F(0), a0).astype(F)
+        a1 = np.where(ok, a1 + w * F(1), a1).astype(F)
+        s = np.where(ok, s + w, s).astype(F)
+    with np.errstate(invalid="ignore"):
+        valid = s > F(1e-6)
+    retry = ~valid
+    for oy in (-1, 0, 1):
+        for ox in (-1, 0, 1):
+            ok, h, m = gather(ax + ox, ay + oy)
+            ok &= retry
+            ps = np.where(ok, ps + h[..., 0], ps).astype(F)
+            pa = np.where(ok, pa + h[..., 1], pa).astype(F)
+            m0 = np.where(ok, m0 + m[..., 0], m0).astype(F)
+            m1 = np.where(ok, m1 + m[..., 1], m1).astype(F)
+            a0 = np.where(ok, a0 + F(0), a0).astype(F)
+            a1 = np.where(ok, a1 + F(1), a1).astype(F)
+            s = np.where(ok, s + F(1), s).astype(F)
+    with np.errstate(invalid="ignore"):
+        valid = np.where(retry, s > F(1e-6), valid)
+    cs, ca = rt[..., 0], rt[..., 1]
+    sm0, sm1, am0, am1 = cs, (cs * cs).astype(F), ca, (ca * ca).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mix = lambda a, b, t: (a * (F(1) - F(t)) + b * F(t)).astype(F)   # noqa: E731
+        v_sm0, v_sm1 = mix(m0 / s, sm0, 0.2), mix(m1 / s, sm1, 0.2)
+        v_am0, v_am1 = mix(a0 / s, am0, 0.2), mix(a1 / s, am1, 0.2)
+        v_s, v_a = mix(ps / s, cs, 0.2), mix(pa / s, ca, 0.2)
+    sm0 = np.where(valid, v_sm0, sm0)
+    sm1 = np.where(valid, v_sm1, sm1)
+    am0 = np.where(valid, v_am0, am0)
+    am1 = np.where(valid, v_am1, am1)
+    out_s = np.where(valid, v_s, cs)
+    out_a = np.where(valid, v_a, ca)
+    sv = np.maximum(F(0), sm1 - sm0 * sm0).astype(F)
+    av = np.maximum(F(0), am1 - am0 * am0).astype(F)
+    return f2h(np.stack([out_s, out_a, sv, av], -1)), f2h(np.stack([sm0, sm1], -1))

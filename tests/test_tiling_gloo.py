@@ -1,0 +1,53 @@
+"""Multi-process (gloo, CPU) check of the strip / halo logic, plus unit checks of the plan arithmetic."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from vulkanhybridrenderer_amd import tiling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_overlap_formula():
+    assert tiling.atrous_overlap(5) == 30          # 2 + 4 + 8 + 16: iterations 0..3 feed the published image
+    assert tiling.atrous_overlap(4) == 14
+    assert tiling.atrous_overlap(2) == 2
+    assert tiling.atrous_overlap(1) == 0
+
+
+def test_plans_partition_the_image():
+    for H, N in [(1080, 8), (2160, 8), (1080, 4), (270, 2), (1080, 1)]:
+        plans = [tiling.make_plan(H, N, r, 3) for r in range(N)]
+        assert plans[0].row_begin == 0 and plans[-1].row_end == H
+        assert all(a.row_end == b.row_begin for a, b in zip(plans, plans[1:]))
+        if N > 1:
+            assert all(p.overlap == 30 and p.halo == 35 for p in plans)
+            for p in plans:
+                for peer, (sa, sb), (ra, rb) in p.exchanges(p.halo):
+                    q = plans[peer]
+                    assert q.row_begin <= ra and rb <= q.row_end            # I receive rows the peer owns
+                    assert p.row_begin <= sa and sb <= p.row_end            # I send rows I own
+                    back = [e for e in q.exchanges(p.halo) if e[0] == p.rank][0]
+                    assert back[1] == (ra, rb) and back[2] == (sa, sb)      # and the peer's plan mirrors mine
+    assert plans[0].rows == 1080
+    with pytest.raises(ValueError):
+        tiling.make_plan(256, 8, 0, 4)             # 32-row strips cannot hold a 36-row halo
+
+
+@pytest.mark.parametrize("world,shrink", [(2, 0), (3, 0), (2, 1)])
+def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink):
+    out = tmp_path / "result.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + world), OMP_NUM_THREADS="2",
+               VHR_TEST_SHRINK_OVERLAP=str(shrink))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29611 + world), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "64", "120", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad, overlap, halo = out.read_text().split()
+    if shrink:      # negative control: one row less than the derived overlap is already wrong
+        assert int(bad) > 0
+        return
+    assert int(bad) == 0, f"{bad} (rank, frame) pairs differ from the single-process result"
+    assert int(overlap) == 30

@@ -1,0 +1,97 @@
+"""Worker of tests/test_tiling_gloo.py: one rank of an N-strip run of the hot path's schedule on CPU.
+
+The compute bodies are the ORACLE's kernels (this is a test); what is under test is the product's placement logic
+(vulkanhybridrenderer_amd/tiling.py): strip bounds, overlap E, history halo Hh, which images are exchanged and
+when.  Every row a rank did not compute or receive is poisoned with NaN, so any read of an invalid row shows up
+in the owned rows of the result, which must equal the single-process result bit for bit."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob                                   # noqa: E402
+from vulkanhybridrenderer_amd import abi, camera, scenes, tiling    # noqa: E402
+
+NAN16 = np.uint16(0x7e00)
+
+
+def poison_outside(img, a, b):
+    img[:max(0, a)] = NAN16
+    img[min(img.shape[0], b):] = NAN16
+
+
+def main():
+    out_path, W, H, n_frames = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    scene = scenes.tiny_scene()
+    osc = ob.Scene(scene)
+    tp = abi.default_trace_params(reflections=False)
+    pfds = camera.dolly_frames(scene, W, H, n_frames)
+    gbufs = [osc.gbuffer(p, W, H) for p in pfds]
+    mvy = max(float(np.nanmax(np.abs(g[1].view(np.float16)[..., 1].astype(np.float32)[g[2] != 0]), initial=0.0)) * H for g in gbufs[1:])
+    plan = tiling.make_plan(H, world, rank, int(np.ceil(mvy)))
+    shrink = int(os.environ.get("VHR_TEST_SHRINK_OVERLAP", "0"))      # negative control: a too-small overlap must be caught
+    if shrink:
+        plan = tiling.StripPlan(plan.rank, plan.world, plan.height, plan.row_begin, plan.row_end, plan.overlap - shrink, plan.halo - shrink)
+    y0, y1, E, Hh = plan.row_begin, plan.row_end, plan.overlap, plan.halo
+    c0, c1 = max(0, y0 - E), min(H, y1 + E)               # rows the SVGF kernels compute
+    b0, b1 = max(0, y0 - Hh), min(H, y1 + Hh)             # rows the blits copy
+
+    # reference: the whole frame in one piece
+    ref_svgf = ob.SVGF(W, H)
+    ref = []
+    for pfd, g in zip(pfds, gbufs):
+        sa, _, _, _ = osc.raygen(pfd, tp, g[0], g[2], want_reflections=False)
+        ref.append(ref_svgf.frame(pfd, g[0], g[1], sa))
+
+    A = np.zeros((H, W, 4), np.uint16)
+    B = np.zeros((H, W, 4), np.uint16)
+    prev_normals = np.zeros((H, W, 4), np.uint16)
+    history = np.zeros((H, W, 4), np.uint16)
+    moments = np.zeros((H, W, 2), np.uint16)
+    worst = 0
+    for f, (pfd, g) in enumerate(zip(pfds, gbufs)):
+        normals, motion, depth = g
+        # Raytrace Pass: owned rows only
+        rt, _, _, _ = osc.raygen(pfd, tp, normals, depth, rows=(y0, y1), want_reflections=False)
+        poison_outside(rt, y0, y1)
+        t = torch.from_numpy(rt)
+        tiling.exchange_rows(dist, [t], plan, E)                                  # exchange #1
+        # SVGF Denoise Pass on [y0-E, y1+E)
+        x, y = A, B
+        integ, mom_new = ob.svgf_temporal(pfd, normals, motion, rt, prev_normals, history, moments)
+        poison_outside(integ, c0, c1)
+        poison_outside(mom_new, c0, c1)
+        x[:] = integ
+        moments = mom_new
+        for i in range(5):
+            out = ob.svgf_atrous(pfd, normals, x, 1 << i)
+            poison_outside(out, c0, c1)
+            y[:] = out
+            if i == 0:
+                history[b0:b1] = y[b0:b1]
+            x, y = y, x
+        prev_normals[b0:b1] = normals[b0:b1]
+        denoised = y.copy()
+        x, y = y, x
+        th, tm = torch.from_numpy(history), torch.from_numpy(moments)
+        tiling.exchange_rows(dist, [th, tm], plan, Hh)                            # exchange #2
+        same = np.array_equal(denoised[y0:y1], ref[f][y0:y1])
+        if not same:
+            worst += 1
+    res = torch.tensor([worst], dtype=torch.int64)
+    dist.all_reduce(res)
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            fh.write(f"{int(res[0])} {plan.overlap} {plan.halo}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

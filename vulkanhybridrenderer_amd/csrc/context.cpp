@@ -81,7 +81,7 @@ int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable) {
 
 int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset) {
     if (!ctx || kind < 0 || kind >= kKernelKinds) return VHR_ERROR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     KernelTimer &t = ctx->kernel_timers[kind];
     for (size_t i = 0; i + 1 < t.used; i += 2) {
         float ms = 0.0f;
@@ -116,6 +116,19 @@ void vhr_default_trace_params(vhr_trace_params *p) {
 
 int vhr_create(const vhr_create_info *info, vhr_context **out) {
     if (!info || !out || info->width == 0 || info->height == 0) { g_create_error = "vhr_create: invalid arguments"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (info->flags & VHR_CREATE_HOST_ONLY) {
+        // graph bookkeeping only (pass registry, execution order, SanityCheck): no device is touched and
+        // nothing can be executed, uploaded or downloaded
+        vhr_context *ctx = new vhr_context();
+        ctx->host_only = true;
+        ctx->width = info->width;
+        ctx->height = info->height;
+        ctx->row_end = info->height;
+        ctx->storage_images.resize(vhr_context::kMaxGlobalResources);
+        vhr_default_trace_params(&ctx->trace_params);
+        *out = ctx;
+        return VHR_OK;
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         // the product path never falls back to the CPU
@@ -166,6 +179,11 @@ static void free_scene(vhr_context *ctx) {
 
 void vhr_destroy(vhr_context *ctx) {
     if (!ctx) return;
+    if (ctx->host_only) {
+        vhr_graph_destroy_resources(ctx);
+        delete ctx;
+        return;
+    }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     vhr_graph_destroy_resources(ctx);
@@ -188,6 +206,7 @@ const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_s
 
 int vhr_synchronize(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return VHR_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VHR_OK;
 }
@@ -209,6 +228,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
                         uint32_t index_count, const vhr_primitive *primitives, uint32_t primitive_count) {
     if (!ctx || (!vertices && vertex_count) || (!indices && index_count) || (!primitives && primitive_count))
         return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: null array") : VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     // Validate every offset the kernels will dereference (an out-of-range index would fault the GPU).
     for (uint32_t p = 0; p < primitive_count; ++p) {
         const vhr_primitive &pr = primitives[p];
@@ -257,6 +277,7 @@ int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t 
     if (!ctx || !data || !width || !height) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
     if (format != VHR_FORMAT_R8G8B8A8_SRGB && format != VHR_FORMAT_R8G8B8A8_UNORM)
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: format must be R8G8B8A8_SRGB or R8G8B8A8_UNORM");
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (ctx->textures.size() >= vhr_context::kMaxGlobalResources) { ctx->error = "texture table exhausted"; return -1; }   // resource_manager.cpp:847-848
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     vhr_context::Texture t{};
@@ -285,12 +306,13 @@ int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t 
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     const uint32_t bpp = format_stride(format);
     if (!bpp || !width || !height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadNewStorageImage: unsupported format or empty extent");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->host_only) HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (uint32_t i = 0; i < vhr_context::kMaxGlobalResources; ++i) {         // first free slot, resource_manager.cpp:866-878
         Image &im = ctx->storage_images[i];
         if (im.used) continue;
         im = Image{};
         im.width = width; im.height = height; im.format = format; im.bpp = bpp;
+        if (ctx->host_only) { im.used = true; return int32_t(i); }
         HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
         HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
         im.ptr = im.owned;
@@ -310,6 +332,7 @@ int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t 
 int vhr_destroy_storage_image(vhr_context *ctx, int32_t id) {
     if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "DestroyStorageImage: no such image") : VHR_ERROR_INVALID_ARGUMENT;   // assert at resource_manager.cpp:266
+    if (ctx->host_only) { ctx->storage_images[id] = Image{}; return VHR_OK; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     Image &im = ctx->storage_images[id];
     // ptr/alt may have been flipped: free both distinct allocations
@@ -351,7 +374,7 @@ int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable) {
 
 int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const vhr_trace_params &tp = ctx->trace_params;
     const uint64_t covered = ctx->h_ray_stats.covered_pixels;
     out[0] = covered * (uint64_t(tp.shadow_enable ? 1 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));
@@ -395,6 +418,7 @@ int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out) {
 }
 
 static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t bytes, bool to_device) {
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -433,6 +457,7 @@ int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *nor
         return ctx->fail(VHR_ERROR_NOT_FOUND, "standin_gbuffer: unknown transient image");
     if (n->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || m->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || d->second.format != VHR_FORMAT_D32_SFLOAT)
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: formats must be RGBA16F, RGBA16F, D32F (hybrid_render_path.cpp:16-19)");
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_standin_gbuffer(ctx, ctx->per_frame[resource_idx], n->second, m->second, d->second);
 }

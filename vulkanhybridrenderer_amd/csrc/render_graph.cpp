@@ -94,10 +94,12 @@ extern "C" {
 
 int vhr_graph_destroy_resources(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    for (auto &kv : ctx->pass_descriptions) free_pass_events(kv.second);
-    for (auto &kv : ctx->images) hipFree(kv.second.owned);
+    if (!ctx->host_only) {
+        hipSetDevice(ctx->device);
+        if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        for (auto &kv : ctx->pass_descriptions) free_pass_events(kv.second);
+        for (auto &kv : ctx->images) hipFree(kv.second.owned);
+    }
     ctx->pass_descriptions.clear();
     ctx->registration_order.clear();
     ctx->execution_order.clear();
@@ -183,8 +185,10 @@ static int actualize(vhr_context *ctx, const vhr_transient_resource &r) {
     im.format = r.image.format;
     im.bpp = format_stride(r.image.format);
     if (!im.bpp || !im.width || !im.height) return ctx->fail(VHR_ERROR_GRAPH, std::string("transient image '") + r.name + "': unsupported format or empty extent");
-    HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
-    HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
+    if (!ctx->host_only) {
+        HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
+        HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
+    }
     im.ptr = im.owned;
     im.used = true;
     ctx->images[r.name] = im;
@@ -237,14 +241,14 @@ static int sanity_check(vhr_context *ctx) {
 
 int vhr_graph_build(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->host_only) HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::map<std::string, std::vector<std::string>> writers;
     // the reference iterates an unordered_map; registration order is the deterministic choice here
     for (auto &name : ctx->registration_order) {
         PassDescription &p = ctx->pass_descriptions[name];
         for (auto &r : p.dependencies) { int rc = actualize(ctx, r); if (rc) return rc; }
         for (auto &r : p.outputs) { writers[r.name].push_back(p.name); int rc = actualize(ctx, r); if (rc) return rc; }
-        if (!p.ev_begin) {
+        if (!p.ev_begin && !ctx->host_only) {
             HIP_TRY(ctx, hipEventCreate(&p.ev_begin));
             HIP_TRY(ctx, hipEventCreate(&p.ev_end));
         }
@@ -260,6 +264,7 @@ int vhr_graph_build(vhr_context *ctx) {
 int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_idx) {
     (void)image_idx;
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: Execute needs a device");
     if (!ctx->built) return ctx->fail(VHR_ERROR_GRAPH, "Execute before Build");
     if (resource_idx >= 3) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "resource_idx >= MAX_FRAMES_IN_FLIGHT");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -286,6 +291,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
 
 int vhr_graph_gather_performance_statistics(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return VHR_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           // VK_QUERY_RESULT_WAIT_BIT, render_graph.cpp:192-193
     for (auto &name : ctx->execution_order) {
         PassDescription &p = ctx->pass_descriptions[name];

@@ -138,6 +138,7 @@ struct vhr_compute_execution_context {
 
 struct vhr_context {
     int device = 0;
+    bool host_only = false;          // VHR_CREATE_HOST_ONLY: graph bookkeeping without a device
     uint32_t width = 0, height = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
