@@ -46,6 +46,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=2)
     p.add_argument("--max-gbuffers", type=int, default=64, help="distinct precomputed G-buffer frames (wraps beyond)")
+    p.add_argument("--verify-frames", type=int, default=3,
+                   help="N > 1 only: before timing, check that the gathered strips equal a single full-frame context bit for bit")
+    p.add_argument("--backend", default=os.environ.get("VHR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                   help="gloo + --share-device lets several ranks run on ONE GPU (functional check of the strip path only)")
+    p.add_argument("--share-device", action="store_true", default=bool(os.environ.get("VHR_BENCH_SHARE_DEVICE")))
     return p.parse_args()
 
 
@@ -70,6 +75,43 @@ def cpu_baseline(scene, W, H, tp, n_frames, rays_per_pixel):
                 ms_per_frame=dt / n_frames * 1e3)
 
 
+def verify_strips(args, scene, loop, dist, rank, world, device):
+    """Strips gathered from all ranks == one full-frame context, bit for bit (same kernels, same inputs)."""
+    import torch
+    from vulkanhybridrenderer_amd import lib
+    from vulkanhybridrenderer_amd.harness import HybridFrameLoop, alias_tensor
+    W, H, V = args.width, args.height, args.verify_frames
+    ref = HybridFrameLoop(scene, W, H, V, shadow=True, ao_spp=args.ao_spp, reflections=args.reflections, denoise=True, device=device) if rank == 0 else None
+    ok = True
+    cpu = args.backend == "gloo"
+    for i in range(V):
+        loop.frame(i)
+        torch.cuda.synchronize()
+        y0, y1 = loop.owned_rows()
+        mine = alias_tensor(loop.ctx.transient_info(lib.DENOISED))[y0:y1].contiguous().view(torch.int16)
+        mine = mine.cpu() if cpu else mine
+        sizes = [None] * world
+        dist.all_gather_object(sizes, (y0, y1))
+        if rank == 0:
+            ref.frame(i)
+            torch.cuda.synchronize()
+            full = alias_tensor(ref.ctx.transient_info(lib.DENOISED)).view(torch.int16)
+            full = full.cpu() if cpu else full
+            ok &= bool(torch.equal(mine, full[y0:y1]))
+            for r in range(1, world):
+                a, b = sizes[r]
+                buf = torch.empty((b - a, W, 4), dtype=torch.int16, device=mine.device)
+                dist.recv(buf, src=r)
+                ok &= bool(torch.equal(buf, full[a:b]))
+        else:
+            dist.send(mine, dst=0)
+    if ref is not None:
+        ref.close()
+    flag = torch.tensor([1 if ok else 0], device="cpu" if cpu else "cuda")
+    dist.broadcast(flag, src=0)
+    return "bit-identical" if int(flag[0]) else "MISMATCH"
+
+
 def main():
     args = parse()
     import torch
@@ -84,10 +126,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
     W, H = args.width, args.height
@@ -100,6 +147,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    strip_check = None
+    if world > 1 and args.verify_frames > 0:
+        strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
+        barrier()
 
     for i in range(args.warmup):
         loop.frame(i)
@@ -116,7 +168,7 @@ def main():
     ctx.gather_performance_statistics()
 
     my_rays = sum(loop.rays_in_frame(i) for i in range(args.warmup, args.warmup + args.steps))
-    stats = torch.tensor([dt, float(my_rays)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([dt, float(my_rays)], dtype=torch.float64, device="cpu" if (world > 1 and args.backend == "gloo") else "cuda")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,6 +214,7 @@ def main():
                 "reference_issued_rays_per_covered_pixel": loop.reference_rays_per_pixel,
                 "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
                 "strip_overlap_rows": loop.plan.overlap, "history_halo_rows": loop.plan.halo,
+                "strips_vs_single_context": strip_check,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
             },

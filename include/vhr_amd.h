@@ -9,8 +9,9 @@
  * vulkan_common.h:4-7); pool exhaustion returns -1 like resource_manager.cpp:847-848,876-877.
  *
  * Threading: like the reference (renderer.cpp:184-235) one host thread drives one context; all device
- * work of a context is issued in order on ONE HIP stream (the one given at creation, or an internal
- * one).  One context per GPU / per process for multi-GPU (row strips, vhr_set_strip).
+
+ * work of a context is issued in order on ONE HIP stream (the one given at creation, or an internal one
+ * with VHR_CREATE_INTERNAL_STREAM).  One context per GPU / per process for multi-GPU (row strips, vhr_set_strip).
  */
 #ifndef VHR_AMD_H
 #define VHR_AMD_H
@@ -43,15 +44,17 @@ enum {
 enum {
     /* Pass registry / execution order / SanityCheck only: no HIP call is made, nothing can be uploaded,
      * executed or downloaded.  Lets the host-side graph logic be checked on a machine without a GPU. */
-    VHR_CREATE_HOST_ONLY = 1
+    VHR_CREATE_HOST_ONLY = 1,
+    /* Ignore vhr_create_info.stream and create an internal (non-blocking) HIP stream. */
+    VHR_CREATE_INTERNAL_STREAM = 2
 };
 
 typedef struct vhr_create_info {
     int32_t  device;          /* HIP device ordinal */
     uint32_t width;           /* display ("swapchain") size: context.swapchain.extent */
     uint32_t height;
-    void    *stream;          /* hipStream_t to issue all work on; NULL = create an internal stream */
-    uint32_t flags;           /* 0 or VHR_CREATE_HOST_ONLY */
+    void    *stream;          /* hipStream_t to issue all work on, used as given (NULL = the default stream) */
+    uint32_t flags;           /* 0 or VHR_CREATE_* bits */
 } vhr_create_info;
 
 int  vhr_create(const vhr_create_info *info, vhr_context **out);

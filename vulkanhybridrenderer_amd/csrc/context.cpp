@@ -143,15 +143,17 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
     ctx->height = info->height;
     ctx->row_begin = 0;
     ctx->row_end = info->height;
-    if (info->stream) {
-        ctx->stream = static_cast<hipStream_t>(info->stream);
-    } else {
+    if (info->flags & VHR_CREATE_INTERNAL_STREAM) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
             g_create_error = "vhr_create: hipStreamCreate failed";
             delete ctx;
             return VHR_ERROR_DEVICE;
         }
         ctx->own_stream = true;
+    } else {
+        // the caller's stream, used as given; NULL is the device's default stream (which is also what
+        // torch.cuda.current_stream().cuda_stream reports for PyTorch's default stream)
+        ctx->stream = static_cast<hipStream_t>(info->stream);
     }
     ctx->storage_images.resize(vhr_context::kMaxGlobalResources);
     vhr_default_trace_params(&ctx->trace_params);

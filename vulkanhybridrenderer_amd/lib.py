@@ -201,10 +201,11 @@ def _p(a):
 class Context:
     """vhr_context: device + ResourceManager + RenderGraph state for one GPU."""
 
-    def __init__(self, width, height, device=0, stream=None, host_only=False):
+    def __init__(self, width, height, device=0, stream=None, host_only=False, internal_stream=False):
+        """stream: a hipStream_t handle used as given (None / 0 = the device's default stream)."""
         self.L = load()
         self.handle = C.c_void_p()
-        info = CreateInfo(device, width, height, stream, 1 if host_only else 0)
+        info = CreateInfo(device, width, height, stream, (1 if host_only else 0) | (2 if internal_stream else 0))
         rc = self.L.vhr_create(C.byref(info), C.byref(self.handle))
         if rc < 0:
             self.handle = None

@@ -88,18 +88,28 @@ def exchange_rows(dist, tensors, plan, n_rows, group=None):
     neighbour pair talks over its direct xGMI link; no collective involves more than two ranks."""
     if plan.world == 1 or n_rows <= 0:
         return
+    # Device tensors travel device-to-device under "nccl" (RCCL).  Under "gloo" (CPU transport: the CI route
+    # for exercising this code with several ranks on one GPU) they are staged through host memory.
+    stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
     ops = []
-    recvs = []
+    keep = []
+    staged = []
     for peer, (sa, sb), (ra, rb) in plan.exchanges(n_rows):
         for t in tensors:
-            send = t[sa:sb].contiguous()
             recv = t[ra:rb]
             if not recv.is_contiguous():
                 raise ValueError("row slices of a [H, ...] tensor must be contiguous")
+            send = t[sa:sb].cpu() if stage else t[sa:sb].contiguous()
+            if stage:
+                host = recv.cpu()
+                staged.append((recv, host))
+                recv = host
             ops.append(dist.P2POp(dist.isend, send, peer, group=group))
             ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
-            recvs.append(send)      # keep the send buffers alive until completion
+            keep.append(send)      # keep the send buffers alive until completion
     if not ops:
         return
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+    for dst, host in staged:
+        dst.copy_(host)
