@@ -237,12 +237,24 @@ int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32
 int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable);
 int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
 
+/* Tuning knobs for A/B measurements; every setting computes identical results.
+ *   "raygen_variant"   0 = one thread per pixel tracing its rays in sequence, 1 = block work queue (default)
+ *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
+ *   "raygen_blocks_per_cu" persistent blocks launched per CU by the work-queue raygen (default 6)
+ *   "atrous_variant", "temporal_variant"  kernel variants of K4 / K3 */
+int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
+
 /* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel
  * kind: 0 = raygen (K1+K2), 1 = svgf.comp (K3), 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5).
  * vhr_get_kernel_time synchronises, folds the recorded pairs into (total milliseconds, launch count) and
  * optionally resets the totals. */
 int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable);
 int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset);
+
+/* Traversal work of the last vhr_trace_rays (work-queue raygen, statistics enabled): out[0] = inner-node
+ * visits summed over lanes, out[1] = leaf visits, out[2] = ray/triangle tests, out[3] = wave loop trips.
+ * Active-lane utilisation of the traversal loop = (out[0] + out[1]) / (64 * out[3]). */
+int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

@@ -4,7 +4,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if not k.startswith("vhr::"):
+        if "vhr::" not in k:
             continue
         a = acc[k][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1

@@ -162,7 +162,10 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
         double c = i / 255.0;
         lut[i] = float(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
     }
-    if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), sizeof(RayStats)) != hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, info->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), sizeof(RayStats)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_tile_counter), sizeof(uint32_t)) != hipSuccess) {
         g_create_error = "vhr_create: device initialisation failed";
         vhr_destroy(ctx);
         return VHR_ERROR_DEVICE;
@@ -198,6 +201,7 @@ void vhr_destroy(vhr_context *ctx) {
     hipFree(ctx->d_textures);
     free_scene(ctx);
     hipFree(ctx->d_ray_stats);
+    hipFree(ctx->d_tile_counter);
     for (auto &t : ctx->kernel_timers)
         for (hipEvent_t e : t.events) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -368,6 +372,14 @@ int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32
     return VHR_OK;
 }
 
+int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
+    if (!ctx || !key) return VHR_ERROR_INVALID_ARGUMENT;
+    static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu" };
+    for (int i = 0; i < 5; ++i)
+        if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
+    return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");
+}
+
 int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     ctx->ray_stats_enabled = enable != 0;
@@ -383,6 +395,14 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
     out[1] = covered * (uint64_t(tp.shadow_enable ? 4 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));   // raygen.rgen:38-40 duplicates
     out[2] = covered;
     out[3] = ctx->h_ray_stats.stack_overflows;
+    return VHR_OK;
+}
+
+int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = ctx->h_ray_stats.node_visits; out[1] = ctx->h_ray_stats.leaf_visits;
+    out[2] = ctx->h_ray_stats.triangle_tests; out[3] = ctx->h_ray_stats.wave_iterations;
     return VHR_OK;
 }
 

@@ -364,6 +364,233 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K1 (work-queue form): the same visibility rays as raygen_kernel, scheduled for wave64 occupancy.
+//
+// raygen.rgen traces its rays one after another per pixel, so on a SIMD machine every lane of a wave waits
+// for the slowest lane of EACH ray (measured: 43 % of VALU lanes active).  Here a 16x16-pixel block first
+// compacts its covered pixels (wave ballot + one LDS atomic per wave), which defines a block-local queue of
+// `covered * (1 + ao_spp)` any-hit rays, kind-major (all shadow rays, then AO sample 0, AO sample 1, ...) so
+// that rays in flight together are of one kind.  Lanes pull rays from the queue whenever at least
+// `refill_threshold` lanes of the wave are idle -- one LDS atomic per refill, ranks from the idle ballot
+// ("wavefront-ballot compaction") -- regenerate the ray from (pixel, kind) with raygen.rgen's exact arithmetic
+// (the RNG state is recomputed from the seed), and walk the BVH one node or leaf per loop trip.  Visibility
+// results are integers accumulated in LDS (order independent), so the output is bit-identical to the
+// sequential form: shadow = !any_hit, ao = float(visible) / float(spp).  The mirror ray (closest hit +
+// shading, a different register budget) runs in reflection_kernel.
+// ---------------------------------------------------------------------------------------------
+// One wave per block owning an 8x8-pixel tile: a block's slot frees the moment its wave is done.
+__device__ __forceinline__ void tile_pixel(uint32_t local, uint32_t row_begin, uint32_t &x, uint32_t &y) {
+    x = blockIdx.x * 8u + (local & 7u);
+    y = row_begin + blockIdx.y * 8u + (local >> 3);
+}
+
+// Slab test with the subtraction folded into an FMA against precomputed -o * (1/d).  Box tests only cull
+// (boxes are padded, NaNs drop out of min/max), so they are outside the exact-arithmetic contract: 1/d may
+// come from v_rcp_f32 and the FMA may round differently from (lo - o) * inv without changing any result.
+__device__ __forceinline__ bool box_test_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 inv, f3 noi,
+                                             float tmin, float tlimit, float &tnear) {
+    const float t0x = __builtin_fmaf(lox, inv.x, noi.x), t1x = __builtin_fmaf(hix, inv.x, noi.x);
+    const float t0y = __builtin_fmaf(loy, inv.y, noi.y), t1y = __builtin_fmaf(hiy, inv.y, noi.y);
+    const float t0z = __builtin_fmaf(loz, inv.z, noi.z), t1z = __builtin_fmaf(hiz, inv.z, noi.z);
+    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tlimit));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// 1/d for the slab test.  A zero (or denormal) component must not become inf: fma(lo, inf, -o*inf) is NaN on one
+// side of the slab only, which would cull boxes the ray is inside of.  1e30 keeps lo * inv finite for any scene
+// coordinate and classifies "parallel to the slab" correctly: inside -> (-huge, +huge), outside -> both beyond tmax.
+// (The exact direction d itself is untouched: Moeller-Trumbore never sees this value.)
+__device__ __forceinline__ float cull_reciprocal(float d) {
+    return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : __frcp_rn(d);
+}
+
+constexpr int kQueueBlock = 64;
+
+__global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold) {
+    extern __shared__ int s_stack[];                 // stack_levels x 64
+    __shared__ uint32_t s_vis[kQueueBlock];           // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
+    __shared__ float s_ray[7][kQueueBlock];           // per covered pixel: ray origin (3), normal (3), RNG seed (1)
+    __shared__ uint8_t s_list[kQueueBlock];           // compacted covered pixels
+    const uint32_t lane = threadIdx.x;
+    int *stack = s_stack + lane;
+    const uint32_t W = a.width, H = a.height;
+    uint32_t x, y;
+    tile_pixel(lane, a.row_begin, x, y);
+    const bool in_range = x < W && y < a.row_end;
+    bool covered = false;
+    float depth = 0.0f;
+    if (in_range) {
+        depth = a.depth[size_t(y) * W + x];                                                  // rgen:19
+        covered = depth != 0.0f;
+        if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                         // rgen:20-21
+    }
+    s_vis[lane] = 0;
+    if (covered) {
+        // ---- raygen.rgen:15-29 once per pixel (shared by all of the pixel's rays) ----
+        const float u = (float(x) + 0.5f) / float(W);
+        const float v = (float(y) + 0.5f) / float(H);
+        const f3 P = get_world_space_position(a.pfd, depth, u, v);                           // rgen:26
+        const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
+        const f3 N = f3{ nid.x, nid.y, nid.z };
+        const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
+        s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
+        s_ray[3][lane] = N.x; s_ray[4][lane] = N.y; s_ray[5][lane] = N.z;
+        s_ray[6][lane] = __uint_as_float(seed_thread((y * H + x) * a.pfd.frame_index));      // rgen:17
+    }
+    const unsigned long long cov_mask = __ballot(covered);
+    const uint32_t ncov = uint32_t(__popcll(cov_mask));
+    if (covered) s_list[__popcll(cov_mask & ((1ull << lane) - 1ull))] = uint8_t(lane);
+    __syncthreads();
+    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
+    const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + a.tp.ao_spp - first_kind);
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    float tmax = 0.0f;
+    int cur = 0, sp = 0;
+    uint32_t pix = 0, kind = 0;
+    bool has = false;
+    uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
+    uint32_t overflow = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0;      // statistics (only flushed when a.stats)
+    const float tmin = a.tp.tmin;
+    for (;;) {
+        // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
+            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            next += n_idle;
+            if (!has && r < total) {
+                const uint32_t k = r / ncov;
+                kind = k + first_kind;
+                pix = s_list[r - k * ncov];
+                ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+                uint32_t rng = __float_as_uint(s_ray[6][pix]);
+                float rnd1 = random01(rng), rnd2 = random01(rng);                            // rgen:32-33
+                if (kind == 0) {                                                             // rgen:34-41
+                    const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));
+                    rd = onb_transform(L, cone_dir);
+                    tmax = a.tp.tmax;
+                } else {                                                                     // rgen:44-53
+                    for (uint32_t i = 0; i < kind; ++i) { rnd1 = random01(rng); rnd2 = random01(rng); }
+                    const f3 N = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+                    rd = onb_transform(N, cosine_hemisphere(rnd1, rnd2));
+                    tmax = a.tp.ao_tmax;
+                }
+                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                cur = 0; sp = 0;
+                has = true;
+            }
+        }
+        if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
+        ++n_iters;
+        // ---- inner nodes: descend until this lane holds a leaf (or ran out of stack) ----
+        bool finished = false, found = false;
+        while (has && cur >= 0) {
+            ++n_nodes;
+            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int4 q3 = reinterpret_cast<const int4 *>(np)[3];
+            float tn0, tn1;
+            const bool h0 = box_test_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rinv, noi, tmin, tmax, tn0);
+            const bool h1 = box_test_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rinv, noi, tmin, tmax, tn1);
+            if (h0 && h1) {
+                const bool first0 = tn0 <= tn1;
+                const int farc = first0 ? q3.y : q3.x;
+                if (uint32_t(sp) < stack_levels) { stack[sp * kQueueBlock] = farc; ++sp; } else { overflow = 1; }
+                cur = first0 ? q3.x : q3.y;
+            } else if (h0) {
+                cur = q3.x;
+            } else if (h1) {
+                cur = q3.y;
+            } else if (sp == 0) {
+                finished = true;
+                break;
+            } else {
+                --sp;
+                cur = stack[sp * kQueueBlock];
+            }
+        }
+        // ---- leaf ----
+        if (has && !finished) {
+            const uint32_t vv = ~uint32_t(cur);
+            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
+            ++n_leaves;
+            for (uint32_t i = 0; i < count; ++i) {
+                ++n_tris;
+                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
+                const float4 ta = tp[0], tb = tp[1];
+                const float tcx = reinterpret_cast<const float *>(tp)[8];
+                float t, uu, ww;
+                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax, t, uu, ww)) {
+                    found = true;
+                    break;
+                }
+            }
+            if (found || sp == 0) finished = true;
+            else { --sp; cur = stack[sp * kQueueBlock]; }
+        }
+        if (has && finished) {
+            has = false;
+            if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }                         // miss.rmiss:7 leaves 1.0
+            else if (!found) atomicAdd(&s_vis[pix], 256u);
+        }
+    }
+    __syncthreads();
+    if (covered) {
+        const uint32_t vis = s_vis[lane];
+        const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
+        float ao_payload = 1.0f;
+        if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
+        store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
+    }
+    if (a.stats) {
+        const unsigned long long ovf = __ballot(overflow != 0);
+        if (lane == 0) {
+            if (cov_mask) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov_mask));
+            if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
+            atomicAdd(&a.stats->wave_iterations, (unsigned long long)n_iters);
+        }
+        atomicAdd(&a.stats->node_visits, (unsigned long long)n_nodes);
+        atomicAdd(&a.stats->leaf_visits, (unsigned long long)n_leaves);
+        atomicAdd(&a.stats->triangle_tests, (unsigned long long)n_tris);
+    }
+}
+
+// Mirror ray of raygen.rgen:59-65 (closest hit, reflection_hit.rchit / reflection_miss.rmiss), one pixel per thread.
+__global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArgs a) {
+    __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
+    int *stack = s_refl_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, a.row_begin);
+    if (x >= a.width || y >= a.row_end) return;
+    const uint32_t W = a.width, H = a.height;
+    f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const float depth = a.depth[size_t(y) * W + x];
+    if (depth != 0.0f && a.tp.reflections) {
+        const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
+        const f3 P = get_world_space_position(a.pfd, depth, u, v);
+        const f4 nid = load_rgba16f(a.normals, W, x, y);
+        const f3 N = f3{ nid.x, nid.y, nid.z };
+        const f3 origin = P + N * a.tp.normal_bias;
+        const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+        const f3 I = normalize3(P - cam);
+        const float ni2 = 2.0f * dot3(N, I);
+        const f3 rdir = I - N * ni2;
+        Hit hit;
+        uint32_t overflow = 0;
+        if (traverse<false>(a.scene, origin, rdir, a.tp.tmin, a.tp.tmax, stack, hit, overflow))
+            payload = shade_reflection_hit(a.scene, a.pfd, hit);
+    }
+    store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+}
+
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
                   const Image &depth, Image &shadow_ao, Image *reflections) {
     if (width != normals.width || height != normals.height || width != depth.width || height != depth.height ||
@@ -389,7 +616,17 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     }
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
-    hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    if (ctx->options[kOptRaygenVariant] == 0) {
+        hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    } else {
+        // the traversal stack is sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU
+        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(kTraceStack)));
+        const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
+        const dim3 grid8((width + 7) / 8, (a.row_end - a.row_begin + 7) / 8);
+        hipLaunchKernelGGL(raygen_queue_kernel, grid8, dim3(kQueueBlock), size_t(levels) * kQueueBlock * sizeof(int), ctx->stream, a, levels, threshold);
+        // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
+        if (a.reflections && a.tp.reflections) hipLaunchKernelGGL(reflection_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    }
     ctx->time_end(kKernelRaygen);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {

@@ -112,7 +112,10 @@ struct PassDescription {
     double ema_ms = 0.0, last_ms = 0.0;
 };
 
-struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, pad; };
+struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, pad; };
+
+// tuning knobs (vhr_set_option): every variant computes identical results
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptCount = 8 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };
@@ -179,6 +182,9 @@ struct vhr_context {
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
 
+    int options[vhr::kOptCount] = { 1, 16, 0, 0, 6, 0, 0, 0 };     // see vhr_set_option
+    int cu_count = 256;
+    uint32_t *d_tile_counter = nullptr;
     bool kernel_timing = false;
     vhr::KernelTimer kernel_timers[vhr::kKernelKinds];
     void time_begin(int kind);

@@ -31,7 +31,7 @@ EXPORTS = [
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_set_strip",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics",
 ]
 
 
@@ -153,6 +153,8 @@ def load():
     L.vhr_set_ray_statistics.argtypes = [vp, i32]
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
@@ -399,12 +401,22 @@ class Context:
         self.check(self.L.vhr_get_ray_statistics(self.handle, out), "ray_statistics")
         return dict(unique_rays=out[0], reference_issued_rays=out[1], covered_pixels=out[2], stack_overflows=out[3])
 
+    def traversal_statistics(self):
+        out = (C.c_uint64 * 4)()
+        self.check(self.L.vhr_get_traversal_statistics(self.handle, out), "traversal_statistics")
+        d = dict(node_visits=out[0], leaf_visits=out[1], triangle_tests=out[2], wave_iterations=out[3])
+        d["active_lane_utilisation"] = (out[0] + out[1]) / (64.0 * out[3]) if out[3] else 0.0
+        return d
+
     def bvh_statistics(self):
         out = (C.c_uint64 * 5)()
         self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
 
     KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3}
+
+    def set_option(self, key, value):
+        self.check(self.L.vhr_set_option(self.handle, key.encode(), int(value)), "set_option")
 
     def set_kernel_timing(self, enable):
         self.check(self.L.vhr_set_kernel_timing(self.handle, int(enable)), "set_kernel_timing")
