@@ -249,6 +249,134 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(c
     a.out[idx] = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4, LDS-tiled form.
+//
+// The direct kernel above issues 58 cached loads per pixel and is bound by the CU's L1 (TCP) line rate
+// (PMC: 33 M line accesses per 1080p launch ~ 54 us at one line per clock per CU), not by HBM.  An a-trous
+// pass with step s only ever combines pixels that are s apart, so a block here owns a COMB of rows:
+// output rows y0 + k*s (k = 0..R-1) over 64 consecutive columns.  It stages rows y0 + (k-2..R+1)*s over columns
+// [x0 - 2s, x0 + 64 + 2s) of both inputs into LDS once -- (R+4)/R * (64+4s)/64 = 1.3x .. 2.5x the compulsory
+// bytes instead of 25x -- plus three rows of the variance channels per output row for the 3x3 pre-filter
+// (svgf_atrous_filter.comp:17-38), and every one of the 25 taps of every output is then an LDS read
+// (ds_read_b64, lanes on consecutive 8-byte slots: conflict free).  Different blocks take the s row phases.
+//
+// While staging, the normals/id texel is preprocessed once per texel instead of once per tap: the object id
+// is truncated like int() (svgf_atrous_filter.comp:57,83) and kept as a half next to nz, out-of-image texels
+// get an id no pixel can have (a NaN pattern) so that their weight is exactly 0, which is what the shader's
+// `continue` amounts to.  The normal dot product uses v_dot2_f32_f16 on the packed halves.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half2_t as_half2(uint32_t u) { return *reinterpret_cast<const half2_t *>(&u); }
+
+constexpr int kTileX = 64;
+constexpr uint32_t kInvalidId = 0xffffu;     // NaN half: never equal to a truncated object id
+
+template <int STEP, int R>
+__global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs a) {
+    constexpr int TW = kTileX + 4 * STEP;            // staged columns
+    constexpr int TH = R + 4;                        // staged comb rows
+    constexpr int VW = kTileX + 2;                   // variance columns
+    __shared__ uint2 s_in[TH][TW];
+    __shared__ uint2 s_nm[TH][TW];
+    __shared__ uint32_t s_var[R][3][VW];
+    const int W = int(a.width), H = int(a.height);
+    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
+    const int x0 = int(blockIdx.x) * kTileX;
+    const int group = int(blockIdx.y) / STEP, phase = int(blockIdx.y) - group * STEP;
+    const int y0 = int(a.row_begin) + group * (R * STEP) + phase;
+    const int tid = int(threadIdx.x);
+
+    // ---- stage the comb tile ----
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int kk = i / TW, c = i - kk * TW;
+        const int sx = x0 - 2 * STEP + c, sy = y0 + (kk - 2) * STEP;
+        uint2 vin = make_uint2(0u, 0u), vnm = make_uint2(0u, kInvalidId << 16);
+        if (sx >= 0 && sx < max_x && sy >= 0 && sy < max_y) {
+            const size_t sidx = size_t(sy) * W + sx;
+            vin = a.in[sidx];
+            const uint2 n = a.normals[sidx];
+            // int(w) as a half: trunc toward zero, -0 folded into +0 (both are int 0)
+            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
+            uint32_t idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
+            if ((idb & 0x7fffu) == 0u) idb = 0u;
+            if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;          // NaN: int(NaN) = 0 in the oracle; keep it unequal to real ids
+            vnm = make_uint2(n.x, (n.y & 0xffffu) | (idb << 16));
+        }
+        s_in[kk][c] = vin;
+        s_nm[kk][c] = vnm;
+    }
+    for (int i = tid; i < R * 3 * VW; i += 256) {
+        const int k = i / (3 * VW), rem = i - k * (3 * VW), j = rem / VW, c = rem - j * VW;
+        const int sx = x0 - 1 + c, sy = y0 + k * STEP + (j - 1);
+        uint32_t v = 0u;
+        if (sx >= 0 && sx < max_x && sy >= 0 && sy < max_y) v = a.in[size_t(sy) * W + sx].y;      // .zw = the two variances
+        s_var[k][j][c] = v;
+    }
+    __syncthreads();
+
+    const int tx = tid & 63, ty = tid >> 6;
+    const int cx = x0 + tx;
+#pragma unroll 1
+    for (int k = ty; k < R; k += 4) {
+        const int cy = y0 + k * STEP;
+        if (uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
+        const uint2 pin = s_in[k + 2][tx + 2 * STEP];
+        const uint2 pnm = s_nm[k + 2][tx + 2 * STEP];
+        const f4 p = unpack_rgba16f(pin);
+        const half2_t np_xy = as_half2(pnm.x);
+        const half2_t np_z0 = as_half2(pnm.y & 0xffffu);            // (nz, 0): the id lane must not enter the dot product
+        const uint32_t idp = pnm.y >> 16;
+
+        float var_s = 0.0f, var_a = 0.0f;                                                   // :17-38
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float w = (c == 1 ? 0.5f : 0.25f) * (j == 1 ? 0.5f : 0.25f);
+                const float2 q = unpack_rg16f(s_var[k][j][tx + c]);
+                var_s += w * q.x;
+                var_a += w * q.y;
+            }
+        const float inv_s = __frcp_rn(4.0f * sqrtf(var_s) + 1e-6f) * 1.44269504088896341f;  // :48-50, log2(e) folded in
+        const float inv_a = __frcp_rn(4.0f * sqrtf(var_a) + 1e-6f) * 1.44269504088896341f;
+
+        float sw_s = 1.0f, sw_a = 1.0f;                                                     // :70-71
+        float s0 = p.x, s1 = p.y, s2 = p.z, s3 = p.w;
+#pragma unroll
+        for (int y = -2; y <= 2; ++y)
+#pragma unroll
+            for (int x = -2; x <= 2; ++x) {                                                 // :72-94
+                if (x == 0 && y == 0) continue;
+                const uint2 qin = s_in[k + 2 + y][tx + 2 * STEP + x * STEP];
+                const uint2 qnm = s_nm[k + 2 + y][tx + 2 * STEP + x * STEP];
+                const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
+                const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
+                const float kernel = kx * ky;                                               // :62-68
+                float d = __builtin_amdgcn_fdot2(np_z0, as_half2(qnm.y), 0.0f, false);
+                d = __builtin_amdgcn_fdot2(np_xy, as_half2(qnm.x), d, false);              // :44-46
+                const float wn = pow128(d);
+                const float w = ((qnm.y >> 16) == idp) ? kernel * wn : 0.0f;                // :40-42, :87
+                const f4 q = unpack_rgba16f(qin);
+                const float wx = w * __builtin_amdgcn_exp2f(-(fabsf(p.x - q.x) * inv_s));   // :88
+                const float wy = w * __builtin_amdgcn_exp2f(-(fabsf(p.y - q.y) * inv_a));   // :89
+                sw_s += wx; sw_a += wy;                                                     // :91
+                s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;   // :92
+            }
+        const float rs = __frcp_rn(sw_s), ra = __frcp_rn(sw_a);
+        a.out[size_t(cy) * W + cx] = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+    }
+}
+
+template <int STEP, int R>
+static void launch_atrous_tiled(vhr_context *ctx, const AtrousArgs &a) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
+    const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
+    hipLaunchKernelGGL((svgf_atrous_tiled_kernel<STEP, R>), grid, dim3(256), 0, ctx->stream, a);
+}
+
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in, Image &out,
                        int32_t step, uint32_t x_groups, uint32_t y_groups) {
     const uint32_t W = normals.width, H = normals.height;
@@ -273,7 +401,19 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
     const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
     ctx->time_begin(kKernelAtrous);
-    hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+    const int variant = ctx->options[kOptAtrousVariant];
+    bool tiled = variant != 0;
+    if (tiled) {
+        switch (step) {
+            case 1: if (variant == 2) launch_atrous_tiled<1, 8>(ctx, a); else launch_atrous_tiled<1, 16>(ctx, a); break;
+            case 2: if (variant == 2) launch_atrous_tiled<2, 8>(ctx, a); else launch_atrous_tiled<2, 16>(ctx, a); break;
+            case 4: if (variant == 2) launch_atrous_tiled<4, 8>(ctx, a); else launch_atrous_tiled<4, 16>(ctx, a); break;
+            case 8: if (variant == 2) launch_atrous_tiled<8, 8>(ctx, a); else launch_atrous_tiled<8, 16>(ctx, a); break;
+            case 16: if (variant == 2) launch_atrous_tiled<16, 8>(ctx, a); else launch_atrous_tiled<16, 16>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    }
+    if (!tiled) hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
     ctx->time_end(kKernelAtrous);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
     return VHR_OK;

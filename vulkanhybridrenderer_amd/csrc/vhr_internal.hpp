@@ -182,7 +182,7 @@ struct vhr_context {
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
 
-    int options[vhr::kOptCount] = { 1, 16, 0, 0, 6, 0, 0, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 2, 0, 6, 0, 0, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     bool kernel_timing = false;
