@@ -240,15 +240,19 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
 /* Tuning knobs for A/B measurements; every setting computes identical results.
  *   "raygen_variant"   0 = one thread per pixel tracing its rays in sequence, 1 = block work queue (default)
  *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
- *   "raygen_blocks_per_cu" persistent blocks launched per CU by the work-queue raygen (default 6)
+ *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 12)
+ *   "lds_top_nodes"    BVH nodes (breadth-first = top of the tree) staged in LDS per workgroup (default 0: measured slower)
+ *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default)
+ *   "raygen_waves_per_block" 1, 2 or 4 independent 8x8-pixel tiles (waves) per workgroup (default 2)
+ *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)
  *   "atrous_variant", "temporal_variant"  kernel variants of K4 / K3 */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
 /* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel
  * kind: 0 = raygen (K1+K2), 1 = svgf.comp (K3), 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5).
- * vhr_get_kernel_time synchronises, folds the recorded pairs into (total milliseconds, launch count) and
- * optionally resets the totals. */
-int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable);
+ * kind_mask has bit (1 << kind) set for every kind to time (0 = off).  vhr_get_kernel_time synchronises, folds
+ * the recorded pairs into (total milliseconds, launch count) and optionally resets the totals. */
+int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask);
 int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset);
 
 /* Traversal work of the last vhr_trace_rays (work-queue raygen, statistics enabled): out[0] = inner-node

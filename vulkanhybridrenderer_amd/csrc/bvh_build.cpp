@@ -21,6 +21,7 @@
 #include "vhr_internal.hpp"
 
 namespace vhr {
+int g_leaf_tris = kMaxLeafTris;
 namespace {
 
 struct Box {
@@ -57,7 +58,7 @@ struct Builder {
     uint32_t max_depth = 0;
 
     static uint32_t levels_needed(uint32_t count) {
-        uint32_t leaves = (count + kMaxLeafTris - 1) / kMaxLeafTris;
+        uint32_t leaves = (count + g_leaf_tris - 1) / g_leaf_tris;
         uint32_t l = 0;
         while ((1u << l) < leaves) ++l;
         return l;
@@ -78,7 +79,7 @@ struct Builder {
         n.count = count;
         n.depth = depth;
         max_depth = std::max(max_depth, depth);
-        if (count <= uint32_t(kMaxLeafTris)) {
+        if (count <= uint32_t(g_leaf_tris)) {
             nodes[id] = n;
             return id;
         }
@@ -230,8 +231,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     auto set_child = [&](BvhNode &node, int which, const TmpNode &child, int32_t link) {
         float lo[3], hi[3];
         padded(child.box, lo, hi);
-        std::memcpy(which == 0 ? node.lo0 : node.lo1, lo, sizeof lo);
-        std::memcpy(which == 0 ? node.hi0 : node.hi1, hi, sizeof hi);
+        float *dst = which == 0 ? node.box0 : node.box1;
+        for (int a = 0; a < 3; ++a) { dst[2 * a] = lo[a]; dst[2 * a + 1] = hi[a]; }
         (which == 0 ? node.child0 : node.child1) = link;
     };
 
@@ -239,7 +240,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     if (root.left < 0) {                       // whole scene fits one leaf
         BvhNode node{};
         set_child(node, 0, root, leaf_link(root.first, root.count));
-        for (int a = 0; a < 3; ++a) { node.lo1[a] = inf; node.hi1[a] = -inf; }
+        for (int a = 0; a < 3; ++a) { node.box1[2 * a] = inf; node.box1[2 * a + 1] = -inf; }
         node.child1 = node.child0;
         out.nodes.push_back(node);
         return;

@@ -53,7 +53,7 @@ vhr::DeviceScene vhr_context::device_scene() const {
 static constexpr size_t kTimerCapacity = 16384;     // events per kernel kind (8192 launches between drains)
 
 void vhr_context::time_begin(int kind) {
-    if (!kernel_timing) return;
+    if (!(kernel_timing_mask & (1u << kind))) return;
     KernelTimer &t = kernel_timers[kind];
     if (t.used + 2 > kTimerCapacity) return;
     while (t.events.size() < t.used + 2) {
@@ -64,7 +64,7 @@ void vhr_context::time_begin(int kind) {
     hipEventRecord(t.events[t.used], stream);
 }
 void vhr_context::time_end(int kind) {
-    if (!kernel_timing) return;
+    if (!(kernel_timing_mask & (1u << kind))) return;
     KernelTimer &t = kernel_timers[kind];
     if (t.used + 2 > kTimerCapacity || t.events.size() < t.used + 2) return;
     hipEventRecord(t.events[t.used + 1], stream);
@@ -73,9 +73,9 @@ void vhr_context::time_end(int kind) {
 
 extern "C" {
 
-int vhr_set_kernel_timing(vhr_context *ctx, int32_t enable) {
+int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
-    ctx->kernel_timing = enable != 0;
+    ctx->kernel_timing_mask = uint32_t(kind_mask);
     return VHR_OK;
 }
 
@@ -374,8 +374,14 @@ int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32
 
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!ctx || !key) return VHR_ERROR_INVALID_ARGUMENT;
-    static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu" };
-    for (int i = 0; i < 5; ++i)
+    if (!std::strcmp(key, "bvh_leaf_triangles")) {          // applies to the next vhr_update_geometry
+        if (value < 1 || value > kMaxLeafTris) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_leaf_triangles must be 1..4");
+        g_leaf_tris = value;
+        return VHR_OK;
+    }
+    static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "lds_top_nodes", "xcd_aware" };
+    for (int i = 0; i < 10; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
     return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");
 }

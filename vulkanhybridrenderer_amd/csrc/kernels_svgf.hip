@@ -82,18 +82,34 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel
 
     float prev_shadow = 0.0f, prev_ao = 0.0f, sum = 0.0f;
     float psm0 = 0.0f, psm1 = 0.0f, pam0 = 0.0f, pam1 = 0.0f;
+    {   // :65-77 -- the four bilinear taps.  All twelve gathers are issued before any is consumed (addresses
+        // clamped into the image, the in-bounds test applied afterwards), so their latencies overlap.
+        uint2 pn[4], hs[4];
+        uint32_t mo[4];
+        bool inb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                                                           // :65-77
-        const int sx = ax + (i & 1), sy = ay + (i >> 1);
-        if (is_valid_reprojection(a, sx, sy, current_object_id, current_normal)) {
-            const size_t sidx = size_t(sy) * a.width + sx;
-            const f4 hs = unpack_rgba16f(a.history[sidx]);
-            prev_shadow += bw[i] * hs.x;
-            prev_ao += bw[i] * hs.y;
-            const float2 m = unpack_rg16f(a.moments_in[sidx]);       // RG16F read as vec4 = (r, g, 0, 1)
-            psm0 += bw[i] * m.x; psm1 += bw[i] * m.y;
-            pam0 += bw[i] * 0.0f; pam1 += bw[i] * 1.0f;
-            sum += bw[i];
+        for (int i = 0; i < 4; ++i) {
+            const int sx = ax + (i & 1), sy = ay + (i >> 1);
+            inb[i] = sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h && uint32_t(sx) < a.width && uint32_t(sy) < a.height;
+            const size_t sidx = size_t(min(max(sy, 0), int(a.height) - 1)) * a.width + size_t(min(max(sx, 0), int(a.width) - 1));
+            pn[i] = a.prev_normals[sidx];
+            hs[i] = a.history[sidx];
+            mo[i] = a.moments_in[sidx];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f4 n4 = unpack_rgba16f(pn[i]);
+            const bool ok = inb[i] && current_object_id == f2i(n4.w) &&
+                            !(dot3(current_normal, f3{ n4.x, n4.y, n4.z }) < 0.70710678118654752440084f);      // :16-39
+            if (ok) {
+                const f4 h4 = unpack_rgba16f(hs[i]);
+                const float2 m = unpack_rg16f(mo[i]);                // RG16F read as vec4 = (r, g, 0, 1)
+                prev_shadow += bw[i] * h4.x;
+                prev_ao += bw[i] * h4.y;
+                psm0 += bw[i] * m.x; psm1 += bw[i] * m.y;
+                pam0 += bw[i] * 0.0f; pam1 += bw[i] * 1.0f;
+                sum += bw[i];
+            }
         }
     }
     bool valid = sum > 1e-6f;                                                               // :78

@@ -78,8 +78,8 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const int4 q3 = reinterpret_cast<const int4 *>(np)[3];
             float tn0, tn1;
-            const bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, tbest, tn0);
-            const bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, tbest, tn1);
+            const bool h0 = box_test(q0.x, q0.z, q1.x, q0.y, q0.w, q1.y, o, inv, tmin, tbest, tn0);
+            const bool h1 = box_test(q1.z, q2.x, q2.z, q1.w, q2.y, q2.w, o, inv, tmin, tbest, tn1);
             if (h0 && h1) {
                 const bool first0 = tn0 <= tn1;
                 const int nearc = first0 ? q3.x : q3.y, farc = first0 ? q3.y : q3.x;
@@ -380,22 +380,18 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a)
 // sequential form: shadow = !any_hit, ao = float(visible) / float(spp).  The mirror ray (closest hit +
 // shading, a different register budget) runs in reflection_kernel.
 // ---------------------------------------------------------------------------------------------
-// One wave per block owning an 8x8-pixel tile: a block's slot frees the moment its wave is done.
-__device__ __forceinline__ void tile_pixel(uint32_t local, uint32_t row_begin, uint32_t &x, uint32_t &y) {
-    x = blockIdx.x * 8u + (local & 7u);
-    y = row_begin + blockIdx.y * 8u + (local >> 3);
-}
+// Slab test of one child box, (lo, hi) pairs per axis, as three packed FMAs against precomputed 1/d and -o/d.
+// Box tests only cull (boxes are padded, NaNs drop out of min/max), so they are outside the exact-arithmetic
+// contract: 1/d may come from v_rcp_f32 and the FMA may round differently from (lo - o) * inv without changing
+// any result.
+typedef float f2v __attribute__((ext_vector_type(2)));
 
-// Slab test with the subtraction folded into an FMA against precomputed -o * (1/d).  Box tests only cull
-// (boxes are padded, NaNs drop out of min/max), so they are outside the exact-arithmetic contract: 1/d may
-// come from v_rcp_f32 and the FMA may round differently from (lo - o) * inv without changing any result.
-__device__ __forceinline__ bool box_test_fma(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 inv, f3 noi,
-                                             float tmin, float tlimit, float &tnear) {
-    const float t0x = __builtin_fmaf(lox, inv.x, noi.x), t1x = __builtin_fmaf(hix, inv.x, noi.x);
-    const float t0y = __builtin_fmaf(loy, inv.y, noi.y), t1y = __builtin_fmaf(hiy, inv.y, noi.y);
-    const float t0z = __builtin_fmaf(loz, inv.z, noi.z), t1z = __builtin_fmaf(hiz, inv.z, noi.z);
-    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tlimit));
+__device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 noi, float tmin, float tlimit, float &tnear) {
+    const f2v tx = __builtin_elementwise_fma(bx, f2v{ inv.x, inv.x }, f2v{ noi.x, noi.x });
+    const f2v ty = __builtin_elementwise_fma(by, f2v{ inv.y, inv.y }, f2v{ noi.y, noi.y });
+    const f2v tz = __builtin_elementwise_fma(bz, f2v{ inv.z, inv.z }, f2v{ noi.z, noi.z });
+    const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
+    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
     tnear = tn;
     return tn <= tf;
 }
@@ -409,17 +405,84 @@ __device__ __forceinline__ float cull_reciprocal(float d) {
 }
 
 constexpr int kQueueBlock = 64;
+constexpr uint32_t kMaxPregenKinds = 17;       // 1 shadow + up to 16 AO samples pre-generated into LDS (13 KB)
 
-__global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold) {
-    extern __shared__ int s_stack[];                 // stack_levels x 64
-    __shared__ uint32_t s_vis[kQueueBlock];           // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
-    __shared__ float s_ray[7][kQueueBlock];           // per covered pixel: ray origin (3), normal (3), RNG seed (1)
-    __shared__ uint8_t s_list[kQueueBlock];           // compacted covered pixels
-    const uint32_t lane = threadIdx.x;
-    int *stack = s_stack + lane;
+// raygen.rgen:32-53 for one (pixel, kind): the ray direction, exact arithmetic
+__device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t seed, uint32_t kind, f3 L, f3 N) {
+    uint32_t rng = seed;
+    float rnd1 = random01(rng), rnd2 = random01(rng);                                        // rgen:32-33
+    if (kind == 0) {                                                                         // rgen:34-41
+        const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, tp.cone_cos_max));
+        return onb_transform(L, cone_dir);
+    }
+    for (uint32_t i = 0; i < kind; ++i) { rnd1 = random01(rng); rnd2 = random01(rng); }       // rgen:46-48
+    return onb_transform(N, cosine_hemisphere(rnd1, rnd2));                                  // rgen:49-51
+}
+
+// Every wave owns one 8x8-pixel tile and runs its own queue; a block is WAVES such waves side by side (a CU
+// accepts at most 16 workgroups, so single-wave blocks cap occupancy at 4 waves per SIMD: measured).  Waves of a
+// block share nothing and never synchronise with each other.
+// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one),
+// and each XCD has its own 4 MiB L2.  With the natural order every XCD would walk tiles from all over the screen
+// and pull the whole visible BVH / triangle set (> 4 MiB) through its L2; instead the blocks that share an XCD get
+// one contiguous band of tile rows, so each L2 only holds the geometry its band's rays meet.  Bijective for any
+// block count (the remainder rows go to the first bands); placement is a speed hint only, never correctness.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
+    const uint32_t xcd = id & 7u, slot = id >> 3;
+    const uint32_t q = n >> 3, r = n & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}
+
+template <int WAVES>
+__device__ __forceinline__ void tile_pixel(uint32_t block_tile, uint32_t tiles_x, uint32_t wave, uint32_t local, uint32_t row_begin, uint32_t &x, uint32_t &y) {
+    const uint32_t by = block_tile / tiles_x, bx = block_tile - by * tiles_x;
+    x = (bx * WAVES + wave) * 8u + (local & 7u);
+    y = row_begin + by * 8u + (local >> 3);
+}
+
+// orders this wave's LDS writes before its later LDS reads by other lanes (no cross-wave communication exists)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// PREGEN: every pixel generates all of its rays up front with the whole wave active (ray generation costs
+// several hundred instructions -- divisions, sqrt, the sin/cos polynomial -- and would otherwise run inside
+// the refill with a fraction of the lanes); the queue refill then only fetches 3 floats.  !PREGEN (more than
+// kMaxPregenKinds ray kinds): directions are generated inside the refill.
+template <bool PREGEN, int WAVES>
+__global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
+                                                                          const uint32_t pregen_kinds, const uint32_t top_nodes,
+                                                                          const uint32_t block_tiles_x, const uint32_t xcd_aware) {
+    // dynamic LDS: [top_nodes x 64 B node packets][per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats]
+    extern __shared__ __attribute__((aligned(16))) int s_dyn_raw[];
+    // LDS-staged node packets: the first `top_nodes` nodes in breadth-first order are the top of the tree, which
+    // every ray walks through.  The CU's vector L1 serves a 64-lane gather of 16-byte pieces at roughly one cache
+    // line per clock (PMC: 128 M TCP accesses per 1080p launch, the busiest unit of this kernel), LDS serves the
+    // same gather at 128 B per clock, so the hot levels are copied into LDS once per block.
+    const float4 *s_nodes = reinterpret_cast<const float4 *>(s_dyn_raw);
+    int *s_dyn = s_dyn_raw + top_nodes * 16u;
+    if (top_nodes) {
+        float4 *dst = reinterpret_cast<float4 *>(s_dyn_raw);
+        const float4 *src = reinterpret_cast<const float4 *>(a.scene.nodes);
+        for (uint32_t i = threadIdx.x; i < top_nodes * 4u; i += kQueueBlock * WAVES) dst[i] = src[i];
+        __syncthreads();                              // the only block-wide synchronisation: before any wave starts walking
+    }
+    __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
+    __shared__ float s_ray_all[WAVES][7][kQueueBlock];    // per covered pixel: ray origin (3), normal (3), RNG seed (1)
+    __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t (&s_vis)[kQueueBlock] = s_vis_all[wave];
+    float (&s_ray)[7][kQueueBlock] = s_ray_all[wave];
+    uint8_t (&s_list)[kQueueBlock] = s_list_all[wave];
+    int *wave_dyn = s_dyn + wave * (stack_levels + pregen_kinds * 3u) * kQueueBlock;
+    int *stack = wave_dyn + lane;
+    float *s_dir = reinterpret_cast<float *>(wave_dyn + stack_levels * kQueueBlock);
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
-    tile_pixel(lane, a.row_begin, x, y);
+    const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, x, y);
     const bool in_range = x < W && y < a.row_end;
     bool covered = false;
     float depth = 0.0f;
@@ -429,6 +492,9 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
         if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                         // rgen:20-21
     }
     s_vis[lane] = 0;
+    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
+    const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     if (covered) {
         // ---- raygen.rgen:15-29 once per pixel (shared by all of the pixel's rays) ----
         const float u = (float(x) + 0.5f) / float(W);
@@ -437,17 +503,24 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
         const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
         const f3 N = f3{ nid.x, nid.y, nid.z };
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
+        const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
-        s_ray[3][lane] = N.x; s_ray[4][lane] = N.y; s_ray[5][lane] = N.z;
-        s_ray[6][lane] = __uint_as_float(seed_thread((y * H + x) * a.pfd.frame_index));      // rgen:17
+        if (PREGEN) {
+            for (uint32_t kind = first_kind; kind <= last_kind; ++kind) {
+                const f3 d = ray_direction(a.tp, seed, kind, L, N);
+                float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + lane;
+                slot[0] = d.x; slot[kQueueBlock] = d.y; slot[2 * kQueueBlock] = d.z;
+            }
+        } else {
+            s_ray[3][lane] = N.x; s_ray[4][lane] = N.y; s_ray[5][lane] = N.z;
+            s_ray[6][lane] = __uint_as_float(seed);
+        }
     }
     const unsigned long long cov_mask = __ballot(covered);
     const uint32_t ncov = uint32_t(__popcll(cov_mask));
     if (covered) s_list[__popcll(cov_mask & ((1ull << lane) - 1ull))] = uint8_t(lane);
-    __syncthreads();
-    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
-    const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + a.tp.ao_spp - first_kind);
-    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+    wave_lds_sync();
+    const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
 
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
     float tmax = 0.0f;
@@ -456,6 +529,10 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
+    // Entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely go deeper than
+    // a dozen pending subtrees, so the LDS part can be much smaller than the tree depth -- more waves per CU --
+    // without giving up the guarantee that a stack of kTraceStack entries can never overflow (builder depth bound).
+    int spill[kTraceStack];
     uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0;      // statistics (only flushed when a.stats)
     const float tmin = a.tp.tmin;
     for (;;) {
@@ -470,18 +547,13 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
                 kind = k + first_kind;
                 pix = s_list[r - k * ncov];
                 ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
-                uint32_t rng = __float_as_uint(s_ray[6][pix]);
-                float rnd1 = random01(rng), rnd2 = random01(rng);                            // rgen:32-33
-                if (kind == 0) {                                                             // rgen:34-41
-                    const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));
-                    rd = onb_transform(L, cone_dir);
-                    tmax = a.tp.tmax;
-                } else {                                                                     // rgen:44-53
-                    for (uint32_t i = 0; i < kind; ++i) { rnd1 = random01(rng); rnd2 = random01(rng); }
-                    const f3 N = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
-                    rd = onb_transform(N, cosine_hemisphere(rnd1, rnd2));
-                    tmax = a.tp.ao_tmax;
+                if (PREGEN) {
+                    const float *slot = s_dir + k * 3u * kQueueBlock + pix;
+                    rd = f3{ slot[0], slot[kQueueBlock], slot[2 * kQueueBlock] };
+                } else {
+                    rd = ray_direction(a.tp, __float_as_uint(s_ray[6][pix]), kind, L, f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] });
                 }
+                tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
                 cur = 0; sp = 0;
@@ -494,16 +566,27 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
         bool finished = false, found = false;
         while (has && cur >= 0) {
             ++n_nodes;
-            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            const int4 q3 = reinterpret_cast<const int4 *>(np)[3];
+            float4 q0, q1, q2;
+            int4 q3;
+            if (uint32_t(cur) < top_nodes) {
+                const float4 *np = s_nodes + uint32_t(cur) * 4u;
+                q0 = np[0]; q1 = np[1]; q2 = np[2];
+                q3 = reinterpret_cast<const int4 *>(np)[3];
+            } else {
+                const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+                q0 = np[0]; q1 = np[1]; q2 = np[2];
+                q3 = reinterpret_cast<const int4 *>(np)[3];
+            }
             float tn0, tn1;
-            const bool h0 = box_test_fma(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, rinv, noi, tmin, tmax, tn0);
-            const bool h1 = box_test_fma(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, rinv, noi, tmin, tmax, tn1);
+            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin, tmax, tn0);
+            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin, tmax, tn1);
             if (h0 && h1) {
                 const bool first0 = tn0 <= tn1;
                 const int farc = first0 ? q3.y : q3.x;
-                if (uint32_t(sp) < stack_levels) { stack[sp * kQueueBlock] = farc; ++sp; } else { overflow = 1; }
+                if (uint32_t(sp) < stack_levels) stack[sp * kQueueBlock] = farc;
+                else if (uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                else overflow = 1;
+                ++sp;
                 cur = first0 ? q3.x : q3.y;
             } else if (h0) {
                 cur = q3.x;
@@ -514,7 +597,7 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
                 break;
             } else {
                 --sp;
-                cur = stack[sp * kQueueBlock];
+                cur = uint32_t(sp) < stack_levels ? stack[sp * kQueueBlock] : spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
             }
         }
         // ---- leaf ----
@@ -534,7 +617,10 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
                 }
             }
             if (found || sp == 0) finished = true;
-            else { --sp; cur = stack[sp * kQueueBlock]; }
+            else {
+                --sp;
+                cur = uint32_t(sp) < stack_levels ? stack[sp * kQueueBlock] : spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
+            }
         }
         if (has && finished) {
             has = false;
@@ -542,7 +628,7 @@ __global__ __launch_bounds__(kQueueBlock) void raygen_queue_kernel(const RaygenA
             else if (!found) atomicAdd(&s_vis[pix], 256u);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (covered) {
         const uint32_t vis = s_vis[lane];
         const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
@@ -620,10 +706,26 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
     } else {
         // the traversal stack is sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU
-        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(kTraceStack)));
+        // LDS part of the traversal stack (the rest spills to scratch): small enough for 7-8 waves per SIMD
+        uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
         const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
-        const dim3 grid8((width + 7) / 8, (a.row_end - a.row_begin + 7) / 8);
-        hipLaunchKernelGGL(raygen_queue_kernel, grid8, dim3(kQueueBlock), size_t(levels) * kQueueBlock * sizeof(int), ctx->stream, a, levels, threshold);
+        const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
+        const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
+        const uint32_t pregen_kinds = pregen ? kinds : 0u;
+        const size_t wave_bytes = (size_t(levels) + size_t(pregen_kinds) * 3) * kQueueBlock * sizeof(int);
+        const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
+        const int waves = ctx->options[kOptWavesPerBlock];
+        const uint32_t top_nodes = std::min<uint32_t>(ctx->node_count, uint32_t(std::max(0, ctx->options[kOptTopNodes])));
+        const size_t top_bytes = size_t(top_nodes) * sizeof(BvhNode);
+#define VHR_LAUNCH_QUEUE(P, WV)                                                                                                   \
+    hipLaunchKernelGGL((raygen_queue_kernel<P, WV>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), top_bytes + wave_bytes * WV, \
+                       ctx->stream, a, levels, threshold, pregen_kinds, top_nodes, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]))
+        if (pregen) {
+            if (waves >= 4) VHR_LAUNCH_QUEUE(true, 4); else if (waves >= 2) VHR_LAUNCH_QUEUE(true, 2); else VHR_LAUNCH_QUEUE(true, 1);
+        } else {
+            if (waves >= 4) VHR_LAUNCH_QUEUE(false, 4); else if (waves >= 2) VHR_LAUNCH_QUEUE(false, 2); else VHR_LAUNCH_QUEUE(false, 1);
+        }
+#undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
         if (a.reflections && a.tp.reflections) hipLaunchKernelGGL(reflection_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
     }

@@ -16,14 +16,16 @@ namespace vhr {
 // ---------------------------------------------------------------------------------------------
 // device-visible scene layout
 // ---------------------------------------------------------------------------------------------
-// BVH2 node = the two child boxes + two child links, 64 B = 4 x dwordx4 loads.
-//   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
-//   q2 = (lo1.z, hi1.x, hi1.y, hi1.z)  q3 = (child0, child1, 0, 0) as int bits
+// BVH2 node = the two child boxes + two child links, 64 B = 4 x dwordx4 loads.  Each box is stored as
+// (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z) so that the two slab planes of an axis sit in one aligned register pair:
+// the slab test is then three v_pk_fma_f32 per box.
+//   q0 = (b0.lox, b0.hix, b0.loy, b0.hiy)  q1 = (b0.loz, b0.hiz, b1.lox, b1.hix)
+//   q2 = (b1.loy, b1.hiy, b1.loz, b1.hiz)  q3 = (child0, child1, 0, 0) as int bits
 // child >= 0: inner node index.  child < 0: leaf, v = ~child, first = v >> 2, count = (v & 3) + 1.
 // An absent child (single-leaf scene) has an inverted box (lo = +inf, hi = -inf) and is never entered.
 struct BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+    float box0[6];
+    float box1[6];
     int32_t child0, child1;
     int32_t pad[2];
 };
@@ -41,7 +43,8 @@ struct BvhTri {
 };
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 
-constexpr int kMaxLeafTris = 4;
+constexpr int kMaxLeafTris = 4;      // encoding limit of a leaf link
+extern int g_leaf_tris;               // builder's leaf size (<= kMaxLeafTris); tunable for experiments
 constexpr int kMaxBvhDepth = 32;     // builder guarantee == traversal stack capacity
 constexpr int kTraceStack = 32;
 
@@ -115,7 +118,7 @@ struct PassDescription {
 struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, pad; };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptCount = 8 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptTopNodes = 8, kOptXcdAware = 9, kOptCount = 12 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };
@@ -182,10 +185,10 @@ struct vhr_context {
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
 
-    int options[vhr::kOptCount] = { 1, 16, 2, 0, 6, 0, 0, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 2, 0, 6, 12, 0, 2, 0, 0, 0, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
-    bool kernel_timing = false;
+    uint32_t kernel_timing_mask = 0;   // bit per KernelKind
     vhr::KernelTimer kernel_timers[vhr::kKernelKinds];
     void time_begin(int kind);
     void time_end(int kind);

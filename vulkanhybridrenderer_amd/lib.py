@@ -418,8 +418,15 @@ class Context:
     def set_option(self, key, value):
         self.check(self.L.vhr_set_option(self.handle, key.encode(), int(value)), "set_option")
 
-    def set_kernel_timing(self, enable):
-        self.check(self.L.vhr_set_kernel_timing(self.handle, int(enable)), "set_kernel_timing")
+    def set_kernel_timing(self, kinds):
+        """kinds: True (all), False (off) or an iterable of kind names from KERNEL_KINDS."""
+        if kinds is True:
+            mask = 0xF
+        elif not kinds:
+            mask = 0
+        else:
+            mask = sum(1 << self.KERNEL_KINDS[k] for k in kinds)
+        self.check(self.L.vhr_set_kernel_timing(self.handle, mask), "set_kernel_timing")
 
     def kernel_time(self, kind, reset=False):
         """(total_ms, launches) of a kernel kind, measured with HIP events on the context stream."""
