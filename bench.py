@@ -86,6 +86,7 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     cpu = args.backend == "gloo"
     for i in range(V):
         loop.frame(i)
+        loop.finish_pending_exchange()
         torch.cuda.synchronize()
         y0, y1 = loop.owned_rows()
         mine = alias_tensor(loop.ctx.transient_info(lib.DENOISED))[y0:y1].contiguous().view(torch.int16)
@@ -144,6 +145,7 @@ def main():
     ctx = loop.ctx
 
     def barrier():
+        loop.finish_pending_exchange()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

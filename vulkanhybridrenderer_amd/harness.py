@@ -45,6 +45,8 @@ class HybridFrameLoop:
         self.reference_rays_per_pixel = 4 * int(shadow) + ao_spp + int(reflections)     # raygen.rgen:38-40 duplicates
         self.pfds = camera.dolly_frames(scene, width, height, n_frames, start_frame_index)
         self.current = 0
+        self._aliases = {}
+        self._pending = None
         self.path = lib.HybridRenderPath(self.ctx, shadow_mode=0 if shadow else 2, ambient_occlusion_mode=0 if ao_spp else 2,
                                          reflection_mode=0 if reflections else 2, denoise=denoise, atrous_steps=atrous_steps,
                                          gbuffer_pass=self._gbuffer_pass)
@@ -92,14 +94,30 @@ class HybridFrameLoop:
         ctx.bind_external_image(lib.DEPTH, d.data_ptr())
 
     # ---- multi-GPU halo exchanges (tiling.py) ----
+    def _alias(self, info):
+        """torch views of context images, cached by device pointer (the moments history alternates between two)."""
+        key = int(info.device_ptr)
+        t = self._aliases.get(key)
+        if t is None:
+            t = self._aliases[key] = alias_tensor(info)
+        return t
+
+    def finish_pending_exchange(self):
+        if self._pending is not None:
+            self._pending.finish()
+            self._pending = None
+
     def _exchange_raytraced(self, ctx):
-        t = alias_tensor(ctx.transient_info(lib.RAYTRACED))
-        tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)
+        # exchange #2 of the previous frame (history + moments) was left in flight behind this frame's ray tracing;
+        # it has to land before svgf.comp, which runs right after this epilogue
+        self.finish_pending_exchange()
+        t = self._alias(ctx.transient_info(lib.RAYTRACED))
+        tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
 
     def _exchange_history(self, ctx):
-        hist = alias_tensor(ctx.storage_info(int(self.pc["shadow_and_ao_history"])))
-        mom = alias_tensor(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))     # current (just written) buffer
-        tiling.exchange_rows(self.dist, [hist, mom], self.plan, self.plan.halo)
+        hist = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_history"])))
+        mom = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))     # current (just written) buffer
+        self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)   # consumed by the NEXT frame
 
     # ---- one frame of the hot path ----
     def frame(self, i):
@@ -118,5 +136,6 @@ class HybridFrameLoop:
         return int(self.torch.count_nonzero(d).item()) * self.rays_per_pixel
 
     def close(self):
+        self.finish_pending_exchange()
         self.path.destroy()
         self.ctx.close()

@@ -81,13 +81,28 @@ def make_plan(height, world, rank, max_motion_rows, atrous_steps=5):
     return StripPlan(rank, world, height, y0, y1, overlap, halo)
 
 
-def exchange_rows(dist, tensors, plan, n_rows, group=None):
-    """Neighbour halo exchange of `n_rows` rows of each [H, ...] tensor (device or host), in place.
+class PendingExchange:
+    """A started neighbour exchange; finish() makes the current stream (or the host, for staged gloo) wait for it."""
+
+    def __init__(self, reqs, staged, keep):
+        self.reqs, self.staged, self.keep = reqs, staged, keep
+
+    def finish(self):
+        for req in self.reqs:
+            req.wait()
+        for dst, host in self.staged:
+            dst.copy_(host)
+        self.reqs, self.staged, self.keep = [], [], []
+
+
+def start_exchange(dist, tensors, plan, n_rows, group=None):
+    """Neighbour halo exchange of `n_rows` rows of each [H, ...] tensor (device or host), in place; returns a
+    PendingExchange (or None if there is nothing to exchange).
 
     One grouped batch of point-to-point ops (ncclGroupStart/End under the "nccl" = RCCL backend): each
     neighbour pair talks over its direct xGMI link; no collective involves more than two ranks."""
     if plan.world == 1 or n_rows <= 0:
-        return
+        return None
     # Device tensors travel device-to-device under "nccl" (RCCL).  Under "gloo" (CPU transport: the CI route
     # for exercising this code with several ranks on one GPU) they are staged through host memory.
     stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
@@ -99,7 +114,7 @@ def exchange_rows(dist, tensors, plan, n_rows, group=None):
             recv = t[ra:rb]
             if not recv.is_contiguous():
                 raise ValueError("row slices of a [H, ...] tensor must be contiguous")
-            send = t[sa:sb].cpu() if stage else t[sa:sb].contiguous()
+            send = t[sa:sb].cpu() if stage else t[sa:sb]
             if stage:
                 host = recv.cpu()
                 staged.append((recv, host))
@@ -108,8 +123,12 @@ def exchange_rows(dist, tensors, plan, n_rows, group=None):
             ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
             keep.append(send)      # keep the send buffers alive until completion
     if not ops:
-        return
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    for dst, host in staged:
-        dst.copy_(host)
+        return None
+    return PendingExchange(dist.batch_isend_irecv(ops), staged, keep)
+
+
+def exchange_rows(dist, tensors, plan, n_rows, group=None):
+    """Blocking form of start_exchange (the exchange is complete, in stream order, when this returns)."""
+    pending = start_exchange(dist, tensors, plan, n_rows, group)
+    if pending is not None:
+        pending.finish()
