@@ -1,0 +1,145 @@
+"""Edge cases of the hot path on the GPU, each checked against the oracle: textured closest-hit shading and fp16
+object-id aliasing (> 2048 primitives), empty and single-triangle scenes, image sizes that are not multiples of
+the tile sizes, axis-parallel rays (zero direction components), the BASELINE ao_spp extensions, sky-only frames."""
+import numpy as np
+import pytest
+
+from tests.helpers import GpuHybrid, f16, oracle_frames
+from vulkanhybridrenderer_amd import abi, camera, lib, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, scene, W, H, n_frames, tp, denoise=True, refl_steps=2):
+    frames, osc, _ = oracle_frames(oracle, scene, W, H, n_frames, tp, denoise=denoise)
+    g = GpuHybrid(scene, W, H, denoise=denoise, trace_params=tp)
+    try:
+        for i, fr in enumerate(frames):
+            g.frame(fr["pfd"], fr["gbuf"])
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"frame {i}: visibility"
+            if tp["reflections"]:
+                a, b = f16(g.ctx.download(lib.REFLECTIONS)), f16(fr["reflections"])
+                assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0), f"frame {i}: reflection hit mask"
+                tol = refl_steps * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)
+                assert (np.abs(a - b) <= tol).all(), f"frame {i}: reflection colour off by {np.abs(a - b).max()}"
+            if denoise:
+                den, ref = f16(g.ctx.download(lib.DENOISED)), f16(fr["denoised"])
+                assert float(np.sqrt(np.mean((den - ref) ** 2))) <= 1e-4, f"frame {i}: denoised RMSE"
+        return frames
+    finally:
+        g.close()
+
+
+def test_textured_scene_with_id_aliasing(oracle):
+    """bistro_proc in miniature: 2200 primitives (ids above 2048 alias in fp16, gbuf.frag:43), sRGB base-colour
+    textures with REPEAT/LINEAR samplers sampled by the closest-hit shader (reflection_hit.rchit:27-39)."""
+    scene = scenes.bistro_proc(detail=0.02, n_primitives=2200, n_textures=8, texture_size=64)
+    frames = _check(oracle, scene, 160, 90, 3, abi.default_trace_params(), refl_steps=3)
+    ids = f16(frames[1]["gbuf"][0])[..., 3]
+    assert ids.max() > 2048 and (ids[ids > 2048] % 2 == 0).all()          # odd ids above 2048 are not representable
+    assert (f16(frames[1]["reflections"])[..., 3] > 0).mean() > 0.5
+
+
+def test_empty_scene(oracle):
+    scene = scenes.tiny_scene()
+    scene.primitives = scene.primitives[:0]
+    W, H = 40, 24
+    tp = abi.default_trace_params()
+    pfd = camera.dolly_frames(scene, W, H, 2)[1]
+    # a G-buffer that claims coverage although nothing can be hit: every ray escapes
+    n = np.zeros((H, W, 4), np.float16); n[..., 1] = 1.0
+    gbuf = (n.view(np.uint16), np.zeros((H, W, 4), np.uint16), np.full((H, W), 0.5, np.float32))
+    osc = oracle.Scene(scene)
+    sa, refl, _, _ = osc.raygen(pfd, tp, gbuf[0], gbuf[2])
+    assert (f16(sa) == 1.0).all() and not refl.any()
+    for variant in (0, 1):
+        g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
+        try:
+            g.ctx.set_option("raygen_variant", variant)
+            g.frame(pfd, gbuf)
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), sa)
+            assert not g.ctx.download(lib.REFLECTIONS).any()
+            assert g.ctx.bvh_statistics()["nodes"] == 0
+        finally:
+            g.close()
+
+
+def test_single_triangle_scene(oracle):
+    scene = scenes.tiny_scene()
+    p = scene.primitives[:1].copy()
+    p["index_count"] = 3
+    scene.primitives = p
+    _check(oracle, scene, 64, 40, 2, abi.default_trace_params(), denoise=False)
+
+
+@pytest.mark.parametrize("W,H", [(67, 45), (130, 9), (8, 8)])
+def test_odd_image_sizes(oracle, W, H):
+    _check(oracle, scenes.tiny_scene(), W, H, 3, abi.default_trace_params())
+
+
+def test_axis_parallel_light_and_rays(oracle):
+    """Light straight down: shadow rays have exactly-zero direction components on the frame where every pixel
+    draws the same cone sample; the slab test must not cull on 0 * inf."""
+    scene = scenes.tiny_scene()
+    scene.light = camera.directional_light((0.0, -1.0, 0.0))
+    frames = _check(oracle, scene, 96, 64, 3, abi.default_trace_params())
+    assert 0.05 < (f16(frames[1]["shadow_ao"])[..., 0] == 0).mean() < 0.95
+
+
+@pytest.mark.parametrize("ao_spp", [0, 1, 4, 16, 20])
+def test_ao_sample_counts(oracle, ao_spp):
+    """BASELINE.json configs 3 and 5 use 4 and 16 AO samples; 20 exceeds the pre-generation limit (other code path)."""
+    tp = abi.default_trace_params(ao_spp=ao_spp, reflections=False)
+    for pregen in (0, 1):
+        frames, _, _ = oracle_frames(oracle, scenes.tiny_scene(), 64, 40, 2, tp, denoise=False)
+        g = GpuHybrid(scenes.tiny_scene(), 64, 40, denoise=False, trace_params=tp, reflections=False)
+        try:
+            g.ctx.set_option("raygen_pregen", pregen)
+            for fr in frames:
+                g.frame(fr["pfd"], fr["gbuf"])
+                assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"])
+        finally:
+            g.close()
+
+
+def test_shadows_disabled_extension(oracle):
+    tp = abi.default_trace_params(shadow=False, reflections=False)
+    frames = _check(oracle, scenes.tiny_scene(), 64, 40, 2, tp, denoise=False)
+    assert (f16(frames[1]["shadow_ao"])[..., 0] == 1.0).all()
+
+
+@pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)),
+                                           ("lds_top_nodes", (0, 15, 200)), ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)),
+                                           ("atrous_variant", (0, 1, 2))])
+def test_every_tuning_option_is_result_neutral(oracle, option, values):
+    scene = scenes.tiny_scene()
+    W, H = 72, 56
+    tp = abi.default_trace_params(reflections=False)
+    frames, _, _ = oracle_frames(oracle, scene, W, H, 3, tp)
+    outs = []
+    for v in values:
+        g = GpuHybrid(scene, W, H, trace_params=tp, reflections=False)
+        try:
+            g.ctx.set_option(option, v)
+            for fr in frames:
+                g.frame(fr["pfd"], fr["gbuf"])
+                assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), (option, v)
+            outs.append(g.ctx.download(lib.DENOISED))
+            if option in ("lds_stack_levels", "lds_top_nodes"):
+                g.ctx.set_ray_statistics(True)
+                g.frame(frames[-1]["pfd"], frames[-1]["gbuf"])
+                assert g.ctx.ray_statistics()["stack_overflows"] == 0
+        finally:
+            g.close()
+    if option != "atrous_variant":        # the a-trous variants may differ in the last fp16 step (dot2 vs three FMAs)
+        assert all(np.array_equal(o, outs[0]) for o in outs)
+    else:
+        assert all(float(np.sqrt(np.mean((f16(o) - f16(frames[-1]["denoised"])) ** 2))) <= 1e-4 for o in outs)
+
+
+def test_sky_only_frame(oracle):
+    scene = scenes.tiny_scene()
+    scene.camera = dict(scene.camera, pitch=1.45)        # look straight up: nothing but sky
+    frames = _check(oracle, scene, 64, 40, 2, abi.default_trace_params())
+    assert not frames[1]["gbuf"][2].any()
+    assert (f16(frames[1]["shadow_ao"]) == 1.0).all()
