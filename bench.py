@@ -113,6 +113,18 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     return "bit-identical" if int(flag[0]) else "MISMATCH"
 
 
+def pmc_traffic(args):
+    """HBM-side bytes per a-trous launch from the committed PMC run (tools/profile_traffic.sh -> profiles/traffic.json:
+    FETCH_SIZE x the calibrated gfx950 correction + WRITE_SIZE, separate --pmc passes).  Only valid for the default workload."""
+    if (args.width, args.height, args.scene, args.gpus) != (1920, 1080, "sponza_proc", 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return int(json.load(f)["svgf_atrous_mean_traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -229,9 +241,10 @@ def main():
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
             },
             "roofline": {
-                "kernel": "svgf_atrous_kernel (svgf_atrous_filter.comp)",
+                "kernel": "svgf_atrous_tiled_kernel<step, 8> (svgf_atrous_filter.comp)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits)",
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
                 "algorithmic_bytes_per_launch": int(atrous_bytes),
             },

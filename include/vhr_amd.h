@@ -260,6 +260,10 @@ int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64
  * Active-lane utilisation of the traversal loop = (out[0] + out[1]) / (64 * out[3]). */
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 
+/* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
+ * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */
+int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_t bytes_per_lane);
+
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */
 int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);

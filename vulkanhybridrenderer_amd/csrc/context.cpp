@@ -412,6 +412,12 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
     return VHR_OK;
 }
 
+int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_t bytes_per_lane) {
+    if (!ctx || ctx->host_only || storage_image < 0 || uint32_t(storage_image) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[storage_image].used)
+        return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "calibration: no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    return launch_calibration_read(ctx, ctx->storage_images[storage_image], bytes_per_lane, ctx->d_tile_counter);
+}
+
 int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     out[0] = ctx->node_count; out[1] = ctx->tri_count; out[2] = ctx->bvh_depth;

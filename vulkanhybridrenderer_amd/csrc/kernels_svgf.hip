@@ -436,6 +436,35 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
 }
 
 // ---------------------------------------------------------------------------------------------
+// Counter calibration: a streaming read of a known byte count with the access width the SVGF kernels use
+// (8 B per lane for RGBA16F, 4 B for RG16F, 16 B for reference).  rocprofv3's FETCH_SIZE is known to under-report
+// wide streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section); tools/profile_traffic.sh runs this kernel
+// under --pmc FETCH_SIZE to obtain the correction factor for OUR access pattern before pricing the a-trous traffic.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void calibration_read_kernel(const T *src, size_t count, uint32_t *sink) {
+    uint32_t acc = 0;
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256) {
+        const T v = src[i];
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&v);
+#pragma unroll
+        for (int k = 0; k < int(sizeof(T) / 4); ++k) acc ^= w[k];
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;        // practically never true: keeps the loads alive
+}
+
+int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink) {
+    const size_t bytes = img.bytes();
+    const dim3 grid(2048);
+    if (bytes_per_lane == 4) hipLaunchKernelGGL(calibration_read_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(img.ptr), bytes / 4, sink);
+    else if (bytes_per_lane == 8) hipLaunchKernelGGL(calibration_read_kernel<uint2>, grid, dim3(256), 0, ctx->stream, static_cast<const uint2 *>(img.ptr), bytes / 8, sink);
+    else if (bytes_per_lane == 16) hipLaunchKernelGGL(calibration_read_kernel<uint4>, grid, dim3(256), 0, ctx->stream, static_cast<const uint4 *>(img.ptr), bytes / 16, sink);
+    else return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "calibration: bytes_per_lane must be 4, 8 or 16");
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "calibration kernel launch failed");
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K5: same-extent, same-format VK_FILTER_NEAREST blit == copy (compute_execution_context.cpp:178-211)
 // ---------------------------------------------------------------------------------------------
 int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {

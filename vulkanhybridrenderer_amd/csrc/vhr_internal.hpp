@@ -212,5 +212,6 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in,
                        Image &out, int32_t step, uint32_t x_groups, uint32_t y_groups);
 int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst);
+int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink);
 
 }  // namespace vhr

@@ -32,6 +32,7 @@ EXPORTS = [
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_set_strip",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics",
+    "vhr_calibration_stream_read",
 ]
 
 
@@ -155,6 +156,7 @@ def load():
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
@@ -400,6 +402,9 @@ class Context:
         out = (C.c_uint64 * 4)()
         self.check(self.L.vhr_get_ray_statistics(self.handle, out), "ray_statistics")
         return dict(unique_rays=out[0], reference_issued_rays=out[1], covered_pixels=out[2], stack_overflows=out[3])
+
+    def calibration_stream_read(self, storage_image, bytes_per_lane):
+        self.check(self.L.vhr_calibration_stream_read(self.handle, storage_image, bytes_per_lane), "calibration_stream_read")
 
     def traversal_statistics(self):
         out = (C.c_uint64 * 4)()
