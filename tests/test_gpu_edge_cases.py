@@ -108,8 +108,8 @@ def test_shadows_disabled_extension(oracle):
     assert (f16(frames[1]["shadow_ao"])[..., 0] == 1.0).all()
 
 
-@pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)),
-                                           ("lds_top_nodes", (0, 15, 200)), ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)),
+@pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)), ("compact_nodes", (0, 1)),
+                                           ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)),
                                            ("atrous_variant", (0, 1, 2))])
 def test_every_tuning_option_is_result_neutral(oracle, option, values):
     scene = scenes.tiny_scene()
@@ -125,7 +125,7 @@ def test_every_tuning_option_is_result_neutral(oracle, option, values):
                 g.frame(fr["pfd"], fr["gbuf"])
                 assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), (option, v)
             outs.append(g.ctx.download(lib.DENOISED))
-            if option in ("lds_stack_levels", "lds_top_nodes"):
+            if option in ("lds_stack_levels", "compact_nodes"):
                 g.ctx.set_ray_statistics(True)
                 g.frame(frames[-1]["pfd"], frames[-1]["gbuf"])
                 assert g.ctx.ray_statistics()["stack_overflows"] == 0

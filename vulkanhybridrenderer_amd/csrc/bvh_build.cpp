@@ -164,6 +164,50 @@ inline void padded(const Box &b, float lo[3], float hi[3]) {
     }
 }
 
+// float -> half bits, rounded toward -inf (down = true) or +inf; |x| beyond the half range saturates outward to +-inf
+inline uint16_t half_directed(float x, bool down) {
+    if (std::isnan(x)) return 0x7e00;
+    if (std::isinf(x)) return x < 0 ? 0xfc00 : 0x7c00;
+    // nearest-even conversion first, then step one ulp outward if it landed on the wrong side
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const float ax = std::fabs(x);
+    uint16_t h;
+    if (ax >= 65520.0f) h = uint16_t(sign | 0x7c00u);
+    else if (ax < 5.9604645e-8f * 0.5f) h = uint16_t(sign);
+    else {
+        int e;
+        const float m = std::frexp(ax, &e);                 // ax = m * 2^e, m in [0.5, 1)
+        int he = e + 14;                                     // half exponent field for normals
+        if (he <= 0) {                                       // subnormal half: units of 2^-24
+            const uint32_t q = uint32_t(std::nearbyint(std::ldexp(ax, 24)));
+            h = uint16_t(sign | q);
+        } else {
+            uint32_t q = uint32_t(std::nearbyint(std::ldexp(m, 11)));   // 11-bit significand incl. implicit bit
+            if (q == 2048u) { q = 1024u; ++he; }
+            h = (he >= 31) ? uint16_t(sign | 0x7c00u) : uint16_t(sign | (uint32_t(he) << 10) | (q & 0x3ffu));
+        }
+    }
+    auto value = [](uint16_t hb) -> float {
+        const uint32_t s2 = hb & 0x8000u, ex = (hb >> 10) & 0x1fu, ma = hb & 0x3ffu;
+        float v;
+        if (ex == 0) v = std::ldexp(float(ma), -24);
+        else if (ex == 31) v = ma ? NAN : INFINITY;
+        else v = std::ldexp(float(ma | 0x400u), int(ex) - 25);
+        return s2 ? -v : v;
+    };
+    auto step = [](uint16_t hb, bool up) -> uint16_t {     // next representable half toward +inf (up) or -inf
+        if ((hb & 0x7fffu) == 0) return up ? uint16_t(0x0001) : uint16_t(0x8001);
+        const bool neg = hb & 0x8000u;
+        return (neg == up) ? uint16_t(hb - 1) : uint16_t(hb + 1);
+    };
+    const float v = value(h);
+    if (down && v > x) h = step(h, false);
+    if (!down && v < x) h = step(h, true);
+    return h;
+}
+
 inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((first << 2) | (count - 1)); }
 
 }  // namespace
@@ -200,6 +244,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     }
     const uint32_t n = uint32_t(b.tris.size());
     out.nodes.clear();
+    out.nodes16.clear();
     out.tris.clear();
     out.max_depth = 0;
     if (n == 0) return;
@@ -236,6 +281,31 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         (which == 0 ? node.child0 : node.child1) = link;
     };
 
+    auto finalize16 = [&]() {
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        for (const BvhNode &nd : out.nodes)
+            for (int a = 0; a < 3; ++a) {
+                if (nd.box0[2 * a] <= nd.box0[2 * a + 1]) { lo[a] = std::min(lo[a], nd.box0[2 * a]); hi[a] = std::max(hi[a], nd.box0[2 * a + 1]); }
+                if (nd.box1[2 * a] <= nd.box1[2 * a + 1]) { lo[a] = std::min(lo[a], nd.box1[2 * a]); hi[a] = std::max(hi[a], nd.box1[2 * a + 1]); }
+            }
+        for (int a = 0; a < 3; ++a) out.centre[a] = (lo[a] <= hi[a]) ? 0.5f * (lo[a] + hi[a]) : 0.0f;
+        out.nodes16.resize(out.nodes.size());
+        for (size_t k = 0; k < out.nodes.size(); ++k) {
+            const BvhNode &nd = out.nodes[k];
+            BvhNode16 c{};
+            for (int a = 0; a < 3; ++a) {
+                // (x - centre) is rounded to fp32 first: go one more ulp outward by rounding the fp32 difference outward too
+                c.h[2 * a] = half_directed(std::nextafter(nd.box0[2 * a] - out.centre[a], -inf), true);
+                c.h[2 * a + 1] = half_directed(std::nextafter(nd.box0[2 * a + 1] - out.centre[a], inf), false);
+                c.h[6 + 2 * a] = half_directed(std::nextafter(nd.box1[2 * a] - out.centre[a], -inf), true);
+                c.h[6 + 2 * a + 1] = half_directed(std::nextafter(nd.box1[2 * a + 1] - out.centre[a], inf), false);
+            }
+            c.child0 = nd.child0;
+            c.child1 = nd.child1;
+            out.nodes16[k] = c;
+        }
+    };
+
     const TmpNode &root = b.nodes[0];
     if (root.left < 0) {                       // whole scene fits one leaf
         BvhNode node{};
@@ -243,6 +313,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         for (int a = 0; a < 3; ++a) { node.box1[2 * a] = inf; node.box1[2 * a + 1] = -inf; }
         node.child1 = node.child0;
         out.nodes.push_back(node);
+        finalize16();
         return;
     }
     // breadth-first numbering of the inner nodes
@@ -268,6 +339,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         set_child(node, 1, r, r.left >= 0 ? bfs_index[t.right] : leaf_link(r.first, r.count));
         out.nodes[k] = node;
     }
+    finalize16();
 }
 
 }  // namespace vhr

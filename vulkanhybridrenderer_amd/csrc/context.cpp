@@ -36,6 +36,9 @@ static std::string g_create_error;
 vhr::DeviceScene vhr_context::device_scene() const {
     DeviceScene s;
     s.nodes = d_nodes;
+    s.nodes16 = d_nodes16;
+    s.centre[0] = bvh_centre[0]; s.centre[1] = bvh_centre[1]; s.centre[2] = bvh_centre[2];
+    s.pad0 = 0.0f;
     s.tris = d_tris;
     s.vertices = d_vertices;
     s.indices = d_indices;
@@ -176,9 +179,9 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
 
 static void free_scene(vhr_context *ctx) {
     hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
-    hipFree(ctx->d_nodes); hipFree(ctx->d_tris);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_tris);
     ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_tris = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_tris = nullptr;
     ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
 }
 
@@ -268,7 +271,9 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_primitives), primitives, sizeof(vhr_primitive) * primitive_count));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_normal_matrices), nm.data(), sizeof(float) * nm.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
+    for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
     ctx->vertex_count = vertex_count;
     ctx->index_count = index_count;
     ctx->primitive_count = primitive_count;
@@ -380,7 +385,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "lds_top_nodes", "xcd_aware" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware" };
     for (int i = 0; i < 10; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
     return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");

@@ -451,24 +451,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 // several hundred instructions -- divisions, sqrt, the sin/cos polynomial -- and would otherwise run inside
 // the refill with a fraction of the lanes); the queue refill then only fetches 3 floats.  !PREGEN (more than
 // kMaxPregenKinds ray kinds): directions are generated inside the refill.
-template <bool PREGEN, int WAVES>
+template <bool PREGEN, int WAVES, bool COMPACT>
 __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
-                                                                          const uint32_t pregen_kinds, const uint32_t top_nodes,
-                                                                          const uint32_t block_tiles_x, const uint32_t xcd_aware) {
-    // dynamic LDS: [top_nodes x 64 B node packets][per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats]
-    extern __shared__ __attribute__((aligned(16))) int s_dyn_raw[];
-    // LDS-staged node packets: the first `top_nodes` nodes in breadth-first order are the top of the tree, which
-    // every ray walks through.  The CU's vector L1 serves a 64-lane gather of 16-byte pieces at roughly one cache
-    // line per clock (PMC: 128 M TCP accesses per 1080p launch, the busiest unit of this kernel), LDS serves the
-    // same gather at 128 B per clock, so the hot levels are copied into LDS once per block.
-    const float4 *s_nodes = reinterpret_cast<const float4 *>(s_dyn_raw);
-    int *s_dyn = s_dyn_raw + top_nodes * 16u;
-    if (top_nodes) {
-        float4 *dst = reinterpret_cast<float4 *>(s_dyn_raw);
-        const float4 *src = reinterpret_cast<const float4 *>(a.scene.nodes);
-        for (uint32_t i = threadIdx.x; i < top_nodes * 4u; i += kQueueBlock * WAVES) dst[i] = src[i];
-        __syncthreads();                              // the only block-wide synchronisation: before any wave starts walking
-    }
+                                                                          const uint32_t pregen_kinds, const uint32_t block_tiles_x,
+                                                                          const uint32_t xcd_aware) {
+    extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
     __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
     __shared__ float s_ray_all[WAVES][7][kQueueBlock];    // per covered pixel: ray origin (3), normal (3), RNG seed (1)
     __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
@@ -529,11 +516,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
-    // Entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely go deeper than
-    // a dozen pending subtrees, so the LDS part can be much smaller than the tree depth -- more waves per CU --
-    // without giving up the guarantee that a stack of kTraceStack entries can never overflow (builder depth bound).
-    int spill[kTraceStack];
     uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0;      // statistics (only flushed when a.stats)
+    // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
+    // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
+    // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
+    int spill[kTraceStack];
     const float tmin = a.tp.tmin;
     for (;;) {
         // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
@@ -555,50 +542,51 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
                 }
                 tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
-                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                // COMPACT boxes are relative to the scene centre: shift the origin used by the slab test (only)
+                const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
+                noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 cur = 0; sp = 0;
                 has = true;
             }
         }
         if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
         ++n_iters;
-        // ---- inner nodes: descend until this lane holds a leaf (or ran out of stack) ----
+        // ---- inner nodes: descend until this lane holds a leaf or its ray has run out of subtrees ----
+        // The step is written without branches (selects + one unconditional LDS write and read per trip): divergent
+        // if/else chains here cost more scalar exec-mask bookkeeping than the box tests themselves.  The write goes to
+        // slot `sp` (level stack_levels - 1 at most: the builder bounds the depth), the read takes the current top.
         bool finished = false, found = false;
-        while (has && cur >= 0) {
+        while (has && cur >= 0 && !finished) {
             ++n_nodes;
-            float4 q0, q1, q2;
-            int4 q3;
-            if (uint32_t(cur) < top_nodes) {
-                const float4 *np = s_nodes + uint32_t(cur) * 4u;
-                q0 = np[0]; q1 = np[1]; q2 = np[2];
-                q3 = reinterpret_cast<const int4 *>(np)[3];
+            float tn0, tn1;
+            bool h0, h1;
+            int2 links;
+            if (COMPACT) {
+                const uint4 *np = reinterpret_cast<const uint4 *>(a.scene.nodes16 + cur);
+                const uint4 c0 = np[0], c1 = np[1];
+                auto unpack = [](uint32_t w) { const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w)); return f2v{ f.x, f.y }; };
+                h0 = box_test_pk(unpack(c0.x), unpack(c0.y), unpack(c0.z), rinv, noi, tmin, tmax, tn0);
+                h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin, tmax, tn1);
+                links = int2{ int(c1.z), int(c1.w) };
             } else {
                 const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
-                q0 = np[0]; q1 = np[1]; q2 = np[2];
-                q3 = reinterpret_cast<const int4 *>(np)[3];
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+                links = *reinterpret_cast<const int2 *>(np + 3);
+                h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin, tmax, tn0);
+                h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin, tmax, tn1);
             }
-            float tn0, tn1;
-            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin, tmax, tn0);
-            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin, tmax, tn1);
-            if (h0 && h1) {
-                const bool first0 = tn0 <= tn1;
-                const int farc = first0 ? q3.y : q3.x;
-                if (uint32_t(sp) < stack_levels) stack[sp * kQueueBlock] = farc;
-                else if (uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
-                else overflow = 1;
-                ++sp;
-                cur = first0 ? q3.x : q3.y;
-            } else if (h0) {
-                cur = q3.x;
-            } else if (h1) {
-                cur = q3.y;
-            } else if (sp == 0) {
-                finished = true;
-                break;
-            } else {
-                --sp;
-                cur = uint32_t(sp) < stack_levels ? stack[sp * kQueueBlock] : spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
-            }
+            const bool both = h0 && h1, none = !(h0 || h1);
+            const bool first0 = tn0 <= tn1;
+            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            const uint32_t below = sp > 0 ? uint32_t(sp) - 1u : 0u;
+            const int top = below < stack_levels ? stack[below * kQueueBlock] : spill[(below - stack_levels) & uint32_t(kTraceStack - 1)];
+            // the write is harmless when !both: slot sp is above the top of the stack
+            if (uint32_t(sp) < stack_levels) stack[sp * kQueueBlock] = farc;
+            else if (uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+            else overflow |= both ? 1u : 0u;                                      // cannot happen (builder depth bound); counted
+            finished = none && sp == 0;
+            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
+            sp += (both ? 1 : 0) - ((none && sp > 0) ? 1 : 0);
         }
         // ---- leaf ----
         if (has && !finished) {
@@ -706,8 +694,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
     } else {
         // the traversal stack is sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU
-        // LDS part of the traversal stack (the rest spills to scratch): small enough for 7-8 waves per SIMD
-        uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
+        // LDS part of the traversal stack; deeper entries spill to scratch (see the kernel)
+        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
         const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
         const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
         const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
@@ -715,16 +703,15 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const size_t wave_bytes = (size_t(levels) + size_t(pregen_kinds) * 3) * kQueueBlock * sizeof(int);
         const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
         const int waves = ctx->options[kOptWavesPerBlock];
-        const uint32_t top_nodes = std::min<uint32_t>(ctx->node_count, uint32_t(std::max(0, ctx->options[kOptTopNodes])));
-        const size_t top_bytes = size_t(top_nodes) * sizeof(BvhNode);
-#define VHR_LAUNCH_QUEUE(P, WV)                                                                                                   \
-    hipLaunchKernelGGL((raygen_queue_kernel<P, WV>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), top_bytes + wave_bytes * WV, \
-                       ctx->stream, a, levels, threshold, pregen_kinds, top_nodes, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]))
-        if (pregen) {
-            if (waves >= 4) VHR_LAUNCH_QUEUE(true, 4); else if (waves >= 2) VHR_LAUNCH_QUEUE(true, 2); else VHR_LAUNCH_QUEUE(true, 1);
-        } else {
-            if (waves >= 4) VHR_LAUNCH_QUEUE(false, 4); else if (waves >= 2) VHR_LAUNCH_QUEUE(false, 2); else VHR_LAUNCH_QUEUE(false, 1);
-        }
+#define VHR_LAUNCH_QUEUE(P, WV, C)                                                                                                \
+    hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), wave_bytes * WV, \
+                       ctx->stream, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]))
+#define VHR_LAUNCH_QUEUE_W(P, C)                                                                                                   \
+    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C); else VHR_LAUNCH_QUEUE(P, 1, C); } while (0)
+        const bool compact = ctx->options[kOptCompactNodes] != 0;
+        if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true); else VHR_LAUNCH_QUEUE_W(true, false); }
+        else { if (compact) VHR_LAUNCH_QUEUE_W(false, true); else VHR_LAUNCH_QUEUE_W(false, false); }
+#undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
         if (a.reflections && a.tp.reflections) hipLaunchKernelGGL(reflection_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);

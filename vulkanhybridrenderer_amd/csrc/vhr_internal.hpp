@@ -31,6 +31,17 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 
+// The same node with its boxes as IEEE halves RELATIVE TO THE SCENE CENTRE, rounded outward (lo toward -inf, hi
+// toward +inf) -- 32 B = 2 x dwordx4 loads per visit instead of 4.  Boxes only cull, and an outward-rounded box
+// contains the fp32 one, so the set of triangles tested can only grow and results are unchanged; what shrinks is
+// the number of L1 line accesses per visit, the throughput limit of the traversal kernel (PMC: ~0.5 TCP accesses
+// per clock per CU).  h[0..5] = box0 (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), h[6..11] = box1.
+struct BvhNode16 {
+    uint16_t h[12];
+    int32_t child0, child1;
+};
+static_assert(sizeof(BvhNode16) == 32, "BvhNode16");
+
 // Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
 // (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
 struct BvhTri {
@@ -58,6 +69,9 @@ struct DeviceTexture {
 
 struct DeviceScene {
     const BvhNode *nodes;
+    const BvhNode16 *nodes16;
+    float centre[3];                 // origin of the half-precision boxes
+    float pad0;
     const BvhTri *tris;
     const vhr_vertex *vertices;
     const uint32_t *indices;
@@ -83,6 +97,8 @@ struct Image {
 
 struct HostBvh {
     std::vector<BvhNode> nodes;
+    std::vector<BvhNode16> nodes16;
+    float centre[3] = { 0, 0, 0 };
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
 };
@@ -118,7 +134,7 @@ struct PassDescription {
 struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, pad; };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptTopNodes = 8, kOptXcdAware = 9, kOptCount = 12 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptCount = 12 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };
@@ -166,6 +182,8 @@ struct vhr_context {
     vhr_primitive *d_primitives = nullptr;
     float *d_normal_matrices = nullptr;
     vhr::BvhNode *d_nodes = nullptr;
+    vhr::BvhNode16 *d_nodes16 = nullptr;
+    float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
 
