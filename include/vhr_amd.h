@@ -242,7 +242,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
  *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 12)
  *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)
- *   "raygen_waves_per_block" 1, 2 or 4 independent 8x8-pixel tiles (waves) per workgroup (default 2)
+ *   "raygen_waves_per_block" 1..4 waves per workgroup (default 2)
+ *   "raygen_shared_tile" 1 = the waves of a workgroup split ONE 8x8-pixel tile's ray queue, 0 = one tile per wave
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)

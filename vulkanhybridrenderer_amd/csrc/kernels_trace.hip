@@ -451,34 +451,41 @@ __device__ __forceinline__ void wave_lds_sync() {
 // several hundred instructions -- divisions, sqrt, the sin/cos polynomial -- and would otherwise run inside
 // the refill with a fraction of the lanes); the queue refill then only fetches 3 floats.  !PREGEN (more than
 // kMaxPregenKinds ray kinds): directions are generated inside the refill.
-template <bool PREGEN, int WAVES, bool COMPACT>
+// SHARED: the WAVES waves of a block split the queue of ONE 8x8 tile between them (queue head in LDS) instead of
+// owning a tile each: a wave then lives for about a third as long, which matters whenever few waves are in flight
+// (the end of a launch, or a thin strip of a multi-GPU run), at the price of one block-wide barrier on either side.
+template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED>
 __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
                                                                           const uint32_t xcd_aware) {
     extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
-    __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
-    __shared__ float s_ray_all[WAVES][7][kQueueBlock];    // per covered pixel: ray origin (3), normal (3), RNG seed (1)
-    __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
+    constexpr int COPIES = SHARED ? 1 : WAVES;
+    __shared__ uint32_t s_vis_all[COPIES][kQueueBlock];   // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
+    __shared__ float s_ray_all[COPIES][7][kQueueBlock];   // per covered pixel: ray origin (3), normal (3), RNG seed (1)
+    __shared__ uint8_t s_list_all[COPIES][kQueueBlock];   // compacted covered pixels
+    __shared__ uint32_t s_next, s_ncov;                   // SHARED: queue head and covered-pixel count of the tile
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t (&s_vis)[kQueueBlock] = s_vis_all[wave];
-    float (&s_ray)[7][kQueueBlock] = s_ray_all[wave];
-    uint8_t (&s_list)[kQueueBlock] = s_list_all[wave];
-    int *wave_dyn = s_dyn + wave * (stack_levels + pregen_kinds * 3u) * kQueueBlock;
-    int *stack = wave_dyn + lane;
-    float *s_dir = reinterpret_cast<float *>(wave_dyn + stack_levels * kQueueBlock);
+    uint32_t (&s_vis)[kQueueBlock] = s_vis_all[SHARED ? 0 : wave];
+    float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
+    uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
+    // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
+    int *stack = s_dyn + wave * stack_levels * kQueueBlock + lane;
+    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * stack_levels * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, x, y);
+    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, x, y);
+    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, x, y);
     const bool in_range = x < W && y < a.row_end;
+    const bool setup_wave = !SHARED || wave == 0;         // SHARED: wave 0 prepares the tile, the others join at the barrier
     bool covered = false;
     float depth = 0.0f;
-    if (in_range) {
+    if (in_range && setup_wave) {
         depth = a.depth[size_t(y) * W + x];                                                  // rgen:19
         covered = depth != 0.0f;
         if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                         // rgen:20-21
     }
-    s_vis[lane] = 0;
+    if (setup_wave) s_vis[lane] = 0;
     const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
@@ -504,9 +511,15 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         }
     }
     const unsigned long long cov_mask = __ballot(covered);
-    const uint32_t ncov = uint32_t(__popcll(cov_mask));
+    uint32_t ncov = uint32_t(__popcll(cov_mask));
     if (covered) s_list[__popcll(cov_mask & ((1ull << lane) - 1ull))] = uint8_t(lane);
-    wave_lds_sync();
+    if (SHARED) {
+        if (threadIdx.x == 0) { s_ncov = ncov; s_next = 0; }
+        __syncthreads();
+        ncov = s_ncov;
+    } else {
+        wave_lds_sync();
+    }
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
 
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
@@ -527,6 +540,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = uint32_t(__popcll(idle));
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
+            if (SHARED) {                             // one LDS atomic per refill, issued by the first idle lane
+                const int leader = __ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                if (int(lane) == leader) base = atomicAdd(&s_next, n_idle);
+                next = __shfl(base, leader);
+            }
             const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
             next += n_idle;
             if (!has && r < total) {
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             else if (!found) atomicAdd(&s_vis[pix], 256u);
         }
     }
-    wave_lds_sync();
+    if (SHARED) __syncthreads(); else wave_lds_sync();
     if (covered) {
         const uint32_t vis = s_vis[lane];
         const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
@@ -700,14 +719,22 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
         const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
         const uint32_t pregen_kinds = pregen ? kinds : 0u;
-        const size_t wave_bytes = (size_t(levels) + size_t(pregen_kinds) * 3) * kQueueBlock * sizeof(int);
+        const bool shared_tile = ctx->options[kOptSharedTile] != 0;
+        const size_t stack_bytes = size_t(levels) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
         const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
         const int waves = ctx->options[kOptWavesPerBlock];
 #define VHR_LAUNCH_QUEUE(P, WV, C)                                                                                                \
-    hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), wave_bytes * WV, \
-                       ctx->stream, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]))
+    do {                                                                                                                          \
+        if (shared_tile)                                                                                                          \
+            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, true>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
+                               ctx->stream, a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]));    \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+                               (stack_bytes + dir_bytes) * WV, ctx->stream, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
+                               uint32_t(ctx->options[kOptXcdAware]));                                                              \
+    } while (0)
 #define VHR_LAUNCH_QUEUE_W(P, C)                                                                                                   \
-    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C); else VHR_LAUNCH_QUEUE(P, 1, C); } while (0)
+    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C); else if (waves >= 3) VHR_LAUNCH_QUEUE(P, 3, C); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C); else VHR_LAUNCH_QUEUE(P, 1, C); } while (0)
         const bool compact = ctx->options[kOptCompactNodes] != 0;
         if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true); else VHR_LAUNCH_QUEUE_W(true, false); }
         else { if (compact) VHR_LAUNCH_QUEUE_W(false, true); else VHR_LAUNCH_QUEUE_W(false, false); }

@@ -134,7 +134,7 @@ struct PassDescription {
 struct RayStats { unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, pad; };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptCount = 12 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptCount = 12 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };
