@@ -202,6 +202,12 @@ def main():
     kt = {k: ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "blit")}
     kt["svgf_atrous"] = atrous_timed
     ctx.set_kernel_timing(False)
+    # traversal work counters (one extra, untimed frame with the in-kernel statistics enabled)
+    ctx.set_ray_statistics(True)
+    loop.frame(args.warmup)
+    barrier()
+    ray_stats, trav_stats = ctx.ray_statistics(), ctx.traversal_statistics()
+    ctx.set_ray_statistics(False)
     y0, y1 = loop.owned_rows()
     rows_svgf = min(H, y1 + loop.plan.overlap) - max(0, y0 - loop.plan.overlap)
     atrous_us = kt["svgf_atrous"][0] / max(1, kt["svgf_atrous"][1]) * 1e3
@@ -253,6 +259,12 @@ def main():
                 "avg_launch_ms": round(raygen_ms, 4),
                 "mrays_per_s": round(loop.rays_in_frame(args.warmup) / max(raygen_ms, 1e-9) / 1e3, 1),
                 "bvh_nodes": int(bvh["nodes"]), "bvh_bytes": int(bvh["node_bytes"] + bvh["triangle_bytes"]), "bvh_max_depth": int(bvh["max_depth"]),
+                "active_lane_utilisation": round(trav_stats["active_lane_utilisation"], 3),
+                "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["unique_rays"] - (ray_stats["covered_pixels"] if args.reflections else 0)), 2),
+                "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["unique_rays"] - (ray_stats["covered_pixels"] if args.reflections else 0)), 2),
+                "effective_traversal_gbs": round((trav_stats["node_visits"] * 64 + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6, 1),
+                "stack_overflows": int(ray_stats["stack_overflows"]),
+                "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = lane visits / (64 x wave loop trips)",
             },
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),

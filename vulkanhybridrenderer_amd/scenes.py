@@ -292,9 +292,11 @@ def sponza_proc(detail=1.0):
 def _procedural_texture(k, size=512):
     """Deterministic RGBA8 texture (checker + stripes + hash noise), sRGB base-colour content."""
     y, x = np.mgrid[0:size, 0:size].astype(np.uint32)
-    h = (x * np.uint32(73856093)) ^ (y * np.uint32(19349663)) ^ np.uint32(k * 83492791 + 12345)
+    with np.errstate(over="ignore"):
+        h = (x * np.uint32(73856093)) ^ (y * np.uint32(19349663)) ^ np.uint32((k * 83492791 + 12345) & 0xffffffff)
     h ^= h >> np.uint32(13)
-    h = h * np.uint32(0x5bd1e995)
+    with np.errstate(over="ignore"):
+        h = h * np.uint32(0x5bd1e995)
     h ^= h >> np.uint32(15)
     noise = (h & np.uint32(63)).astype(np.int32)
     cell = 8 << (k % 4)
