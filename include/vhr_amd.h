@@ -222,6 +222,22 @@ int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, ui
  * hybrid_render_path.cpp:16-19.  Uses the per-frame data of resource_idx. */
 int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image,
                         const char *motion_image, const char *depth_image);
+/* same, also writing the "Albedo" attachment (B8G8R8A8_UNORM, gbuf.frag:19-33; alpha discard not modelled) */
+int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, const char *albedo_image, const char *normals_image,
+                                    const char *motion_image, const char *depth_image);
+
+/* Next row: stand-in for the untouched composition stage -- composition.vert:5-8 +
+ * composition.frag:60-161 for the ray-traced modes (0) and off (2); the raster alternatives (shadow map PCF, SSAO,
+ * SSR; mode 1) stay outside.  Reads the named transient images, writes swapchain-format texels (B8G8R8A8_SRGB, bytes
+ * b g r a, presentation orientation: row 0 = top) into a storage image of 4-byte texels. */
+typedef struct vhr_composition_desc {
+    int32_t shadow_mode, ambient_occlusion_mode, reflection_mode;      /* the three specialization constants, :6-8 */
+    const char *albedo_image, *normals_image, *motion_image, *depth_image;
+    const char *shadow_ao_image;      /* "Denoised Raytraced Shadows and Ambient Occlusion" or the raw RG16F image (:353-355) */
+    const char *reflections_image;    /* may be NULL when reflection_mode != 0 */
+    int32_t output_storage_image;
+} vhr_composition_desc;
+int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_composition_desc *desc);
 
 /* Multi-GPU row strips: this context owns rows [row_begin, row_end) of the
  * display.  Ray tracing runs on the owned rows; the SVGF kernels on the owned rows extended by `overlap`

@@ -98,6 +98,7 @@ enum {
     VHR_FORMAT_R8G8B8A8_UNORM      = 37,
     VHR_FORMAT_R8G8B8A8_SRGB       = 43,
     VHR_FORMAT_B8G8R8A8_UNORM      = 44,
+    VHR_FORMAT_B8G8R8A8_SRGB       = 50,
     VHR_FORMAT_R16G16_SFLOAT       = 83,
     VHR_FORMAT_R16G16B16A16_SFLOAT = 97,
     VHR_FORMAT_D32_SFLOAT          = 126

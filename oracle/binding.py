@@ -67,6 +67,8 @@ def lib():
         L.orc_scene_closest.argtypes = [vp, vp, vp, f32, f32, i32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32),
                                         C.POINTER(u32), C.POINTER(u32)]
         L.orc_gbuffer.argtypes = [vp, vp, u32, u32, vp, vp, vp]
+        L.orc_gbuffer_albedo.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
+        L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]
         L.orc_raygen.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, i32]
         L.orc_svgf_temporal.argtypes = [vp, u32, u32] + [vp] * 8
         L.orc_svgf_atrous.argtypes = [vp, u32, u32, vp, vp, vp, C.c_int32]
@@ -146,13 +148,14 @@ class Scene:
                                       C.byref(v), C.byref(pr), C.byref(tr))
         return (np.float32(t.value), np.float32(u.value), np.float32(v.value), pr.value, tr.value) if hit else None
 
-    def gbuffer(self, pfd, W, H):
+    def gbuffer(self, pfd, W, H, with_albedo=False):
         normals = np.zeros((H, W, 4), np.uint16)
         motion = np.zeros((H, W, 4), np.uint16)
         depth = np.zeros((H, W), np.float32)
+        albedo = np.zeros((H, W, 4), np.uint8) if with_albedo else None
         pfd = _c(pfd)
-        lib().orc_gbuffer(self.handle, _p(pfd), W, H, _p(normals), _p(motion), _p(depth))
-        return normals, motion, depth
+        lib().orc_gbuffer_albedo(self.handle, _p(pfd), W, H, _p(normals), _p(motion), _p(depth), _p(albedo))
+        return (normals, motion, depth, albedo) if with_albedo else (normals, motion, depth)
 
     def raygen(self, pfd, tp, normals, depth, rows=None, use_bvh=True, want_reflections=True):
         H, W = depth.shape
@@ -166,6 +169,19 @@ class Scene:
         lib().orc_raygen(self.handle, _p(pfd), _p(tp), W, H, r0, r1, _p(normals), _p(depth), _p(shadow_ao), _p(refl),
                          _p(mask), C.byref(rays), int(use_bvh))
         return shadow_ao, refl, mask, rays.value
+
+
+def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections):
+    """composition.frag with (shadow_mode, ao_mode, reflection_mode); returns B8G8R8A8_SRGB texels (H, W, 4)."""
+    H, W = depth.shape
+    out = np.zeros((H, W, 4), np.uint8)
+    pfd = _c(pfd)
+    albedo, normals, motion = _c(albedo, np.uint8), _c(normals, np.uint16), _c(motion, np.uint16)
+    depth, shadow_ao = _c(depth, np.float32), _c(shadow_ao, np.uint16)
+    reflections = _c(reflections, np.uint16) if reflections is not None else np.zeros((H, W, 4), np.uint16)
+    lib().orc_composition(_p(pfd), W, H, modes[0], modes[1], modes[2], _p(albedo), _p(normals), _p(motion), _p(depth), _p(shadow_ao),
+                          shadow_ao.shape[-1], _p(reflections), _p(out))
+    return out
 
 
 def svgf_temporal(pfd, normals, motion, raytraced, prev_normals, history, moments_in):

@@ -298,6 +298,8 @@ static inline v3 m3_mul(m3 M, v3 v) {
               (M.c0.z * v.x + M.c1.z * v.y) + M.c2.z * v.z);
 }
 
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
 /* common.glsl:116-150 BRDF helpers */
 static v3 fresnel_schlick(v3 f0, v3 H, v3 V) {
     float hv = fmaxf(dot3(H, V), 0.0f);
@@ -765,8 +767,19 @@ static void normal_matrix3(const float *m, float out[9]) {  /* inverseTranspose(
     out[2] = (float)(c20 * id); out[5] = (float)(c21 * id); out[8] = (float)(c22 * id);
 }
 
+static inline uint8_t unorm8(float f) {       /* UNORM store: clamp, round to nearest */
+    if (!(f > 0.0f)) return 0;
+    if (f >= 1.0f) return 255;
+    return (uint8_t)(f * 255.0f + 0.5f);
+}
+
 void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint16_t *normals_ids,
                  uint16_t *motion_mr, float *depth) {
+    orc_gbuffer_albedo(s, pfd, W, H, normals_ids, motion_mr, depth, NULL);
+}
+
+void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint16_t *normals_ids,
+                        uint16_t *motion_mr, float *depth, uint8_t *albedo) {
     float *nm = (float *)malloc(sizeof(float) * 9 * (s->np ? s->np : 1));
     for (uint32_t p = 0; p < s->np; ++p) normal_matrix3(s->prims[p].transform, nm + 9 * p);
     float projview[16], prev_projview[16];
@@ -786,6 +799,7 @@ void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, 
                 store_rgba16f(normals_ids, W, x, y, 0, 0, 0, 0);
                 store_rgba16f(motion_mr, W, x, y, 0, 0, -1.0f, -1.0f);
                 depth[px] = 0.0f;
+                if (albedo) memset(albedo + px * 4, 0, 4);
                 continue;
             }
             const orc_tri *tr = &s->tris[h.flat];
@@ -814,16 +828,83 @@ void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, 
             v4 rp = mat4_mul_v4(prev_projview, (v4){ P.x, P.y, P.z, 1.0f });
             float px_ = (rp.x / rp.w) * 0.5f + 0.5f, py_ = (rp.y / rp.w) * 0.5f + 0.5f;
             float metallic = prim->material.metallic_factor, roughness = prim->material.roughness_factor;
+            float uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;
+            float uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
             if (prim->material.metallic_roughness_texture != -1) {    /* gbuf.frag:50-56 */
-                float uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;
-                float uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
                 v4 mr = sample_texture(s, prim->material.metallic_roughness_texture, uvx, uvy);
                 metallic *= mr.y; roughness *= mr.z;
+            }
+            if (albedo) {                                              /* gbuf.frag:19-33 (alpha discard not modelled) */
+                v4 al = { prim->material.base_color[0], prim->material.base_color[1], prim->material.base_color[2], prim->material.base_color[3] };
+                if (prim->material.base_color_texture != -1) al = sample_texture(s, prim->material.base_color_texture, uvx, uvy);
+                uint8_t *o = albedo + px * 4;                          /* B8G8R8A8 */
+                o[0] = unorm8(al.z); o[1] = unorm8(al.y); o[2] = unorm8(al.x); o[3] = unorm8(al.w);
             }
             store_rgba16f(motion_mr, W, x, y, cx - px_, cy - py_, metallic, roughness);   /* gbuf.frag:58 */
         }
     }
     free(nm);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * composition.frag:60-161 (next row f3)
+ * ---------------------------------------------------------------------------------------- */
+static inline uint8_t srgb8(float c) {          /* B8G8R8A8_SRGB store: NaN -> 0, clamp, encode, round */
+    if (!(c > 0.0f)) return 0;
+    if (c >= 1.0f) return 255;
+    double e = c <= 0.0031308 ? 12.92 * c : 1.055 * pow((double)c, 1.0 / 2.4) - 0.055;
+    return (uint8_t)(e * 255.0 + 0.5);
+}
+
+void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
+                     const uint8_t *albedo_img, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
+                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, uint8_t *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t jj = 0; jj < (int64_t)H; ++jj) {
+        int j = (int)jj;
+        int gy = (int)H - 1 - j;                                  /* flipped presentation viewport, pipeline.cpp:175-178 */
+        for (int x = 0; x < (int)W; ++x) {
+            float u = ((float)x + 0.5f) / (float)W, v = ((float)gy + 0.5f) / (float)H;       /* composition.vert:6 at the texel centre */
+            const uint8_t *ap = albedo_img + ((size_t)gy * W + x) * 4;
+            v3 albedo = V3(ap[2] * (1.0f / 255.0f), ap[1] * (1.0f / 255.0f), ap[0] * (1.0f / 255.0f));   /* :61 */
+            float d = depth[(size_t)gy * W + x];                                               /* :62 */
+            v3 P = get_world_space_position(pfd, d, u, v);                                     /* :63 */
+            v4 nid = load_rgba16f(normals_ids, W, x, gy);                                      /* :64 */
+            v3 N = V3(nid.x, nid.y, nid.z);
+            v4 mm = load_rgba16f(motion_mr, W, x, gy);                                         /* :65 .zw */
+            float rs = 1.0f, ra = 1.0f;                                                        /* :67-70 */
+            if (shadow_mode == 0 || ao_mode == 0) {
+                v4 t = shadow_ao_channels == 4 ? load_rgba16f(shadow_ao, W, x, gy) : load_rg16f(shadow_ao, W, x, gy);
+                rs = t.x; ra = t.y;
+            }
+            v3 cam = V3(pfd->camera_view_inverse[12], pfd->camera_view_inverse[13], pfd->camera_view_inverse[14]);
+            v3 Vv = normalize3(v3sub(cam, P));                                                 /* :72-75 */
+            v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
+            v3 Hh = normalize3(v3add(L, Vv));
+            float shadow = shadow_mode == 0 ? rs : 1.0f;                                       /* :77-80 */
+            float ao = ao_mode == 0 ? ra : 1.0f;                                               /* :115-121 */
+            float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f);                                   /* :123-125 */
+            float roughness = fminf(fmaxf(mm.w, 0.04f), 1.0f);
+            v3 li = V3(pfd->directional_light.intensity[0], pfd->directional_light.intensity[1], pfd->directional_light.intensity[2]);
+            v3 lc = V3(pfd->directional_light.color[0], pfd->directional_light.color[1], pfd->directional_light.color[2]);
+            v3 f0 = V3(0.04f * (1.0f - metallic) + albedo.x * metallic, 0.04f * (1.0f - metallic) + albedo.y * metallic,
+                       0.04f * (1.0f - metallic) + albedo.z * metallic);                       /* :131-132 */
+            v3 F = fresnel_schlick(f0, Hh, Vv);
+            float ndl = fmaxf(dot3(N, L), 0.0f);                                               /* :135 */
+            v3 ambient = v3scale(albedo, ao * ORC_PI_INVERSE);                                 /* :137 */
+            v3 diff = v3scale(v3mul(v3mul(v3scale(diffuse_brdf(metallic, albedo, F), ndl), li), lc), shadow);   /* :138 */
+            v3 spec = v3scale(v3mul(v3mul(v3scale(specular_brdf(roughness, F, Vv, L, N, Hh), ndl), li), lc), shadow);   /* :139 */
+            if (reflection_mode == 0) {                                                        /* :141-149 */
+                v4 r = load_rgba16f(reflections, W, x, gy);
+                v3 refl = v3scale(V3(r.x, r.y, r.z), shadow);
+                if (metallic == 1.0f) spec = refl;
+                else spec = V3(mixf(spec.x, refl.x, roughness), mixf(spec.y, refl.y, roughness), mixf(spec.z, refl.z, roughness));
+            }
+            v3 lighting = v3add(v3add(ambient, diff), spec);                                   /* :160-162 */
+            uint8_t *o = out + ((size_t)j * W + x) * 4;
+            o[0] = srgb8(lighting.z); o[1] = srgb8(lighting.y); o[2] = srgb8(lighting.x); o[3] = 255;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -839,7 +920,6 @@ static int is_valid_reprojection(const orc_per_frame_data *pfd, const uint16_t *
     if (dot3(current_normal, V3(pn.x, pn.y, pn.z)) < ORC_COS_PI_4) return 0;
     return 1;
 }
-static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
 /* svgf.comp:41-145 */
 void orc_svgf_temporal(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, const uint16_t *normals_ids,

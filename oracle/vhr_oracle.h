@@ -96,6 +96,17 @@ int      orc_scene_closest(const orc_scene *s, const float o[3], const float d[3
 /* ---- stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 encodings; primary rays) ---- */
 void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
                  uint16_t *normals_ids /*RGBA16F*/, uint16_t *motion_mr /*RGBA16F*/, float *depth /*D32F*/);
+/* same, plus the albedo attachment (B8G8R8A8_UNORM: bytes b, g, r, a; gbuf.frag:19-33); albedo may be NULL */
+void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
+                        uint16_t *normals_ids, uint16_t *motion_mr, float *depth, uint8_t *albedo_bgra8);
+
+/* ---- next row f3: composition.vert:5-8 + composition.frag:60-161 (ray-traced modes only) ----
+ * modes: 0 ray traced, 2 off (1 = the raster alternatives, not restated).  shadow_ao: RGBA16F (denoised) if
+ * shadow_ao_channels == 4 else RG16F.  Output: B8G8R8A8_SRGB swapchain texels (bytes b, g, r, a), row 0 = top of the
+ * presented image = G-buffer row H-1 (the composition viewport is flipped, pipeline.cpp:175-178). */
+void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
+                     const uint8_t *albedo_bgra8, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
+                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, uint8_t *out_bgra8_srgb);
 
 /* ---- K1 + K2: raygen.rgen:14-66, miss.rmiss, reflection_miss.rmiss, reflection_hit.rchit ---- */
 /* vis_mask (optional, may be NULL): per pixel bit0 = shadow ray missed (lit), bit(1+i) = AO ray i missed,

@@ -51,4 +51,8 @@ n, m, d = osc.gbuffer(pfd, TW, TH)
 sa, refl, mask, rays = osc.raygen(pfd, abi.default_trace_params(), n, d)
 np.savez_compressed(os.path.join(HERE, "trace_tiny.npz"), W=TW, H=TH, normals=n, motion=m, depth=d, shadow_ao=sa, reflections=refl,
                     mask=mask, rays=rays, pfd=np.frombuffer(pfd.tobytes(), np.uint8))
+# next row f3: composition of the same tiny frame (raw shadow/AO, mirror reflections)
+n4, m4, d4, al4 = osc.gbuffer(pfd, TW, TH, with_albedo=True)
+comp = ob.composition(pfd, (0, 0, 0), al4, n4, m4, d4, sa, refl)
+np.savez_compressed(os.path.join(HERE, "composition_tiny.npz"), albedo=al4, composition=comp)
 print("golden fixtures written")

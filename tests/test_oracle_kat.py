@@ -239,3 +239,18 @@ def test_golden_crops(oracle):
     n, m, d = osc.gbuffer(pfd, int(t["W"]), int(t["H"]))
     sa, refl, mask, rays = osc.raygen(pfd, abi.default_trace_params(), n, d)
     assert np.array_equal(sa, t["shadow_ao"]) and np.array_equal(mask, t["mask"]) and rays == int(t["rays"])
+
+
+def test_composition_golden_and_orientation(oracle):
+    """composition.frag restatement: pinned by a committed crop; the presented image is the G-buffer flipped vertically
+    (pipeline.cpp:175-178) and sky pixels come out black."""
+    t = np.load(os.path.join(GOLDEN, "trace_tiny.npz"))
+    c = np.load(os.path.join(GOLDEN, "composition_tiny.npz"))
+    pfd = np.frombuffer(t["pfd"].tobytes(), abi.per_frame_dtype)[0]
+    out = oracle.composition(pfd, (0, 0, 0), c["albedo"], t["normals"], t["motion"], t["depth"], t["shadow_ao"], t["reflections"])
+    assert np.array_equal(out, c["composition"])
+    sky = (t["depth"] == 0)[::-1]
+    assert sky.any() and not out[sky][:, :3].any() and (out[..., 3] == 255).all()
+    off = oracle.composition(pfd, (2, 2, 2), c["albedo"], t["normals"], t["motion"], t["depth"], t["shadow_ao"], t["reflections"])
+    lit = oracle.composition(pfd, (0, 2, 2), c["albedo"], t["normals"], t["motion"], t["depth"], t["shadow_ao"], t["reflections"])
+    assert (lit[..., :3].astype(int) <= off[..., :3].astype(int)).all() and (lit != off).any()      # shadows only darken

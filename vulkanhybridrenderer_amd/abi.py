@@ -13,12 +13,13 @@ import numpy as np
 FORMAT_R8G8B8A8_UNORM = 37
 FORMAT_R8G8B8A8_SRGB = 43
 FORMAT_B8G8R8A8_UNORM = 44
+FORMAT_B8G8R8A8_SRGB = 50
 FORMAT_R16G16_SFLOAT = 83
 FORMAT_R16G16B16A16_SFLOAT = 97
 FORMAT_D32_SFLOAT = 126
 
 FORMAT_STRIDE = {
-    FORMAT_R8G8B8A8_UNORM: 4, FORMAT_R8G8B8A8_SRGB: 4, FORMAT_B8G8R8A8_UNORM: 4,
+    FORMAT_R8G8B8A8_UNORM: 4, FORMAT_R8G8B8A8_SRGB: 4, FORMAT_B8G8R8A8_UNORM: 4, FORMAT_B8G8R8A8_SRGB: 4,
     FORMAT_R16G16_SFLOAT: 4, FORMAT_R16G16B16A16_SFLOAT: 8, FORMAT_D32_SFLOAT: 4,
 }
 

@@ -15,6 +15,7 @@ uint32_t format_stride(int32_t format) {      // VkUtils::FormatStride, vulkan_u
         case VHR_FORMAT_R8G8B8A8_UNORM:
         case VHR_FORMAT_R8G8B8A8_SRGB:
         case VHR_FORMAT_B8G8R8A8_UNORM:
+        case VHR_FORMAT_B8G8R8A8_SRGB:
         case VHR_FORMAT_R16G16_SFLOAT:
         case VHR_FORMAT_D32_SFLOAT: return 4;
         case VHR_FORMAT_R16G16B16A16_SFLOAT: return 8;
@@ -490,6 +491,26 @@ int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, ui
 }
 
 int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image, const char *motion_image, const char *depth_image) {
+    return vhr_standin_gbuffer_with_albedo(ctx, resource_idx, nullptr, normals_image, motion_image, depth_image);
+}
+
+int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_composition_desc *d) {
+    if (!ctx || !d || resource_idx >= 3 || !d->albedo_image || !d->normals_image || !d->motion_image || !d->depth_image || !d->shadow_ao_image)
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: missing image name") : VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    auto find = [&](const char *n) -> Image * { auto it = ctx->images.find(n); return it == ctx->images.end() ? nullptr : &it->second; };
+    Image *al = find(d->albedo_image), *no = find(d->normals_image), *mo = find(d->motion_image), *de = find(d->depth_image), *sa = find(d->shadow_ao_image);
+    Image *re = d->reflections_image ? find(d->reflections_image) : nullptr;
+    if (!al || !no || !mo || !de || !sa || (d->reflections_image && !re)) return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: unknown transient image");
+    if (d->reflection_mode == 0 && !re) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: reflection_mode 0 needs a reflections image");
+    if (d->output_storage_image < 0 || uint32_t(d->output_storage_image) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[d->output_storage_image].used)
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: output storage image is not allocated");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_composition(ctx, ctx->per_frame[resource_idx], *d, *al, *no, *mo, *de, *sa, re, ctx->storage_images[d->output_storage_image]);
+}
+
+int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, const char *albedo_image, const char *normals_image,
+                                    const char *motion_image, const char *depth_image) {
     if (!ctx || !normals_image || !motion_image || !depth_image || resource_idx >= 3) return VHR_ERROR_INVALID_ARGUMENT;
     auto n = ctx->images.find(normals_image), m = ctx->images.find(motion_image), d = ctx->images.find(depth_image);
     if (n == ctx->images.end() || m == ctx->images.end() || d == ctx->images.end())
@@ -497,8 +518,14 @@ int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *nor
     if (n->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || m->second.format != VHR_FORMAT_R16G16B16A16_SFLOAT || d->second.format != VHR_FORMAT_D32_SFLOAT)
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: formats must be RGBA16F, RGBA16F, D32F (hybrid_render_path.cpp:16-19)");
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    Image *albedo = nullptr;
+    if (albedo_image) {
+        auto al = ctx->images.find(albedo_image);
+        if (al == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, "standin_gbuffer: unknown albedo image");
+        albedo = &al->second;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_standin_gbuffer(ctx, ctx->per_frame[resource_idx], n->second, m->second, d->second);
+    return launch_standin_gbuffer(ctx, ctx->per_frame[resource_idx], n->second, m->second, d->second, albedo);
 }
 
 }  // extern "C"

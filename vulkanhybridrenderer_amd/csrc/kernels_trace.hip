@@ -761,8 +761,11 @@ struct GbufferArgs {
     float projview[16], prev_projview[16];
     void *normals, *motion;
     float *depth;
+    uchar4 *albedo;          // B8G8R8A8_UNORM, optional
     uint32_t width, height;
 };
+
+__device__ __forceinline__ uint32_t unorm8(float f) { return uint32_t(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f + 0.5f); }
 
 __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs a) {
     __shared__ int s_stack[kTraceStack * kTraceBlock];
@@ -781,6 +784,7 @@ __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs 
         store_rgba16f(a.normals, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
         store_rgba16f(a.motion, W, x, y, 0.0f, 0.0f, -1.0f, -1.0f);
         a.depth[size_t(y) * W + x] = 0.0f;
+        if (a.albedo) a.albedo[size_t(y) * W + x] = make_uchar4(0, 0, 0, 0);
         return;
     }
     const BvhTri &bt = a.scene.tris[h.tri_index];
@@ -805,6 +809,11 @@ __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs 
         roughness *= mr.z;
     }
     store_rgba16f(a.motion, W, x, y, cx - px, cy - py, metallic, roughness);                 // gbuf.frag:58
+    if (a.albedo) {                                                                          // gbuf.frag:19-33 (alpha discard not modelled)
+        f4 al = f4{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2], prim.material.base_color[3] };
+        if (prim.material.base_color_texture != -1) al = sample_texture(a.scene, prim.material.base_color_texture, at.uvx, at.uvy);
+        a.albedo[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(al.z)), uint8_t(unorm8(al.y)), uint8_t(unorm8(al.x)), uint8_t(unorm8(al.w)));
+    }
 }
 
 static void host_mat4_mul(const float *a, const float *b, float *out) {
@@ -813,7 +822,9 @@ static void host_mat4_mul(const float *a, const float *b, float *out) {
             out[c * 4 + i] = ((a[0 * 4 + i] * b[c * 4 + 0] + a[1 * 4 + i] * b[c * 4 + 1]) + a[2 * 4 + i] * b[c * 4 + 2]) + a[3 * 4 + i] * b[c * 4 + 3];
 }
 
-int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth) {
+int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth, Image *albedo) {
+    if (albedo && (albedo->width != depth.width || albedo->height != depth.height || albedo->bpp != 4))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: albedo image must be B8G8R8A8 of the same extent");
     if (normals.width != depth.width || normals.height != depth.height || motion.width != depth.width || motion.height != depth.height)
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_gbuffer: image extents differ");
     GbufferArgs a;
@@ -824,11 +835,112 @@ int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Imag
     a.normals = normals.ptr;
     a.motion = motion.ptr;
     a.depth = static_cast<float *>(depth.ptr);
+    a.albedo = albedo ? static_cast<uchar4 *>(albedo->ptr) : nullptr;
     a.width = depth.width;
     a.height = depth.height;
     const dim3 grid((a.width + 15) / 16, (a.height + 15) / 16);
     hipLaunchKernelGGL(gbuffer_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "gbuffer kernel launch failed");
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// next row f3: stand-in for the composition stage (composition.vert:5-8, composition.frag:60-161), ray-traced modes
+// ---------------------------------------------------------------------------------------------
+struct CompositionArgs {
+    vhr_per_frame_data pfd;
+    const uchar4 *albedo;        // B8G8R8A8_UNORM
+    const void *normals, *motion;
+    const float *depth;
+    const void *shadow_ao;       // RGBA16F (denoised) or RG16F (raw)
+    const void *reflections;     // RGBA16F or nullptr
+    uchar4 *out;                 // B8G8R8A8_SRGB
+    uint32_t width, height;
+    int shadow_mode, ao_mode, reflection_mode, shadow_ao_is_rgba;
+};
+
+__device__ __forceinline__ uint8_t srgb8(float c) {       // sRGB attachment store: NaN -> 0, clamp, encode, round
+    if (!(c > 0.0f)) return 0;
+    if (c >= 1.0f) return 255;
+    const float e = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    return uint8_t(e * 255.0f + 0.5f);
+}
+
+__global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs a) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.width || j >= a.height) return;
+    const uint32_t W = a.width, H = a.height, gy = H - 1 - j;         // flipped presentation viewport (pipeline.cpp:175-178)
+    const float u = (float(x) + 0.5f) / float(W), v = (float(gy) + 0.5f) / float(H);
+    const uchar4 ab = a.albedo[size_t(gy) * W + x];
+    const f3 albedo = f3{ ab.z * (1.0f / 255.0f), ab.y * (1.0f / 255.0f), ab.x * (1.0f / 255.0f) };             // :61
+    const float depth = a.depth[size_t(gy) * W + x];                                                               // :62
+    const f3 P = get_world_space_position(a.pfd, depth, u, v);                                                     // :63
+    const f4 nid = load_rgba16f(a.normals, W, x, gy);                                                              // :64
+    const f3 N = f3{ nid.x, nid.y, nid.z };
+    const f4 mm = load_rgba16f(a.motion, W, x, gy);                                                                // :65
+    float rs = 1.0f, ra = 1.0f;                                                                                    // :67-70
+    if (a.shadow_mode == 0 || a.ao_mode == 0) {
+        if (a.shadow_ao_is_rgba) { const f4 t = load_rgba16f(a.shadow_ao, W, x, gy); rs = t.x; ra = t.y; }
+        else {
+            const uint32_t raw = reinterpret_cast<const uint32_t *>(a.shadow_ao)[size_t(gy) * W + x];
+            rs = half_bits_to_float(uint16_t(raw & 0xffffu)); ra = half_bits_to_float(uint16_t(raw >> 16));
+        }
+    }
+    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+    const f3 V = normalize3(cam - P);                                                                              // :72-75
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+    const f3 Hh = normalize3(L + V);
+    const float shadow = a.shadow_mode == 0 ? rs : 1.0f;                                                           // :77-80
+    const float ao = a.ao_mode == 0 ? ra : 1.0f;                                                                   // :115-121
+    const float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f), roughness = fminf(fmaxf(mm.w, 0.04f), 1.0f);            // :123-125
+    const f3 li = f3{ a.pfd.directional_light.intensity[0], a.pfd.directional_light.intensity[1], a.pfd.directional_light.intensity[2] };
+    const f3 lc = f3{ a.pfd.directional_light.color[0], a.pfd.directional_light.color[1], a.pfd.directional_light.color[2] };
+    const f3 f0 = f3{ 0.04f * (1.0f - metallic) + albedo.x * metallic, 0.04f * (1.0f - metallic) + albedo.y * metallic,
+                      0.04f * (1.0f - metallic) + albedo.z * metallic };                                           // :131-132
+    const f3 F = fresnel_schlick(f0, Hh, V);
+    const float ndl = fmaxf(dot3(N, L), 0.0f);                                                                     // :135
+    const f3 ambient = albedo * (ao * VHR_PI_INVERSE);                                                             // :137
+    const f3 dp = f3{ (1.0f - F.x) * (1.0f - metallic), (1.0f - F.y) * (1.0f - metallic), (1.0f - F.z) * (1.0f - metallic) };
+    const f3 diffuse = mul3(mul3(f3{ dp.x * albedo.x / VHR_PI, dp.y * albedo.y / VHR_PI, dp.z * albedo.z / VHR_PI } * ndl, li), lc) * shadow;   // :138
+    const float dg = D_GGX(roughness, N, Hh) * G_GGX(roughness, N, V, L);
+    const float invd = 1.0f / fmaxf(4.0f * fmaxf(dot3(N, V), 0.0f) * fmaxf(dot3(N, L), 0.0f), 1e-6f);
+    f3 spec = mul3(mul3(f3{ dg * F.x * invd, dg * F.y * invd, dg * F.z * invd } * ndl, li), lc) * shadow;          // :139
+    if (a.reflection_mode == 0 && a.reflections) {                                                                 // :141-149
+        const f4 r = load_rgba16f(a.reflections, W, x, gy);
+        const f3 refl = f3{ r.x, r.y, r.z } * shadow;
+        if (metallic == 1.0f) spec = refl;
+        else spec = f3{ spec.x * (1.0f - roughness) + refl.x * roughness, spec.y * (1.0f - roughness) + refl.y * roughness,
+                        spec.z * (1.0f - roughness) + refl.z * roughness };
+    }
+    const f3 lighting = ambient + diffuse + spec;                                                                  // :160-162
+    a.out[size_t(j) * W + x] = make_uchar4(srgb8(lighting.z), srgb8(lighting.y), srgb8(lighting.x), 255);
+}
+
+int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, Image &out) {
+    const uint32_t W = depth.width, H = depth.height;
+    const Image *all[] = { &albedo, &normals, &motion, &shadow_ao, &out };
+    for (const Image *im : all)
+        if (im->width != W || im->height != H) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: image extents differ");
+    if (reflections && (reflections->width != W || reflections->height != H)) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: image extents differ");
+    if (albedo.bpp != 4 || out.bpp != 4 || normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || motion.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
+        depth.format != VHR_FORMAT_D32_SFLOAT || (shadow_ao.format != VHR_FORMAT_R16G16B16A16_SFLOAT && shadow_ao.format != VHR_FORMAT_R16G16_SFLOAT))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: unexpected image format");
+    for (int m : { d.shadow_mode, d.ambient_occlusion_mode, d.reflection_mode })
+        if (m != 0 && m != 2) return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: only the ray-traced (0) and off (2) modes exist here; shadow map / SSAO / SSR are raster-side");
+    CompositionArgs a;
+    a.pfd = pfd;
+    a.albedo = static_cast<const uchar4 *>(albedo.ptr);
+    a.normals = normals.ptr; a.motion = motion.ptr;
+    a.depth = static_cast<const float *>(depth.ptr);
+    a.shadow_ao = shadow_ao.ptr;
+    a.reflections = reflections ? reflections->ptr : nullptr;
+    a.out = static_cast<uchar4 *>(out.ptr);
+    a.width = W; a.height = H;
+    a.shadow_mode = d.shadow_mode; a.ao_mode = d.ambient_occlusion_mode; a.reflection_mode = d.reflection_mode;
+    a.shadow_ao_is_rgba = shadow_ao.format == VHR_FORMAT_R16G16B16A16_SFLOAT;
+    hipLaunchKernelGGL(composition_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, ctx->stream, a);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "composition kernel launch failed");
     return VHR_OK;
 }
 

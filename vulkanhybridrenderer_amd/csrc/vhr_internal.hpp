@@ -223,7 +223,9 @@ uint32_t format_stride(int32_t format);   // VkUtils::FormatStride (vulkan_utils
 struct ImageView { void *ptr; uint32_t width, height; };
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height,
                   const Image &normals, const Image &depth, Image &shadow_ao, Image *reflections);
-int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth);
+int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth, Image *albedo);
+int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, Image &out);
 int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
                          const Image &raytraced, const Image &prev_normals, const Image &history,
                          Image &moments, Image &integrated_out, uint32_t x_groups, uint32_t y_groups);

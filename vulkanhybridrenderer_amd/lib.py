@@ -29,7 +29,7 @@ EXPORTS = [
     "vhr_compute_blit_image_storage_to_storage", "vhr_hybrid_create", "vhr_hybrid_destroy", "vhr_hybrid_build",
     "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
-    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_set_strip",
+    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_set_strip",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics",
     "vhr_calibration_stream_read",
@@ -70,6 +70,12 @@ class ComputePipelineDescription(C.Structure):
 class ImageInfo(C.Structure):
     _fields_ = [("device_ptr", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_int32),
                 ("bytes_per_pixel", C.c_uint32)]
+
+
+class CompositionDesc(C.Structure):
+    _fields_ = [("shadow_mode", C.c_int32), ("ambient_occlusion_mode", C.c_int32), ("reflection_mode", C.c_int32),
+                ("albedo_image", C.c_char_p), ("normals_image", C.c_char_p), ("motion_image", C.c_char_p), ("depth_image", C.c_char_p),
+                ("shadow_ao_image", C.c_char_p), ("reflections_image", C.c_char_p), ("output_storage_image", C.c_int32)]
 
 
 class HybridSettings(C.Structure):
@@ -150,6 +156,8 @@ def load():
     L.vhr_upload_storage_image.argtypes = [vp, i32, vp, u64]
     L.vhr_download_storage_image.argtypes = [vp, i32, vp, u64]
     L.vhr_standin_gbuffer.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.vhr_standin_gbuffer_with_albedo.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.vhr_standin_composition.argtypes = [vp, u32, C.POINTER(CompositionDesc)]
     L.vhr_set_strip.argtypes = [vp, u32, u32, u32, u32]
     L.vhr_set_ray_statistics.argtypes = [vp, i32]
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
@@ -170,6 +178,7 @@ DEPTH = "Depth"
 RAYTRACED = "Raytraced Shadows and Ambient Occlusion"
 REFLECTIONS = "Raytraced Reflections"
 DENOISED = "Denoised Raytraced Shadows and Ambient Occlusion"
+ALBEDO = "Albedo"
 SVGF_SHADER = "hybrid_render_path/svgf.comp"
 ATROUS_SHADER = "hybrid_render_path/svgf_atrous_filter.comp"
 
@@ -195,7 +204,8 @@ def render_output(binding=0):
 
 _NP_FORMATS = {abi.FORMAT_R16G16B16A16_SFLOAT: (np.uint16, 4), abi.FORMAT_R16G16_SFLOAT: (np.uint16, 2),
                abi.FORMAT_D32_SFLOAT: (np.float32, 1), abi.FORMAT_B8G8R8A8_UNORM: (np.uint8, 4),
-               abi.FORMAT_R8G8B8A8_UNORM: (np.uint8, 4), abi.FORMAT_R8G8B8A8_SRGB: (np.uint8, 4)}
+               abi.FORMAT_R8G8B8A8_UNORM: (np.uint8, 4), abi.FORMAT_R8G8B8A8_SRGB: (np.uint8, 4),
+               abi.FORMAT_B8G8R8A8_SRGB: (np.uint8, 4)}
 
 
 def _p(a):
@@ -394,6 +404,16 @@ class Context:
     def standin_gbuffer(self, resource_idx=0, normals=NORMALS, motion=MOTION, depth=DEPTH):
         self.check(self.L.vhr_standin_gbuffer(self.handle, resource_idx, normals.encode(), motion.encode(), depth.encode()),
                    "standin_gbuffer")
+
+    def standin_gbuffer_with_albedo(self, resource_idx=0, albedo=ALBEDO, normals=NORMALS, motion=MOTION, depth=DEPTH):
+        self.check(self.L.vhr_standin_gbuffer_with_albedo(self.handle, resource_idx, albedo.encode(), normals.encode(), motion.encode(),
+                                                          depth.encode()), "standin_gbuffer_with_albedo")
+
+    def standin_composition(self, output_storage_image, shadow_mode=0, ao_mode=0, reflection_mode=0, shadow_ao=DENOISED,
+                            reflections=REFLECTIONS, resource_idx=0):
+        d = CompositionDesc(shadow_mode, ao_mode, reflection_mode, ALBEDO.encode(), NORMALS.encode(), MOTION.encode(), DEPTH.encode(),
+                            shadow_ao.encode(), reflections.encode() if reflections else None, output_storage_image)
+        self.check(self.L.vhr_standin_composition(self.handle, resource_idx, C.byref(d)), "standin_composition")
 
     def set_ray_statistics(self, enable):
         self.check(self.L.vhr_set_ray_statistics(self.handle, int(enable)), "set_ray_statistics")
