@@ -65,11 +65,11 @@ def param_surface(fn, nu, nv, wrap_u=False, flip=False):
 
 def plane(origin, eu, ev, nu, nv):
     origin, eu, ev = (np.asarray(a, float) for a in (origin, eu, ev))
-    n = np.cross(ev, eu)
+    n = np.cross(eu, ev)          # the side the normal (and the winding) faces: floors up, walls into the room
 
     def fn(u, v):
         return origin + u[:, None] * eu + v[:, None] * ev, np.broadcast_to(n, (u.size, 3)).copy()
-    return param_surface(fn, nu, nv, flip=True)
+    return param_surface(fn, nu, nv)
 
 
 def cylinder(radius, height, sides, segs, caps=True):
