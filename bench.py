@@ -264,7 +264,7 @@ def main():
                 "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["unique_rays"] - (ray_stats["covered_pixels"] if args.reflections else 0)), 2),
                 "effective_traversal_gbs": round((trav_stats["node_visits"] * 64 + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6, 1),
                 "stack_overflows": int(ray_stats["stack_overflows"]),
-                "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = lane visits / (64 x wave loop trips)",
+                "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
             },
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),

@@ -274,8 +274,9 @@ int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask);
 int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset);
 
 /* Traversal work of the last vhr_trace_rays (work-queue raygen, statistics enabled): out[0] = inner-node
- * visits summed over lanes, out[1] = leaf visits, out[2] = ray/triangle tests, out[3] = wave loop trips.
- * Active-lane utilisation of the traversal loop = (out[0] + out[1]) / (64 * out[3]). */
+ * visits summed over lanes, out[1] = leaf visits, out[2] = ray/triangle tests, out[3] = trips of the two inner
+ * loops (node steps + triangle tests) counted once per wave, i.e. by the slowest lane of each round.
+ * Active-lane utilisation of the traversal loops = (out[0] + out[2]) / (64 * out[3]). */
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *

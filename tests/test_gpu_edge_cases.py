@@ -83,7 +83,7 @@ def test_axis_parallel_light_and_rays(oracle):
     scene = scenes.tiny_scene()
     scene.light = camera.directional_light((0.0, -1.0, 0.0))
     frames = _check(oracle, scene, 96, 64, 3, abi.default_trace_params())
-    assert 0.05 < (f16(frames[1]["shadow_ao"])[..., 0] == 0).mean() < 0.95
+    assert 0.01 < (f16(frames[1]["shadow_ao"])[..., 0] == 0).mean() < 0.95
 
 
 @pytest.mark.parametrize("ao_spp", [0, 1, 4, 16, 20])

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0;      // statistics (only flushed when a.stats)
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0, n_wave_trips = 0;      // statistics (only flushed when a.stats)
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         // if/else chains here cost more scalar exec-mask bookkeeping than the box tests themselves.  The write goes to
         // slot `sp` (level stack_levels - 1 at most: the builder bounds the depth), the read takes the current top.
         bool finished = false, found = false;
+        const uint32_t nodes_before = n_nodes, tris_before = n_tris;
         while (has && cur >= 0 && !finished) {
             ++n_nodes;
             float tn0, tn1;
@@ -634,6 +635,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }                         // miss.rmiss:7 leaves 1.0
             else if (!found) atomicAdd(&s_vis[pix], 256u);
         }
+        if (a.stats) {       // wave-level trip counts of the two inner loops = the slowest lane's (for lane utilisation)
+            uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
+            for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
+            n_wave_trips += tn + tt;
+        }
     }
     if (SHARED) __syncthreads(); else wave_lds_sync();
     if (covered) {
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         if (lane == 0) {
             if (cov_mask) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov_mask));
             if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
-            atomicAdd(&a.stats->wave_iterations, (unsigned long long)n_iters);
+            atomicAdd(&a.stats->wave_iterations, (unsigned long long)n_wave_trips);
         }
         atomicAdd(&a.stats->node_visits, (unsigned long long)n_nodes);
         atomicAdd(&a.stats->leaf_visits, (unsigned long long)n_leaves);

@@ -430,7 +430,7 @@ class Context:
         out = (C.c_uint64 * 4)()
         self.check(self.L.vhr_get_traversal_statistics(self.handle, out), "traversal_statistics")
         d = dict(node_visits=out[0], leaf_visits=out[1], triangle_tests=out[2], wave_iterations=out[3])
-        d["active_lane_utilisation"] = (out[0] + out[1]) / (64.0 * out[3]) if out[3] else 0.0
+        d["active_lane_utilisation"] = (out[0] + out[2]) / (64.0 * out[3]) if out[3] else 0.0
         return d
 
     def bvh_statistics(self):
