@@ -50,6 +50,9 @@ def parse():
                    help="N > 1 only: before timing, check that the gathered strips equal a single full-frame context bit for bit")
     p.add_argument("--backend", default=os.environ.get("VHR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                    help="gloo + --share-device lets several ranks run on ONE GPU (functional check of the strip path only)")
+    p.add_argument("--exchange-raytraced", action="store_true",
+                   help="N > 1: trace owned rows only and fetch the overlap rows' raw shadow/AO from the neighbours "
+                        "(default: every rank also traces its 30 overlap rows; no exchange on the critical path)")
     p.add_argument("--share-device", action="store_true", default=bool(os.environ.get("VHR_BENCH_SHARE_DEVICE")))
     return p.parse_args()
 
@@ -153,7 +156,7 @@ def main():
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup, args.max_gbuffers)
     loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=args.reflections, denoise=True,
-                           device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None)
+                           device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, trace_overlap=not args.exchange_raytraced)
     ctx = loop.ctx
 
     def barrier():
@@ -242,6 +245,7 @@ def main():
                 "reference_issued_rays_per_covered_pixel": loop.reference_rays_per_pixel,
                 "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
                 "strip_overlap_rows": loop.plan.overlap, "history_halo_rows": loop.plan.halo,
+                "overlap_rows_raytraced": ("recomputed locally" if getattr(loop, "trace_overlap", False) else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",

@@ -260,6 +260,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)
  *   "raygen_waves_per_block" 1..4 waves per workgroup (default 2)
  *   "raygen_shared_tile" 1 = the waves of a workgroup split ONE 8x8-pixel tile's ray queue, 0 = one tile per wave
+ *   "trace_overlap"    strips only: 1 = the shadow/AO rays of the overlap rows are traced by this context as well, so
+ *                      the raw visibility needs no neighbour exchange before svgf.comp (default 0: owned rows only)
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)

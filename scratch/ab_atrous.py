@@ -1,30 +1,17 @@
-import sys, os
-sys.path.insert(0, os.getcwd())
-import numpy as np
-from vulkanhybridrenderer_amd import lib, abi
-from tests.helpers import GpuSvgfHarness, synthetic_svgf_inputs, simple_pfd
-W, H = 1920, 1080
-normals, motion, rt = synthetic_svgf_inputs(W, H, seed=1)
-rng = np.random.default_rng(0)
-integ = np.stack([rng.random((H, W)), rng.random((H, W)), 0.2 * rng.random((H, W)), 0.2 * rng.random((H, W))], -1).astype(np.float16).view(np.uint16)
-state = dict(step=1)
-h = None
-def body(ec):
-    for _ in range(10):
-        ec.dispatch(lib.ATROUS_SHADER, (W + 7) // 8, (H + 7) // 8, 1, h.push_constants(state["step"]))
-h = GpuSvgfHarness(W, H, body)
-h.ctx.upload(h.images["a"], integ)
-h.ctx.set_kernel_timing(True)
-pfd = simple_pfd(W, H)
-res = {}
-for rnd in range(3):
-    for variant in (0, 1, 2):
-        for step in (1, 2, 4, 8, 16):
-            h.ctx.set_option("atrous_variant", variant); state["step"] = step
-            h.ctx.kernel_time("svgf_atrous", reset=True)
-            h.run(pfd, (normals, motion, rt))
-            ms, n = h.ctx.kernel_time("svgf_atrous", reset=True)
-            res.setdefault((variant, step), []).append(ms / n * 1e3)
-for variant in (0, 1, 2):
-    print("variant", variant, " ".join(f"step{step}: {np.median(res[(variant, step)]):6.1f}us" for step in (1, 2, 4, 8, 16)),
-          " sum5 %.1f us" % sum(np.median(res[(variant, s)]) for s in (1, 2, 4, 8, 16)))
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from vulkanhybridrenderer_amd import scenes
+from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+scene = scenes.sponza_proc()
+loop = HybridFrameLoop(scene, 1920, 1080, 24)
+for v in (2, 3, 2, 3):
+    loop.ctx.set_option("atrous_variant", v)
+    loop.ctx.set_kernel_timing(["svgf_atrous"])
+    loop.ctx.kernel_time("svgf_atrous", reset=True)
+    for i in range(24): loop.frame(i)
+    torch.cuda.synchronize()
+    t, n = loop.ctx.kernel_time("svgf_atrous")
+    print(f"atrous_variant {v}: {t / n * 1e3:.2f} us/launch ({n} launches)")
+    loop.ctx.set_kernel_timing(False)
+loop.close()

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False):
     tp = abi.default_trace_params(reflections=False)
     plans = [tiling.make_plan(H, world, r, max_motion_rows) for r in range(world)]
     ranks = [GpuHybrid(scene, W, H, reflections=False, trace_params=tp, gbuffer="standin") for _ in range(world)]
@@ -40,7 +40,9 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows):
             g, plan = ranks[rank], plans[rank]
             g.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
             pc = g.path.push_constants()
-            g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], plan.overlap))
+            g.ctx.set_option("trace_overlap", 1 if trace_overlap else 0)
+            if not trace_overlap:
+                g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], plan.overlap))
             g.ctx.set_pass_epilogue("SVGF Denoise Pass", lambda c: exchange(
                 rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], plan.halo))
             for pfd in pfds:
@@ -64,8 +66,8 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows):
     return plans, results
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_virtual_strips_bit_identical(world):
+@pytest.mark.parametrize("world,trace_overlap", [(2, False), (3, False), (2, True), (3, True)])
+def test_virtual_strips_bit_identical(world, trace_overlap):
     scene = scenes.tiny_scene()
     W, H = 96, 132
     pfds = camera.dolly_frames(scene, W, H, 5)
@@ -82,7 +84,7 @@ def test_virtual_strips_bit_identical(world):
                 max_mv = max(max_mv, float(np.nanmax(np.abs(np.nan_to_num(mv[d != 0])))) * H)
     finally:
         single.close()
-    plans, results = _run_strips(scene, W, H, world, pfds, int(np.ceil(max_mv)))
+    plans, results = _run_strips(scene, W, H, world, pfds, int(np.ceil(max_mv)), trace_overlap)
     for r, plan in enumerate(plans):
         for f, (rt, den) in enumerate(results[r]):
             assert np.array_equal(rt, ref[f][0][plan.row_begin:plan.row_end]), f"rank {r} frame {f}: raytraced rows differ"

@@ -2,7 +2,8 @@
 
 Float tolerance (stated here, checked below): the HIP kernels evaluate the shaders' formulas in fp32 with
 hardware exp / reciprocal approximations and store fp16, so a pixel may land on a neighbouring fp16 value.
-Bar per kernel: every channel within 2 fp16 steps of the oracle and >= 99% of channels bit-identical; bar
+Bar for K4 (a-trous): every channel within 2 fp16 steps of the oracle and >= 99% of channels bit-identical; K3
+(temporal: no exp / rcp, compiled without FMA contraction) is held to bit-exact in its single-dispatch test; bar
 for the multi-frame denoised image: RMSE <= 1e-4 (BASELINE.json) and max abs error <= 4e-3."""
 import numpy as np
 import pytest
@@ -66,8 +67,9 @@ def test_temporal_single_dispatch(oracle, motion):
         integ = h.ctx.download(h.images["a"])
         mom = h.ctx.download(h.images["moments"])
         ref_i, ref_m = oracle.svgf_temporal(pfd, normals, motion_img, rt, prev_normals, history, moments)
-        _close(integ, ref_i, "temporal integrated")
-        _close(mom, ref_m, "temporal moments")
+        # K3 is compiled without FMA contraction and uses IEEE division: bit-exact against the oracle
+        _close(integ, ref_i, "temporal integrated", max_steps=0, min_exact=1.0)
+        _close(mom, ref_m, "temporal moments", max_steps=0, min_exact=1.0)
         # reprojection must actually have been exercised: some pixels blended, some rejected
         blended = (f16(ref_i)[..., 0] != f16(rt)[..., 0]).mean()
         assert blended > 0.05

@@ -14,6 +14,8 @@
 
 namespace vhr {
 
+#pragma clang fp contract(off)      // K3; K4 switches contraction back on below
+
 constexpr int kSvgfBlockX = 64;    // one wave per image row segment: fully coalesced 512-byte row reads
 constexpr int kSvgfBlockY = 4;
 
@@ -41,6 +43,9 @@ __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1
 // ---------------------------------------------------------------------------------------------
 // K3: svgf.comp
 // ---------------------------------------------------------------------------------------------
+// No FMA contraction in K3 (the pragma sits above the shared helpers, mixf included): the kernel is bound by its
+// gathers, not by arithmetic, and with the shader's (= the oracle's) roundings its output is bit-identical to the
+// oracle's.  (A fused mix(prev, cur, 0.2) lands on the other side of an fp16 tie in ~2 % of the pixels.)
 struct TemporalArgs {
     const uint2 *normals, *motion, *prev_normals, *history;   // RGBA16F
     const uint32_t *raytraced, *moments_in;                   // RG16F
@@ -196,6 +201,7 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
 // ---------------------------------------------------------------------------------------------
 // K4: svgf_atrous_filter.comp
 // ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(fast)
 struct AtrousArgs {
     const uint2 *normals, *in;
     uint2 *out;
@@ -283,6 +289,7 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(c
 // `continue` amounts to.  The normal dot product uses v_dot2_f32_f16 on the packed halves.
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ half2_t as_half2(uint32_t u) { return *reinterpret_cast<const half2_t *>(&u); }
 
@@ -393,6 +400,186 @@ static void launch_atrous_tiled(vhr_context *ctx, const AtrousArgs &a) {
     hipLaunchKernelGGL((svgf_atrous_tiled_kernel<STEP, R>), grid, dim3(256), 0, ctx->stream, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4, LDS-tiled + packed-math form (the default).
+//
+// The tiled kernel above is bound by VALU issue (PMC: ~800 wave instructions per pixel, ~34 per tap), not by
+// LDS or HBM.  This form keeps its comb tiling and halves the per-tap instruction count:
+//   * the staged texel is converted ONCE: shadow/AO as fp32 (so the taps need no v_cvt), the two variances stay
+//     packed halves and enter the sums through v_fma_mix_f32, nz (fp32) and the truncated id (16 bit) sit in side arrays
+//     (an extra ds_read is free for a VALU-bound kernel; it replaces the shift/xor of the packed word);
+//   * shadow and AO are one float2: difference, scale, weight, both sums -> v_pk_add/mul/fma_f32;
+//   * taps are processed in pairs so the 7 squarings of pow(n.n', 128) and the B3 kernel factor are v_pk_mul_f32.
+// Same operation order per channel as svgf_atrous_filter.comp:72-94, fp32 throughout.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// One row of the two variance channels, 3-tap vertical Gaussian (svgf_atrous_filter.comp:17-38 is separable:
+// its weights are the outer product of (1/4, 1/2, 1/4)); taps outside the image are skipped = contribute 0.
+__device__ __forceinline__ f2v variance_column(const AtrousArgs &a, int x, int y, int max_x, int max_y) {
+    f2v acc = f2v{ 0.0f, 0.0f };
+    if (x >= 0 && x < max_x) {
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const int sy = y + j;
+            if (sy >= 0 && sy < max_y) {
+                const float2 q = unpack_rg16f(a.in[size_t(sy) * a.width + x].y);            // .zw = the two variances
+                const float w = j == 0 ? 0.5f : 0.25f;
+                acc += f2v{ w * q.x, w * q.y };
+            }
+        }
+    }
+    return acc;
+}
+
+// lane i receives lane i-1's (i+1's) value; lane 0 (63) keeps `edge`
+__device__ __forceinline__ float wave_shr1(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int STEP, int R>
+__global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArgs a) {
+    constexpr int TW = kTileX + 4 * STEP;            // staged columns
+    constexpr int TH = R + 4;                        // staged comb rows
+    constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block (TW <= 128 columns each)
+    static_assert(TW <= 256, "one thread per staged column");
+    __shared__ uint4 s_a[TH][TW];                    // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
+    __shared__ float s_nz[TH][TW];                   // nz (fp32: its product with the centre's nz is one v_mul)
+    __shared__ uint16_t s_id[TH][TW];                // int(id) as a half bit pattern; kInvalidId outside the image
+    const int W = int(a.width), H = int(a.height);
+    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
+    const int x0 = int(blockIdx.x) * kTileX;
+    const int group = int(blockIdx.y) / STEP, phase = int(blockIdx.y) - group * STEP;
+    const int y0 = int(a.row_begin) + group * (R * STEP) + phase;
+    const int tid = int(threadIdx.x);
+    const int tx = tid & 63, ty = tid >> 6;
+    const int cx = x0 + tx;
+
+    // ---- the 3x3 variance pre-filter of this thread's output pixels (:17-38): vertical taps are three coalesced
+    // row reads per lane, horizontal taps come from the neighbouring lanes (DPP), the two tile-edge lanes also read
+    // the column just outside.  Issued before the tile staging so that their latency hides behind it. ----
+    f2v var_p[(R + 3) / 4];
+#pragma unroll
+    for (int kq = 0; kq < (R + 3) / 4; ++kq) {
+        const int cy = y0 + (ty + 4 * kq) * STEP;
+        const f2v own = variance_column(a, cx, cy, max_x, max_y);
+        f2v edge = f2v{ 0.0f, 0.0f };
+        if (tx == 0 || tx == 63) edge = variance_column(a, tx == 0 ? cx - 1 : cx + 1, cy, max_x, max_y);
+        const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
+        const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
+        var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
+    }
+
+    // ---- stage the comb tile: thread = (column, row within the pass) ----
+    {
+        const int c = tid % TW, r0 = tid / TW;
+        const int sx = x0 - 2 * STEP + c;
+        const bool col_ok = tid < PASS * TW && sx >= 0 && sx < max_x;
+#pragma unroll
+        for (int kk0 = 0; kk0 < TH; kk0 += PASS) {
+            const int kk = kk0 + r0;
+            const int sy = y0 + (kk - 2) * STEP;
+            uint4 va = make_uint4(0u, 0u, 0u, 0u);
+            float nz = 0.0f;
+            uint32_t idb = kInvalidId;
+            if (col_ok && sy >= 0 && sy < max_y && kk < TH) {
+                const size_t sidx = size_t(sy) * W + sx;
+                const uint2 vin = a.in[sidx];
+                const uint2 n = a.normals[sidx];
+                const float2 xy = unpack_rg16f(vin.x);
+                va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
+                nz = float(as_half2(n.y).x);
+                // int(w) as a half: trunc toward zero, -0 folded into +0 (both are int 0)
+                _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
+                idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
+                if ((idb & 0x7fffu) == 0u) idb = 0u;
+                if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;      // NaN: int(NaN) = 0 in the oracle; keep it unequal to real ids
+            }
+            if (tid < PASS * TW && kk < TH) {
+                s_a[kk][c] = va;
+                s_nz[kk][c] = nz;
+                s_id[kk][c] = uint16_t(idb);
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int kq = 0; kq < (R + 3) / 4; ++kq) {
+        const int k = ty + 4 * kq;
+        const int cy = y0 + k * STEP;
+        if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
+        const uint4 pa = s_a[k + 2][tx + 2 * STEP];
+        const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
+        const float2 p_zw = unpack_rg16f(pa.z);
+        const half2_t np_xy = as_half2(pa.w);
+        const float np_z = s_nz[k + 2][tx + 2 * STEP];
+        const uint32_t idp = s_id[k + 2][tx + 2 * STEP];
+        // :48-50, log2(e) folded in.  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded expansions (~10
+        // instructions each): the quotient only scales the exponent of a weight
+        const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
+                             __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
+
+        f2v sw = f2v{ 1.0f, 1.0f };                                                         // :70-71
+        f2v s01 = p_xy;
+        float s2 = p_zw.x, s3 = p_zw.y;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {                                                       // :72-94, four taps per trip
+            uint4 qa[4];
+            f2v d[2];
+            bool same[4];
+            float kern[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                          // skip the centre (:77)
+                const int y = idx / 5 - 2, x = idx % 5 - 2;
+                const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+                qa[h] = s_a[row][col];
+                const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
+                const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
+                kern[h] = kx * ky;                                                          // :62-68
+                // n.n' = nz*nz' (exact in fp32: both are widened halves) + v_dot2 over the packed (nx, ny)
+                float dd = np_z * s_nz[row][col];
+                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);          // :44-46
+                d[h >> 1][h & 1] = fmaxf(dd, 0.0f);
+                same[h] = uint32_t(s_id[row][col]) == idp;                                  // :40-42
+            }
+            // pow(., 128): two packed chains of 7 squarings, interleaved so that neither waits on its own result
+#pragma unroll
+            for (int sq = 0; sq < 7; ++sq) { d[0] *= d[0]; d[1] *= d[1]; }
+            d[0] *= f2v{ kern[0], kern[1] };
+            d[1] *= f2v{ kern[2], kern[3] };
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float w = same[h] ? d[h >> 1][h & 1] : 0.0f;                          // :87
+                const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
+                const f2v tt = (p_xy - q_xy) * inv;
+                const f2v e = f2v{ __builtin_amdgcn_exp2f(-fabsf(tt.x)), __builtin_amdgcn_exp2f(-fabsf(tt.y)) };   // :88-89
+                const f2v w2 = e * f2v{ w, w };
+                sw += w2;                                                                   // :91
+                s01 = __builtin_elementwise_fma(w2, q_xy, s01);                             // :92
+                const f2v wq = w2 * w2;
+                const half2_t q_zw = as_half2(qa[h].z);
+                s2 = fmaf(wq.x, float(q_zw.x), s2);
+                s3 = fmaf(wq.y, float(q_zw.y), s3);
+            }
+        }
+        const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
+        a.out[size_t(cy) * W + cx] = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+    }
+}
+
+template <int STEP, int R>
+static void launch_atrous_packed(vhr_context *ctx, const AtrousArgs &a) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
+    const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
+    hipLaunchKernelGGL((svgf_atrous_packed_kernel<STEP, R>), grid, dim3(256), 0, ctx->stream, a);
+}
+
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in, Image &out,
                        int32_t step, uint32_t x_groups, uint32_t y_groups) {
     const uint32_t W = normals.width, H = normals.height;
@@ -419,7 +606,16 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     ctx->time_begin(kKernelAtrous);
     const int variant = ctx->options[kOptAtrousVariant];
     bool tiled = variant != 0;
-    if (tiled) {
+    if (variant == 3) {
+        switch (step) {
+            case 1: launch_atrous_packed<1, 8>(ctx, a); break;
+            case 2: launch_atrous_packed<2, 8>(ctx, a); break;
+            case 4: launch_atrous_packed<4, 8>(ctx, a); break;
+            case 8: launch_atrous_packed<8, 8>(ctx, a); break;
+            case 16: launch_atrous_packed<16, 8>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    } else if (tiled) {
         switch (step) {
             case 1: if (variant == 2) launch_atrous_tiled<1, 8>(ctx, a); else launch_atrous_tiled<1, 16>(ctx, a); break;
             case 2: if (variant == 2) launch_atrous_tiled<2, 8>(ctx, a); else launch_atrous_tiled<2, 16>(ctx, a); break;

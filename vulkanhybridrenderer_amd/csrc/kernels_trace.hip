@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_iters = 0, n_wave_trips = 0;      // statistics (only flushed when a.stats)
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0;      // statistics (only flushed when a.stats)
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
@@ -569,7 +569,6 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             }
         }
         if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
-        ++n_iters;
         // ---- inner nodes: descend until this lane holds a leaf or its ray has run out of subtrees ----
         // The step is written without branches (selects + one unconditional LDS write and read per trip): divergent
         // if/else chains here cost more scalar exec-mask bookkeeping than the box tests themselves.  The write goes to
@@ -705,10 +704,15 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     a.reflections = reflections ? reflections->ptr : nullptr;
     a.width = width;
     a.height = height;
-    a.row_begin = std::min(ctx->row_begin, height);
-    a.row_end = std::min(ctx->row_end, height);
+    const uint32_t owned_begin = std::min(ctx->row_begin, height), owned_end = std::min(ctx->row_end, height);
+    a.row_begin = owned_begin;
+    a.row_end = owned_end;
     a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
     if (a.row_end <= a.row_begin) return VHR_OK;
+    if (ctx->options[kOptTraceOverlap]) {      // strips: trace the rows the denoiser recomputes too (no exchange of raw visibility)
+        a.row_begin = owned_begin > ctx->overlap ? owned_begin - ctx->overlap : 0u;
+        a.row_end = uint32_t(std::min<uint64_t>(height, uint64_t(owned_end) + ctx->overlap));
+    }
     if (a.stats) {
         if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
@@ -747,7 +751,11 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
-        if (a.reflections && a.tp.reflections) hipLaunchKernelGGL(reflection_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+        if (a.reflections && a.tp.reflections) {       // not denoised: owned rows only
+            a.row_begin = owned_begin;
+            a.row_end = owned_end;
+            hipLaunchKernelGGL(reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, ctx->stream, a);
+        }
     }
     ctx->time_end(kKernelRaygen);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");

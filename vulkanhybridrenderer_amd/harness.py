@@ -30,7 +30,7 @@ def alias_tensor(info):
 
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
-                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0):
+                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True):
         import torch
         self.torch = torch
         self.scene, self.W, self.H = scene, width, height
@@ -59,6 +59,10 @@ class HybridFrameLoop:
             # thin strips keep few waves in flight: let two waves split each tile's ray queue (measured -20 % on a 1/8 strip)
             self.ctx.set_option("raygen_shared_tile", 1)
             self.ctx.set_strip(self.plan.row_begin, self.plan.row_end, self.plan.overlap, self.plan.halo)
+            # trace_overlap: the overlap rows' shadow/AO rays are traced here too (rays are per-pixel independent), which
+            # removes exchange #1 from the critical path; only the deferred history exchange remains (tiling.py)
+            self.trace_overlap = bool(trace_overlap) and denoise
+            self.ctx.set_option("trace_overlap", 1 if self.trace_overlap else 0)
             self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
             if denoise:
                 self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)
@@ -113,6 +117,8 @@ class HybridFrameLoop:
         # exchange #2 of the previous frame (history + moments) was left in flight behind this frame's ray tracing;
         # it has to land before svgf.comp, which runs right after this epilogue
         self.finish_pending_exchange()
+        if self.trace_overlap or not self.denoise:
+            return
         t = self._alias(ctx.transient_info(lib.RAYTRACED))
         tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
 
