@@ -251,7 +251,7 @@ def main():
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
             },
             "roofline": {
-                "kernel": "svgf_atrous_tiled_kernel<step, 8> (svgf_atrous_filter.comp)",
+                "kernel": "svgf_atrous_stream_kernel<step, 8> (svgf_atrous_filter.comp)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits)",

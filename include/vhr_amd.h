@@ -265,7 +265,10 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)
- *   "atrous_variant", "temporal_variant"  kernel variants of K4 / K3 */
+ *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
+ *                      persistent workgroups that prefetch the next tile into registers (default)
+ *   "atrous_blocks_per_cu" (default 8), "atrous_xcd_aware" (default 1): launch shape of variant 4
+ *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
 /* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel

@@ -123,4 +123,15 @@ __device__ __forceinline__ f3 onb_transform(f3 n, f3 v) {
                (c0.z * v.x + c1.z * v.y) + n.z * v.z };
 }
 
+// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one),
+// and each XCD has its own 4 MiB L2.  With the natural order every XCD would walk tiles from all over the screen
+// and pull the whole visible BVH / triangle set (> 4 MiB) through its L2; instead the blocks that share an XCD get
+// one contiguous band of tile rows, so each L2 only holds the geometry its band's rays meet.  Bijective for any
+// block count (the remainder rows go to the first bands); placement is a speed hint only, never correctness.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
+    const uint32_t xcd = id & 7u, slot = id >> 3;
+    const uint32_t q = n >> 3, r = n & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}
+
 }  // namespace vhr

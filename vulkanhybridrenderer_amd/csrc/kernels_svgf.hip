@@ -572,6 +572,206 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4, streaming form of the packed kernel (the default): persistent workgroups walk over the comb tiles and fetch
+// the NEXT tile's texels into registers while the taps of the current tile run out of LDS.  The one-tile-per-block
+// form above launches ~2 rounds of resident blocks that all load, then all compute: its global-load phases are
+// exposed (PMC: VALU busy 75 %).  Same arithmetic, same tile geometry; only the schedule differs.
+// ---------------------------------------------------------------------------------------------
+template <int STEP, int R>
+__global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total,
+                                                                 const uint32_t xcd_aware) {
+    constexpr int TW = kTileX + 4 * STEP;            // staged columns
+    constexpr int TH = R + 4;                        // staged comb rows
+    constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block
+    constexpr int NP = (TH + PASS - 1) / PASS;       // passes = texels prefetched per thread
+    constexpr int NK = (R + 3) / 4;                  // output pixels per thread
+    static_assert(TW <= 256, "one thread per staged column");
+    __shared__ uint4 s_a[TH][TW];                    // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
+    __shared__ float s_nz[TH][TW];
+    __shared__ uint16_t s_id[TH][TW];
+    const int W = int(a.width), H = int(a.height);
+    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
+    const int tid = int(threadIdx.x);
+    const int tx = tid & 63, ty = tid >> 6;
+    const int c = tid % TW, r0 = tid / TW;
+    const bool stager = tid < PASS * TW;
+
+    // prefetch registers: the raw texels of the next tile and the raw variance columns of this thread's pixels
+    uint2 pf_in[NP], pf_nm[NP];
+    uint32_t pf_ok = 0;
+    uint32_t pv_own[NK][3], pv_edge[NK][3];
+
+    auto tile_origin = [&](uint32_t v, int &x0, int &y0) {
+        const uint32_t t = xcd_aware ? xcd_remap(v, tiles_total) : v;
+        const uint32_t by = t / tiles_x, bx = t - by * tiles_x;
+        const int group = int(by) / STEP, phase = int(by) - group * STEP;
+        x0 = int(bx) * kTileX;
+        y0 = int(a.row_begin) + group * (R * STEP) + phase;
+    };
+    auto prefetch = [&](uint32_t v) {
+        int x0, y0;
+        tile_origin(v, x0, y0);
+        const int sx = x0 - 2 * STEP + c;
+        const bool col_ok = stager && sx >= 0 && sx < max_x;
+        pf_ok = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int kk = p * PASS + r0;
+            const int sy = y0 + (kk - 2) * STEP;
+            pf_in[p] = make_uint2(0u, 0u);
+            pf_nm[p] = make_uint2(0u, 0u);
+            if (col_ok && kk < TH && sy >= 0 && sy < max_y) {
+                const size_t sidx = size_t(sy) * W + sx;
+                pf_in[p] = a.in[sidx];
+                pf_nm[p] = a.normals[sidx];
+                pf_ok |= 1u << p;
+            }
+        }
+        const int cx = x0 + tx;
+        const int ex = tx == 0 ? cx - 1 : cx + 1;
+        const bool edge_lane = (tx == 0 || tx == 63) && ex >= 0 && ex < max_x;
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) {
+            const int cy = y0 + (ty + 4 * kq) * STEP;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sy = cy + j - 1;
+                const bool row_ok = sy >= 0 && sy < max_y;
+                pv_own[kq][j] = (row_ok && cx < max_x) ? a.in[size_t(sy) * W + cx].y : 0u;      // .zw = the two variances
+                pv_edge[kq][j] = (row_ok && edge_lane) ? a.in[size_t(sy) * W + ex].y : 0u;
+            }
+        }
+    };
+
+    uint32_t v = blockIdx.x;
+    if (v >= tiles_total) return;
+    prefetch(v);
+    for (;;) {
+        int x0, y0;
+        tile_origin(v, x0, y0);
+        // ---- the 3x3 variance pre-filter (:17-38) from the prefetched columns: vertical taps in-lane, horizontal via DPP ----
+        f2v var_p[NK];
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) {
+            f2v own = f2v{ 0.0f, 0.0f }, edge = f2v{ 0.0f, 0.0f };
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float w = j == 1 ? 0.5f : 0.25f;
+                const float2 qo = unpack_rg16f(pv_own[kq][j]), qe = unpack_rg16f(pv_edge[kq][j]);
+                own += f2v{ w * qo.x, w * qo.y };
+                edge += f2v{ w * qe.x, w * qe.y };
+            }
+            const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
+            const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
+            var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
+        }
+        // ---- registers -> LDS (converted once per texel) ----
+        if (stager) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int kk = p * PASS + r0;
+                if (kk < TH) {
+                    uint4 va = make_uint4(0u, 0u, 0u, 0u);
+                    float nz = 0.0f;
+                    uint32_t idb = kInvalidId;
+                    if (pf_ok & (1u << p)) {
+                        const uint2 vin = pf_in[p], n = pf_nm[p];
+                        const float2 xy = unpack_rg16f(vin.x);
+                        va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
+                        nz = float(as_half2(n.y).x);
+                        _Float16 idh = __builtin_truncf16(as_half2(n.y).y);   // int(w) as a half; -0 folded into +0
+                        idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
+                        if ((idb & 0x7fffu) == 0u) idb = 0u;
+                        if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;
+                    }
+                    s_a[kk][c] = va;
+                    s_nz[kk][c] = nz;
+                    s_id[kk][c] = uint16_t(idb);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t vn = v + gridDim.x;
+        const bool more = vn < tiles_total;          // block-uniform
+        if (more) prefetch(vn);                      // in flight while the taps below run
+
+        const int cx = x0 + tx;
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) {
+            const int k = ty + 4 * kq;
+            const int cy = y0 + k * STEP;
+            if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
+            const uint4 pa = s_a[k + 2][tx + 2 * STEP];
+            const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
+            const float2 p_zw = unpack_rg16f(pa.z);
+            const half2_t np_xy = as_half2(pa.w);
+            const float np_z = s_nz[k + 2][tx + 2 * STEP];
+            const uint32_t idp = s_id[k + 2][tx + 2 * STEP];
+            const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
+                                 __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
+            f2v sw = f2v{ 1.0f, 1.0f };                                                     // :70-71
+            f2v s01 = p_xy;
+            float s2 = p_zw.x, s3 = p_zw.y;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
+                uint4 qa[4];
+                f2v d[2];
+                bool same[4];
+                float kern[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                      // skip the centre (:77)
+                    const int y = idx / 5 - 2, x = idx % 5 - 2;
+                    const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+                    qa[h] = s_a[row][col];
+                    const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
+                    const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
+                    kern[h] = kx * ky;                                                      // :62-68
+                    float dd = np_z * s_nz[row][col];
+                    dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // :44-46
+                    d[h >> 1][h & 1] = fmaxf(dd, 0.0f);
+                    same[h] = uint32_t(s_id[row][col]) == idp;                              // :40-42
+                }
+#pragma unroll
+                for (int sq = 0; sq < 7; ++sq) { d[0] *= d[0]; d[1] *= d[1]; }              // pow(., 128), interleaved chains
+                d[0] *= f2v{ kern[0], kern[1] };
+                d[1] *= f2v{ kern[2], kern[3] };
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float w = same[h] ? d[h >> 1][h & 1] : 0.0f;                      // :87
+                    const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
+                    const f2v tt = (p_xy - q_xy) * inv;
+                    const f2v e = f2v{ __builtin_amdgcn_exp2f(-fabsf(tt.x)), __builtin_amdgcn_exp2f(-fabsf(tt.y)) };   // :88-89
+                    const f2v w2 = e * f2v{ w, w };
+                    sw += w2;                                                               // :91
+                    s01 = __builtin_elementwise_fma(w2, q_xy, s01);                         // :92
+                    const f2v wq = w2 * w2;
+                    const half2_t q_zw = as_half2(qa[h].z);
+                    s2 = fmaf(wq.x, float(q_zw.x), s2);
+                    s3 = fmaf(wq.y, float(q_zw.y), s3);
+                }
+            }
+            const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
+            a.out[size_t(cy) * W + cx] = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+        }
+        if (!more) break;
+        __syncthreads();                             // every wave is done with this tile's LDS image
+        v = vn;
+    }
+}
+
+template <int STEP, int R>
+static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
+    const uint32_t tiles_x = (a.limit_x + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
+    const uint32_t per_cu = uint32_t(std::max(1, std::min(16, ctx->options[kOptAtrousBlocksPerCu])));
+    const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
+    hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
+                       uint32_t(ctx->options[kOptAtrousXcdAware]));
+}
+
 template <int STEP, int R>
 static void launch_atrous_packed(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
@@ -606,7 +806,16 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     ctx->time_begin(kKernelAtrous);
     const int variant = ctx->options[kOptAtrousVariant];
     bool tiled = variant != 0;
-    if (variant == 3) {
+    if (variant == 4) {
+        switch (step) {
+            case 1: launch_atrous_stream<1, 8>(ctx, a); break;
+            case 2: launch_atrous_stream<2, 8>(ctx, a); break;
+            case 4: launch_atrous_stream<4, 8>(ctx, a); break;
+            case 8: launch_atrous_stream<8, 8>(ctx, a); break;
+            case 16: launch_atrous_stream<16, 8>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    } else if (variant == 3) {
         switch (step) {
             case 1: launch_atrous_packed<1, 8>(ctx, a); break;
             case 2: launch_atrous_packed<2, 8>(ctx, a); break;

@@ -422,17 +422,6 @@ __device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t
 // Every wave owns one 8x8-pixel tile and runs its own queue; a block is WAVES such waves side by side (a CU
 // accepts at most 16 workgroups, so single-wave blocks cap occupancy at 4 waves per SIMD: measured).  Waves of a
 // block share nothing and never synchronise with each other.
-// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one),
-// and each XCD has its own 4 MiB L2.  With the natural order every XCD would walk tiles from all over the screen
-// and pull the whole visible BVH / triangle set (> 4 MiB) through its L2; instead the blocks that share an XCD get
-// one contiguous band of tile rows, so each L2 only holds the geometry its band's rays meet.  Bijective for any
-// block count (the remainder rows go to the first bands); placement is a speed hint only, never correctness.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
-    const uint32_t xcd = id & 7u, slot = id >> 3;
-    const uint32_t q = n >> 3, r = n & 7u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
-}
-
 template <int WAVES>
 __device__ __forceinline__ void tile_pixel(uint32_t block_tile, uint32_t tiles_x, uint32_t wave, uint32_t local, uint32_t row_begin, uint32_t &x, uint32_t &y) {
     const uint32_t by = block_tile / tiles_x, bx = block_tile - by * tiles_x;
