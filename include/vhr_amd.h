@@ -256,9 +256,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
 /* Tuning knobs for A/B measurements; every setting computes identical results.
  *   "raygen_variant"   0 = one thread per pixel tracing its rays in sequence, 1 = block work queue (default)
  *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
- *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 12)
+ *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 10)
+ *   "raygen_early_exit" n/16: the inner-node loop is left once the walking lanes have dropped to that fraction of
+ *                      those that entered it (0 = only when all are done; default 4)
  *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)
- *   "raygen_waves_per_block" 1..4 waves per workgroup (default 2)
+ *   "raygen_waves_per_block" 1, 2 or 4 waves per workgroup (default 2)
  *   "raygen_shared_tile" 1 = the waves of a workgroup split ONE 8x8-pixel tile's ray queue, 0 = one tile per wave
  *   "trace_overlap"    strips only: 1 = the shadow/AO rays of the overlap rows are traced by this context as well, so
  *                      the raw visibility needs no neighbour exchange before svgf.comp (default 0: owned rows only)
@@ -283,6 +285,11 @@ int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64
  * loops (node steps + triangle tests) counted once per wave, i.e. by the slowest lane of each round.
  * Active-lane utilisation of the traversal loops = (out[0] + out[2]) / (64 * out[3]). */
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
+
+/* Where the waves of the last work-queue raygen launch spent their time (statistics enabled; s_memtime ticks summed
+ * over waves): out[0] = whole kernel, out[1] = per-tile pixel setup, out[2] = queue refills (ray generation),
+ * out[3] = inner-node loop, out[4] = leaf (triangle) stage, out[5] = refills, out[6] = waves, out[7] = 0. */
+int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]);
 
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */

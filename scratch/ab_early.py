@@ -1,0 +1,25 @@
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from vulkanhybridrenderer_amd import scenes
+from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+scene = scenes.sponza_proc()
+loop = HybridFrameLoop(scene, 1920, 1080, 24)
+def run(tag):
+    loop.ctx.set_kernel_timing(["raygen"])
+    loop.ctx.kernel_time("raygen", reset=True)
+    for i in range(4, 24): loop.frame(i)
+    torch.cuda.synchronize()
+    t, n = loop.ctx.kernel_time("raygen")
+    loop.ctx.set_kernel_timing(False)
+    loop.ctx.set_ray_statistics(True)
+    loop.frame(5); torch.cuda.synchronize()
+    c = loop.ctx.traversal_cycles(); ts = loop.ctx.traversal_statistics()
+    loop.ctx.set_ray_statistics(False)
+    print(f"{tag}: {t / n:.4f} ms  util {ts['active_lane_utilisation']:.3f} trips/wave {ts['wave_iterations']/max(1,c['waves']):.1f} refills/wave {c['refills']/max(1,c['waves']):.1f} refill share {c['refill']/max(1,c['total']):.3f}", flush=True)
+for i in range(4): loop.frame(i)
+for rep in range(3):
+    for lv, e in ((12, 4), (8, 4), (10, 4), (12, 0)):
+        loop.ctx.set_option("lds_stack_levels", lv); loop.ctx.set_option("raygen_early_exit", e)
+        run(f"levels {lv} early {e}")
+loop.close()

@@ -386,8 +386,8 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware" };
-    for (int i = 0; i < 14; ++i)
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit" };
+    for (int i = 0; i < 15; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
     return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");
 }
@@ -415,6 +415,15 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out[0] = ctx->h_ray_stats.node_visits; out[1] = ctx->h_ray_stats.leaf_visits;
     out[2] = ctx->h_ray_stats.triangle_tests; out[3] = ctx->h_ray_stats.wave_iterations;
+    return VHR_OK;
+}
+
+int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const RayStats &r = ctx->h_ray_stats;
+    out[0] = r.cycles_total; out[1] = r.cycles_setup; out[2] = r.cycles_refill; out[3] = r.cycles_nodes;
+    out[4] = r.cycles_leaves; out[5] = r.refills; out[6] = r.waves; out[7] = 0;
     return VHR_OK;
 }
 

@@ -443,11 +443,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 // SHARED: the WAVES waves of a block split the queue of ONE 8x8 tile between them (queue head in LDS) instead of
 // owning a tile each: a wave then lives for about a third as long, which matters whenever few waves are in flight
 // (the end of a launch, or a thin strip of a multi-GPU run), at the price of one block-wide barrier on either side.
-template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED>
-__global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
+template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS>
+__global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
-                                                                          const uint32_t xcd_aware) {
+                                                                          const uint32_t xcd_aware, const uint32_t early_exit) {
+    RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
     extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
+    const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
     constexpr int COPIES = SHARED ? 1 : WAVES;
     __shared__ uint32_t s_vis_all[COPIES][kQueueBlock];   // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
     __shared__ float s_ray_all[COPIES][7][kQueueBlock];   // per covered pixel: ray origin (3), normal (3), RNG seed (1)
@@ -458,8 +461,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
     float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
     uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
     // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
-    int *stack = s_dyn + wave * stack_levels * kQueueBlock + lane;
-    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * stack_levels * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
+    int *stack = s_dyn + wave * (stack_levels + 1u) * kQueueBlock + lane;      // + the dummy row
+    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + 1u) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         wave_lds_sync();
     }
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
+    if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
     float tmax = 0.0f;
@@ -518,17 +522,19 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0;      // statistics (only flushed when a.stats)
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0;      // statistics (only flushed when stats)
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
-    int spill[kTraceStack];
+    int spill[SPILL ? kTraceStack : 1];
     const float tmin = a.tp.tmin;
     for (;;) {
         // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = uint32_t(__popcll(idle));
+        const unsigned long long t0 = stats ? __builtin_readcyclecounter() : 0ull;
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
+            ++n_refills;
             if (SHARED) {                             // one LDS atomic per refill, issued by the first idle lane
                 const int leader = __ffsll((long long)idle) - 1;
                 uint32_t base = 0;
@@ -558,13 +564,20 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             }
         }
         if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
+        const unsigned long long t1 = stats ? __builtin_readcyclecounter() : 0ull;
         // ---- inner nodes: descend until this lane holds a leaf or its ray has run out of subtrees ----
         // The step is written without branches (selects + one unconditional LDS write and read per trip): divergent
         // if/else chains here cost more scalar exec-mask bookkeeping than the box tests themselves.  The write goes to
         // slot `sp` (level stack_levels - 1 at most: the builder bounds the depth), the read takes the current top.
+        // Early exit: lanes leave this loop one by one (ray finished, or a leaf reached) and then idle until the LAST
+        // walker leaves it.  With few leaf visits per any-hit ray that wait dominates (measured: 3.7 refills per 192-ray
+        // tile, 44 % of the lanes active), so once the walkers have shrunk to a fraction of those that entered, the
+        // loop is left: waiting lanes test their leaves, finished ones are refilled, the walkers resume where they were.
         bool finished = false, found = false;
         const uint32_t nodes_before = n_nodes, tris_before = n_tris;
+        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
         while (has && cur >= 0 && !finished) {
+            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;   // ballot(true) = the walkers left; early_exit in 0..15 sixteenths, so the first trip always runs
             ++n_nodes;
             float tn0, tn1;
             bool h0, h1;
@@ -586,18 +599,24 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            // LDS rows 0 .. stack_levels-1 hold the stack, row stack_levels is a dummy that absorbs the (rare) accesses
+            // beyond them, so the common path is one unconditional ds_read + ds_write; the real deep entries live in scratch
             const uint32_t below = sp > 0 ? uint32_t(sp) - 1u : 0u;
-            const int top = below < stack_levels ? stack[below * kQueueBlock] : spill[(below - stack_levels) & uint32_t(kTraceStack - 1)];
+            int top = stack[min(below, stack_levels) * kQueueBlock];
+            if (SPILL && below >= stack_levels) top = spill[(below - stack_levels) & uint32_t(kTraceStack - 1)];
             // the write is harmless when !both: slot sp is above the top of the stack
-            if (uint32_t(sp) < stack_levels) stack[sp * kQueueBlock] = farc;
-            else if (uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
-            else overflow |= both ? 1u : 0u;                                      // cannot happen (builder depth bound); counted
+            stack[min(uint32_t(sp), stack_levels) * kQueueBlock] = farc;
+            if (uint32_t(sp) >= stack_levels) {
+                if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                else overflow |= both ? 1u : 0u;                                  // cannot happen (builder depth bound); counted
+            }
             finished = none && sp == 0;
             cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
             sp += (both ? 1 : 0) - ((none && sp > 0) ? 1 : 0);
         }
+        const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
         // ---- leaf ----
-        if (has && !finished) {
+        if (has && !finished && cur < 0) {
             const uint32_t vv = ~uint32_t(cur);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
@@ -615,7 +634,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             if (found || sp == 0) finished = true;
             else {
                 --sp;
-                cur = uint32_t(sp) < stack_levels ? stack[sp * kQueueBlock] : spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
+                cur = stack[min(uint32_t(sp), stack_levels) * kQueueBlock];
+                if (SPILL && uint32_t(sp) >= stack_levels) cur = spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
             }
         }
         if (has && finished) {
@@ -623,7 +643,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
             if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }                         // miss.rmiss:7 leaves 1.0
             else if (!found) atomicAdd(&s_vis[pix], 256u);
         }
-        if (a.stats) {       // wave-level trip counts of the two inner loops = the slowest lane's (for lane utilisation)
+        if (stats) {       // wave-level trip counts of the two inner loops = the slowest lane's (for lane utilisation)
+            const unsigned long long t3 = __builtin_readcyclecounter();
+            t_refill += t1 - t0; t_nodes += t2 - t1; t_leaves += t3 - t2;
             uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
             for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
             n_wave_trips += tn + tt;
@@ -637,16 +659,23 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) void raygen_queue_kernel(const 
         if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
-    if (a.stats) {
+    if (stats) {
         const unsigned long long ovf = __ballot(overflow != 0);
         if (lane == 0) {
-            if (cov_mask) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov_mask));
-            if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
-            atomicAdd(&a.stats->wave_iterations, (unsigned long long)n_wave_trips);
+            if (cov_mask) atomicAdd(&stats->covered_pixels, (unsigned long long)__popcll(cov_mask));
+            if (ovf) atomicAdd(&stats->stack_overflows, (unsigned long long)__popcll(ovf));
+            atomicAdd(&stats->wave_iterations, (unsigned long long)n_wave_trips);
+            atomicAdd(&stats->cycles_total, __builtin_readcyclecounter() - t_start);
+            atomicAdd(&stats->cycles_setup, t_setup);
+            atomicAdd(&stats->cycles_refill, t_refill);
+            atomicAdd(&stats->cycles_nodes, t_nodes);
+            atomicAdd(&stats->cycles_leaves, t_leaves);
+            atomicAdd(&stats->refills, n_refills);
+            atomicAdd(&stats->waves, 1ull);
         }
-        atomicAdd(&a.stats->node_visits, (unsigned long long)n_nodes);
-        atomicAdd(&a.stats->leaf_visits, (unsigned long long)n_leaves);
-        atomicAdd(&a.stats->triangle_tests, (unsigned long long)n_tris);
+        atomicAdd(&stats->node_visits, (unsigned long long)n_nodes);
+        atomicAdd(&stats->leaf_visits, (unsigned long long)n_leaves);
+        atomicAdd(&stats->triangle_tests, (unsigned long long)n_tris);
     }
 }
 
@@ -719,24 +748,30 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
         const uint32_t pregen_kinds = pregen ? kinds : 0u;
         const bool shared_tile = ctx->options[kOptSharedTile] != 0;
-        const size_t stack_bytes = size_t(levels) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
+        const size_t stack_bytes = size_t(levels + 1) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
         const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
         const int waves = ctx->options[kOptWavesPerBlock];
-#define VHR_LAUNCH_QUEUE(P, WV, C)                                                                                                \
+        const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
+#define VHR_LAUNCH_QUEUE(P, WV, C, SP, ST)                                                                                        \
     do {                                                                                                                          \
         if (shared_tile)                                                                                                          \
-            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, true>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
-                               ctx->stream, a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]));    \
+            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
+                               ctx->stream, a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit);    \
         else                                                                                                                      \
-            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                (stack_bytes + dir_bytes) * WV, ctx->stream, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
-                               uint32_t(ctx->options[kOptXcdAware]));                                                              \
+                               uint32_t(ctx->options[kOptXcdAware]), early_exit);                                                  \
     } while (0)
-#define VHR_LAUNCH_QUEUE_W(P, C)                                                                                                   \
-    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C); else if (waves >= 3) VHR_LAUNCH_QUEUE(P, 3, C); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C); else VHR_LAUNCH_QUEUE(P, 1, C); } while (0)
+#define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
+    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
         const bool compact = ctx->options[kOptCompactNodes] != 0;
-        if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true); else VHR_LAUNCH_QUEUE_W(true, false); }
-        else { if (compact) VHR_LAUNCH_QUEUE_W(false, true); else VHR_LAUNCH_QUEUE_W(false, false); }
+        // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
+        const bool spill = levels < ctx->bvh_depth + 1u;
+        // A/B variants (pre-generated directions, compact nodes) exist in the diagnostic flavour only
+        if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true, true, true); else VHR_LAUNCH_QUEUE_W(true, false, true, true); }
+        else if (compact) VHR_LAUNCH_QUEUE_W(false, true, true, true);
+        else if (a.stats) { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, true); else VHR_LAUNCH_QUEUE_W(false, false, false, true); }
+        else { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, false); else VHR_LAUNCH_QUEUE_W(false, false, false, false); }
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)

@@ -31,7 +31,7 @@ EXPORTS = [
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_set_strip",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles",
     "vhr_calibration_stream_read",
 ]
 
@@ -164,6 +164,7 @@ def load():
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
@@ -432,6 +433,11 @@ class Context:
         d = dict(node_visits=out[0], leaf_visits=out[1], triangle_tests=out[2], wave_iterations=out[3])
         d["active_lane_utilisation"] = (out[0] + out[2]) / (64.0 * out[3]) if out[3] else 0.0
         return d
+
+    def traversal_cycles(self):
+        out = (C.c_uint64 * 8)()
+        self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
+        return dict(total=out[0], setup=out[1], refill=out[2], nodes=out[3], leaves=out[4], refills=out[5], waves=out[6])
 
     def bvh_statistics(self):
         out = (C.c_uint64 * 5)()
