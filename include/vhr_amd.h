@@ -256,7 +256,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
 /* Tuning knobs for A/B measurements; every setting computes identical results.
  *   "raygen_variant"   0 = one thread per pixel tracing its rays in sequence, 1 = block work queue (default)
  *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
- *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 10)
+ *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 8)
  *   "raygen_early_exit" n/16: the inner-node loop is left once the walking lanes have dropped to that fraction of
  *                      those that entered it (0 = only when all are done; default 4)
  *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)

@@ -19,7 +19,7 @@ def run(tag):
     print(f"{tag}: {t / n:.4f} ms  util {ts['active_lane_utilisation']:.3f} trips/wave {ts['wave_iterations']/max(1,c['waves']):.1f} refills/wave {c['refills']/max(1,c['waves']):.1f} refill share {c['refill']/max(1,c['total']):.3f}", flush=True)
 for i in range(4): loop.frame(i)
 for rep in range(3):
-    for lv, e in ((12, 4), (8, 4), (10, 4), (12, 0)):
+    for lv, e in ((10, 4), (8, 4), (12, 4), (16, 4)):
         loop.ctx.set_option("lds_stack_levels", lv); loop.ctx.set_option("raygen_early_exit", e)
         run(f"levels {lv} early {e}")
 loop.close()

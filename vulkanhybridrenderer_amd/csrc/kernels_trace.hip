@@ -386,12 +386,21 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a)
 // any result.
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+// v_min / v_max / v_min3 / v_max3 spelled as instructions: fminf / fmaxf lower to llvm.minnum / maxnum, which under the
+// kernel's IEEE mode get a canonicalising v_max_f32 x, x, x in front of every operand the compiler cannot prove quiet
+// (14 extra instructions per node here).  The hardware ops already return the non-NaN operand, which is all the
+// cull needs (and no NaN can arise: see cull_reciprocal).
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 noi, float tmin, float tlimit, float &tnear) {
     const f2v tx = __builtin_elementwise_fma(bx, f2v{ inv.x, inv.x }, f2v{ noi.x, noi.x });
     const f2v ty = __builtin_elementwise_fma(by, f2v{ inv.y, inv.y }, f2v{ noi.y, noi.y });
     const f2v tz = __builtin_elementwise_fma(bz, f2v{ inv.z, inv.z }, f2v{ noi.z, noi.z });
-    const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tmin));
-    const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
+    const float tn = hw_max3(hw_min(tx.x, tx.y), hw_min(ty.x, ty.y), hw_max(hw_min(tz.x, tz.y), tmin));
+    const float tf = hw_min3(hw_max(tx.x, tx.y), hw_max(ty.x, ty.y), hw_min(hw_max(tz.x, tz.y), tlimit));
     tnear = tn;
     return tn <= tf;
 }
@@ -405,6 +414,7 @@ __device__ __forceinline__ float cull_reciprocal(float d) {
 }
 
 constexpr int kQueueBlock = 64;
+constexpr int kStackSentinel = int(0x80000000u);   // not a node (>= 0) and not a leaf code the builder can emit
 constexpr uint32_t kMaxPregenKinds = 17;       // 1 shadow + up to 16 AO samples pre-generated into LDS (13 KB)
 
 // raygen.rgen:32-53 for one (pixel, kind): the ray direction, exact arithmetic
@@ -461,8 +471,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
     uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
     // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
-    int *stack = s_dyn + wave * (stack_levels + 1u) * kQueueBlock + lane;      // + the dummy row
-    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + 1u) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
+    // LDS stack rows: [0] = sentinel (what a pop of the empty stack returns), [1 .. stack_levels] = entries
+    // 0 .. stack_levels-1, [stack_levels+1, +2] = dummies that absorb the accesses of entries living in scratch
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    stack[0] = kStackSentinel;
+    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + 3u) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -528,6 +541,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
     int spill[SPILL ? kTraceStack : 1];
     const float tmin = a.tp.tmin;
+    float tmin_v = tmin;                              // one VGPR copy for the asm-operand min/max of the slab test
+    asm volatile("" : "+v"(tmin_v));
     for (;;) {
         // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
         const unsigned long long idle = __ballot(!has);
@@ -573,10 +588,10 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         // walker leaves it.  With few leaf visits per any-hit ray that wait dominates (measured: 3.7 refills per 192-ray
         // tile, 44 % of the lanes active), so once the walkers have shrunk to a fraction of those that entered, the
         // loop is left: waiting lanes test their leaves, finished ones are refilled, the walkers resume where they were.
-        bool finished = false, found = false;
+        bool found = false;
         const uint32_t nodes_before = n_nodes, tris_before = n_tris;
         const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
-        while (has && cur >= 0 && !finished) {
+        while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;   // ballot(true) = the walkers left; early_exit in 0..15 sixteenths, so the first trip always runs
             ++n_nodes;
             float tn0, tn1;
@@ -586,37 +601,39 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const uint4 *np = reinterpret_cast<const uint4 *>(a.scene.nodes16 + cur);
                 const uint4 c0 = np[0], c1 = np[1];
                 auto unpack = [](uint32_t w) { const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w)); return f2v{ f.x, f.y }; };
-                h0 = box_test_pk(unpack(c0.x), unpack(c0.y), unpack(c0.z), rinv, noi, tmin, tmax, tn0);
-                h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin, tmax, tn1);
+                h0 = box_test_pk(unpack(c0.x), unpack(c0.y), unpack(c0.z), rinv, noi, tmin_v, tmax, tn0);
+                h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin_v, tmax, tn1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
                 const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2];
                 links = *reinterpret_cast<const int2 *>(np + 3);
-                h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin, tmax, tn0);
-                h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin, tmax, tn1);
+                h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax, tn0);
+                h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax, tn1);
             }
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
-            // LDS rows 0 .. stack_levels-1 hold the stack, row stack_levels is a dummy that absorbs the (rare) accesses
-            // beyond them, so the common path is one unconditional ds_read + ds_write; the real deep entries live in scratch
-            const uint32_t below = sp > 0 ? uint32_t(sp) - 1u : 0u;
-            int top = stack[min(below, stack_levels) * kQueueBlock];
-            if (SPILL && below >= stack_levels) top = spill[(below - stack_levels) & uint32_t(kTraceStack - 1)];
-            // the write is harmless when !both: slot sp is above the top of the stack
-            stack[min(uint32_t(sp), stack_levels) * kQueueBlock] = farc;
-            if (uint32_t(sp) >= stack_levels) {
-                if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
-                else overflow |= both ? 1u : 0u;                                  // cannot happen (builder depth bound); counted
+            // One address serves both accesses: row min(sp, L+1) holds the top entry (sp - 1; the sentinel when the stack
+            // is empty), the row after it is where entry sp goes.  The write is harmless when !both (above the top).
+            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
+            int top = row[0];
+            row[kQueueBlock] = farc;
+            // deep entries: behind a wave-uniform test, so that the hot path keeps plain ds_read / ds_write (an
+            // if-converted "LDS or scratch" access becomes a flat load plus ten instructions of pointer selection)
+            if (__any(uint32_t(sp) >= stack_levels)) {
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (uint32_t(sp) >= stack_levels) {
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    else overflow |= both ? 1u : 0u;                              // cannot happen (builder depth bound); counted
+                }
             }
-            finished = none && sp == 0;
-            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
-            sp += (both ? 1 : 0) - ((none && sp > 0) ? 1 : 0);
+            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));         // popping the empty stack yields the sentinel
+            sp += (both ? 1 : 0) - (none ? 1 : 0);                                // (-1 then, together with the sentinel)
         }
         const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
         // ---- leaf ----
-        if (has && !finished && cur < 0) {
+        if (has && cur < 0 && cur != kStackSentinel) {
             const uint32_t vv = ~uint32_t(cur);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
@@ -631,13 +648,15 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     break;
                 }
             }
-            if (found || sp == 0) finished = true;
-            else {
+            if (!found) {                                                          // pop (the sentinel if nothing is pending)
+                cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
+                if (SPILL && __any(uint32_t(sp) > stack_levels)) {
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                }
                 --sp;
-                cur = stack[min(uint32_t(sp), stack_levels) * kQueueBlock];
-                if (SPILL && uint32_t(sp) >= stack_levels) cur = spill[(uint32_t(sp) - stack_levels) & uint32_t(kTraceStack - 1)];
             }
         }
+        const bool finished = found || cur == kStackSentinel;
         if (has && finished) {
             has = false;
             if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }                         // miss.rmiss:7 leaves 1.0
@@ -748,7 +767,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
         const uint32_t pregen_kinds = pregen ? kinds : 0u;
         const bool shared_tile = ctx->options[kOptSharedTile] != 0;
-        const size_t stack_bytes = size_t(levels + 1) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
+        const size_t stack_bytes = size_t(levels + 3) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
         const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
         const int waves = ctx->options[kOptWavesPerBlock];
         const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));

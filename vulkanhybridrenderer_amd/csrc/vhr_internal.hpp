@@ -206,7 +206,7 @@ struct vhr_context {
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
 
-    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 10, 0, 2, 0, 0, 0, 0, 8, 1, 4 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 8, 1, 4 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     uint32_t kernel_timing_mask = 0;   // bit per KernelKind
