@@ -270,6 +270,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
  *                      persistent workgroups that prefetch the next tile into registers (default)
  *   "atrous_blocks_per_cu" (default 8), "atrous_xcd_aware" (default 1): launch shape of variant 4
+ *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 4 tiles per CU (default),
+ *                      0 = never, 1 = always
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -1,5 +1,5 @@
 """Compute-only frame time of ONE rank's strip (middle rank of N), no exchanges: the lower bound a rank of an
-N-GPU run needs per frame, with the overlap rows' rays traced locally (1) or assumed delivered by a neighbour (0)."""
+N-GPU run needs per frame, with the overlap rows' rays traced locally."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -10,20 +10,28 @@ W, H = 1920, 1080
 scene = scenes.sponza_proc()
 loop = HybridFrameLoop(scene, W, H, 24, shadow=True, ao_spp=2, reflections=False, denoise=True)
 for n in (1, 2, 4, 8):
-    for shared in (0, 1):
-        for to in ((0, 1) if n > 1 else (0,)):
-            r = n // 2
-            plan = tiling.make_plan(H, n, r, loop.max_motion_rows)
-            loop.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
-            loop.ctx.set_option("trace_overlap", to)
-            loop.ctx.set_option("raygen_shared_tile", shared)
-            for i in range(4): loop.frame(i)
+    for shared, small in ((0, -1), (1, -1), (0, 0)):
+        if n == 1 and (shared or small == 0): continue
+        r = n // 2
+        plan = tiling.make_plan(H, n, r, loop.max_motion_rows)
+        loop.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
+        loop.ctx.set_option("trace_overlap", 1 if n > 1 else 0)
+        loop.ctx.set_option("raygen_shared_tile", shared)
+        loop.ctx.set_option("atrous_small_tiles", small)
+        for i in range(4): loop.frame(i)
+        torch.cuda.synchronize()
+        ts = []
+        for rep in range(5):
+            t0 = time.perf_counter()
+            for i in range(4, 24): loop.frame(i)
             torch.cuda.synchronize()
-            ts = []
-            for rep in range(5):
-                t0 = time.perf_counter()
-                for i in range(4, 24): loop.frame(i)
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t0) / 20 * 1e3)
-            print(f"N={n} rank {r} rows {plan.rows}+{2*plan.overlap if n>1 else 0} shared_tile={shared} trace_overlap={to}: {np.median(ts):.4f} ms/frame", flush=True)
+            ts.append((time.perf_counter() - t0) / 20 * 1e3)
+        loop.ctx.set_kernel_timing(["raygen", "svgf_temporal", "svgf_atrous", "blit"])
+        for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit"): loop.ctx.kernel_time(k, reset=True)
+        for i in range(4, 24): loop.frame(i)
+        torch.cuda.synchronize()
+        kt = {k: loop.ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit")}
+        loop.ctx.set_kernel_timing(False)
+        print(f"N={n} rows {plan.rows}+{2*plan.overlap if n>1 else 0} shared_tile={shared} small_tiles={small}: {np.median(ts):.4f} ms/frame  " +
+              " ".join(f"{k} {v[0]/max(1,v[1])*1e3:.1f}us" for k, v in kt.items()), flush=True)
 loop.close()

@@ -772,6 +772,18 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
                        uint32_t(ctx->options[kOptAtrousXcdAware]));
 }
 
+// Thin launches (the row strip of one GPU out of 4 or 8) do not fill the chip with 8-row tiles: 195 rows x 1920 are 750
+// tiles for 256 CUs, and the launch then takes as long as one tile does at low occupancy.  Below ~4 tiles per CU the
+// 4-row tile (one pixel per thread, twice the blocks) is used instead.
+template <int STEP>
+static void launch_atrous_stream_auto(vhr_context *ctx, const AtrousArgs &a) {
+    const uint32_t rows = a.row_end - a.row_begin;
+    const uint32_t tiles8 = ((a.limit_x + kTileX - 1) / kTileX) * ((rows + 8 * STEP - 1) / (8 * STEP)) * STEP;
+    const int small = ctx->options[kOptAtrousSmallTiles];        // -1 auto, 0 never, 1 always
+    if (small > 0 || (small < 0 && tiles8 < 4u * uint32_t(ctx->cu_count))) launch_atrous_stream<STEP, 4>(ctx, a);
+    else launch_atrous_stream<STEP, 8>(ctx, a);
+}
+
 template <int STEP, int R>
 static void launch_atrous_packed(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
@@ -808,11 +820,11 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     bool tiled = variant != 0;
     if (variant == 4) {
         switch (step) {
-            case 1: launch_atrous_stream<1, 8>(ctx, a); break;
-            case 2: launch_atrous_stream<2, 8>(ctx, a); break;
-            case 4: launch_atrous_stream<4, 8>(ctx, a); break;
-            case 8: launch_atrous_stream<8, 8>(ctx, a); break;
-            case 16: launch_atrous_stream<16, 8>(ctx, a); break;
+            case 1: launch_atrous_stream_auto<1>(ctx, a); break;
+            case 2: launch_atrous_stream_auto<2>(ctx, a); break;
+            case 4: launch_atrous_stream_auto<4>(ctx, a); break;
+            case 8: launch_atrous_stream_auto<8>(ctx, a); break;
+            case 16: launch_atrous_stream_auto<16>(ctx, a); break;
             default: tiled = false; break;       // other steps: the direct kernel
         }
     } else if (variant == 3) {
@@ -872,6 +884,19 @@ int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_p
 // ---------------------------------------------------------------------------------------------
 // K5: same-extent, same-format VK_FILTER_NEAREST blit == copy (compute_execution_context.cpp:178-211)
 // ---------------------------------------------------------------------------------------------
+// 16 bytes per lane, 4 independent loads in flight per lane.  A plain kernel instead of hipMemcpyAsync: same bandwidth
+// on a full 1080p image, but the runtime's copy path costs ~7 us however small the copy is, which is what the row
+// strips of a multi-GPU run would pay three times per frame.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t count) {
+    const size_t stride = size_t(gridDim.x) * 256;
+    size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + 3 * stride < count; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < count; i += stride) dst[i] = src[i];
+}
+
 int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     if (src.width != dst.width || src.height != dst.height)          // asserts at compute_execution_context.cpp:179-180
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: extents differ");
@@ -879,12 +904,22 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     uint32_t r0, r1;
     strip_rows(ctx, src.height, ctx->halo, r0, r1);
     if (r1 <= r0 || src.ptr == dst.ptr) return VHR_OK;
-    const size_t row = size_t(src.width) * src.bpp;
+    const size_t row = size_t(src.width) * src.bpp, offset = r0 * row, bytes = (r1 - r0) * row;
+    const char *s8 = static_cast<const char *>(src.ptr) + offset;
+    char *d8 = static_cast<char *>(dst.ptr) + offset;
+    hipError_t copy_rc = hipSuccess;
     ctx->time_begin(kKernelCopy);
-    const hipError_t copy_rc = hipMemcpyAsync(static_cast<char *>(dst.ptr) + r0 * row, static_cast<const char *>(src.ptr) + r0 * row, (r1 - r0) * row,
-                       hipMemcpyDeviceToDevice, ctx->stream);
+    if (((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(d8) | bytes) & 15u) == 0) {
+        const size_t count = bytes / 16;
+        const uint32_t blocks = uint32_t(std::min<size_t>((count + 1023) / 1024, size_t(ctx->cu_count) * 8));
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(s8),
+                           reinterpret_cast<uint4 *>(d8), count);
+        copy_rc = hipGetLastError();
+    } else {
+        copy_rc = hipMemcpyAsync(d8, s8, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    }
     ctx->time_end(kKernelCopy);
-    if (copy_rc != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: hipMemcpyAsync failed");
+    if (copy_rc != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: device copy failed");
     return VHR_OK;
 }
 

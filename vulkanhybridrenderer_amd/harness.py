@@ -56,8 +56,6 @@ class HybridFrameLoop:
         self._precompute_gbuffers()
         self.plan = tiling.make_plan(height, world, rank, self.max_motion_rows, atrous_steps)
         if world > 1:
-            # thin strips keep few waves in flight: let two waves split each tile's ray queue (measured -20 % on a 1/8 strip)
-            self.ctx.set_option("raygen_shared_tile", 1)
             self.ctx.set_strip(self.plan.row_begin, self.plan.row_end, self.plan.overlap, self.plan.halo)
             # trace_overlap: the overlap rows' shadow/AO rays are traced here too (rays are per-pixel independent), which
             # removes exchange #1 from the critical path; only the deferred history exchange remains (tiling.py)
