@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--ao-spp", type=int, default=2)
     p.add_argument("--reflections", action="store_true", help="also trace the mirror ray raygen.rgen always issues")
     p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "tiny"])
+    p.add_argument("--gltf", default=None, help="load this .gltf / .glb instead of a procedural scene (vulkanhybridrenderer_amd/gltf.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=2)
     p.add_argument("--max-gbuffers", type=int, default=64, help="distinct precomputed G-buffer frames (wraps beyond)")
@@ -152,7 +153,11 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
+    if args.gltf:                                  # a real asset (Sponza.gltf, Bistro.glb ...) through the scene_loader.cpp-equivalent host
+        from vulkanhybridrenderer_amd import gltf
+        scene = gltf.load(args.gltf)
+    else:
+        scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup, args.max_gbuffers)
     loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=args.reflections, denoise=True,

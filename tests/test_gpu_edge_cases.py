@@ -143,3 +143,16 @@ def test_sky_only_frame(oracle):
     frames = _check(oracle, scene, 64, 40, 2, abi.default_trace_params())
     assert not frames[1]["gbuf"][2].any()
     assert (f16(frames[1]["shadow_ao"]) == 1.0).all()
+
+
+def test_scene_through_the_gltf_host(oracle, tmp_path):
+    """Row f1: a scene that went through the glTF container (export, then the scene_loader.cpp-equivalent import with
+    PNG-decoded textures) renders with the same parity as the in-memory one: visibility bit-exact, mirror ray shaded
+    from the loaded sRGB textures."""
+    from vulkanhybridrenderer_amd import gltf
+    src = scenes.bistro_proc(detail=0.004, n_primitives=60, n_textures=4, texture_size=32)
+    path = str(tmp_path / "scene.glb")
+    gltf.save(src, path)
+    scene = gltf.load(path)
+    assert np.array_equal(scene.vertices, src.vertices) and len(scene.textures) == 4
+    _check(oracle, scene, 96, 64, 2, abi.default_trace_params())

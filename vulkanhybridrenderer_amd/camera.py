@@ -92,5 +92,5 @@ def dolly_frames(scene, width, height, n_frames, start_frame_index=0):
     step = np.asarray(scene.camera["dolly"], dtype=np.float64)
     out = []
     for i in range(n_frames):
-        out.append(drv.next(pos + step * i, scene.camera["yaw"], scene.camera["pitch"]))
+        out.append(drv.next(pos + step * i, scene.camera["yaw"], scene.camera["pitch"], scene.camera.get("roll", 0.0)))
     return out
