@@ -219,10 +219,12 @@ int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, ui
 /* Stand-in producer for the untouched G-buffer stage (gbuf.vert:19-28, gbuf.frag:17-59): casts primary
  * rays through the same BVH and writes the three named transient images with gbuf.frag's encodings
  * (normals+object id RGBA16F, motion+metallic/roughness RGBA16F, reverse-Z depth D32F) and the clears of
- * hybrid_render_path.cpp:16-19.  Uses the per-frame data of resource_idx. */
+ * hybrid_render_path.cpp:16-19.  Alpha-masked / fully transparent fragments are discarded like gbuf.frag:27-32 (the
+ * primary ray steps past them, up to 32 layers) and normal maps perturb the normal like :35-41 (SURVEY.md section 8 row
+ * f2).  Uses the per-frame data of resource_idx. */
 int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image,
                         const char *motion_image, const char *depth_image);
-/* same, also writing the "Albedo" attachment (B8G8R8A8_UNORM, gbuf.frag:19-33; alpha discard not modelled) */
+/* same, also writing the "Albedo" attachment (B8G8R8A8_UNORM, gbuf.frag:19-33) */
 int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, const char *albedo_image, const char *normals_image,
                                     const char *motion_image, const char *depth_image);
 

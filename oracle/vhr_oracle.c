@@ -767,6 +767,7 @@ static void normal_matrix3(const float *m, float out[9]) {  /* inverseTranspose(
     out[2] = (float)(c20 * id); out[5] = (float)(c21 * id); out[8] = (float)(c22 * id);
 }
 
+#define ORC_GBUFFER_MAX_LAYERS 32   /* discarded surfaces a primary ray may step through */
 static inline uint8_t unorm8(float f) {       /* UNORM store: clamp, round to nearest */
     if (!(f > 0.0f)) return 0;
     if (f >= 1.0f) return 255;
@@ -793,33 +794,67 @@ void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint3
             float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
             v3 pnear = get_world_space_position(pfd, 1.0f, u, v);     /* reverse-Z: depth 1 == near plane */
             v3 dir = v3sub(pnear, cam);
-            orc_hit h = trace(s, cam, dir, 1.0f, 3.0e38f, 0, 1);
             size_t px = (size_t)y * W + (size_t)x;
-            if (!h.hit) {                                              /* clears: hybrid_render_path.cpp:16-19 */
+            /* Row f2: gbuf.frag:27-32 discards alpha-masked / fully transparent fragments, so the surface behind shows.
+             * A primary-ray caster gets the same picture by stepping past a discarded hit (tmin = its t) and casting again. */
+            orc_hit h;
+            const orc_tri *tr = NULL;
+            const orc_primitive *prim = NULL;
+            const orc_vertex *a = NULL, *b = NULL, *c = NULL;
+            float bx = 0, by = 0, bz = 0, uvx = 0, uvy = 0, tmin = 1.0f;
+            v4 al = { 0, 0, 0, 0 };
+            int visible = 0;
+            for (int layer = 0; layer < ORC_GBUFFER_MAX_LAYERS; ++layer) {
+                h = trace(s, cam, dir, tmin, 3.0e38f, 0, 1);
+                if (!h.hit) break;
+                tr = &s->tris[h.flat];
+                prim = &s->prims[tr->prim];
+                uint32_t i0 = s->indices[prim->index_offset + 3 * tr->tri + 0];
+                uint32_t i1 = s->indices[prim->index_offset + 3 * tr->tri + 1];
+                uint32_t i2 = s->indices[prim->index_offset + 3 * tr->tri + 2];
+                a = &s->vertices[prim->vertex_offset + i0];
+                b = &s->vertices[prim->vertex_offset + i1];
+                c = &s->vertices[prim->vertex_offset + i2];
+                bx = 1.0f - h.u - h.v; by = h.u; bz = h.v;
+                uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;
+                uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
+                al = (v4){ prim->material.base_color[0], prim->material.base_color[1], prim->material.base_color[2], prim->material.base_color[3] };
+                if (prim->material.base_color_texture != -1) al = sample_texture(s, prim->material.base_color_texture, uvx, uvy);   /* :19-26 */
+                if ((prim->material.alpha_mask == 1 && al.w < prim->material.alpha_cutoff) || al.w == 0.0f) {                      /* :27-32 */
+                    tmin = h.t;
+                    continue;
+                }
+                visible = 1;
+                break;
+            }
+            if (!visible) {                                            /* clears: hybrid_render_path.cpp:16-19 */
                 store_rgba16f(normals_ids, W, x, y, 0, 0, 0, 0);
                 store_rgba16f(motion_mr, W, x, y, 0, 0, -1.0f, -1.0f);
                 depth[px] = 0.0f;
                 if (albedo) memset(albedo + px * 4, 0, 4);
                 continue;
             }
-            const orc_tri *tr = &s->tris[h.flat];
-            const orc_primitive *prim = &s->prims[tr->prim];
             v3 P = v3add(cam, v3scale(dir, h.t));
             v4 clip = mat4_mul_v4(projview, (v4){ P.x, P.y, P.z, 1.0f });
             depth[px] = clip.z / clip.w;
-            uint32_t i0 = s->indices[prim->index_offset + 3 * tr->tri + 0];
-            uint32_t i1 = s->indices[prim->index_offset + 3 * tr->tri + 1];
-            uint32_t i2 = s->indices[prim->index_offset + 3 * tr->tri + 2];
-            const orc_vertex *a = &s->vertices[prim->vertex_offset + i0];
-            const orc_vertex *b = &s->vertices[prim->vertex_offset + i1];
-            const orc_vertex *c = &s->vertices[prim->vertex_offset + i2];
-            float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
             v3 n = V3(a->normal[0] * bx + b->normal[0] * by + c->normal[0] * bz,
                       a->normal[1] * bx + b->normal[1] * by + c->normal[1] * bz,
                       a->normal[2] * bx + b->normal[2] * by + c->normal[2] * bz);
+            v3 N = n;
+            if (prim->material.normal_map >= 0) {                       /* gbuf.frag:35-41 */
+                v4 tx = sample_texture(s, prim->material.normal_map, uvx, uvy);
+                v3 tsn = normalize3(V3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
+                v3 T = V3(a->tangent[0] * bx + b->tangent[0] * by + c->tangent[0] * bz,
+                          a->tangent[1] * bx + b->tangent[1] * by + c->tangent[1] * bz,
+                          a->tangent[2] * bx + b->tangent[2] * by + c->tangent[2] * bz);
+                float tw = a->tangent[3] * bx + b->tangent[3] * by + c->tangent[3] * bz;
+                v3 bitangent = v3scale(cross3(tsn, T), tw);              /* sic: cross(tangent_space_normal, in_tangent.xyz) */
+                v3 tangent = normalize3(v3sub(T, v3scale(n, dot3(T, n))));
+                N = v3add(v3add(v3scale(tangent, tsn.x), v3scale(bitangent, tsn.y)), v3scale(n, tsn.z));
+            }
             const float *M = nm + 9 * tr->prim;
-            v3 wn = V3((M[0] * n.x + M[3] * n.y) + M[6] * n.z, (M[1] * n.x + M[4] * n.y) + M[7] * n.z,
-                       (M[2] * n.x + M[5] * n.y) + M[8] * n.z);
+            v3 wn = V3((M[0] * N.x + M[3] * N.y) + M[6] * N.z, (M[1] * N.x + M[4] * N.y) + M[7] * N.z,
+                       (M[2] * N.x + M[5] * N.y) + M[8] * N.z);
             wn = normalize3(wn);                                        /* gbuf.frag:43 */
             store_rgba16f(normals_ids, W, x, y, wn.x, wn.y, wn.z, (float)tr->prim);
             /* gbuf.frag:46-47: current = gl_FragCoord.xy * display_size_inverse, prev = reprojected ndc*0.5+0.5 */
@@ -828,15 +863,11 @@ void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint3
             v4 rp = mat4_mul_v4(prev_projview, (v4){ P.x, P.y, P.z, 1.0f });
             float px_ = (rp.x / rp.w) * 0.5f + 0.5f, py_ = (rp.y / rp.w) * 0.5f + 0.5f;
             float metallic = prim->material.metallic_factor, roughness = prim->material.roughness_factor;
-            float uvx = a->uv0[0] * bx + b->uv0[0] * by + c->uv0[0] * bz;
-            float uvy = a->uv0[1] * bx + b->uv0[1] * by + c->uv0[1] * bz;
             if (prim->material.metallic_roughness_texture != -1) {    /* gbuf.frag:50-56 */
                 v4 mr = sample_texture(s, prim->material.metallic_roughness_texture, uvx, uvy);
                 metallic *= mr.y; roughness *= mr.z;
             }
-            if (albedo) {                                              /* gbuf.frag:19-33 (alpha discard not modelled) */
-                v4 al = { prim->material.base_color[0], prim->material.base_color[1], prim->material.base_color[2], prim->material.base_color[3] };
-                if (prim->material.base_color_texture != -1) al = sample_texture(s, prim->material.base_color_texture, uvx, uvy);
+            if (albedo) {                                              /* gbuf.frag:33 */
                 uint8_t *o = albedo + px * 4;                          /* B8G8R8A8 */
                 o[0] = unorm8(al.z); o[1] = unorm8(al.y); o[2] = unorm8(al.x); o[3] = unorm8(al.w);
             }

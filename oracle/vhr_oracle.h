@@ -93,7 +93,8 @@ int      orc_scene_occluded(const orc_scene *s, const float o[3], const float d[
 int      orc_scene_closest(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
                            float *t, float *u, float *v, uint32_t *prim, uint32_t *tri_in_prim);
 
-/* ---- stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 encodings; primary rays) ---- */
+/* ---- stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 incl. alpha discard :27-32 and normal mapping
+ * :35-41; primary rays that step past discarded fragments) ---- */
 void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
                  uint16_t *normals_ids /*RGBA16F*/, uint16_t *motion_mr /*RGBA16F*/, float *depth /*D32F*/);
 /* same, plus the albedo attachment (B8G8R8A8_UNORM: bytes b, g, r, a; gbuf.frag:19-33); albedo may be NULL */

@@ -226,6 +226,16 @@ __device__ __forceinline__ TriAttributes interpolate(const DeviceScene &sc, cons
     return r;
 }
 
+// gbuf.vert:21 passes the vertex tangent through; the rasteriser interpolates it like the normal
+__device__ __forceinline__ f4 interpolate_tangent(const DeviceScene &sc, const vhr_primitive &prim, uint32_t tri, float u, float v) {
+    const vhr_vertex &a = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * tri + 0]];
+    const vhr_vertex &b = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * tri + 1]];
+    const vhr_vertex &c = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * tri + 2]];
+    const float bx = 1.0f - u - v, by = u, bz = v;
+    return f4{ a.tangent[0] * bx + b.tangent[0] * by + c.tangent[0] * bz, a.tangent[1] * bx + b.tangent[1] * by + c.tangent[1] * bz,
+               a.tangent[2] * bx + b.tangent[2] * by + c.tangent[2] * bz, a.tangent[3] * bx + b.tangent[3] * by + c.tangent[3] * bz };
+}
+
 __device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_data &pfd, const Hit &h) {
     const BvhTri &bt = sc.tris[h.tri_index];
     const vhr_primitive &prim = sc.primitives[bt.prim];                                 // rchit:11
@@ -822,6 +832,8 @@ struct GbufferArgs {
     uint32_t width, height;
 };
 
+constexpr int kGbufferMaxLayers = 32;      // discarded surfaces a primary ray may step through
+
 __device__ __forceinline__ uint32_t unorm8(float f) { return uint32_t(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f + 0.5f); }
 
 __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs a) {
@@ -835,9 +847,27 @@ __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs 
     const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
     const f3 pnear = get_world_space_position(a.pfd, 1.0f, u, v);      // reverse-Z: depth 1 is the near plane
     const f3 dir = pnear - cam;
+    // Row f2: gbuf.frag:27-32 discards alpha-masked / fully transparent fragments, so the surface behind shows.  A
+    // primary-ray caster gets the same picture by stepping past a discarded hit (tmin = its t) and casting again.
     Hit h;
     uint32_t overflow = 0;
-    if (!traverse<false>(a.scene, cam, dir, 1.0f, 3.0e38f, stack, h, overflow)) {   // clears: hybrid_render_path.cpp:16-19
+    bool visible = false;
+    float tmin = 1.0f;
+    f4 al = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    float uvx = 0.0f, uvy = 0.0f;
+    for (int layer = 0; layer < kGbufferMaxLayers; ++layer) {
+        if (!traverse<false>(a.scene, cam, dir, tmin, 3.0e38f, stack, h, overflow)) break;
+        const BvhTri &bt = a.scene.tris[h.tri_index];
+        const vhr_primitive &prim = a.scene.primitives[bt.prim];
+        const TriAttributes at = interpolate(a.scene, prim, bt.tri, h.u, h.v);
+        uvx = at.uvx; uvy = at.uvy;
+        al = f4{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2], prim.material.base_color[3] };
+        if (prim.material.base_color_texture != -1) al = sample_texture(a.scene, prim.material.base_color_texture, uvx, uvy);   // :19-26
+        if ((prim.material.alpha_mask == 1 && al.w < prim.material.alpha_cutoff) || al.w == 0.0f) { tmin = h.t; continue; }    // :27-32
+        visible = true;
+        break;
+    }
+    if (!visible) {                                                                          // clears: hybrid_render_path.cpp:16-19
         store_rgba16f(a.normals, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
         store_rgba16f(a.motion, W, x, y, 0.0f, 0.0f, -1.0f, -1.0f);
         a.depth[size_t(y) * W + x] = 0.0f;
@@ -852,8 +882,18 @@ __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs 
     const TriAttributes at = interpolate(a.scene, prim, bt.tri, h.u, h.v);
     const float *M = a.scene.normal_matrices + 9 * size_t(bt.prim);
     const f3 n = at.normal;
-    const f3 wn = normalize3(f3{ (M[0] * n.x + M[3] * n.y) + M[6] * n.z, (M[1] * n.x + M[4] * n.y) + M[7] * n.z,
-                                 (M[2] * n.x + M[5] * n.y) + M[8] * n.z });                  // gbuf.frag:43
+    f3 N = n;
+    if (prim.material.normal_map >= 0) {                                                     // gbuf.frag:35-41
+        const f4 tx = sample_texture(a.scene, prim.material.normal_map, uvx, uvy);
+        const f3 tsn = normalize3(f3{ tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f });
+        const f4 tg = interpolate_tangent(a.scene, prim, bt.tri, h.u, h.v);
+        const f3 T = f3{ tg.x, tg.y, tg.z };
+        const f3 bitangent = cross3(tsn, T) * tg.w;                  // sic: cross(tangent_space_normal, in_tangent.xyz)
+        const f3 tangent = normalize3(T - n * dot3(T, n));
+        N = (tangent * tsn.x + bitangent * tsn.y) + n * tsn.z;
+    }
+    const f3 wn = normalize3(f3{ (M[0] * N.x + M[3] * N.y) + M[6] * N.z, (M[1] * N.x + M[4] * N.y) + M[7] * N.z,
+                                 (M[2] * N.x + M[5] * N.y) + M[8] * N.z });                  // gbuf.frag:43
     store_rgba16f(a.normals, W, x, y, wn.x, wn.y, wn.z, float(bt.prim));
     const float cx = (float(x) + 0.5f) * a.pfd.display_size_inverse[0];                      // gbuf.frag:46
     const float cy = (float(y) + 0.5f) * a.pfd.display_size_inverse[1];
@@ -861,16 +901,13 @@ __global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs 
     const float px = (rp.x / rp.w) * 0.5f + 0.5f, py = (rp.y / rp.w) * 0.5f + 0.5f;          // gbuf.frag:47
     float metallic = prim.material.metallic_factor, roughness = prim.material.roughness_factor;
     if (prim.material.metallic_roughness_texture != -1) {                                    // gbuf.frag:50-56
-        const f4 mr = sample_texture(a.scene, prim.material.metallic_roughness_texture, at.uvx, at.uvy);
+        const f4 mr = sample_texture(a.scene, prim.material.metallic_roughness_texture, uvx, uvy);
         metallic *= mr.y;
         roughness *= mr.z;
     }
     store_rgba16f(a.motion, W, x, y, cx - px, cy - py, metallic, roughness);                 // gbuf.frag:58
-    if (a.albedo) {                                                                          // gbuf.frag:19-33 (alpha discard not modelled)
-        f4 al = f4{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2], prim.material.base_color[3] };
-        if (prim.material.base_color_texture != -1) al = sample_texture(a.scene, prim.material.base_color_texture, at.uvx, at.uvy);
+    if (a.albedo)                                                                            // gbuf.frag:33
         a.albedo[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(al.z)), uint8_t(unorm8(al.y)), uint8_t(unorm8(al.x)), uint8_t(unorm8(al.w)));
-    }
 }
 
 static void host_mat4_mul(const float *a, const float *b, float *out) {
