@@ -198,6 +198,19 @@ int  vhr_hybrid_get_push_constants(vhr_hybrid_render_path *path, vhr_svgf_push_c
 const char *vhr_hybrid_last_error(vhr_hybrid_render_path *path);
 
 /* ---------------------------------------------------------------------------------------------
+ * RaytracedRenderPath (src/render_paths/raytraced_render_path.{h,cpp}) re-hosted on
+ * the API above (csrc/raytraced_render_path.cpp): "Raytracing Pass" -> "RaytracedOutput" (B8G8R8A8_UNORM) ->
+ * external "Composition Pass".  use_anyhit_shader = the "Alpha test for shadows" switch (raytraced_render_path.h:15).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vhr_raytraced_render_path vhr_raytraced_render_path;
+int  vhr_raytraced_create(vhr_context *ctx, int32_t use_anyhit_shader, vhr_external_pass_callback composition_pass,
+                          void *composition_user, vhr_raytraced_render_path **out);
+void vhr_raytraced_destroy(vhr_raytraced_render_path *path);
+int  vhr_raytraced_build(vhr_raytraced_render_path *path);                              /* RenderPath::Build (render_path.cpp:14-20) */
+int  vhr_raytraced_rebuild(vhr_raytraced_render_path *path, int32_t use_anyhit_shader); /* toggle + Rebuild (raytraced_render_path.cpp:90-92) */
+const char *vhr_raytraced_last_error(vhr_raytraced_render_path *path);
+
+/* ---------------------------------------------------------------------------------------------
  * Harness / test access (no reference counterpart: the reference inspects images through its ImGui
  * debug-texture viewer, renderer.cpp:215-224)
  * ------------------------------------------------------------------------------------------- */
@@ -240,6 +253,18 @@ typedef struct vhr_composition_desc {
     int32_t output_storage_image;
 } vhr_composition_desc;
 int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_composition_desc *desc);
+
+/* Next row: the raytraced render path (raytraced_render_path.cpp:11-76).  Its "Raytracing Pass"
+ * is registered through vhr_graph_add_raytracing_pass with the shader set
+ *   raygen "raytraced_render_path/raygen.rgen", miss { ".../miss.rmiss", ".../shadow_miss.rmiss" },
+ *   hit group 0 { closest_hit ".../closesthit.rchit" }                                   (:19-34, use_anyhit_shader == 0)
+ * or raygen ".../raygen_test_alpha.rgen", the same miss shaders,
+ *   hit group 0 { closest_hit ".../closesthit_test_alpha.rchit", any_hit ".../shadow_anyhit.rahit" }   (use_anyhit_shader == 1)
+ * and one storage-image output at binding 0 ("RaytracedOutput", B8G8R8A8_UNORM, :15); vhr_trace_rays then launches the
+ * primary-ray kernel.  This entry is the stand-in for the path's untouched composition stage
+ * (raytraced_render_path/composition.vert:5-8, composition.frag:11-13): the named image sampled at the texel centres and
+ * written as swapchain texels (B8G8R8A8_SRGB, presentation orientation) into a storage image of 4-byte texels. */
+int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_output_image, int32_t output_storage_image);
 
 /* Multi-GPU row strips: this context owns rows [row_begin, row_end) of the
  * display.  Ray tracing runs on the owned rows; the SVGF kernels on the owned rows extended by `overlap`

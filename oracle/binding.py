@@ -70,6 +70,8 @@ def lib():
         L.orc_gbuffer_albedo.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
         L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]
         L.orc_raygen.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, i32]
+        L.orc_raytraced.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, vp, i32]
+        L.orc_raytraced_composition.argtypes = [u32, u32, vp, vp]
         L.orc_svgf_temporal.argtypes = [vp, u32, u32] + [vp] * 8
         L.orc_svgf_atrous.argtypes = [vp, u32, u32, vp, vp, vp, C.c_int32]
         L.orc_svgf_create.restype = vp
@@ -116,6 +118,15 @@ def sincos(phi):
 
 
 class Scene:
+    def raytraced(self, pfd, W, H, use_anyhit_shader=False, rows=None, use_bvh=True):
+        """The raytraced render path's "Raytracing Pass": (B8G8R8A8_UNORM image (H, W, 4), rays traced)."""
+        r0, r1 = rows if rows is not None else (0, H)
+        out = np.zeros((H, W, 4), np.uint8)
+        rays = C.c_uint64()
+        pfd = _c(pfd)
+        lib().orc_raytraced(self.handle, _p(pfd), W, H, r0, r1, int(bool(use_anyhit_shader)), _p(out), C.byref(rays), int(use_bvh))
+        return out, rays.value
+
     def __init__(self, scene):
         L = lib()
         self._v = _c(scene.vertices)
@@ -169,6 +180,15 @@ class Scene:
         lib().orc_raygen(self.handle, _p(pfd), _p(tp), W, H, r0, r1, _p(normals), _p(depth), _p(shadow_ao), _p(refl),
                          _p(mask), C.byref(rays), int(use_bvh))
         return shadow_ao, refl, mask, rays.value
+
+
+def raytraced_composition(raytraced_bgra8):
+    """raytraced_render_path/composition.frag: B8G8R8A8_UNORM image -> presented B8G8R8A8_SRGB texels (H, W, 4)."""
+    H, W = raytraced_bgra8.shape[:2]
+    src = _c(raytraced_bgra8, np.uint8)
+    out = np.zeros((H, W, 4), np.uint8)
+    lib().orc_raytraced_composition(W, H, _p(src), _p(out))
+    return out
 
 
 def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections):

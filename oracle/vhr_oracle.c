@@ -512,7 +512,10 @@ typedef struct { int hit; float t, u, v; uint32_t flat; } orc_hit;
 
 /* any_hit != 0: return on the first accepted triangle (gl_RayFlagsTerminateOnFirstHitEXT,
  * raygen.rgen:39); otherwise closest hit with the flat-index tie break (decision vi) */
-static orc_hit trace(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit, int use_bvh) {
+/* alpha_test != 0: every candidate first runs shadow_anyhit.rahit (rays traced with gl_RayFlagsNoOpaqueEXT by the
+ * raytraced render path, raygen_test_alpha.rgen:20 / closesthit_test_alpha.rchit:42); an ignored candidate does not exist */
+static int alpha_ignored(const orc_scene *s, uint32_t flat, float u, float v);
+static orc_hit trace_filtered(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit, int use_bvh, int alpha_test) {
     orc_hit best = { 0, tmax, 0, 0, 0xffffffffu };
     if (s->ntris == 0) return best;
     if (!use_bvh) {
@@ -520,6 +523,7 @@ static orc_hit trace(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int
             const orc_tri *tr = &s->tris[i];
             float t, u, v;
             if (ray_triangle(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t, &u, &v)) {
+                if (alpha_test && alpha_ignored(s, i, u, v)) continue;
                 if (any_hit) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = i; return best; }
                 if (!best.hit || t < best.t || (t == best.t && i < best.flat)) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = i; }
             }
@@ -541,12 +545,16 @@ static orc_hit trace(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int
             const orc_tri *tr = &s->tris[flat];
             float t, u, v;
             if (ray_triangle(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t, &u, &v)) {
+                if (alpha_test && alpha_ignored(s, flat, u, v)) continue;
                 if (any_hit) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = flat; return best; }
                 if (!best.hit || t < best.t || (t == best.t && flat < best.flat)) { best.hit = 1; best.t = t; best.u = u; best.v = v; best.flat = flat; }
             }
         }
     }
     return best;
+}
+static orc_hit trace(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit, int use_bvh) {
+    return trace_filtered(s, o, d, tmin, tmax, any_hit, use_bvh, 0);        /* all-opaque geometry, resource_manager.cpp:633 */
 }
 
 int orc_scene_occluded(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int use_bvh) {
@@ -748,6 +756,130 @@ void orc_raygen(const orc_scene *s, const orc_per_frame_data *pfd, const orc_tra
         }
     }
     if (rays_out) *rays_out = rays;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * next row f4: the raytraced render path (raytraced_render_path.cpp:11-76)
+ *   raytraced_render_path/raygen.rgen:10-23, raygen_test_alpha.rgen:10-23, miss.rmiss:6-8, shadow_miss.rmiss:6-8,
+ *   closesthit.rchit:10-58, closesthit_test_alpha.rchit:10-51, shadow_anyhit.rahit:8-27, composition.frag:11-13
+ * Decision (ix): `textures[-1]` (a primitive without a base colour texture, sampled unconditionally by
+ * shadow_anyhit.rahit:23 and closesthit_test_alpha.rchit:26) is out of bounds in the reference; here it reads
+ * (0, 0, 0, 0), like any out-of-range texture index.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { const orc_vertex *a, *b, *c; const orc_primitive *prim; float bx, by, bz, uvx, uvy; } orc_tri_fetch;
+static inline uint8_t unorm8(float f);
+static inline uint8_t srgb8(float c);
+
+static orc_tri_fetch fetch_triangle(const orc_scene *s, uint32_t flat, float u, float v) {
+    orc_tri_fetch f;
+    const orc_tri *tr = &s->tris[flat];
+    f.prim = &s->prims[tr->prim];                                                   /* gl_GeometryIndexEXT */
+    uint32_t i0 = s->indices[f.prim->index_offset + 3 * tr->tri + 0];              /* gl_PrimitiveID */
+    uint32_t i1 = s->indices[f.prim->index_offset + 3 * tr->tri + 1];
+    uint32_t i2 = s->indices[f.prim->index_offset + 3 * tr->tri + 2];
+    f.a = &s->vertices[f.prim->vertex_offset + i0];
+    f.b = &s->vertices[f.prim->vertex_offset + i1];
+    f.c = &s->vertices[f.prim->vertex_offset + i2];
+    f.bx = 1.0f - u - v; f.by = u; f.bz = v;
+    f.uvx = f.a->uv0[0] * f.bx + f.b->uv0[0] * f.by + f.c->uv0[0] * f.bz;
+    f.uvy = f.a->uv0[1] * f.bx + f.b->uv0[1] * f.by + f.c->uv0[1] * f.bz;
+    return f;
+}
+
+/* shadow_anyhit.rahit:8-27: 1 = ignoreIntersectionEXT */
+static int alpha_ignored(const orc_scene *s, uint32_t flat, float u, float v) {
+    orc_tri_fetch f = fetch_triangle(s, flat, u, v);                                 /* :9-20 */
+    v4 albedo = sample_texture(s, f.prim->material.base_color_texture, f.uvx, f.uvy); /* :23 (unconditional) */
+    return f.prim->material.alpha_mask == 1 && albedo.w < f.prim->material.alpha_cutoff;   /* :24-26 */
+}
+
+/* closesthit.rchit:10-58 (alpha == 0) / closesthit_test_alpha.rchit:10-51 (alpha == 1); returns the payload */
+static v4 raytraced_closest_hit(const orc_scene *s, const orc_per_frame_data *pfd, const orc_hit *h, int alpha, int use_bvh,
+                                uint64_t *rays) {
+    orc_tri_fetch f = fetch_triangle(s, h->flat, h->u, h->v);                        /* :11-22 */
+    const orc_vertex *a = f.a, *b = f.b, *c = f.c;
+    float bx = f.bx, by = f.by, bz = f.bz;
+    v3 normal = V3(a->normal[0] * bx + b->normal[0] * by + c->normal[0] * bz,       /* :23 object space, unnormalised */
+                   a->normal[1] * bx + b->normal[1] * by + c->normal[1] * bz,
+                   a->normal[2] * bx + b->normal[2] * by + c->normal[2] * bz);
+    v3 opos = V3(a->pos[0] * bx + b->pos[0] * by + c->pos[0] * bz, a->pos[1] * bx + b->pos[1] * by + c->pos[1] * bz,
+                 a->pos[2] * bx + b->pos[2] * by + c->pos[2] * bz);
+    v3 position = mat4_mul_point(f.prim->transform, opos);                           /* :24 */
+    v3 albedo;
+    if (!alpha && f.prim->material.base_color_texture == -1)                        /* :26-32 */
+        albedo = V3(f.prim->material.base_color[0], f.prim->material.base_color[1], f.prim->material.base_color[2]);
+    else { v4 t = sample_texture(s, f.prim->material.base_color_texture, f.uvx, f.uvy); albedo = V3(t.x, t.y, t.z); }   /* alpha: :26 */
+    v3 N = normal;                                                                   /* :34-41 */
+    if (f.prim->material.normal_map >= 0) {
+        v3 T = V3(a->tangent[0] * bx + b->tangent[0] * by + c->tangent[0] * bz, a->tangent[1] * bx + b->tangent[1] * by + c->tangent[1] * bz,
+                  a->tangent[2] * bx + b->tangent[2] * by + c->tangent[2] * bz);
+        float tw = a->tangent[3] * bx + b->tangent[3] * by + c->tangent[3] * bz;
+        v4 tx = sample_texture(s, f.prim->material.normal_map, f.uvx, f.uvy);
+        v3 tsn = normalize3(V3(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
+        v3 bitangent = v3scale(cross3(tsn, T), tw);                                  /* sic: cross(tangent_space_normal, in_tangent.xyz) */
+        v3 tangent = normalize3(v3sub(T, v3scale(normal, dot3(T, normal))));
+        N = v3add(v3add(v3scale(tangent, tsn.x), v3scale(bitangent, tsn.y)), v3scale(normal, tsn.z));
+    }
+    v3 light_dir = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
+    v3 lc = V3(pfd->directional_light.color[0], pfd->directional_light.color[1], pfd->directional_light.color[2]);
+    v3 li = V3(pfd->directional_light.intensity[0], pfd->directional_light.intensity[1], pfd->directional_light.intensity[2]);
+    v3 albedo_lighting = alpha ? v3scale(albedo, 0.2f) : v3scale(albedo, ORC_PI_INVERSE);   /* alpha :39 / :46 */
+    /* shadow ray (:48-50 / alpha :41-43): payload starts true, shadow_miss.rmiss:7 clears it.  Without the any-hit
+     * shader the ray terminates on the first hit; with it the walk runs to the end -- the boolean is the same */
+    int shadowed = trace_filtered(s, position, light_dir, 0.1f, 10000.0f, 1, use_bvh, alpha).hit;
+    ++*rays;
+    v3 col = albedo_lighting;
+    if (!shadowed) {                                                                 /* :52-54 / alpha :45-47 */
+        float nl = fmaxf(dot3(N, light_dir), 0.0f);
+        v3 lit = v3scale(albedo, nl);
+        if (!alpha) lit = v3mul(lit, li);                                            /* the alpha variant drops light_intensity */
+        lit = v3mul(lit, lc);
+        col = v3add(albedo_lighting, lit);
+    }
+    v4 r = { col.x, col.y, col.z, 1.0f };
+    return r;
+}
+
+void orc_raytraced(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                   int use_anyhit_shader, uint8_t *out_bgra8, uint64_t *rays_out, int use_bvh) {
+    uint64_t rays = 0;
+    int alpha = use_anyhit_shader != 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays)
+    for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; ++yy) {
+        uint32_t y = (uint32_t)yy;
+        for (uint32_t x = 0; x < W; ++x) {
+            float ux = (((float)x + 0.5f) / (float)W) * 2.0f - 1.0f;                 /* raygen.rgen:11-13 */
+            float uy = (((float)y + 0.5f) / (float)H) * 2.0f - 1.0f;
+            v4 origin = mat4_mul_v4(pfd->camera_view_inverse, (v4){ 0.0f, 0.0f, 0.0f, 1.0f });      /* :15 */
+            v4 target = mat4_mul_v4(pfd->camera_proj_inverse, (v4){ ux, uy, 1.0f, 1.0f });          /* :16 */
+            v3 tn = normalize3(V3(target.x, target.y, target.z));
+            v4 direction = mat4_mul_v4(pfd->camera_view_inverse, (v4){ tn.x, tn.y, tn.z, 0.0f });   /* :17 */
+            v4 payload = { 0.0f, 0.0f, 0.0f, 0.0f };                                                /* :19 */
+            /* :20 gl_RayFlagsOpaqueEXT (alpha: gl_RayFlagsNoOpaqueEXT -> shadow_anyhit.rahit filters candidates), miss 0 */
+            orc_hit h = trace_filtered(s, V3(origin.x, origin.y, origin.z), V3(direction.x, direction.y, direction.z), 0.1f, 10000.0f,
+                                       0, use_bvh, alpha);
+            ++rays;
+            if (h.hit) payload = raytraced_closest_hit(s, pfd, &h, alpha, use_bvh, &rays);
+            else payload = (v4){ 0.3f, 0.8f, 0.2f, 1.0f };                                          /* miss.rmiss:7 */
+            uint8_t *o = out_bgra8 + ((size_t)y * W + x) * 4;                        /* :22 imageStore to B8G8R8A8_UNORM */
+            o[0] = unorm8(payload.z); o[1] = unorm8(payload.y); o[2] = unorm8(payload.x); o[3] = unorm8(payload.w);
+        }
+    }
+    if (rays_out) *rays_out = rays;
+}
+
+/* raytraced_render_path/composition.vert:5-8 + composition.frag:11-13: the UNORM image sampled at the texel centre and
+ * written to the B8G8R8A8_SRGB swapchain through the flipped presentation viewport (pipeline.cpp:175-178) */
+void orc_raytraced_composition(uint32_t W, uint32_t H, const uint8_t *raytraced_bgra8, uint8_t *out_bgra8_srgb) {
+    for (uint32_t j = 0; j < H; ++j) {
+        uint32_t gy = H - 1 - j;
+        for (uint32_t x = 0; x < W; ++x) {
+            const uint8_t *p = raytraced_bgra8 + ((size_t)gy * W + x) * 4;
+            uint8_t *o = out_bgra8_srgb + ((size_t)j * W + x) * 4;
+            o[0] = srgb8(p[0] * (1.0f / 255.0f)); o[1] = srgb8(p[1] * (1.0f / 255.0f)); o[2] = srgb8(p[2] * (1.0f / 255.0f));
+            o[3] = p[3];                                                             /* alpha is stored linearly */
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -118,6 +118,15 @@ void orc_raygen(const orc_scene *s, const orc_per_frame_data *pfd, const orc_tra
                 uint16_t *shadow_ao /*RG16F*/, uint16_t *reflections /*RGBA16F*/,
                 uint8_t *vis_mask, uint64_t *rays_out, int use_bvh);
 
+/* ---- next row f4: the raytraced render path (raytraced_render_path.cpp:11-76) ----
+ * raytraced_render_path/raygen.rgen + miss.rmiss + shadow_miss.rmiss + closesthit.rchit, or with use_anyhit_shader != 0
+ * raygen_test_alpha.rgen + closesthit_test_alpha.rchit + shadow_anyhit.rahit.  Output: "RaytracedOutput", B8G8R8A8_UNORM
+ * texels (bytes b, g, r, a).  rays_out (optional): primary + shadow rays traced. */
+void orc_raytraced(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                   int use_anyhit_shader, uint8_t *out_bgra8, uint64_t *rays_out, int use_bvh);
+/* raytraced_render_path/composition.frag:11-13 through the flipped presentation viewport -> B8G8R8A8_SRGB */
+void orc_raytraced_composition(uint32_t W, uint32_t H, const uint8_t *raytraced_bgra8, uint8_t *out_bgra8_srgb);
+
 /* ---- K3: svgf.comp:41-145 ---- */
 void orc_svgf_temporal(const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
                        const uint16_t *normals_ids, const uint16_t *motion_mr, const uint16_t *raytraced /*RG16F*/,

@@ -39,3 +39,37 @@ def scene():
                      address_u=abi.ADDRESS_REPEAT, address_v=abi.ADDRESS_REPEAT)]
     cam = dict(position=(0.0, 1.6, 6.0), yaw=0.0, pitch=-0.1, yfov=0.9, znear=0.1, dolly=(0.0, 0.0, -0.05))
     return b.finish("f2", cam, directional_light((0.2, -0.9, -0.4)), textures)
+
+
+# ---- row f4 (the raytraced render path): the same ingredients without the pane that hides them all, plus a rotated,
+# textured box that throws a shadow and an alpha-masked quad WITHOUT a base colour texture (oracle decision ix)
+F4_WALL, F4_FENCE, F4_FLOOR, F4_BOX, F4_MASKED_UNTEXTURED, F4_CANOPY = 0, 1, 2, 3, 4, 5
+
+
+def scene_f4():
+    from vulkanhybridrenderer_amd.scenes import box, trs
+    b = _Builder()
+    b.add(plane([-4, 0, -3], [8, 0, 0], [0, 5, 0], 2, 2), base_color=(0.2, 0.4, 0.8, 1.0))                    # WALL, faces +z
+    b.add(plane([-3, 0.2, -1], [6, 0, 0], [0, 3, 0], 2, 2), base_color_texture=0, uv_scale=1.0)              # FENCE (alpha mask)
+    b.p[-1]["material"]["alpha_mask"] = 1
+    b.p[-1]["material"]["alpha_cutoff"] = 0.5
+    b.add(plane([-4, 0, 4], [8, 0, 0], [0, 0, -8], 4, 4), base_color=(0.7, 0.7, 0.7, 1.0), base_color_texture=2, uv_scale=2.0)   # FLOOR
+    b.p[-1]["material"]["normal_map"] = 1
+    b.v[-1]["tangent"] = [1, 0, 0, 1]
+    b.add(box([0.8, 0.8, 0.8], 2), transform=trs((1.4, 0.9, 1.5), rot_y=0.6, rot_x=0.3), base_color_texture=2)    # BOX (transformed)
+    b.add(plane([-3.5, 0.3, 2.0], [1.2, 0, 0], [0, 1.2, 0], 1, 1), base_color=(0.9, 0.1, 0.1, 1.0))           # masked, no texture
+    b.p[-1]["material"]["alpha_mask"] = 1
+    b.p[-1]["material"]["alpha_cutoff"] = 0.5
+    b.add(plane([-4, 5, -3], [4, 0, 0], [0, 0, 0.4], 1, 1), base_color=(0.5, 0.5, 0.5, 1.0))                  # CANOPY: shades the wall's top left
+    base = scene()                                                             # textures 0 (checker alpha) and 1 (normal map)
+    yy, xx = np.mgrid[0:32, 0:32]
+    tex = np.zeros((32, 32, 4), np.uint8)
+    tex[..., 0] = 120 + 100 * (((xx // 4) + (yy // 4)) % 2)
+    tex[..., 1] = 90 + 5 * xx
+    tex[..., 2] = 60 + 4 * yy
+    tex[..., 3] = 255
+    textures = list(base.textures) + [dict(rgba8=tex, format=abi.FORMAT_R8G8B8A8_SRGB, mag=abi.FILTER_LINEAR, min=abi.FILTER_LINEAR,
+                                           address_u=abi.ADDRESS_REPEAT, address_v=abi.ADDRESS_MIRRORED_REPEAT)]
+    cam = dict(position=(0.0, 1.6, 6.0), yaw=0.0, pitch=-0.1, yfov=0.9, znear=0.1, dolly=(0.0, 0.0, -0.05))
+    # intensity 2 (the reference's Pica value, scene_loader.cpp:97) and a tinted colour so lit texels stay below the UNORM clamp
+    return b.finish("f4", cam, directional_light((0.2, -0.9, -0.4), color=(1.0, 0.9, 0.7), intensity=2.0), textures)

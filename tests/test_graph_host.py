@@ -68,6 +68,8 @@ def test_registration_rules(ctx):
     with pytest.raises(lib.VhrError, match="no HIP kernel"):
         ctx.add_compute_pass("C3", [], [], ["hybrid_render_path/ssao.comp"], 4, noop)
     with pytest.raises(lib.VhrError, match="no HIP kernel"):
+        ctx.add_raytracing_pass("R", [], [], noop, raygen="rayquery_render_path/anything.rgen")
+    with pytest.raises(lib.VhrError, match="shadow_miss"):              # the raytraced path's raygen with the hybrid path's shader set
         ctx.add_raytracing_pass("R", [], [], noop, raygen="raytraced_render_path/raygen.rgen")
     with pytest.raises(lib.VhrError, match="RENDER_OUTPUT"):              # no sink yet (:687)
         ctx.build()

@@ -1,0 +1,219 @@
+"""Row f4 of SURVEY.md section 8: the raytraced render path (raytraced_render_path.cpp:11-76 and its shaders).
+CPU: the oracle on a purpose-built scene (BVH == brute force, alpha test opens the fence, decision ix), the host graph on a
+host-only context, strips.  GPU: the HIP primary-ray kernel and the composition stand-in against the oracle."""
+import numpy as np
+import pytest
+
+from tests import f2_scene
+from vulkanhybridrenderer_amd import abi, camera, lib
+
+W, H = 128, 80
+SKY = (51, 204, 77, 255)            # miss.rmiss:7 (0.3, 0.8, 0.2, 1) as B8G8R8A8_UNORM bytes b, g, r, a (0.3f * 255 = 76.500003)
+
+
+def _pfd(sc, k=1):
+    return camera.dolly_frames(sc, W, H, k + 1)[k]
+
+
+def test_oracle_bvh_equals_brute_force_and_alpha_opens_the_fence(oracle):
+    sc = f2_scene.scene_f4()
+    osc = oracle.Scene(sc)
+    pfd = _pfd(sc)
+    imgs = {}
+    for alpha in (False, True):
+        a, rays_a = osc.raytraced(pfd, W, H, alpha)
+        b, rays_b = osc.raytraced(pfd, W, H, alpha, use_bvh=False)
+        assert np.array_equal(a, b) and rays_a == rays_b              # any-hit filtering is traversal-order independent
+        assert (a[..., 3] == 255).all()
+        assert W * H < rays_a <= 2 * W * H                            # one primary ray per pixel + one shadow ray per hit
+        imgs[alpha] = a
+    opaque, alpha = imgs[False], imgs[True]
+    sky_o = (opaque == SKY).all(-1)
+    assert 0.02 < sky_o.mean() < 0.6 and (alpha == SKY).all(-1).sum() >= sky_o.sum()
+    # the masked, untextured quad: opaque variant shades base_color (red-ish), alpha variant ignores it (decision ix: texel alpha 0)
+    gb = osc.gbuffer(pfd, W, H)                                       # ids via the G-buffer producer, which does NOT discard this quad
+    from tests.helpers import f16
+    ids = f16(gb[0])[..., 3]
+    quad = (ids == f2_scene.F4_MASKED_UNTEXTURED) & (gb[2] != 0)
+    assert quad.sum() > 20
+    assert (opaque[quad][:, 2] > opaque[quad][:, 0]).all()            # r > b
+    assert not np.array_equal(opaque[quad], alpha[quad])
+    # the fence: with the alpha test the wall shows through its masked texels and its shadow has holes
+    assert (opaque != alpha).any(-1).mean() > 0.05
+
+
+def test_oracle_known_pixels(oracle):
+    """Hand-checkable values: an unshadowed untextured wall pixel = albedo/pi + max(N.L, 0) * albedo * intensity * color."""
+    sc = f2_scene.scene_f4()
+    osc = oracle.Scene(sc)
+    pfd = _pfd(sc)
+    img, _ = osc.raytraced(pfd, W, H, False)
+    L = -np.asarray(pfd["directional_light"]["direction"][:3], np.float32)
+    inten = np.asarray(pfd["directional_light"]["intensity"][:3], np.float32)
+    col = np.asarray(pfd["directional_light"]["color"][:3], np.float32)
+    albedo = np.array([0.2, 0.4, 0.8], np.float32)
+    lit = albedo / np.float32(np.pi) + max(float(L[2]), 0.0) * albedo * inten * col        # wall normal (0, 0, 1)
+    shadowed = albedo / np.float32(np.pi)
+    to8 = lambda v: np.floor(np.clip(v, 0, 1) * 255 + 0.5).astype(int)
+    from tests.helpers import f16
+    gb = osc.gbuffer(pfd, W, H)
+    ids = np.where(gb[2] != 0, f16(gb[0])[..., 3], -1)
+    fence_rows = np.nonzero((ids == f2_scene.F4_FENCE).any(1))[0]          # outside the fence's rows both producers see the wall directly
+    wall = ids == f2_scene.F4_WALL
+    wall[fence_rows.min():fence_rows.max() + 1] = False
+    px = img[wall][:, [2, 1, 0]].astype(int)
+    is_lit = np.abs(px - to8(lit)).max(-1) <= 1
+    is_shadow = np.abs(px - to8(shadowed)).max(-1) <= 1
+    assert (is_lit | is_shadow).mean() > 0.98 and is_lit.sum() > 50 and is_shadow.sum() > 50      # the canopy shades the top left
+
+
+def test_oracle_composition_flips_and_encodes(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    out = oracle.raytraced_composition(img)
+    c = img[::-1].astype(np.float64) / 255.0
+    enc = np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.power(c, 1 / 2.4) - 0.055)
+    want = np.floor(enc * 255 + 0.5).astype(np.uint8)
+    assert np.array_equal(out[..., :3], want[..., :3]) and np.array_equal(out[..., 3], img[::-1][..., 3])
+
+
+def test_oracle_rows_are_independent(oracle):
+    sc = f2_scene.scene_f4()
+    osc = oracle.Scene(sc)
+    pfd = _pfd(sc)
+    full, _ = osc.raytraced(pfd, W, H, True)
+    top, _ = osc.raytraced(pfd, W, H, True, rows=(0, 37))
+    bot, _ = osc.raytraced(pfd, W, H, True, rows=(37, H))
+    assert np.array_equal(top[:37], full[:37]) and np.array_equal(bot[37:], full[37:]) and not top[37:].any()
+
+
+def test_host_graph(vhr):
+    """raytraced_render_path.cpp on a host-only context: passes, order, image, shader-set validation, Rebuild toggle."""
+    ctx = lib.Context(1920, 1080, host_only=True)
+    try:
+        p = lib.RaytracedRenderPath(ctx, use_anyhit_shader=False)
+        p.build()
+        assert ctx.execution_order() == ["Raytracing Pass", "Composition Pass"]
+        assert ctx.contains_image(lib.RAYTRACED_OUTPUT) and ctx.image_format(lib.RAYTRACED_OUTPUT) == abi.FORMAT_B8G8R8A8_UNORM
+        info = ctx.transient_info(lib.RAYTRACED_OUTPUT)
+        assert (info.width, info.height, info.bytes_per_pixel) == (1920, 1080, 4)
+        p.rebuild(True)                                               # the radio button + Rebuild() (:90-92)
+        assert ctx.execution_order() == ["Raytracing Pass", "Composition Pass"]
+        p.destroy()
+        assert ctx.upload_new_storage_image(8, 8, abi.FORMAT_B8G8R8A8_UNORM) == 0      # the path owns no pool images (:79)
+        ctx.destroy_resources()
+        out = [lib.transient(lib.RAYTRACED_OUTPUT, abi.FORMAT_B8G8R8A8_UNORM, 0)]
+        miss = ("raytraced_render_path/miss.rmiss", "raytraced_render_path/shadow_miss.rmiss")
+        with pytest.raises(lib.VhrError, match="any-hit"):            # an any-hit shader without the alpha raygen
+            ctx.add_raytracing_pass("A", [], out, lambda e: None, raygen="raytraced_render_path/raygen.rgen", miss=miss,
+                                    closest_hit=("raytraced_render_path/closesthit.rchit",), any_hit=("raytraced_render_path/shadow_anyhit.rahit",))
+        with pytest.raises(lib.VhrError, match="closesthit_test_alpha"):   # alpha raygen with the opaque hit group
+            ctx.add_raytracing_pass("B", [], out, lambda e: None, raygen="raytraced_render_path/raygen_test_alpha.rgen", miss=miss,
+                                    closest_hit=("raytraced_render_path/closesthit.rchit",))
+        with pytest.raises(lib.VhrError, match="shadow_miss"):        # the hybrid path's miss shaders do not fit
+            ctx.add_raytracing_pass("C", [], out, lambda e: None, raygen="raytraced_render_path/raygen.rgen",
+                                    closest_hit=("raytraced_render_path/closesthit.rchit",))
+        with pytest.raises(lib.VhrError, match="no HIP kernel"):
+            ctx.add_raytracing_pass("D", [], out, lambda e: None, raygen="rayquery_render_path/nope.rgen", miss=miss,
+                                    closest_hit=("raytraced_render_path/closesthit.rchit",))
+    finally:
+        ctx.close()
+
+
+# --------------------------------------------------------------------------------------------- GPU
+def _run_gpu(sc, pfds, alpha, strip=None):
+    ctx = lib.Context(W, H)
+    ctx.upload_scene(sc)
+    ctx.set_ray_statistics(True)
+    present = ctx.upload_new_storage_image(W, H, abi.FORMAT_B8G8R8A8_SRGB)
+    path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=alpha, composition_pass=lambda c: c.standin_raytraced_composition(present))
+    path.build()
+    if strip:
+        ctx.set_strip(*strip)
+    outs = []
+    try:
+        for pfd in pfds:
+            ctx.update_per_frame_ubo(0, pfd)
+            ctx.execute(0, 0)
+            ctx.synchronize()
+            outs.append((ctx.download(lib.RAYTRACED_OUTPUT), ctx.download(present), ctx.ray_statistics()))
+    finally:
+        path.destroy()
+        ctx.close()
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha", [False, True])
+def test_gpu_matches_oracle(oracle, alpha):
+    sc = f2_scene.scene_f4()
+    osc = oracle.Scene(sc)
+    pfds = camera.dolly_frames(sc, W, H, 3)
+    got = _run_gpu(sc, pfds, alpha)
+    for pfd, (img, presented, stats) in zip(pfds, got):
+        want, rays = osc.raytraced(pfd, W, H, alpha)
+        d = np.abs(img.astype(int) - want.astype(int))
+        # tolerance: UNORM8 texels; same hit everywhere except at silhouettes where a texture / shading value sits on a
+        # rounding boundary: >= 99.5 % of the channels identical, the rest within 1 step except isolated silhouette pixels
+        assert (d == 0).mean() > 0.995, (d == 0).mean()
+        assert (d.max(-1) > 1).mean() < 0.002
+        assert stats["unique_rays"] == rays or abs(int(stats["unique_rays"]) - rays) <= 4
+        assert stats["stack_overflows"] == 0
+        assert np.array_equal(presented, oracle.raytraced_composition(img))      # composition stand-in: exact on its own input
+
+
+@pytest.mark.gpu
+def test_gpu_rebuild_toggles_the_alpha_test_and_strips_compose(oracle):
+    sc = f2_scene.scene_f4()
+    pfd = _pfd(sc)
+    full = _run_gpu(sc, [pfd], True)[0][0]
+    opaque = _run_gpu(sc, [pfd], False)[0][0]
+    assert (full != opaque).any(-1).mean() > 0.05
+    top = _run_gpu(sc, [pfd], True, strip=(0, 37, 0, 0))[0][0]
+    bot = _run_gpu(sc, [pfd], True, strip=(37, H, 0, 0))[0][0]
+    assert np.array_equal(top[:37], full[:37]) and np.array_equal(bot[37:], full[37:])
+    # Rebuild() on a live path switches the shader set
+    ctx = lib.Context(W, H)
+    ctx.upload_scene(sc)
+    path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=False)
+    path.build()
+    try:
+        ctx.update_per_frame_ubo(0, pfd)
+        ctx.execute(0, 0)
+        a = ctx.download(lib.RAYTRACED_OUTPUT)
+        path.rebuild(True)
+        ctx.execute(0, 0)
+        b = ctx.download(lib.RAYTRACED_OUTPUT)
+        assert np.array_equal(a, opaque) and np.array_equal(b, full)
+    finally:
+        path.destroy()
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sponza_proc_1080p_properties(oracle):
+    """Full-size run: sky where the G-buffer producer sees sky, alpha == opaque on a scene without masked materials."""
+    from vulkanhybridrenderer_amd import scenes
+    sc = scenes.sponza_proc()
+    Wf, Hf = 1920, 1080
+    pfd = camera.dolly_frames(sc, Wf, Hf, 2)[1]
+    res = {}
+    for alpha in (False, True):
+        ctx = lib.Context(Wf, Hf)
+        ctx.upload_scene(sc)
+        path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=alpha)
+        path.build()
+        ctx.update_per_frame_ubo(0, pfd)
+        ctx.execute(0, 0)
+        res[alpha] = ctx.download(lib.RAYTRACED_OUTPUT)
+        path.destroy()
+        ctx.close()
+    assert (res[False][..., 3] == 255).all()
+    # the oracle on a 64-row band of the same frame
+    osc = oracle.Scene(sc)
+    want, _ = osc.raytraced(pfd, Wf, Hf, False, rows=(500, 564))
+    d = np.abs(res[False][500:564].astype(int) - want[500:564].astype(int))
+    assert (d == 0).mean() > 0.995 and (d.max(-1) > 1).mean() < 0.002
+    # sponza_proc has no textures: the alpha variant samples textures[-1] = 0 -> black albedo wherever something is hit
+    hit = ~(res[False] == SKY).all(-1)
+    assert (res[True][hit][:, :3] == 0).all() and np.array_equal(res[True][~hit], res[False][~hit])

@@ -403,6 +403,12 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const vhr_trace_params &tp = ctx->trace_params;
     const uint64_t covered = ctx->h_ray_stats.covered_pixels;
+    if (ctx->raytraced_pixels) {          // raytraced render path: one primary ray per pixel + one shadow ray per primary hit
+        out[0] = out[1] = ctx->raytraced_pixels + covered;
+        out[2] = covered;
+        out[3] = ctx->h_ray_stats.stack_overflows;
+        return VHR_OK;
+    }
     out[0] = covered * (uint64_t(tp.shadow_enable ? 1 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));
     out[1] = covered * (uint64_t(tp.shadow_enable ? 4 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));   // raygen.rgen:38-40 duplicates
     out[2] = covered;
@@ -516,6 +522,18 @@ int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_c
         return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: output storage image is not allocated");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_composition(ctx, ctx->per_frame[resource_idx], *d, *al, *no, *mo, *de, *sa, re, ctx->storage_images[d->output_storage_image]);
+}
+
+int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_output_image, int32_t output_storage_image) {
+    if (!ctx || !raytraced_output_image) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: missing image name") : VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    auto it = ctx->images.find(raytraced_output_image);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, "raytraced composition: unknown transient image");
+    if (it->second.format != VHR_FORMAT_B8G8R8A8_UNORM) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: RaytracedOutput must be B8G8R8A8_UNORM (raytraced_render_path.cpp:15)");
+    if (output_storage_image < 0 || uint32_t(output_storage_image) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[output_storage_image].used)
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "raytraced composition: output storage image is not allocated");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_raytraced_composition(ctx, it->second, ctx->storage_images[output_storage_image]);
 }
 
 int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, const char *albedo_image, const char *normals_image,

@@ -63,7 +63,11 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
 // first accepted triangle; the boolean result does not depend on the visiting order.
 // !ANY_HIT: closest hit = min t, ties broken by the smaller flat triangle index; subtrees are pruned with
 // tnear > best t only (strict), so equal-t candidates are always examined.
-template <bool ANY_HIT>
+// ALPHA: rays of the raytraced render path traced with gl_RayFlagsNoOpaqueEXT (raygen_test_alpha.rgen:20,
+// closesthit_test_alpha.rchit:42): every candidate first runs shadow_anyhit.rahit, an ignored candidate does not exist.
+__device__ bool alpha_ignored(const DeviceScene &sc, uint32_t tri_index, float u, float v);
+
+template <bool ANY_HIT, bool ALPHA = false>
 __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, int *stack, Hit &best,
                                          uint32_t &overflow) {
     if (sc.node_count == 0) return false;
@@ -98,6 +102,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
                 const float4 c = tp[2];
                 float t, u, w;
                 if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, tmin, tmax, t, u, w)) {
+                    if (ALPHA && alpha_ignored(sc, first + i, u, w)) continue;
                     if (ANY_HIT) return true;
                     const uint32_t flat = __float_as_uint(c.w);
                     if (!found || t < best.t || (t == best.t && flat < best.flat)) {
@@ -755,6 +760,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     a.row_begin = owned_begin;
     a.row_end = owned_end;
     a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
+    ctx->raytraced_pixels = 0;                 // ray statistics are the hybrid path's again
     if (a.row_end <= a.row_begin) return VHR_OK;
     if (ctx->options[kOptTraceOverlap]) {      // strips: trace the rows the denoiser recomputes too (no exchange of raw visibility)
         a.row_begin = owned_begin > ctx->overlap ? owned_begin - ctx->overlap : 0u;
@@ -816,6 +822,139 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemcpyAsync(ray stats) failed");
     }
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// next row f4: the raytraced render path's "Raytracing Pass" (raytraced_render_path.cpp:11-47)
+//   raytraced_render_path/raygen.rgen:10-23 (+ miss.rmiss:6-8, shadow_miss.rmiss:6-8, closesthit.rchit:10-58), or with the
+//   alpha test for shadows switched on raygen_test_alpha.rgen:10-23 + closesthit_test_alpha.rchit:10-51 +
+//   shadow_anyhit.rahit:8-27.  One pixel per lane, 8x8 pixels per wave: the primary rays of a tile and the shadow rays
+//   towards the directional light are both coherent, so the per-lane walk keeps most lanes on the same nodes.
+// ---------------------------------------------------------------------------------------------
+// shadow_anyhit.rahit:8-27: true = ignoreIntersectionEXT.  textures[-1] (no base colour texture) reads (0, 0, 0, 0)
+// (decision ix of the oracle; out of bounds in the reference).
+__device__ bool alpha_ignored(const DeviceScene &sc, uint32_t tri_index, float u, float v) {
+    const BvhTri &bt = sc.tris[tri_index];
+    const vhr_primitive &prim = sc.primitives[bt.prim];                                  // rahit:9
+    if (prim.material.alpha_mask != 1) return false;                                     // rahit:24 (the texture fetch has no other effect)
+    const vhr_vertex &a = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * bt.tri + 0]];
+    const vhr_vertex &b = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * bt.tri + 1]];
+    const vhr_vertex &c = sc.vertices[prim.vertex_offset + sc.indices[prim.index_offset + 3 * bt.tri + 2]];
+    const float bx = 1.0f - u - v, by = u, bz = v;                                       // rahit:19
+    const float uvx = a.uv0[0] * bx + b.uv0[0] * by + c.uv0[0] * bz;                     // rahit:20
+    const float uvy = a.uv0[1] * bx + b.uv0[1] * by + c.uv0[1] * bz;
+    const f4 albedo = sample_texture(sc, prim.material.base_color_texture, uvx, uvy);    // rahit:23
+    return albedo.w < prim.material.alpha_cutoff;                                        // rahit:24-26
+}
+
+struct RaytracedArgs {
+    DeviceScene scene;
+    vhr_per_frame_data pfd;
+    uchar4 *out;             // "RaytracedOutput", B8G8R8A8_UNORM
+    uint32_t width, height;
+    uint32_t row_begin, row_end;
+    RayStats *stats;         // nullptr = off; covered_pixels counts the primary hits (= shadow rays)
+};
+
+__device__ __forceinline__ uint32_t unorm8(float f);
+
+template <bool ALPHA>
+__global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedArgs a) {
+    __shared__ int s_rt_stack[kTraceStack * kTraceBlock];
+    int *stack = s_rt_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, a.row_begin);
+    bool hit_any = false;
+    uint32_t overflow = 0;
+    if (x < a.width && y < a.row_end) {
+        const uint32_t W = a.width, H = a.height;
+        const float ux = ((float(x) + 0.5f) / float(W)) * 2.0f - 1.0f;                   // rgen:11-13
+        const float uy = ((float(y) + 0.5f) / float(H)) * 2.0f - 1.0f;
+        const f4 origin = mat4_mul(a.pfd.camera_view_inverse, f4{ 0.0f, 0.0f, 0.0f, 1.0f });       // rgen:15
+        const f4 target = mat4_mul(a.pfd.camera_proj_inverse, f4{ ux, uy, 1.0f, 1.0f });           // rgen:16
+        const f3 tn = normalize3(f3{ target.x, target.y, target.z });
+        const f4 direction = mat4_mul(a.pfd.camera_view_inverse, f4{ tn.x, tn.y, tn.z, 0.0f });    // rgen:17
+        f4 payload = f4{ 0.3f, 0.8f, 0.2f, 1.0f };                                       // miss.rmiss:7
+        Hit h;
+        if (traverse<false, ALPHA>(a.scene, f3{ origin.x, origin.y, origin.z }, f3{ direction.x, direction.y, direction.z }, 0.1f, 10000.0f,
+                                   stack, h, overflow)) {                                // rgen:20
+            hit_any = true;
+            const BvhTri &bt = a.scene.tris[h.tri_index];                                // rchit:11-24
+            const vhr_primitive &prim = a.scene.primitives[bt.prim];
+            const TriAttributes at = interpolate(a.scene, prim, bt.tri, h.u, h.v);
+            const f3 position = mat4_mul_point(prim.transform, at.object_pos);
+            f3 albedo;
+            if (!ALPHA && prim.material.base_color_texture == -1) {                      // rchit:26-32 (alpha variant: :26, unconditional)
+                albedo = f3{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2] };
+            } else {
+                const f4 t = sample_texture(a.scene, prim.material.base_color_texture, at.uvx, at.uvy);
+                albedo = f3{ t.x, t.y, t.z };
+            }
+            const f3 normal = at.normal;
+            f3 N = normal;                                                               // rchit:34-41
+            if (prim.material.normal_map >= 0) {
+                const f4 tg = interpolate_tangent(a.scene, prim, bt.tri, h.u, h.v);
+                const f3 T = f3{ tg.x, tg.y, tg.z };
+                const f4 tx = sample_texture(a.scene, prim.material.normal_map, at.uvx, at.uvy);
+                const f3 tsn = normalize3(f3{ tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f });
+                const f3 bitangent = cross3(tsn, T) * tg.w;                              // sic
+                const f3 tangent = normalize3(T - normal * dot3(T, normal));
+                N = (tangent * tsn.x + bitangent * tsn.y) + normal * tsn.z;
+            }
+            const f3 light_dir = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+            const f3 lc = f3{ a.pfd.directional_light.color[0], a.pfd.directional_light.color[1], a.pfd.directional_light.color[2] };
+            const f3 li = f3{ a.pfd.directional_light.intensity[0], a.pfd.directional_light.intensity[1], a.pfd.directional_light.intensity[2] };
+            const f3 albedo_lighting = ALPHA ? albedo * 0.2f : albedo * VHR_PI_INVERSE;  // alpha :39 / :46
+            Hit sh;
+            // shadow ray, rchit:48-50 (alpha :41-43): shadow_payload stays true unless shadow_miss.rmiss:7 runs
+            const bool shadowed = traverse<true, ALPHA>(a.scene, position, light_dir, 0.1f, 10000.0f, stack, sh, overflow);
+            f3 col = albedo_lighting;
+            if (!shadowed) {                                                             // rchit:52-54 / alpha :45-47
+                const float nl = fmaxf(dot3(N, light_dir), 0.0f);
+                f3 lit = albedo * nl;
+                if (!ALPHA) lit = mul3(lit, li);                                         // the alpha variant drops light_intensity
+                lit = mul3(lit, lc);
+                col = albedo_lighting + lit;
+            }
+            payload = f4{ col.x, col.y, col.z, 1.0f };
+        }
+        a.out[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(payload.z)), uint8_t(unorm8(payload.y)), uint8_t(unorm8(payload.x)),
+                                               uint8_t(unorm8(payload.w)));             // rgen:22 imageStore, B8G8R8A8
+    }
+    if (a.stats) {
+        const unsigned long long cov = __ballot(hit_any), ovf = __ballot(overflow != 0);
+        if ((threadIdx.x & 63u) == 0) {
+            if (cov) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov));
+            if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
+        }
+    }
+}
+
+int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, Image &out, bool alpha_test) {
+    if (width != out.width || height != out.height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "TraceRays: launch size must equal the extent of RaytracedOutput");
+    if (out.bpp != 4) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "TraceRays: RaytracedOutput must be B8G8R8A8_UNORM");
+    RaytracedArgs a;
+    a.scene = ctx->device_scene();
+    a.pfd = pfd;
+    a.out = static_cast<uchar4 *>(out.ptr);
+    a.width = width;
+    a.height = height;
+    a.row_begin = std::min(ctx->row_begin, height);          // strips: per-pixel independent, owned rows only
+    a.row_end = std::min(ctx->row_end, height);
+    a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
+    if (a.row_end <= a.row_begin) return VHR_OK;
+    if (a.stats && hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
+        return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
+    const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
+    ctx->time_begin(kKernelRaygen);
+    if (alpha_test) hipLaunchKernelGGL(raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(raytraced_kernel<false>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    ctx->time_end(kKernelRaygen);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raytraced kernel launch failed");
+    if (a.stats && hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return ctx->fail(VHR_ERROR_DEVICE, "hipMemcpyAsync(ray stats) failed");
+    ctx->raytraced_pixels = uint64_t(width) * (a.row_end - a.row_begin);
     return VHR_OK;
 }
 
@@ -1040,6 +1179,24 @@ int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vh
 
 int upload_srgb_lut(const float *lut) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_lut), lut, 256 * sizeof(float)) == hipSuccess ? 0 : -1;
+}
+
+// raytraced_render_path/composition.vert:5-8 + composition.frag:11-13: "RaytracedOutput" sampled at the texel centre,
+// written to the B8G8R8A8_SRGB swapchain through the flipped presentation viewport (pipeline.cpp:175-178).
+__global__ __launch_bounds__(256) void raytraced_composition_kernel(const uchar4 *in, uchar4 *out, uint32_t W, uint32_t H) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || j >= H) return;
+    const uchar4 p = in[size_t(H - 1 - j) * W + x];
+    out[size_t(j) * W + x] = make_uchar4(srgb8(p.x * (1.0f / 255.0f)), srgb8(p.y * (1.0f / 255.0f)), srgb8(p.z * (1.0f / 255.0f)), p.w);
+}
+
+int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out) {
+    if (in.width != out.width || in.height != out.height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: image extents differ");
+    if (in.bpp != 4 || out.bpp != 4) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: 4-byte texels expected");
+    hipLaunchKernelGGL(raytraced_composition_kernel, dim3((in.width + 63) / 64, (in.height + 3) / 4), dim3(256), 0, ctx->stream,
+                       static_cast<const uchar4 *>(in.ptr), static_cast<uchar4 *>(out.ptr), in.width, in.height);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raytraced composition kernel launch failed");
+    return VHR_OK;
 }
 
 }  // namespace vhr

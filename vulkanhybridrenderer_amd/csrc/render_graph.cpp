@@ -25,6 +25,14 @@ static const char *kRaygen = "hybrid_render_path/raygen.rgen";
 static const char *kMiss = "hybrid_render_path/miss.rmiss";
 static const char *kReflectionMiss = "hybrid_render_path/reflection_miss.rmiss";
 static const char *kReflectionHit = "hybrid_render_path/reflection_hit.rchit";
+// the raytraced render path's shader sets (raytraced_render_path.cpp:19-34), SURVEY.md section 8 row f4
+static const char *kRtRaygen = "raytraced_render_path/raygen.rgen";
+static const char *kRtRaygenAlpha = "raytraced_render_path/raygen_test_alpha.rgen";
+static const char *kRtMiss = "raytraced_render_path/miss.rmiss";
+static const char *kRtShadowMiss = "raytraced_render_path/shadow_miss.rmiss";
+static const char *kRtClosestHit = "raytraced_render_path/closesthit.rchit";
+static const char *kRtClosestHitAlpha = "raytraced_render_path/closesthit_test_alpha.rchit";
+static const char *kRtShadowAnyHit = "raytraced_render_path/shadow_anyhit.rahit";
 static const char *kSvgf = "hybrid_render_path/svgf.comp";
 static const char *kAtrous = "hybrid_render_path/svgf_atrous_filter.comp";
 
@@ -127,8 +135,10 @@ int vhr_graph_add_raytracing_pass(vhr_context *ctx, const char *name, const vhr_
                                   const vhr_raytracing_pipeline_description *pipeline, vhr_raytracing_pass_callback cb, void *user) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (!pipeline || !pipeline->raygen_shader || !cb) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "AddRaytracingPass: pipeline description and callback are required");
-    // Shader names select the HIP kernels.  Only the hybrid path's shader set exists here.
-    if (std::strcmp(pipeline->raygen_shader, kRaygen) != 0)
+    // Shader names select the HIP kernels: the hybrid path's set and the raytraced path's two sets exist here.
+    const bool hybrid = !std::strcmp(pipeline->raygen_shader, kRaygen);
+    const bool rt_opaque = !std::strcmp(pipeline->raygen_shader, kRtRaygen), rt_alpha = !std::strcmp(pipeline->raygen_shader, kRtRaygenAlpha);
+    if (!hybrid && !rt_opaque && !rt_alpha)
         return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no HIP kernel for raygen shader '") + pipeline->raygen_shader + "'");
     PassDescription p;
     p.kind = PassKind::Raytracing;
@@ -138,12 +148,25 @@ int vhr_graph_add_raytracing_pass(vhr_context *ctx, const char *name, const vhr_
     p.raygen = pipeline->raygen_shader;
     for (uint32_t i = 0; i < pipeline->miss_shader_count; ++i) p.miss.emplace_back(pipeline->miss_shaders[i] ? pipeline->miss_shaders[i] : "");
     for (uint32_t i = 0; i < pipeline->hit_shader_count; ++i) {
-        if (pipeline->hit_shaders[i].any_hit) return ctx->fail(VHR_ERROR_NOT_FOUND, "any-hit shaders are not part of the hybrid path (all geometry is opaque, resource_manager.cpp:633)");
+        if (pipeline->hit_shaders[i].any_hit && !rt_alpha)
+            return ctx->fail(VHR_ERROR_NOT_FOUND, "an any-hit shader only exists for the raytraced path's alpha test (raytraced_render_path.cpp:25-29); "
+                                                  "the hybrid path's geometry is all opaque (resource_manager.cpp:633)");
         p.closest_hit.emplace_back(pipeline->hit_shaders[i].closest_hit ? pipeline->hit_shaders[i].closest_hit : "");
+        p.any_hit.emplace_back(pipeline->hit_shaders[i].any_hit ? pipeline->hit_shaders[i].any_hit : "");
     }
-    // miss index 0 = visibility, 1 = reflection (raygen.rgen:39,64); hit group 0 = reflection closest hit
-    if (p.miss.size() < 2 || p.miss[0] != kMiss || p.miss[1] != kReflectionMiss || p.closest_hit.empty() || p.closest_hit[0] != kReflectionHit)
-        return ctx->fail(VHR_ERROR_NOT_FOUND, "raytracing pipeline must name miss.rmiss, reflection_miss.rmiss and reflection_hit.rchit (hybrid_render_path.cpp:112-124)");
+    if (hybrid) {
+        // miss index 0 = visibility, 1 = reflection (raygen.rgen:39,64); hit group 0 = reflection closest hit
+        if (p.miss.size() < 2 || p.miss[0] != kMiss || p.miss[1] != kReflectionMiss || p.closest_hit.empty() || p.closest_hit[0] != kReflectionHit)
+            return ctx->fail(VHR_ERROR_NOT_FOUND, "raytracing pipeline must name miss.rmiss, reflection_miss.rmiss and reflection_hit.rchit (hybrid_render_path.cpp:112-124)");
+    } else {
+        // miss index 0 = primary (raygen.rgen:20), 1 = shadow (closesthit.rchit:50); hit group 0 shades, its any-hit filters
+        const char *want_hit = rt_alpha ? kRtClosestHitAlpha : kRtClosestHit;
+        if (p.miss.size() < 2 || p.miss[0] != kRtMiss || p.miss[1] != kRtShadowMiss || p.closest_hit.empty() || p.closest_hit[0] != want_hit ||
+            (rt_alpha && p.any_hit[0] != kRtShadowAnyHit))
+            return ctx->fail(VHR_ERROR_NOT_FOUND, "raytracing pipeline must name the raytraced path's miss.rmiss, shadow_miss.rmiss and "
+                                                  "closesthit.rchit, or with raygen_test_alpha.rgen closesthit_test_alpha.rchit + shadow_anyhit.rahit "
+                                                  "(raytraced_render_path.cpp:19-34)");
+    }
     p.rt_cb = cb;
     p.user = user;
     commit_pass(ctx, std::move(p));
@@ -352,6 +375,12 @@ int vhr_trace_rays(vhr_raytracing_execution_context *exec, uint32_t width, uint3
     if (!exec) return VHR_ERROR_INVALID_ARGUMENT;
     vhr_context *ctx = exec->ctx;
     const PassDescription &p = *exec->pass;
+    if (p.raygen == kRtRaygen || p.raygen == kRtRaygenAlpha) {
+        // set 3 binding 0 of raytraced_render_path/raygen.rgen:6 (declared rgba8, created B8G8R8A8_UNORM, raytraced_render_path.cpp:15)
+        Image *out = pass_image(ctx, p, 0, VHR_FORMAT_B8G8R8A8_UNORM, "output_image");
+        if (!out) return VHR_ERROR_GRAPH;
+        return launch_raytraced(ctx, ctx->per_frame[exec->resource_idx], width, height, *out, p.raygen == kRtRaygenAlpha);
+    }
     // set 3 bindings of raygen.rgen:6-9
     Image *normals = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
     Image *depth = pass_image(ctx, p, 1, VHR_FORMAT_D32_SFLOAT, "depth");

@@ -116,7 +116,7 @@ struct PassDescription {
     std::vector<std::string> resource_names;       // storage for the name strings above
     // raytracing
     std::string pipeline_name, raygen;
-    std::vector<std::string> miss, closest_hit;
+    std::vector<std::string> miss, closest_hit, any_hit;
     // compute
     std::vector<std::string> kernels;
     uint32_t push_constant_size = 0;
@@ -205,6 +205,7 @@ struct vhr_context {
     bool ray_stats_enabled = false;
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
+    uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
     int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 8, 1, 4, -1 };     // see vhr_set_option
     int cu_count = 256;
@@ -226,6 +227,8 @@ uint32_t format_stride(int32_t format);   // VkUtils::FormatStride (vulkan_utils
 struct ImageView { void *ptr; uint32_t width, height; };
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height,
                   const Image &normals, const Image &depth, Image &shadow_ao, Image *reflections);
+int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, Image &out, bool alpha_test);
+int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out);
 int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth, Image *albedo);
 int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
                        const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, Image &out);

@@ -30,6 +30,8 @@ EXPORTS = [
     "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_set_strip",
+    "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
+    "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles",
     "vhr_calibration_stream_read",
@@ -158,6 +160,14 @@ def load():
     L.vhr_standin_gbuffer.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p]
     L.vhr_standin_gbuffer_with_albedo.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
     L.vhr_standin_composition.argtypes = [vp, u32, C.POINTER(CompositionDesc)]
+    L.vhr_standin_raytraced_composition.argtypes = [vp, C.c_char_p, i32]
+    L.vhr_raytraced_create.argtypes = [vp, i32, EXTERNAL_CB, vp, C.POINTER(vp)]
+    L.vhr_raytraced_destroy.argtypes = [vp]
+    L.vhr_raytraced_destroy.restype = None
+    L.vhr_raytraced_build.argtypes = [vp]
+    L.vhr_raytraced_rebuild.argtypes = [vp, i32]
+    L.vhr_raytraced_last_error.argtypes = [vp]
+    L.vhr_raytraced_last_error.restype = C.c_char_p
     L.vhr_set_strip.argtypes = [vp, u32, u32, u32, u32]
     L.vhr_set_ray_statistics.argtypes = [vp, i32]
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
@@ -182,6 +192,7 @@ DENOISED = "Denoised Raytraced Shadows and Ambient Occlusion"
 ALBEDO = "Albedo"
 SVGF_SHADER = "hybrid_render_path/svgf.comp"
 ATROUS_SHADER = "hybrid_render_path/svgf_atrous_filter.comp"
+RAYTRACED_OUTPUT = "RaytracedOutput"        # raytraced_render_path.cpp:15
 
 ATTACHMENT_IMAGE, SAMPLED_IMAGE, STORAGE_IMAGE = 0, 1, 2
 
@@ -309,12 +320,13 @@ class Context:
 
     def add_raytracing_pass(self, name, dependencies, outputs, callback, raygen="hybrid_render_path/raygen.rgen",
                             miss=("hybrid_render_path/miss.rmiss", "hybrid_render_path/reflection_miss.rmiss"),
-                            closest_hit=("hybrid_render_path/reflection_hit.rchit",), pipeline_name="Raytrace Pipeline"):
+                            closest_hit=("hybrid_render_path/reflection_hit.rchit",), pipeline_name="Raytrace Pipeline", any_hit=None):
         cb = RAYTRACING_CB(lambda user, exec_: self._guard(lambda: callback(RaytracingExecutionContext(self, exec_))))
         d, nd = self._resources(dependencies)
         o, no = self._resources(outputs)
         miss_arr = (C.c_char_p * len(miss))(*[m.encode() for m in miss])
-        hits = (HitShader * len(closest_hit))(*[HitShader(h.encode(), None) for h in closest_hit])
+        any_hit = any_hit or (None,) * len(closest_hit)
+        hits = (HitShader * len(closest_hit))(*[HitShader(h.encode(), ah.encode() if ah else None) for h, ah in zip(closest_hit, any_hit)])
         desc = RaytracingPipelineDescription(pipeline_name.encode(), raygen.encode(), miss_arr, len(miss), hits, len(closest_hit))
         self._keep += [cb, d, o, dependencies, outputs, miss_arr, hits, desc]
         self.check(self.L.vhr_graph_add_raytracing_pass(self.handle, name.encode(), d, nd, o, no, C.byref(desc), cb, None),
@@ -415,6 +427,10 @@ class Context:
         d = CompositionDesc(shadow_mode, ao_mode, reflection_mode, ALBEDO.encode(), NORMALS.encode(), MOTION.encode(), DEPTH.encode(),
                             shadow_ao.encode(), reflections.encode() if reflections else None, output_storage_image)
         self.check(self.L.vhr_standin_composition(self.handle, resource_idx, C.byref(d)), "standin_composition")
+
+    def standin_raytraced_composition(self, output_storage_image, raytraced_output=RAYTRACED_OUTPUT):
+        self.check(self.L.vhr_standin_raytraced_composition(self.handle, raytraced_output.encode(), output_storage_image),
+                   "standin_raytraced_composition")
 
     def set_ray_statistics(self, enable):
         self.check(self.L.vhr_set_ray_statistics(self.handle, int(enable)), "set_ray_statistics")
@@ -541,4 +557,32 @@ class HybridRenderPath:
     def destroy(self):
         if self.handle:
             self.ctx.L.vhr_hybrid_destroy(self.handle)
+            self.handle = None
+
+
+class RaytracedRenderPath:
+    """vhr_raytraced_*: the C++ re-host of RaytracedRenderPath (csrc/raytraced_render_path.cpp)."""
+
+    def __init__(self, ctx, use_anyhit_shader=False, composition_pass=None):
+        self.ctx = ctx
+        self.use_anyhit_shader = bool(use_anyhit_shader)
+        self._c = EXTERNAL_CB(lambda user, c: ctx._guard(lambda: composition_pass(ctx))) if composition_pass else EXTERNAL_CB()
+        self.handle = C.c_void_p()
+        ctx.check(ctx.L.vhr_raytraced_create(ctx.handle, int(self.use_anyhit_shader), self._c, None, C.byref(self.handle)),
+                  "vhr_raytraced_create")
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise VhrError(f"{what}: {self.ctx.L.vhr_raytraced_last_error(self.handle).decode()}")
+
+    def build(self):
+        self._check(self.ctx.L.vhr_raytraced_build(self.handle), "RaytracedRenderPath::Build")
+
+    def rebuild(self, use_anyhit_shader):
+        self.use_anyhit_shader = bool(use_anyhit_shader)
+        self._check(self.ctx.L.vhr_raytraced_rebuild(self.handle, int(self.use_anyhit_shader)), "RaytracedRenderPath::Rebuild")
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.L.vhr_raytraced_destroy(self.handle)
             self.handle = None
