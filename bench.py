@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--ao-spp", type=int, default=2)
     p.add_argument("--reflections", action="store_true", help="also trace the mirror ray raygen.rgen always issues")
+    p.add_argument("--refl-bounces", type=int, default=None, choices=[0, 1, 2],
+                   help="mirror bounces (1 = --reflections = the reference; 2 = BASELINE config 5's extension; second-bounce rays are NOT counted in value)")
     p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "tiny"])
     p.add_argument("--gltf", default=None, help="load this .gltf / .glb instead of a procedural scene (vulkanhybridrenderer_amd/gltf.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,6 +58,10 @@ def parse():
                         "(default: every rank also traces its 30 overlap rows; no exchange on the critical path)")
     p.add_argument("--share-device", action="store_true", default=bool(os.environ.get("VHR_BENCH_SHARE_DEVICE")))
     return p.parse_args()
+
+
+def _bounces(args):
+    return args.refl_bounces if args.refl_bounces is not None else int(args.reflections)
 
 
 def cpu_baseline(scene, W, H, tp, n_frames, rays_per_pixel):
@@ -85,7 +91,7 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     from vulkanhybridrenderer_amd import lib
     from vulkanhybridrenderer_amd.harness import HybridFrameLoop, alias_tensor
     W, H, V = args.width, args.height, args.verify_frames
-    ref = HybridFrameLoop(scene, W, H, V, shadow=True, ao_spp=args.ao_spp, reflections=args.reflections, denoise=True, device=device) if rank == 0 else None
+    ref = HybridFrameLoop(scene, W, H, V, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True, device=device) if rank == 0 else None
     ok = True
     cpu = args.backend == "gloo"
     for i in range(V):
@@ -160,7 +166,7 @@ def main():
         scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup, args.max_gbuffers)
-    loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=args.reflections, denoise=True,
+    loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True,
                            device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, trace_overlap=not args.exchange_raytraced)
     ctx = loop.ctx
 
@@ -243,7 +249,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{scene.name} {W}x{H}: 1 shadow + {args.ao_spp} AO" + (" + 1 mirror" if args.reflections else "") +
+                "workload": f"{scene.name} {W}x{H}: 1 shadow + {args.ao_spp} AO" + ({0: "", 1: " + 1 mirror", 2: " + 1 mirror with a second bounce (second-bounce rays not counted)"}[_bounces(args)]) +
                             " unique rays/px + SVGF (1 temporal + 5 a-trous + 3 blits), 0.05 m/frame dolly",
                 "triangles": scene.triangle_count, "primitives": int(len(scene.primitives)),
                 "rays_per_covered_pixel": loop.rays_per_pixel,
@@ -269,8 +275,8 @@ def main():
                 "mrays_per_s": round(loop.rays_in_frame(args.warmup) / max(raygen_ms, 1e-9) / 1e3, 1),
                 "bvh_nodes": int(bvh["nodes"]), "bvh_bytes": int(bvh["node_bytes"] + bvh["triangle_bytes"]), "bvh_max_depth": int(bvh["max_depth"]),
                 "active_lane_utilisation": round(trav_stats["active_lane_utilisation"], 3),
-                "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["unique_rays"] - (ray_stats["covered_pixels"] if args.reflections else 0)), 2),
-                "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["unique_rays"] - (ray_stats["covered_pixels"] if args.reflections else 0)), 2),
+                "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
+                "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
                 "effective_traversal_gbs": round((trav_stats["node_visits"] * 64 + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6, 1),
                 "stack_overflows": int(ray_stats["stack_overflows"]),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",

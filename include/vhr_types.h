@@ -85,7 +85,7 @@ typedef struct vhr_trace_params {
     uint32_t shadow_enable;   /* 1 */
     uint32_t ao_spp;          /* 2 */
     float    ao_tmax;         /* 5.0 */
-    uint32_t reflections;     /* 1 = one mirror bounce shaded by reflection_hit.rchit, 0 = off */
+    uint32_t reflections;     /* 1 = one mirror bounce shaded by reflection_hit.rchit, 0 = off, 2 = two bounces (extension, BASELINE config 5) */
     float    cone_cos_max;    /* 0.999995 */
     float    normal_bias;     /* 0.1 */
     float    tmin;            /* 0.01 */

@@ -615,7 +615,13 @@ static v4 sample_texture(const orc_scene *s, int idx, float u, float v) {
 /* ------------------------------------------------------------------------------------------
  * reflection_hit.rchit:10-72 (closest-hit shading); returns the payload rgb, a = 1
  * ---------------------------------------------------------------------------------------- */
-static v4 reflection_hit(const orc_scene *s, const orc_per_frame_data *pfd, const orc_hit *h) {
+/* second_bounce (may be NULL): the documented 2-bounce extension (BASELINE config 5; the reference traces one bounce and
+ * declares recursion depth 2, pipeline.cpp:285).  When given, *second_bounce is the payload of a mirror ray traced from this
+ * hit and it replaces / blends into the specular term exactly like composition.frag:141-149 blends the first bounce at
+ * the primary hit: metallic == 1 ? reflections : mix(specular_lighting, reflections, roughness).  hit_position / hit_normal
+ * (optional) return the world-space hit point and the shader's N for the caller to build that ray. */
+static v4 reflection_hit_ex(const orc_scene *s, const orc_per_frame_data *pfd, const orc_hit *h, const v4 *second_bounce,
+                            v3 *hit_position, v3 *hit_normal) {
     const orc_tri *tr = &s->tris[h->flat];
     const orc_primitive *prim = &s->prims[tr->prim];                               /* :11 gl_GeometryIndexEXT */
     uint32_t i0 = s->indices[prim->index_offset + 3 * tr->tri + 0];               /* :13-15 gl_PrimitiveID */
@@ -663,10 +669,25 @@ static v4 reflection_hit(const orc_scene *s, const orc_per_frame_data *pfd, cons
     v3 diffuse = diffuse_brdf(metallic, albedo, F);
     v3 specular = specular_brdf(roughness, F, V, L, N, H);
     float nl = fmaxf(dot3(N, L), 0.0f);
+    if (hit_position) *hit_position = position;
+    if (hit_normal) *hit_normal = N;
+    if (second_bounce) {
+        v3 dl = v3mul(v3mul(v3scale(diffuse, nl), li), lc);                        /* composition.frag:138 without the shadow factor */
+        v3 sl = v3mul(v3mul(v3scale(specular, nl), li), lc);                       /* :139 */
+        v3 refl = V3(second_bounce->x, second_bounce->y, second_bounce->z);
+        if (metallic == 1.0f) sl = refl;                                           /* :141-149 */
+        else sl = V3(mixf(sl.x, refl.x, roughness), mixf(sl.y, refl.y, roughness), mixf(sl.z, refl.z, roughness));
+        v3 lighting2 = v3add(v3add(ambient, dl), sl);                              /* :160 */
+        v4 r2 = { lighting2.x, lighting2.y, lighting2.z, 1.0f };
+        return r2;
+    }
     v3 lit = v3mul(v3mul(v3scale(v3add(diffuse, specular), nl), li), lc);          /* :70 */
     v3 lighting = v3add(ambient, lit);
     v4 r = { lighting.x, lighting.y, lighting.z, 1.0f };
     return r;
+}
+static v4 reflection_hit(const orc_scene *s, const orc_per_frame_data *pfd, const orc_hit *h) {
+    return reflection_hit_ex(s, pfd, h, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -748,6 +769,23 @@ void orc_raygen(const orc_scene *s, const orc_per_frame_data *pfd, const orc_tra
                     v3 rdir = v3sub(I, v3scale(N, ni2));                                   /* reflect(I, N) */
                     orc_hit h = trace(s, origin, rdir, tp->tmin, tp->tmax, 0, use_bvh);
                     ++rays;
+                    if (h.hit && tp->reflections >= 2) {
+                        /* 2-bounce extension: a mirror ray from the first hit, about the shader's N (normalised, facing the
+                         * incoming ray), origin biased like raygen.rgen:29, shaded by reflection_hit.rchit without recursion */
+                        v3 hp, hn;
+                        (void)reflection_hit_ex(s, pfd, &h, NULL, &hp, &hn);
+                        v3 nn = normalize3(hn);
+                        float ni = dot3(nn, rdir);
+                        v3 nf = ni < 0.0f ? nn : v3neg(nn);
+                        v3 d2 = v3sub(rdir, v3scale(nn, 2.0f * ni));
+                        v3 o2 = v3add(hp, v3scale(nf, tp->normal_bias));
+                        orc_hit h2 = trace(s, o2, d2, tp->tmin, tp->tmax, 0, use_bvh);
+                        ++rays;
+                        v4 second = { 0, 0, 0, 0 };                                        /* reflection_miss.rmiss:7 */
+                        if (h2.hit) second = reflection_hit(s, pfd, &h2);
+                        payload = reflection_hit_ex(s, pfd, &h, &second, NULL, NULL);
+                        mask |= 0x80;
+                    } else
                     if (h.hit) { payload = reflection_hit(s, pfd, &h); mask |= 0x80; }     /* else reflection_miss.rmiss:7 */
                 }
                 store_rgba16f(reflections, W, (int)x, (int)y, payload.x, payload.y, payload.z, payload.w);

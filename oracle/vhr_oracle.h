@@ -50,7 +50,7 @@ typedef struct {
     uint32_t shadow_enable;   /* raygen.rgen:31-41 (1) */
     uint32_t ao_spp;          /* raygen.rgen:45 (2) */
     float    ao_tmax;         /* raygen.rgen:52 (5.0) */
-    uint32_t reflections;     /* raygen.rgen:59-65 (1 = one bounce, 0 = off) */
+    uint32_t reflections;     /* raygen.rgen:59-65 (1 = one bounce, 0 = off; 2 = the two-bounce extension of BASELINE config 5) */
     float    cone_cos_max;    /* raygen.rgen:34 (0.999995) */
     float    normal_bias;     /* raygen.rgen:29 (0.1) */
     float    tmin;            /* raygen.rgen:40 (0.01) */

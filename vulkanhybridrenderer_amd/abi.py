@@ -68,7 +68,7 @@ def default_trace_params(shadow=True, ao_spp=2, reflections=True):
     p["shadow_enable"] = 1 if shadow else 0
     p["ao_spp"] = ao_spp
     p["ao_tmax"] = 5.0
-    p["reflections"] = 1 if reflections else 0
+    p["reflections"] = int(reflections)          # True / 1 = the reference's single bounce, 2 = the two-bounce extension
     p["cone_cos_max"] = 0.999995
     p["normal_bias"] = 0.1
     p["tmin"] = 0.01

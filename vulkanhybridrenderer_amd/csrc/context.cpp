@@ -409,8 +409,9 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
         out[3] = ctx->h_ray_stats.stack_overflows;
         return VHR_OK;
     }
-    out[0] = covered * (uint64_t(tp.shadow_enable ? 1 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));
-    out[1] = covered * (uint64_t(tp.shadow_enable ? 4 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0));   // raygen.rgen:38-40 duplicates
+    const uint64_t second = ctx->h_ray_stats.second_bounce_rays;       // two-bounce extension: one more ray per first-bounce hit
+    out[0] = covered * (uint64_t(tp.shadow_enable ? 1 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0)) + second;
+    out[1] = covered * (uint64_t(tp.shadow_enable ? 4 : 0) + tp.ao_spp + (tp.reflections ? 1 : 0)) + second;   // raygen.rgen:38-40 duplicates
     out[2] = covered;
     out[3] = ctx->h_ray_stats.stack_overflows;
     return VHR_OK;

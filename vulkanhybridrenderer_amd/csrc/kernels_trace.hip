@@ -241,7 +241,12 @@ __device__ __forceinline__ f4 interpolate_tangent(const DeviceScene &sc, const v
                a.tangent[2] * bx + b.tangent[2] * by + c.tangent[2] * bz, a.tangent[3] * bx + b.tangent[3] * by + c.tangent[3] * bz };
 }
 
-__device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_data &pfd, const Hit &h) {
+// second_bounce (may be nullptr): the documented 2-bounce extension (BASELINE config 5; the reference traces one bounce and
+// declares recursion depth 2, pipeline.cpp:285): the payload of a mirror ray traced from this hit replaces / blends into the
+// specular term exactly like composition.frag:141-149 blends the first bounce at the primary hit.  hit_position / hit_normal
+// (optional) return the world-space hit point and the shader's N for the caller to build that ray.
+__device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_data &pfd, const Hit &h, const f4 *second_bounce = nullptr,
+                                   f3 *hit_position = nullptr, f3 *hit_normal = nullptr) {
     const BvhTri &bt = sc.tris[h.tri_index];
     const vhr_primitive &prim = sc.primitives[bt.prim];                                 // rchit:11
     const TriAttributes at = interpolate(sc, prim, bt.tri, h.u, h.v);
@@ -280,9 +285,43 @@ __device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_da
     const float invd = 1.0f / fmaxf(denom, 1e-6f);
     const f3 specular = f3{ dg * F.x * invd, dg * F.y * invd, dg * F.z * invd };
     const float nl = fmaxf(dot3(N, L), 0.0f);
+    if (hit_position) *hit_position = position;
+    if (hit_normal) *hit_normal = N;
+    if (second_bounce) {
+        const f3 dl = mul3(mul3(diffuse * nl, li), lc);                                 // composition.frag:138 without the shadow factor
+        f3 sl = mul3(mul3(specular * nl, li), lc);                                      // :139
+        const f3 refl = f3{ second_bounce->x, second_bounce->y, second_bounce->z };
+        if (metallic == 1.0f) sl = refl;                                                // :141-149
+        else sl = f3{ sl.x * (1.0f - roughness) + refl.x * roughness, sl.y * (1.0f - roughness) + refl.y * roughness,
+                      sl.z * (1.0f - roughness) + refl.z * roughness };
+        const f3 lighting2 = (ambient + dl) + sl;                                       // :160
+        return f4{ lighting2.x, lighting2.y, lighting2.z, 1.0f };
+    }
     const f3 lit = mul3(mul3((diffuse + specular) * nl, li), lc);                       // rchit:70
     const f3 lighting = ambient + lit;
     return f4{ lighting.x, lighting.y, lighting.z, 1.0f };
+}
+
+// The mirror ray of raygen.rgen:59-65 with the optional second bounce: a mirror ray from the first hit about the shader's N
+// (normalised, facing the incoming ray), origin biased like raygen.rgen:29, shaded by reflection_hit.rchit without recursion.
+__device__ __forceinline__ f4 trace_reflection(const DeviceScene &sc, const vhr_per_frame_data &pfd, const vhr_trace_params &tp, f3 origin,
+                                               f3 rdir, int *stack, uint32_t &overflow, bool &second_ray) {
+    Hit hit;
+    second_ray = false;
+    if (!traverse<false>(sc, origin, rdir, tp.tmin, tp.tmax, stack, hit, overflow)) return f4{ 0.0f, 0.0f, 0.0f, 0.0f };   // reflection_miss.rmiss:7
+    if (tp.reflections < 2) return shade_reflection_hit(sc, pfd, hit);
+    f3 hp, hn;
+    (void)shade_reflection_hit(sc, pfd, hit, nullptr, &hp, &hn);
+    const f3 nn = normalize3(hn);
+    const float ni = dot3(nn, rdir);
+    const f3 nf = ni < 0.0f ? nn : -nn;
+    const f3 d2 = rdir - nn * (2.0f * ni);
+    const f3 o2 = hp + nf * tp.normal_bias;
+    second_ray = true;
+    Hit hit2;
+    f4 second = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (traverse<false>(sc, o2, d2, tp.tmin, tp.tmax, stack, hit2, overflow)) second = shade_reflection_hit(sc, pfd, hit2);
+    return shade_reflection_hit(sc, pfd, hit, &second);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,7 +353,7 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a)
     uint32_t x, y;
     pixel_of_thread(x, y, a.row_begin);
     uint32_t overflow = 0;
-    bool covered = false;
+    bool covered = false, second_ray = false;
     if (x < a.width && y < a.row_end) {
         const uint32_t W = a.width, H = a.height;
         const float u = (float(x) + 0.5f) / float(W);                                        // rgen:15-16
@@ -363,18 +402,18 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a)
                     const f3 I = normalize3(P - cam);
                     const float ni2 = 2.0f * dot3(N, I);
                     const f3 rdir = I - N * ni2;                                             // reflect(I, N)
-                    if (traverse<false>(a.scene, origin, rdir, a.tp.tmin, a.tp.tmax, stack, hit, overflow))
-                        payload = shade_reflection_hit(a.scene, a.pfd, hit);                 // else reflection_miss.rmiss:7
+                    payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
                 }
                 store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
             }
         }
     }
     if (a.stats) {
-        const unsigned long long cov = __ballot(covered), ovf = __ballot(overflow != 0);
+        const unsigned long long cov = __ballot(covered), ovf = __ballot(overflow != 0), sec = __ballot(second_ray);
         if ((threadIdx.x & 63u) == 0) {
             if (cov) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov));
             if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
+            if (sec) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)__popcll(sec));
         }
     }
 }
@@ -719,10 +758,11 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
     int *stack = s_refl_stack + threadIdx.x;
     uint32_t x, y;
     pixel_of_thread(x, y, a.row_begin);
-    if (x >= a.width || y >= a.row_end) return;
+    bool second_ray = false;
+    const bool inside = x < a.width && y < a.row_end;
     const uint32_t W = a.width, H = a.height;
     f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    const float depth = a.depth[size_t(y) * W + x];
+    const float depth = inside ? a.depth[size_t(y) * W + x] : 0.0f;
     if (depth != 0.0f && a.tp.reflections) {
         const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
         const f3 P = get_world_space_position(a.pfd, depth, u, v);
@@ -733,12 +773,14 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
         const f3 I = normalize3(P - cam);
         const float ni2 = 2.0f * dot3(N, I);
         const f3 rdir = I - N * ni2;
-        Hit hit;
         uint32_t overflow = 0;
-        if (traverse<false>(a.scene, origin, rdir, a.tp.tmin, a.tp.tmax, stack, hit, overflow))
-            payload = shade_reflection_hit(a.scene, a.pfd, hit);
+        payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
     }
-    store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+    if (inside) store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+    if (a.stats) {
+        const unsigned long long sec = __ballot(second_ray);
+        if ((threadIdx.x & 63u) == 0 && sec) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)__popcll(sec));
+    }
 }
 
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,

@@ -132,7 +132,7 @@ struct PassDescription {
 };
 
 struct RayStats {
-    unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, pad;
+    unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, second_bounce_rays;
     unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, pad2;   // per-wave s_memtime sums
 };
 

@@ -41,8 +41,10 @@ class HybridFrameLoop:
         self.ctx.upload_scene(scene)
         self.tp = abi.default_trace_params(shadow=shadow, ao_spp=ao_spp, reflections=reflections)
         self.ctx.set_trace_params(self.tp)
-        self.rays_per_pixel = int(shadow) + ao_spp + int(reflections)
-        self.reference_rays_per_pixel = 4 * int(shadow) + ao_spp + int(reflections)     # raygen.rgen:38-40 duplicates
+        # `reflections` = mirror bounces (True / 1 = the reference, 2 = the two-bounce extension).  Second-bounce rays exist
+        # only where the first bounce hits; they are left out of the ray counts below (a conservative Mrays/s).
+        self.rays_per_pixel = int(shadow) + ao_spp + int(bool(reflections))
+        self.reference_rays_per_pixel = 4 * int(shadow) + ao_spp + int(bool(reflections))     # raygen.rgen:38-40 duplicates
         self.pfds = camera.dolly_frames(scene, width, height, n_frames, start_frame_index)
         self.current = 0
         self._aliases = {}
