@@ -299,6 +299,10 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "atrous_blocks_per_cu" (default 8), "atrous_xcd_aware" (default 1): launch shape of variant 4
  *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 4 tiles per CU (default),
  *                      0 = never, 1 = always
+ *   "strip_shrink_overlap" strips only (vhr_set_strip): 1 = an a-trous launch with step s computes the owned rows extended by
+ *                      overlap - (4s - 2) rows instead of the full overlap -- all that can be valid, and all that is needed,
+ *                      after the reference's doubling schedule 1, 2, 4, ... s (hybrid_render_path.cpp:299-319); only for callers
+ *                      that run that schedule (default 0).  Owned rows are bit-identical either way.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

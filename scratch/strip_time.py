@@ -10,14 +10,15 @@ W, H = 1920, 1080
 scene = scenes.sponza_proc()
 loop = HybridFrameLoop(scene, W, H, 24, shadow=True, ao_spp=2, reflections=False, denoise=True)
 for n in (1, 2, 4, 8):
-    for shared, small in ((0, -1), (1, -1), (0, 0)):
-        if n == 1 and (shared or small == 0): continue
+    for shared, small, shrink in ((0, -1, 0), (0, -1, 1)):
+        if n == 1 and shrink: continue
         r = n // 2
         plan = tiling.make_plan(H, n, r, loop.max_motion_rows)
         loop.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
         loop.ctx.set_option("trace_overlap", 1 if n > 1 else 0)
         loop.ctx.set_option("raygen_shared_tile", shared)
         loop.ctx.set_option("atrous_small_tiles", small)
+        loop.ctx.set_option("strip_shrink_overlap", shrink)
         for i in range(4): loop.frame(i)
         torch.cuda.synchronize()
         ts = []
@@ -32,6 +33,6 @@ for n in (1, 2, 4, 8):
         torch.cuda.synchronize()
         kt = {k: loop.ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit")}
         loop.ctx.set_kernel_timing(False)
-        print(f"N={n} rows {plan.rows}+{2*plan.overlap if n>1 else 0} shared_tile={shared} small_tiles={small}: {np.median(ts):.4f} ms/frame  " +
+        print(f"N={n} rows {plan.rows}+{2*plan.overlap if n>1 else 0} shrink_overlap={shrink}: {np.median(ts):.4f} ms/frame  " +
               " ".join(f"{k} {v[0]/max(1,v[1])*1e3:.1f}us" for k, v in kt.items()), flush=True)
 loop.close()

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False):
     tp = abi.default_trace_params(reflections=False)
     plans = [tiling.make_plan(H, world, r, max_motion_rows) for r in range(world)]
     ranks = [GpuHybrid(scene, W, H, reflections=False, trace_params=tp, gbuffer="standin") for _ in range(world)]
@@ -41,6 +41,7 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False):
             g.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
             pc = g.path.push_constants()
             g.ctx.set_option("trace_overlap", 1 if trace_overlap else 0)
+            g.ctx.set_option("strip_shrink_overlap", 1 if shrink else 0)
             if not trace_overlap:
                 g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], plan.overlap))
             g.ctx.set_pass_epilogue("SVGF Denoise Pass", lambda c: exchange(
@@ -66,8 +67,9 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False):
     return plans, results
 
 
-@pytest.mark.parametrize("world,trace_overlap", [(2, False), (3, False), (2, True), (3, True)])
-def test_virtual_strips_bit_identical(world, trace_overlap):
+@pytest.mark.parametrize("world,trace_overlap,shrink", [(2, False, False), (3, False, False), (2, True, False), (3, True, False),
+                                                        (2, True, True), (3, True, True), (3, False, True)])
+def test_virtual_strips_bit_identical(world, trace_overlap, shrink):
     scene = scenes.tiny_scene()
     W, H = 96, 132
     pfds = camera.dolly_frames(scene, W, H, 5)
@@ -84,7 +86,7 @@ def test_virtual_strips_bit_identical(world, trace_overlap):
                 max_mv = max(max_mv, float(np.nanmax(np.abs(np.nan_to_num(mv[d != 0])))) * H)
     finally:
         single.close()
-    plans, results = _run_strips(scene, W, H, world, pfds, int(np.ceil(max_mv)), trace_overlap)
+    plans, results = _run_strips(scene, W, H, world, pfds, int(np.ceil(max_mv)), trace_overlap, shrink)
     for r, plan in enumerate(plans):
         for f, (rt, den) in enumerate(results[r]):
             assert np.array_equal(rt, ref[f][0][plan.row_begin:plan.row_end]), f"rank {r} frame {f}: raytraced rows differ"

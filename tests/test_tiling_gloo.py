@@ -36,17 +36,26 @@ def test_plans_partition_the_image():
         tiling.make_plan(256, 8, 0, 4)             # 32-row strips cannot hold a 36-row halo
 
 
-@pytest.mark.parametrize("world,shrink", [(2, 0), (3, 0), (2, 1)])
-def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink):
+def test_shrinking_extents():
+    # n = 5, E = 30: the rows beyond the strip each iteration still has to produce (the last two feed nothing beyond it)
+    assert [tiling.atrous_output_extent(30, 1 << i) for i in range(5)] == [28, 24, 16, 0, 0]
+    assert [tiling.atrous_output_extent(14, 1 << i) for i in range(4)] == [12, 8, 0, 0]
+    assert tiling.atrous_output_extent(0, 1) == 0
+
+
+# (world, overlap shortfall, per-iteration shrinking extents, bias on those extents)
+@pytest.mark.parametrize("world,shrink,strip_shrink,bias", [(2, 0, 0, 0), (3, 0, 0, 0), (2, 1, 0, 0), (2, 0, 1, 0), (3, 0, 1, 0), (2, 0, 1, -1)])
+def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink, strip_shrink, bias):
     out = tmp_path / "result.txt"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + world), OMP_NUM_THREADS="2",
-               VHR_TEST_SHRINK_OVERLAP=str(shrink))
+    port = 29611 + world + 10 * strip_shrink + 20 * (bias != 0) + 40 * shrink
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+               VHR_TEST_SHRINK_OVERLAP=str(shrink), VHR_TEST_STRIP_SHRINK=str(strip_shrink), VHR_TEST_STRIP_SHRINK_BIAS=str(bias))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29611 + world), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "64", "120", "4"]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "64", "120", "4"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     bad, overlap, halo = out.read_text().split()
-    if shrink:      # negative control: one row less than the derived overlap is already wrong
+    if shrink or bias:      # negative controls: one row less than the derived overlap / extents is already wrong
         assert int(bad) > 0
         return
     assert int(bad) == 0, f"{bad} (rank, frame) pairs differ from the single-process result"

@@ -71,7 +71,11 @@ def main():
         moments = mom_new
         for i in range(5):
             out = ob.svgf_atrous(pfd, normals, x, 1 << i)
-            poison_outside(out, c0, c1)
+            if int(os.environ.get("VHR_TEST_STRIP_SHRINK", "0")):      # the product's "strip_shrink_overlap": later iterations compute fewer rows
+                ext = tiling.atrous_output_extent(E, 1 << i) + int(os.environ.get("VHR_TEST_STRIP_SHRINK_BIAS", "0"))
+                poison_outside(out, y0 - ext, y1 + ext)
+            else:
+                poison_outside(out, c0, c1)
             y[:] = out
             if i == 0:
                 history[b0:b1] = y[b0:b1]

@@ -809,7 +809,15 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     a.width = W; a.height = H;
     a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
     a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
-    strip_rows(ctx, H, ctx->overlap, a.row_begin, a.row_end);
+    // Strips: an iteration with step s reads +-2s rows, so after the doubling schedule 1, 2, ..., s (hybrid_render_path.cpp:
+    // 299-319) only the rows within overlap - (4s - 2) of the strip can still be valid -- and only those are needed by the
+    // iterations that follow.  With "strip_shrink_overlap" the launch computes just them (tiling.atrous_output_extent).
+    uint32_t extend = ctx->overlap;
+    if (ctx->options[kOptShrinkOverlap]) {
+        const uint64_t consumed = 4ull * uint64_t(step) - 2ull;
+        extend = consumed >= extend ? 0u : uint32_t(extend - consumed);
+    }
+    strip_rows(ctx, H, extend, a.row_begin, a.row_end);
     a.step = step;
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];

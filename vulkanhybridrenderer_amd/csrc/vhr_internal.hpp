@@ -137,7 +137,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptCount = 16 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptCount = 17 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelKinds = 4 };

@@ -63,6 +63,8 @@ class HybridFrameLoop:
             # removes exchange #1 from the critical path; only the deferred history exchange remains (tiling.py)
             self.trace_overlap = bool(trace_overlap) and denoise
             self.ctx.set_option("trace_overlap", 1 if self.trace_overlap else 0)
+            # the path's own host driver runs the doubling a-trous schedule, so later iterations may compute fewer overlap rows
+            self.ctx.set_option("strip_shrink_overlap", 1)
             self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
             if denoise:
                 self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)

@@ -34,6 +34,14 @@ def atrous_overlap(atrous_steps=5):
     return 2 * (2 ** (atrous_steps - 1) - 1)
 
 
+def atrous_output_extent(overlap, step):
+    """Rows beyond the strip an a-trous launch with step `step` has to produce under the reference's doubling schedule
+    (steps 1, 2, 4, ...; hybrid_render_path.cpp:299-319): the iterations up to and including this one have consumed
+    sum 2*2^j = 4*step - 2 rows of validity, and the later ones need exactly what is left.  The product's option
+    "strip_shrink_overlap" makes the kernels compute only these rows (n = 5, E = 30: 28, 24, 16, 0, 0)."""
+    return max(0, overlap - (4 * step - 2))
+
+
 @dataclass(frozen=True)
 class StripPlan:
     rank: int
