@@ -223,9 +223,13 @@ def main():
     ray_stats, trav_stats = ctx.ray_statistics(), ctx.traversal_statistics()
     ctx.set_ray_statistics(False)
     y0, y1 = loop.owned_rows()
-    rows_svgf = min(H, y1 + loop.plan.overlap) - max(0, y0 - loop.plan.overlap)
+    # rows an a-trous launch computes, averaged over the 5 launches of a frame: strips shrink the overlap per iteration
+    # (tiling.atrous_output_extent: 28, 24, 16, 0, 0 of E = 30); at N = 1 this is H
+    from vulkanhybridrenderer_amd import tiling
+    exts = [tiling.atrous_output_extent(loop.plan.overlap, 1 << i) if world > 1 else 0 for i in range(loop.atrous_steps)]
+    rows_svgf = sum(min(H, y1 + e) - max(0, y0 - e) for e in exts) / len(exts)
     atrous_us = kt["svgf_atrous"][0] / max(1, kt["svgf_atrous"][1]) * 1e3
-    atrous_bytes = ATROUS_BYTES_PER_PIXEL * W * rows_svgf
+    atrous_bytes = int(ATROUS_BYTES_PER_PIXEL * W * rows_svgf)
     achieved = atrous_bytes / (atrous_us * 1e-6) / 1e9 if atrous_us > 0 else 0.0
     raygen_ms = kt["raygen"][0] / max(1, kt["raygen"][1])
     passes = {}
