@@ -171,3 +171,67 @@ def temporal(W, H, normals_bits, motion_bits, rt_bits, prev_normals_bits, histor
     sv = np.maximum(F(0), sm1 - sm0 * sm0).astype(F)
     av = np.maximum(F(0), am1 - am0 * am0).astype(F)
     return f2h(np.stack([out_s, out_a, sv, av], -1)), f2h(np.stack([sm0, sm1], -1))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K2 in float64, written from the GLSL (raygen.rgen:59-65, reflection_hit.rchit:10-72, common.glsl:116-150) for untextured
+# materials: a second derivation of the shading formulas, compared with the oracle at fp16 resolution.
+# ---------------------------------------------------------------------------------------------------------
+def _mat(pfd, name):
+    return np.asarray(pfd[name], np.float64).reshape(4, 4).T          # column-major 16 floats -> math matrix
+
+
+def world_position(pfd, depth, u, v):                                  # glsl_common.h:118-122
+    r = _mat(pfd, "camera_viewproj_inverse") @ np.array([u * 2.0 - 1.0, v * 2.0 - 1.0, depth, 1.0])
+    return r[:3] / r[3]
+
+
+def reflection_ray(pfd, depth, normal, x, y, W, H, bias=0.1):           # raygen.rgen:15-16,26-29,60-63
+    P = world_position(pfd, float(depth), (x + 0.5) / W, (y + 0.5) / H)
+    N = np.asarray(normal, np.float64)
+    cam = _mat(pfd, "camera_view_inverse")[:3, 3]
+    I = (P - cam) / np.linalg.norm(P - cam)
+    return P + bias * N, I - 2.0 * np.dot(N, I) * N
+
+
+def interpolate_hit(scene, prim_index, tri, u, v):                      # reflection_hit.rchit:11-24
+    pr = scene.primitives[prim_index]
+    idx = scene.indices[int(pr["index_offset"]) + 3 * tri:int(pr["index_offset"]) + 3 * tri + 3]
+    vs = scene.vertices[int(pr["vertex_offset"]) + idx]
+    b = np.array([1.0 - u - v, u, v])
+    normal = (np.asarray(vs["normal"], np.float64) * b[:, None]).sum(0)           # object space, unnormalised (:23)
+    opos = (np.asarray(vs["pos"], np.float64) * b[:, None]).sum(0)
+    M = np.asarray(pr["transform"], np.float64).reshape(4, 4).T
+    return pr, normal, (M @ np.append(opos, 1.0))[:3]
+
+
+def brdf_terms(albedo, metallic, roughness, N, V, L):                   # common.glsl:116-150
+    H = (L + V) / np.linalg.norm(L + V)
+    f0 = 0.04 * (1.0 - metallic) + albedo * metallic                    # mix(vec3(0.04), albedo, metallic)
+    hv = max(np.dot(H, V), 0.0)
+    F = f0 + (1.0 - f0) * (1.0 - hv) ** 5
+    a2 = roughness * roughness
+    nh = max(np.dot(N, H), 0.0)
+    f = nh * nh * (a2 - 1.0) + 1.0
+    D = a2 / (np.pi * f * f)
+    k = (roughness + 1.0) ** 2 * 0.125
+    nv, nl = max(np.dot(N, V), 0.0), max(np.dot(N, L), 0.0)
+    G = (nv / (nv * (1.0 - k) + k)) * (nl / (nl * (1.0 - k) + k))
+    specular = D * G * F / max(4.0 * nv * nl, 1e-6)
+    diffuse = (1.0 - F) * (1.0 - metallic) * albedo / np.pi
+    return diffuse, specular, nl
+
+
+def reflection_hit(scene, pfd, prim_index, tri, u, v):                  # reflection_hit.rchit:26-71, untextured materials
+    pr, N, position = interpolate_hit(scene, prim_index, tri, u, v)
+    m = pr["material"]
+    assert int(m["base_color_texture"]) == -1 and int(m["metallic_roughness_texture"]) == -1
+    albedo = np.asarray(m["base_color"], np.float64)[:3]
+    roughness = min(max(float(m["roughness_factor"]), 0.04), 1.0)
+    metallic = min(max(float(m["metallic_factor"]), 0.0), 1.0)
+    cam = _mat(pfd, "camera_view_inverse")[:3, 3]
+    V = (cam - position) / np.linalg.norm(cam - position)
+    light = pfd["directional_light"]
+    L = -np.asarray(light["direction"], np.float64)[:3]
+    diffuse, specular, nl = brdf_terms(albedo, metallic, roughness, N, V, L)
+    return albedo * (0.2 / np.pi) + (diffuse + specular) * nl * np.asarray(light["intensity"], np.float64)[:3] * np.asarray(light["color"], np.float64)[:3]

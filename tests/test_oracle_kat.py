@@ -254,3 +254,40 @@ def test_composition_golden_and_orientation(oracle):
     off = oracle.composition(pfd, (2, 2, 2), c["albedo"], t["normals"], t["motion"], t["depth"], t["shadow_ao"], t["reflections"])
     lit = oracle.composition(pfd, (0, 2, 2), c["albedo"], t["normals"], t["motion"], t["depth"], t["shadow_ao"], t["reflections"])
     assert (lit[..., :3].astype(int) <= off[..., :3].astype(int)).all() and (lit != off).any()      # shadows only darken
+
+
+def test_reflection_hit_matches_float64_restatement(oracle):
+    """K2 (raygen.rgen:59-65 + reflection_hit.rchit:10-72 + common.glsl:116-150) against an independent float64 numpy
+    derivation from the GLSL, on the untextured tiny scene: same hit, payload equal at fp16 resolution."""
+    from tests import numpy_restatement as nr
+    from tests.helpers import f16
+    sc = scenes.tiny_scene()
+    osc = oracle.Scene(sc)
+    W, H = 48, 30
+    pfd = camera.dolly_frames(sc, W, H, 3)[2]
+    n, m, d = osc.gbuffer(pfd, W, H)
+    sa, refl, mask, rays = osc.raygen(pfd, abi.default_trace_params(), n, d)
+    normals, got = f16(n), f16(refl)
+    checked = 0
+    mismatched = 0
+    for y in range(H):
+        for x in range(W):
+            if d[y, x] == 0:
+                assert not refl[y, x].any()                                   # raygen.rgen:20-24: sky writes vec4(0)
+                continue
+            o, r = nr.reflection_ray(pfd, d[y, x], normals[y, x, :3], x, y, W, H)
+            hit = osc.closest(o, r, 0.01, 1e4)
+            if hit is None:
+                if not (mask[y, x] & 0x80):
+                    assert not refl[y, x].any()                               # reflection_miss.rmiss:7
+                continue
+            if not (mask[y, x] & 0x80):
+                continue                                                      # float64 vs float32 ray at a silhouette
+            t, u, v, prim, tri = hit
+            want = nr.reflection_hit(sc, pfd, prim, tri, float(u), float(v))
+            tol = 3 * 2.0 ** -10 * np.maximum(np.abs(want), 2.0 ** -14)        # 3 fp16 steps: fp32 chain + the final fp16 store
+            if (np.abs(got[y, x, :3] - want) <= tol).all() and got[y, x, 3] == 1.0:
+                checked += 1
+            else:
+                mismatched += 1           # the float64 ray may pick the neighbouring triangle at an edge; a formula error would hit every pixel
+    assert checked > 300 and mismatched <= checked // 100, (checked, mismatched)
