@@ -187,7 +187,7 @@ def main():
     # Only the roofline kernel (a-trous) carries event pairs inside the timed region; the other kernels are timed
     # in a short extra loop afterwards so that their event records do not sit in the measured frames.
     ctx.set_kernel_timing(["svgf_atrous"])
-    for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit"):
+    for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit", "reflection"):
         ctx.kernel_time(k, reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -197,7 +197,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.gather_performance_statistics()
     atrous_timed = ctx.kernel_time("svgf_atrous")
-    ctx.set_kernel_timing(["raygen", "svgf_temporal", "blit"])
+    ctx.set_kernel_timing(["raygen", "svgf_temporal", "blit", "reflection"])
     for i in range(args.warmup, args.warmup + min(args.steps, 8)):
         loop.frame(i)
     barrier()
@@ -213,7 +213,7 @@ def main():
     else:
         dt_max, total_rays = dt, float(my_rays)
 
-    kt = {k: ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "blit")}
+    kt = {k: ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "blit", "reflection")}
     kt["svgf_atrous"] = atrous_timed
     ctx.set_kernel_timing(False)
     # traversal work counters (one extra, untimed frame with the in-kernel statistics enabled)
@@ -274,9 +274,9 @@ def main():
                 "algorithmic_bytes_per_launch": int(atrous_bytes),
             },
             "traversal": {
-                "kernel": "raygen_kernel (raygen.rgen + miss + reflection_hit)",
+                "kernel": "raygen_queue_kernel (raygen.rgen's shadow + AO rays + miss.rmiss); the mirror ray runs in reflection_kernel (kernels_us.reflection)",
                 "avg_launch_ms": round(raygen_ms, 4),
-                "mrays_per_s": round(loop.rays_in_frame(args.warmup) / max(raygen_ms, 1e-9) / 1e3, 1),
+                "mrays_per_s": round(loop.rays_in_frame(args.warmup) * (1 + args.ao_spp) / max(1, loop.rays_per_pixel) / max(raygen_ms, 1e-9) / 1e3, 1),
                 "bvh_nodes": int(bvh["nodes"]), "bvh_bytes": int(bvh["node_bytes"] + bvh["triangle_bytes"]), "bvh_max_depth": int(bvh["max_depth"]),
                 "active_lane_utilisation": round(trav_stats["active_lane_utilisation"], 3),
                 "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
@@ -287,7 +287,8 @@ def main():
             },
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),
-                           "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2)},
+                           "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2),
+                           "reflection": round(kt["reflection"][0] / max(1, kt["reflection"][1]) * 1e3, 2) if kt["reflection"][1] else None},
             "passes_ms": passes,
         }
         if not args.no_cpu_baseline:

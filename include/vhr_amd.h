@@ -303,11 +303,14 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      overlap - (4s - 2) rows instead of the full overlap -- all that can be valid, and all that is needed,
  *                      after the reference's doubling schedule 1, 2, 4, ... s (hybrid_render_path.cpp:299-319); only for callers
  *                      that run that schedule (default 0).  Owned rows are bit-identical either way.
+ *   "reflection_variant" the mirror ray (one bounce): 1 = work-queue kernel, closest-hit walk per 16x8 tile + shading with the
+ *                      whole wave (default), 0 = one pixel per thread (also what two bounces use)
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
 /* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel
- * kind: 0 = raygen (K1+K2), 1 = svgf.comp (K3), 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5).
+ * kind: 0 = raygen (K1: shadow + AO rays; with raygen_variant 0 also the mirror ray), 1 = svgf.comp (K3),
+ * 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5), 4 = the mirror-ray kernel (K1's reflection ray + K2).
  * kind_mask has bit (1 << kind) set for every kind to time (0 = off).  vhr_get_kernel_time synchronises, folds
  * the recorded pairs into (total milliseconds, launch count) and optionally resets the totals. */
 int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask);

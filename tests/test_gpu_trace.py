@@ -101,3 +101,30 @@ def test_standin_gbuffer_close_to_oracle(oracle):
         assert np.abs(f16(m)[same_id][:, :2] - f16(m0)[same_id][:, :2]).max() < 1e-3
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("tiny", 100, 37), ("sponza", 480, 270), ("bistro_small", 200, 120)])
+def test_mirror_ray_kernels_bit_identical(oracle, scene_name, W, H):
+    """The work-queue mirror-ray kernel (reflection_variant 1, default) and the one-pixel-per-thread kernel (0) trace the same
+    rays with the same arithmetic and shade with the same code: their RGBA16F images are equal bit for bit, at sizes that are
+    not multiples of the 16x8 tile, with and without an LDS-only stack."""
+    scene = {"tiny": scenes.tiny_scene, "sponza": scenes.sponza_proc,
+             "bistro_small": lambda: scenes.bistro_proc(detail=0.02, n_primitives=300, n_textures=8, texture_size=64)}[scene_name]()
+    tp = abi.default_trace_params()
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, gbuffer="standin")
+    try:
+        g.ctx.set_ray_statistics(True)
+        for pfd in camera.dolly_frames(scene, W, H, 3):
+            out = {}
+            for variant, levels in ((0, 8), (1, 8), (1, 32), (1, 2)):
+                g.ctx.set_option("reflection_variant", variant)
+                g.ctx.set_option("lds_stack_levels", levels)
+                g.frame(pfd)
+                out[(variant, levels)] = g.ctx.download(lib.REFLECTIONS)
+                assert g.ctx.ray_statistics()["stack_overflows"] == 0
+            for k, img in out.items():
+                assert np.array_equal(img, out[(0, 8)]), f"reflection_variant {k} differs on {(img != out[(0, 8)]).any(-1).sum()} pixels"
+        assert (f16(out[(0, 8)])[..., 3] > 0).mean() > 0.1
+    finally:
+        g.ctx.set_option("lds_stack_levels", 8)
+        g.close()

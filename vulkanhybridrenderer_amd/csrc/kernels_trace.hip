@@ -783,6 +783,172 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Mirror ray, work-queue form (the default for one bounce): closest-hit traversal with the node step of raygen_queue_kernel.
+//
+// Every wave owns a 16x8-pixel tile = a queue of up to 128 mirror rays.  Phase 1 (whole wave, twice): raygen.rgen:15-29,60-63
+// per pixel -- origin and reflect(I, N) parked in LDS, covered pixels compacted with a ballot.  Phase 2: lanes pull rays from
+// the queue whenever `refill_threshold` of them are idle and walk the BVH "while-while": the branch-free inner-node step
+// (packed-FMA slabs against 1/d and -o/d, near child first, far child pushed, boxes culled against the closest t so far),
+// then the leaf's <= 4 Moeller-Trumbore tests with the (t, flat index) order of decision (vi).  A finished ray leaves its
+// hit record (triangle, u, v) in the LDS slot its origin came from.  Phase 3 (whole wave, twice): reflection_hit.rchit on
+// the records -- the texture fetches and the BRDF run with all lanes active instead of inside the divergent walk.
+// Results are those of reflection_kernel bit for bit: the same rays, the same intersection arithmetic, the same shader.
+// ---------------------------------------------------------------------------------------------
+constexpr int kReflRays = 128;
+constexpr uint32_t kNoHit = 0xffffffffu;
+
+template <bool SPILL>
+__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
+    const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
+    const uint32_t early_exit) {
+    extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
+    __shared__ float s_ray_all[2][6][kReflRays];          // origin (3) + direction (3); rows 0..2 become the hit record
+    __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 2u + wave;
+    if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
+    float (&s_ray)[6][kReflRays] = s_ray_all[wave];
+    uint8_t (&s_list)[kReflRays] = s_list_all[wave];
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    stack[0] = kStackSentinel;
+    const uint32_t W = a.width, H = a.height;
+    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+
+    // ---- phase 1: per-pixel ray setup, whole wave ----
+    unsigned long long covered_mask[2];
+    uint32_t ncov = 0;
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const bool in_range = x < W && y < a.row_end;
+        const float depth = in_range ? a.depth[size_t(y) * W + x] : 0.0f;                    // rgen:19
+        const bool covered = depth != 0.0f;
+        if (in_range && !covered) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);   // rgen:22
+        const uint32_t p = sub * 64u + lane;
+        if (covered) {
+            const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);  // rgen:15-16
+            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
+            const f4 nid = load_rgba16f(a.normals, W, x, y);                                 // rgen:28
+            const f3 N = f3{ nid.x, nid.y, nid.z };
+            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
+            const f3 I = normalize3(P - cam);                                                // rgen:60
+            const float ni2 = 2.0f * dot3(N, I);
+            const f3 rdir = I - N * ni2;                                                     // rgen:61 reflect(I, N)
+            s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
+            s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
+        }
+        const unsigned long long m = __ballot(covered);
+        covered_mask[sub] = m;
+        if (covered) s_list[ncov + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        ncov += uint32_t(__popcll(m));
+    }
+    wave_lds_sync();
+    const uint32_t total = a.scene.node_count == 0 ? 0u : ncov;
+
+    // ---- phase 2: the queue ----
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_tri = kNoHit, best_flat = 0;
+    int cur = 0, sp = 0;
+    uint32_t pix = 0, next = 0, overflow = 0;
+    bool has = false;
+    int spill[SPILL ? kTraceStack : 1];
+    const float tmin = a.tp.tmin, tmax = a.tp.tmax;
+    float tmin_v = tmin;
+    asm volatile("" : "+v"(tmin_v));
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {                 // wave-uniform
+            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            next += n_idle;
+            if (!has && r < total) {
+                pix = s_list[r];
+                ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+                rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
+                cur = 0; sp = 0;
+                has = true;
+            }
+        }
+        if (!__any(has)) break;
+        // ---- inner nodes (see raygen_queue_kernel for the step; here the far child waits on the stack and boxes
+        //      beyond the closest hit so far are culled: tn <= tbest keeps equal-t candidates, decision vi) ----
+        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
+        while (has && cur >= 0) {
+            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
+            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            float tn0, tn1;
+            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tbest, tn0);
+            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tbest, tn1);
+            const bool both = h0 && h1, none = !(h0 || h1);
+            const bool first0 = tn0 <= tn1;
+            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
+            int top = row[0];
+            row[kQueueBlock] = farc;
+            if (__any(uint32_t(sp) >= stack_levels)) {
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (uint32_t(sp) >= stack_levels) {
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    else overflow |= both ? 1u : 0u;
+                }
+            }
+            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
+            sp += (both ? 1 : 0) - (none ? 1 : 0);
+        }
+        // ---- leaf: every triangle of it, closest = min t then smaller flat index ----
+        if (has && cur < 0 && cur != kStackSentinel) {
+            const uint32_t vv = ~uint32_t(cur);
+            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float t, uu, ww;
+                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
+                    const uint32_t flat = __float_as_uint(tc.w);
+                    if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
+                        tbest = t; best_tri = first + i; best_flat = flat; best_u = uu; best_v = ww;
+                    }
+                }
+            }
+            cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];                 // pop (the sentinel if nothing is pending)
+            if (SPILL && __any(uint32_t(sp) > stack_levels)) {
+                if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+            }
+            --sp;
+        }
+        if (has && cur == kStackSentinel) {                                                  // the hit record replaces the ray's origin
+            has = false;
+            s_ray[0][pix] = __uint_as_float(best_tri); s_ray[1][pix] = best_u; s_ray[2][pix] = best_v;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- phase 3: reflection_hit.rchit / reflection_miss.rmiss on the records, whole wave ----
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        if (!((covered_mask[sub] >> lane) & 1ull)) continue;
+        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const uint32_t p = sub * 64u + lane;
+        f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                           // reflection_miss.rmiss:7
+        const uint32_t tri = total ? __float_as_uint(s_ray[0][p]) : kNoHit;
+        if (tri != kNoHit) {
+            Hit h;
+            h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
+            payload = shade_reflection_hit(a.scene, a.pfd, h);
+        }
+        store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);   // rgen:65
+    }
+    if (a.stats && overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
+}
+
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
                   const Image &depth, Image &shadow_ao, Image *reflections) {
     if (width != normals.width || height != normals.height || width != depth.width || height != depth.height ||
@@ -852,13 +1018,27 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
-        if (a.reflections && a.tp.reflections) {       // not denoised: owned rows only
-            a.row_begin = owned_begin;
-            a.row_end = owned_end;
-            hipLaunchKernelGGL(reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, ctx->stream, a);
-        }
     }
     ctx->time_end(kKernelRaygen);
+    if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {       // not denoised: owned rows only
+        a.row_begin = owned_begin;
+        a.row_end = owned_end;
+        ctx->time_begin(kKernelReflection);
+        if (a.tp.reflections == 1 && ctx->options[kOptReflectionVariant] != 0) {
+            const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
+            const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
+            const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
+            const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
+            const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
+            if (levels < ctx->bvh_depth + 1u)
+                hipLaunchKernelGGL(reflection_queue_kernel<true>, dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit);
+            else
+                hipLaunchKernelGGL(reflection_queue_kernel<false>, dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit);
+        } else {
+            hipLaunchKernelGGL(reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, ctx->stream, a);
+        }
+        ctx->time_end(kKernelReflection);
+    }
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {
         if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

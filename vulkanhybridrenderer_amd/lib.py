@@ -460,7 +460,7 @@ class Context:
         self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
 
-    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3}
+    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4}
 
     def set_option(self, key, value):
         self.check(self.L.vhr_set_option(self.handle, key.encode(), int(value)), "set_option")
