@@ -110,21 +110,25 @@ def test_mirror_ray_kernels_bit_identical(oracle, scene_name, W, H):
     not multiples of the 16x8 tile, with and without an LDS-only stack."""
     scene = {"tiny": scenes.tiny_scene, "sponza": scenes.sponza_proc,
              "bistro_small": lambda: scenes.bistro_proc(detail=0.02, n_primitives=300, n_textures=8, texture_size=64)}[scene_name]()
-    tp = abi.default_trace_params()
-    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, gbuffer="standin")
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=abi.default_trace_params(), gbuffer="standin")
     try:
         g.ctx.set_ray_statistics(True)
-        for pfd in camera.dolly_frames(scene, W, H, 3):
-            out = {}
-            for variant, levels in ((0, 8), (1, 8), (1, 32), (1, 2)):
-                g.ctx.set_option("reflection_variant", variant)
-                g.ctx.set_option("lds_stack_levels", levels)
-                g.frame(pfd)
-                out[(variant, levels)] = g.ctx.download(lib.REFLECTIONS)
-                assert g.ctx.ray_statistics()["stack_overflows"] == 0
-            for k, img in out.items():
-                assert np.array_equal(img, out[(0, 8)]), f"reflection_variant {k} differs on {(img != out[(0, 8)]).any(-1).sum()} pixels"
-        assert (f16(out[(0, 8)])[..., 3] > 0).mean() > 0.1
+        for bounces in (1, 2):                                    # 2 = the two-bounce extension (tests/test_two_bounce.py)
+            g.ctx.set_trace_params(abi.default_trace_params(reflections=bounces))
+            for pfd in camera.dolly_frames(scene, W, H, 3):
+                out, rays = {}, {}
+                for variant, levels in ((0, 8), (1, 8), (1, 32), (1, 2)):
+                    g.ctx.set_option("reflection_variant", variant)
+                    g.ctx.set_option("lds_stack_levels", levels)
+                    g.frame(pfd)
+                    out[(variant, levels)] = g.ctx.download(lib.REFLECTIONS)
+                    st = g.ctx.ray_statistics()
+                    assert st["stack_overflows"] == 0
+                    rays[(variant, levels)] = st["unique_rays"]
+                for k, img in out.items():
+                    assert np.array_equal(img, out[(0, 8)]), f"{bounces} bounce(s), reflection_variant {k}: {(img != out[(0, 8)]).any(-1).sum()} pixels differ"
+                    assert rays[k] == rays[(0, 8)]
+            assert (f16(out[(0, 8)])[..., 3] > 0).mean() > 0.1
     finally:
         g.ctx.set_option("lds_stack_levels", 8)
         g.close()

@@ -302,6 +302,16 @@ __device__ f4 shade_reflection_hit(const DeviceScene &sc, const vhr_per_frame_da
     return f4{ lighting.x, lighting.y, lighting.z, 1.0f };
 }
 
+// world-space hit point and the shader's N of reflection_hit.rchit:11-24,44 (what shade_reflection_hit returns through
+// hit_position / hit_normal, without the shading)
+__device__ __forceinline__ void hit_position_normal(const DeviceScene &sc, const Hit &h, f3 &position, f3 &normal) {
+    const BvhTri &bt = sc.tris[h.tri_index];
+    const vhr_primitive &prim = sc.primitives[bt.prim];
+    const TriAttributes at = interpolate(sc, prim, bt.tri, h.u, h.v);
+    position = mat4_mul_point(prim.transform, at.object_pos);
+    normal = at.normal;
+}
+
 // The mirror ray of raygen.rgen:59-65 with the optional second bounce: a mirror ray from the first hit about the shader's N
 // (normalised, facing the incoming ray), origin biased like raygen.rgen:29, shaded by reflection_hit.rchit without recursion.
 __device__ __forceinline__ f4 trace_reflection(const DeviceScene &sc, const vhr_per_frame_data &pfd, const vhr_trace_params &tp, f3 origin,
@@ -798,17 +808,20 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 constexpr int kReflRays = 128;
 constexpr uint32_t kNoHit = 0xffffffffu;
 
-template <bool SPILL>
+template <bool SPILL, int BOUNCES>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
     const uint32_t early_exit) {
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
-    __shared__ float s_ray_all[2][6][kReflRays];          // origin (3) + direction (3); rows 0..2 become the hit record
+    // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
+    // and rows 3-5 are rewritten with the second direction between the two walks
+    constexpr int ROWS = BOUNCES > 1 ? 9 : 6;
+    __shared__ float s_ray_all[2][ROWS][kReflRays];
     __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
-    float (&s_ray)[6][kReflRays] = s_ray_all[wave];
+    float (&s_ray)[ROWS][kReflRays] = s_ray_all[wave];
     uint8_t (&s_list)[kReflRays] = s_list_all[wave];
     int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
@@ -845,9 +858,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         ncov += uint32_t(__popcll(m));
     }
     wave_lds_sync();
-    const uint32_t total = a.scene.node_count == 0 ? 0u : ncov;
+    uint32_t total = a.scene.node_count == 0 ? 0u : ncov;
+    const bool traced = total != 0;
 
-    // ---- phase 2: the queue ----
+    // ---- phase 2: the queue (once per bounce) ----
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
@@ -858,6 +872,11 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const float tmin = a.tp.tmin, tmax = a.tp.tmax;
     float tmin_v = tmin;
     asm volatile("" : "+v"(tmin_v));
+    uint32_t second_rays = 0;
+#pragma unroll 1
+    for (int bounce = 0; bounce < BOUNCES; ++bounce) {
+    const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
+    next = 0;
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = uint32_t(__popcll(idle));
@@ -866,7 +885,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             next += n_idle;
             if (!has && r < total) {
                 pix = s_list[r];
-                ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+                ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
                 rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
@@ -926,10 +945,42 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         }
         if (has && cur == kStackSentinel) {                                                  // the hit record replaces the ray's origin
             has = false;
-            s_ray[0][pix] = __uint_as_float(best_tri); s_ray[1][pix] = best_u; s_ray[2][pix] = best_v;
+            s_ray[orow][pix] = __uint_as_float(best_tri); s_ray[orow + 1][pix] = best_u; s_ray[orow + 2][pix] = best_v;
         }
     }
     wave_lds_sync();
+    if (BOUNCES > 1 && bounce == 0) {
+        // ---- second-bounce rays (trace_reflection's arithmetic), whole wave: a mirror ray from every first hit ----
+        uint32_t n2 = 0;
+#pragma unroll
+        for (uint32_t sub = 0; sub < 2; ++sub) {
+            const uint32_t p = sub * 64u + lane;
+            const bool was_covered = traced && ((covered_mask[sub] >> lane) & 1ull);
+            const uint32_t tri = was_covered ? __float_as_uint(s_ray[0][p]) : kNoHit;
+            const bool hit1 = tri != kNoHit;
+            if (hit1) {
+                Hit h;
+                h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
+                f3 hp, hn;
+                hit_position_normal(a.scene, h, hp, hn);
+                const f3 rdir = f3{ s_ray[3][p], s_ray[4][p], s_ray[5][p] };
+                const f3 nn = normalize3(hn);
+                const float ni = dot3(nn, rdir);
+                const f3 nf = ni < 0.0f ? nn : -nn;
+                const f3 d2 = rdir - nn * (2.0f * ni);
+                const f3 o2 = hp + nf * a.tp.normal_bias;
+                s_ray[6][p] = o2.x; s_ray[7][p] = o2.y; s_ray[8][p] = o2.z;
+                s_ray[3][p] = d2.x; s_ray[4][p] = d2.y; s_ray[5][p] = d2.z;
+            }
+            const unsigned long long m = __ballot(hit1);
+            if (hit1) s_list[n2 + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+            n2 += uint32_t(__popcll(m));
+        }
+        wave_lds_sync();
+        total = n2;
+        second_rays = n2;
+    }
+    }
 
     // ---- phase 3: reflection_hit.rchit / reflection_miss.rmiss on the records, whole wave ----
 #pragma unroll
@@ -938,15 +989,29 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
         const uint32_t p = sub * 64u + lane;
         f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                           // reflection_miss.rmiss:7
-        const uint32_t tri = total ? __float_as_uint(s_ray[0][p]) : kNoHit;
+        const uint32_t tri = traced ? __float_as_uint(s_ray[0][p]) : kNoHit;
         if (tri != kNoHit) {
             Hit h;
             h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
-            payload = shade_reflection_hit(a.scene, a.pfd, h);
+            if (BOUNCES > 1) {
+                f4 second = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                    // reflection_miss.rmiss:7
+                const uint32_t tri2 = __float_as_uint(s_ray[6][p]);
+                if (tri2 != kNoHit) {
+                    Hit h2;
+                    h2.t = 0.0f; h2.u = s_ray[7][p]; h2.v = s_ray[8][p]; h2.tri_index = tri2; h2.flat = 0;
+                    second = shade_reflection_hit(a.scene, a.pfd, h2);
+                }
+                payload = shade_reflection_hit(a.scene, a.pfd, h, &second);
+            } else {
+                payload = shade_reflection_hit(a.scene, a.pfd, h);
+            }
         }
         store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);   // rgen:65
     }
-    if (a.stats && overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
+    if (a.stats && lane == 0) {
+        if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
+        if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
+    }
 }
 
 int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
@@ -1024,16 +1089,17 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         a.row_begin = owned_begin;
         a.row_end = owned_end;
         ctx->time_begin(kKernelReflection);
-        if (a.tp.reflections == 1 && ctx->options[kOptReflectionVariant] != 0) {
+        if (a.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
             const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-            if (levels < ctx->bvh_depth + 1u)
-                hipLaunchKernelGGL(reflection_queue_kernel<true>, dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit);
-            else
-                hipLaunchKernelGGL(reflection_queue_kernel<false>, dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit);
+#define VHR_LAUNCH_REFL(SP, B) hipLaunchKernelGGL((reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit)
+            const bool spill = levels < ctx->bvh_depth + 1u;
+            if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }
+            else { if (spill) VHR_LAUNCH_REFL(true, 1); else VHR_LAUNCH_REFL(false, 1); }
+#undef VHR_LAUNCH_REFL
         } else {
             hipLaunchKernelGGL(reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, ctx->stream, a);
         }
