@@ -48,6 +48,7 @@ class HybridFrameLoop:
         self.pfds = camera.dolly_frames(scene, width, height, n_frames, start_frame_index)
         self.current = 0
         self._aliases = {}
+        self._prepared = {}
         self._pending = None
         self.path = lib.HybridRenderPath(self.ctx, shadow_mode=0 if shadow else 2, ambient_occlusion_mode=0 if ao_spp else 2,
                                          reflection_mode=0 if reflections else 2, denoise=denoise, atrous_steps=atrous_steps,
@@ -125,9 +126,19 @@ class HybridFrameLoop:
         tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
 
     def _exchange_history(self, ctx):
-        hist = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_history"])))
-        mom = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))     # current (just written) buffer
-        self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)   # consumed by the NEXT frame
+        hist_info = ctx.storage_info(int(self.pc["shadow_and_ao_history"]))
+        mom_info = ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"]))            # current (just written) buffer
+        hist, mom = self._alias(hist_info), self._alias(mom_info)
+        if self.dist.get_backend() == "gloo":             # CPU transport (CI route): staged through host memory every frame
+            self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)
+            return
+        # RCCL: the descriptors of this exchange are built once per (history, moments) buffer pair -- the moments history
+        # alternates between two buffers -- and replayed every frame
+        key = (int(hist_info.device_ptr), int(mom_info.device_ptr))
+        prepared = self._prepared.get(key)
+        if prepared is None:
+            prepared = self._prepared[key] = tiling.PreparedExchange(self.dist, [hist, mom], self.plan, self.plan.halo)
+        self._pending = prepared.start()                  # consumed by the NEXT frame
 
     # ---- one frame of the hot path ----
     def frame(self, i):

@@ -137,6 +137,33 @@ def start_exchange(dist, tensors, plan, n_rows, group=None):
     return PendingExchange(dist.batch_isend_irecv(ops), staged, keep)
 
 
+class PreparedExchange:
+    """The P2P descriptors of one recurring device-to-device exchange (same tensors, same rows every frame), built once:
+    start() is then a single batch_isend_irecv call -- per frame the host only pays for the grouped launch, not for slicing
+    tensors and constructing eight P2POps (a 1080p frame on 8 GPUs leaves the host ~0.2 ms per frame in total)."""
+
+    def __init__(self, dist, tensors, plan, n_rows, group=None):
+        self.dist = dist
+        self.ops, self.keep = [], []
+        if plan.world == 1 or n_rows <= 0:
+            return
+        if dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors):
+            raise ValueError("prepared exchanges are device-to-device (RCCL); the staged gloo route goes through start_exchange")
+        for peer, (sa, sb), (ra, rb) in plan.exchanges(n_rows):
+            for t in tensors:
+                send, recv = t[sa:sb], t[ra:rb]
+                if not (send.is_contiguous() and recv.is_contiguous()):
+                    raise ValueError("row slices of a [H, ...] tensor must be contiguous")
+                self.ops.append(dist.P2POp(dist.isend, send, peer, group=group))
+                self.ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
+                self.keep += [send, recv]
+
+    def start(self):
+        if not self.ops:
+            return None
+        return PendingExchange(self.dist.batch_isend_irecv(self.ops), [], self.keep)
+
+
 def exchange_rows(dist, tensors, plan, n_rows, group=None):
     """Blocking form of start_exchange (the exchange is complete, in stream order, when this returns)."""
     pending = start_exchange(dist, tensors, plan, n_rows, group)
