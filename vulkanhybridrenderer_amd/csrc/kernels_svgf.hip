@@ -9,6 +9,8 @@
 // float tolerance stated in tests/test_svgf_gpu.py, not bit-exact.  Images are linear row-major buffers:
 // RGBA16F = one 8-byte uint2 per pixel, RG16F = one 4-byte word per pixel, so a 64-lane wave reading 64
 // consecutive pixels of a row moves 512 contiguous bytes (dwordx2 per lane).
+#include <type_traits>
+
 #include "device_math.hpp"
 #include "vhr_internal.hpp"
 
@@ -589,7 +591,12 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
     static_assert(TW <= 256, "one thread per staged column");
     __shared__ uint4 s_a[TH][TW];                    // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
     __shared__ float s_nz[TH][TW];
-    __shared__ uint16_t s_id[TH][TW];
+    // ids are 16-bit patterns.  With STEP == 1 the taps' ids are neighbours in LDS and the compiler merges their loads into
+    // ds_read_b64 / b96 at 2-byte alignment, which the LDS serialises (the step-1 launch ran 20 % behind the others: 56.7 vs
+    // 47 us); a 32-bit slot per id keeps the merged loads dword aligned.  Wider steps keep 16-bit slots (no merging
+    // possible, and their larger tiles would lose a resident block per CU to the extra LDS).
+    using IdSlot = typename std::conditional<STEP == 1, uint32_t, uint16_t>::type;
+    __shared__ IdSlot s_id[TH][TW];
     const int W = int(a.width), H = int(a.height);
     const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
     const int tid = int(threadIdx.x);
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                     }
                     s_a[kk][c] = va;
                     s_nz[kk][c] = nz;
-                    s_id[kk][c] = uint16_t(idb);
+                    s_id[kk][c] = IdSlot(idb);
                 }
             }
         }
