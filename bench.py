@@ -56,6 +56,9 @@ def parse():
     p.add_argument("--exchange-raytraced", action="store_true",
                    help="N > 1: trace owned rows only and fetch the overlap rows' raw shadow/AO from the neighbours "
                         "(default: every rank also traces its 30 overlap rows; no exchange on the critical path)")
+    p.add_argument("--no-gather", action="store_true",
+                   help="N > 1: leave the denoised strips on their GPUs (default: gathered to rank 0 every frame, asynchronously, "
+                        "inside the timed region -- the frame the composition stage of the display GPU consumes)")
     p.add_argument("--share-device", action="store_true", default=bool(os.environ.get("VHR_BENCH_SHARE_DEVICE")))
     return p.parse_args()
 
@@ -109,6 +112,9 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
             full = alias_tensor(ref.ctx.transient_info(lib.DENOISED)).view(torch.int16)
             full = full.cpu() if cpu else full
             ok &= bool(torch.equal(mine, full[y0:y1]))
+            gathered = loop.gathered_frame()                              # C2: the frame assembled on rank 0 by tiling.StripGather
+            if gathered is not None:
+                ok &= bool(torch.equal(gathered.view(torch.int16).cpu(), full.cpu()))
             for r in range(1, world):
                 a, b = sizes[r]
                 buf = torch.empty((b - a, W, 4), dtype=torch.int16, device=mine.device)
@@ -167,7 +173,8 @@ def main():
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup, args.max_gbuffers)
     loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True,
-                           device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, trace_overlap=not args.exchange_raytraced)
+                           device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, trace_overlap=not args.exchange_raytraced,
+                           gather=not args.no_gather)
     ctx = loop.ctx
 
     def barrier():
@@ -262,6 +269,8 @@ def main():
                 "strip_overlap_rows": loop.plan.overlap, "history_halo_rows": loop.plan.halo,
                 "overlap_rows_raytraced": ("recomputed locally" if getattr(loop, "trace_overlap", False) else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
+                "final_gather": ("denoised strips -> rank 0 every frame (point-to-point over RCCL, overlapped with the next frame's ray tracing, "
+                                 "finished inside the timed region)" if loop.gather else "off") if world > 1 else None,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
             },

@@ -55,6 +55,8 @@ def main():
     history = np.zeros((H, W, 4), np.uint16)
     moments = np.zeros((H, W, 2), np.uint16)
     worst = 0
+    den_t = torch.zeros((H, W, 4), dtype=torch.int16)              # persistent: StripGather's descriptors are built once
+    gather = tiling.StripGather(dist, den_t, plan)
     for f, (pfd, g) in enumerate(zip(pfds, gbufs)):
         normals, motion, depth = g
         # Raytrace Pass: owned rows only
@@ -88,6 +90,14 @@ def main():
         same = np.array_equal(denoised[y0:y1], ref[f][y0:y1])
         if not same:
             worst += 1
+        # C2: every rank's owned rows assembled on rank 0 must be the single-process frame, whatever the other rows held
+        den_t.copy_(torch.from_numpy(denoised.view(np.int16)))
+        pending = gather.start()
+        if pending is not None:
+            pending.finish()
+        if rank == 0 and world > 1 and not shrink and not int(os.environ.get("VHR_TEST_STRIP_SHRINK_BIAS", "0")):
+            if not np.array_equal(gather.full.numpy().view(np.uint16), ref[f]):
+                worst += 1
     res = torch.tensor([worst], dtype=torch.int64)
     dist.all_reduce(res)
     if rank == 0:

@@ -30,7 +30,7 @@ def alias_tensor(info):
 
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
-                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True):
+                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True):
         import torch
         self.torch = torch
         self.scene, self.W, self.H = scene, width, height
@@ -50,6 +50,9 @@ class HybridFrameLoop:
         self._aliases = {}
         self._prepared = {}
         self._pending = None
+        self._gather = None               # tiling.StripGather of the denoised image (C2), built on first use
+        self._pending_gather = None
+        self.gather = bool(gather) and world > 1 and denoise
         self.path = lib.HybridRenderPath(self.ctx, shadow_mode=0 if shadow else 2, ambient_occlusion_mode=0 if ao_spp else 2,
                                          reflection_mode=0 if reflections else 2, denoise=denoise, atrous_steps=atrous_steps,
                                          gbuffer_pass=self._gbuffer_pass)
@@ -115,6 +118,13 @@ class HybridFrameLoop:
         if self._pending is not None:
             self._pending.finish()
             self._pending = None
+        if self._pending_gather is not None:
+            self._pending_gather.finish()
+            self._pending_gather = None
+
+    def gathered_frame(self):
+        """Rank 0: the full denoised frame assembled by the last finished gather (a torch tensor), else None."""
+        return self._gather.full if self._gather is not None else None
 
     def _exchange_raytraced(self, ctx):
         # exchange #2 of the previous frame (history + moments) was left in flight behind this frame's ray tracing;
@@ -126,6 +136,10 @@ class HybridFrameLoop:
         tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
 
     def _exchange_history(self, ctx):
+        if self.gather:                                   # C2: this frame's denoised rows -> rank 0, behind the next frame's ray tracing
+            if self._gather is None:
+                self._gather = tiling.StripGather(self.dist, self._alias(ctx.transient_info(lib.DENOISED)), self.plan)
+            self._pending_gather = self._gather.start()
         hist_info = ctx.storage_info(int(self.pc["shadow_and_ao_history"]))
         mom_info = ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"]))            # current (just written) buffer
         hist, mom = self._alias(hist_info), self._alias(mom_info)

@@ -12,6 +12,8 @@ Per frame and per rank (strip = rows [y0, y1), E = overlap, Hh = history halo):
   exchange #2        Hh rows of the temporal history and the moments history from each neighbour (their
                      owners computed them exactly); consumed by NEXT frame's svgf.comp, so it is off the
                      critical path of this frame's output
+  gather (C2)        every rank's rows of the denoised image to rank 0 (StripGather), where the frame is assembled for the
+                     composition stage; started with exchange #2, finished before the next frame's SVGF pass
 
 Why E: the published image is the output of a-trous iteration n-2 (hybrid_render_path.cpp:322-325 copies the
 image the LAST iteration did not write); iteration i reads +-2*2^i rows (svgf_atrous_filter.comp:72-75; the
@@ -162,6 +164,56 @@ class PreparedExchange:
         if not self.ops:
             return None
         return PendingExchange(self.dist.batch_isend_irecv(self.ops), [], self.keep)
+
+
+class StripGather:
+    """C2 of SURVEY.md section 8e: the owners' rows of a per-strip image (the denoised shadow/AO image) assembled into one
+    full frame on `root` -- what the display GPU's composition stage consumes.  Point-to-point like the halo exchanges (each
+    rank sends its strip straight to the root over its direct xGMI link; strips need not be equally tall), descriptors built
+    once and replayed every frame, started after the SVGF pass and finished before the next frame's SVGF pass rewrites the
+    image, i.e. it overlaps the next frame's ray tracing.  Under gloo with device tensors (CI route) the rows are staged
+    through host memory."""
+
+    def __init__(self, dist, image, plan, root=0, group=None):
+        import torch
+        self.dist, self.plan, self.root, self.image = dist, plan, root, image
+        self.staged = dist.get_backend(group) == "gloo" and image.is_cuda
+        self.group = group
+        self.full = None
+        self.ops, self.keep = [], []
+        if plan.world == 1:
+            return
+        bounds = [strip_bounds(plan.height, plan.world, r) for r in range(plan.world)]
+        if plan.rank == root:
+            self.full = torch.empty_like(image, device="cpu" if self.staged else image.device)
+            self.recv_rows = [(r, a, b) for r, (a, b) in enumerate(bounds) if r != root]
+        if not self.staged:
+            if plan.rank == root:
+                for r, a, b in self.recv_rows:
+                    self.ops.append(dist.P2POp(dist.irecv, self.full[a:b], r, group=group))
+            else:
+                send = image[plan.row_begin:plan.row_end]
+                self.ops.append(dist.P2POp(dist.isend, send, root, group=group))
+                self.keep.append(send)
+
+    def start(self):
+        """Begin gathering the current contents of the image's owned rows; returns a PendingExchange (None for one strip)."""
+        p = self.plan
+        if p.world == 1:
+            return None
+        ops, keep = self.ops, self.keep
+        if self.staged:
+            ops, keep = [], []
+            if p.rank == self.root:
+                for r, a, b in self.recv_rows:
+                    ops.append(self.dist.P2POp(self.dist.irecv, self.full[a:b], r, group=self.group))
+            else:
+                send = self.image[p.row_begin:p.row_end].cpu()
+                ops.append(self.dist.P2POp(self.dist.isend, send, self.root, group=self.group))
+                keep.append(send)
+        if p.rank == self.root:                         # the root's own rows: a local copy, in stream order
+            self.full[p.row_begin:p.row_end].copy_(self.image[p.row_begin:p.row_end], non_blocking=True)
+        return PendingExchange(self.dist.batch_isend_irecv(ops), [], keep)
 
 
 def exchange_rows(dist, tensors, plan, n_rows, group=None):
