@@ -305,6 +305,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      that run that schedule (default 0).  Owned rows are bit-identical either way.
  *   "reflection_variant" the mirror ray (one bounce): 1 = work-queue kernel, closest-hit walk per 16x8 tile + shading with the
  *                      whole wave (default), 0 = one pixel per thread (also what two bounces use)
+ *   "raytraced_variant" the raytraced render path's "Raytracing Pass": 1 = work-queue kernel (primary closest-hit walk, shadow
+ *                      any-hit walk, shading with the whole wave; default), 0 = one pixel per thread
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -217,3 +217,41 @@ def test_gpu_sponza_proc_1080p_properties(oracle):
     # sponza_proc has no textures: the alpha variant samples textures[-1] = 0 -> black albedo wherever something is hit
     hit = ~(res[False] == SKY).all(-1)
     assert (res[True][hit][:, :3] == 0).all() and np.array_equal(res[True][~hit], res[False][~hit])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,Wv,Hv", [("f4", 150, 77), ("bistro_small", 200, 120), ("sponza", 480, 270)])
+def test_gpu_kernel_variants_bit_identical(scene_name, Wv, Hv):
+    """raytraced_variant 1 (work queue: two wave_queue_walk passes + whole-wave shading, default) and 0 (one pixel per thread):
+    same rays, same arithmetic, same shader -> the same B8G8R8A8 image and ray counts, with and without the alpha test, at sizes
+    that are not multiples of the 16x8 tile and with shallow / deep LDS stacks."""
+    from vulkanhybridrenderer_amd import scenes
+    sc = {"f4": f2_scene.scene_f4, "sponza": scenes.sponza_proc,
+          "bistro_small": lambda: scenes.bistro_proc(detail=0.02, n_primitives=300, n_textures=8, texture_size=64)}[scene_name]()
+    pfds = camera.dolly_frames(sc, Wv, Hv, 2)
+    ctx = lib.Context(Wv, Hv)
+    ctx.upload_scene(sc)
+    ctx.set_ray_statistics(True)
+    path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=False)
+    path.build()
+    try:
+        for alpha in (False, True):
+            path.rebuild(alpha)
+            for pfd in pfds:
+                ctx.update_per_frame_ubo(0, pfd)
+                out = {}
+                for variant, levels in ((0, 8), (1, 8), (1, 2), (1, 32)):
+                    ctx.set_option("raytraced_variant", variant)
+                    ctx.set_option("lds_stack_levels", levels)
+                    ctx.execute(0, 0)
+                    ctx.synchronize()
+                    st = ctx.ray_statistics()
+                    assert st["stack_overflows"] == 0
+                    out[(variant, levels)] = (ctx.download(lib.RAYTRACED_OUTPUT), st["unique_rays"])
+                for k, (img, rays) in out.items():
+                    assert np.array_equal(img, out[(0, 8)][0]), f"alpha {alpha}, variant {k}: {(img != out[(0, 8)][0]).any(-1).sum()} pixels differ"
+                    assert rays == out[(0, 8)][1]
+    finally:
+        ctx.set_option("lds_stack_levels", 8)
+        path.destroy()
+        ctx.close()

@@ -794,6 +794,111 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 }
 
 // ---------------------------------------------------------------------------------------------
+// One pass of a wave over its ray queue (`total` rays; fetch(r, pix, origin, direction) delivers the r-th one and the id of
+// its pixel, commit(pix, triangle, u, v) takes its result, kNoHit = miss).  Lanes pull rays whenever `refill_threshold` of
+// them are idle and walk the BVH "while-while" with the node step of raygen_queue_kernel: packed-FMA slabs against 1/d and
+// -o/d, near child first, far child pushed, boxes culled against the closest t so far (tn <= tbest keeps equal-t candidates:
+// decision vi), early exit of the node loop, LDS stack + scratch spill.  Leaves: every triangle, Moeller-Trumbore against the
+// full [tmin, tmax] interval, closest = min t then smaller flat index; with `any_hit` (wave-uniform) the first accepted
+// triangle ends the ray (gl_RayFlagsTerminateOnFirstHitEXT -- the boolean does not depend on the order).  ALPHA: every
+// candidate first runs shadow_anyhit.rahit (alpha_ignored).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kNoHit = 0xffffffffu;
+
+template <bool SPILL, bool ALPHA, typename Fetch, typename Commit>
+__device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
+                                                const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
+                                                const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
+                                                Fetch fetch, Commit commit) {
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_tri = kNoHit, best_flat = 0;
+    int cur = 0, sp = 0;
+    uint32_t pix = 0, next = 0;
+    bool has = false;
+    // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
+    // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
+    volatile int spill[SPILL ? kTraceStack : 1];
+    float tmin_v = tmin;
+    asm volatile("" : "+v"(tmin_v));
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {                 // wave-uniform
+            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            next += n_idle;
+            if (!has && r < total) {
+                fetch(r, pix, ro, rd);
+                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
+                cur = 0; sp = 0;
+                has = true;
+            }
+        }
+        if (!__any(has)) break;
+        // ---- inner nodes ----
+        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
+        while (has && cur >= 0) {
+            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            float tn0, tn1;
+            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tbest, tn0);
+            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tbest, tn1);
+            const bool both = h0 && h1, none = !(h0 || h1);
+            const bool first0 = tn0 <= tn1;
+            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
+            int top = row[0];
+            row[kQueueBlock] = farc;
+            if (__any(uint32_t(sp) >= stack_levels)) {
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (uint32_t(sp) >= stack_levels) {
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    else overflow |= both ? 1u : 0u;
+                }
+            }
+            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
+            sp += (both ? 1 : 0) - (none ? 1 : 0);
+        }
+        // ---- leaf ----
+        if (has && cur < 0 && cur != kStackSentinel) {
+            const uint32_t vv = ~uint32_t(cur);
+            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
+            bool done = false;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float t, uu, ww;
+                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
+                    if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
+                    const uint32_t flat = __float_as_uint(tc.w);
+                    if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
+                        tbest = t; best_tri = first + i; best_flat = flat; best_u = uu; best_v = ww;
+                    }
+                    if (any_hit) { done = true; break; }
+                }
+            }
+            if (done) {
+                cur = kStackSentinel;
+            } else {
+                cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];             // pop (the sentinel if nothing is pending)
+                if (SPILL && __any(uint32_t(sp) > stack_levels)) {
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                }
+                --sp;
+            }
+        }
+        if (has && cur == kStackSentinel) {
+            has = false;
+            commit(pix, best_tri, best_u, best_v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mirror ray, work-queue form (the default for one bounce): closest-hit traversal with the node step of raygen_queue_kernel.
 //
 // Every wave owns a 16x8-pixel tile = a queue of up to 128 mirror rays.  Phase 1 (whole wave, twice): raygen.rgen:15-29,60-63
@@ -806,7 +911,6 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 // Results are those of reflection_kernel bit for bit: the same rays, the same intersection arithmetic, the same shader.
 // ---------------------------------------------------------------------------------------------
 constexpr int kReflRays = 128;
-constexpr uint32_t kNoHit = 0xffffffffu;
 
 template <bool SPILL, int BOUNCES>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
@@ -862,92 +966,20 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const bool traced = total != 0;
 
     // ---- phase 2: the queue (once per bounce) ----
-    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
-    float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
-    uint32_t best_tri = kNoHit, best_flat = 0;
-    int cur = 0, sp = 0;
-    uint32_t pix = 0, next = 0, overflow = 0;
-    bool has = false;
-    int spill[SPILL ? kTraceStack : 1];
-    const float tmin = a.tp.tmin, tmax = a.tp.tmax;
-    float tmin_v = tmin;
-    asm volatile("" : "+v"(tmin_v));
-    uint32_t second_rays = 0;
+    uint32_t overflow = 0, second_rays = 0;
 #pragma unroll 1
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
-    next = 0;
-    for (;;) {
-        const unsigned long long idle = __ballot(!has);
-        const uint32_t n_idle = uint32_t(__popcll(idle));
-        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {                 // wave-uniform
-            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
-            next += n_idle;
-            if (!has && r < total) {
-                pix = s_list[r];
-                ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
-                rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
-                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
-                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
-                tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
-                cur = 0; sp = 0;
-                has = true;
-            }
-        }
-        if (!__any(has)) break;
-        // ---- inner nodes (see raygen_queue_kernel for the step; here the far child waits on the stack and boxes
-        //      beyond the closest hit so far are culled: tn <= tbest keeps equal-t candidates, decision vi) ----
-        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
-        while (has && cur >= 0) {
-            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
-            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
-            float tn0, tn1;
-            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tbest, tn0);
-            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tbest, tn1);
-            const bool both = h0 && h1, none = !(h0 || h1);
-            const bool first0 = tn0 <= tn1;
-            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
-            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
-            int top = row[0];
-            row[kQueueBlock] = farc;
-            if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
-                if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
-                    else overflow |= both ? 1u : 0u;
-                }
-            }
-            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
-            sp += (both ? 1 : 0) - (none ? 1 : 0);
-        }
-        // ---- leaf: every triangle of it, closest = min t then smaller flat index ----
-        if (has && cur < 0 && cur != kStackSentinel) {
-            const uint32_t vv = ~uint32_t(cur);
-            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
-                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                float t, uu, ww;
-                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
-                    const uint32_t flat = __float_as_uint(tc.w);
-                    if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
-                        tbest = t; best_tri = first + i; best_flat = flat; best_u = uu; best_v = ww;
-                    }
-                }
-            }
-            cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];                 // pop (the sentinel if nothing is pending)
-            if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
-            }
-            --sp;
-        }
-        if (has && cur == kStackSentinel) {                                                  // the hit record replaces the ray's origin
-            has = false;
-            s_ray[orow][pix] = __uint_as_float(best_tri); s_ray[orow + 1][pix] = best_u; s_ray[orow + 2][pix] = best_v;
-        }
-    }
+    wave_queue_walk<SPILL, false>(
+        a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow,
+        [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
+            pix = s_list[r];
+            ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
+            rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+        },
+        [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
+            s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
+        });
     wave_lds_sync();
     if (BOUNCES > 1 && bounce == 0) {
         // ---- second-bounce rays (trace_reflection's arithmetic), whole wave: a mirror ray from every first hit ----
@@ -1136,6 +1168,45 @@ __device__ bool alpha_ignored(const DeviceScene &sc, uint32_t tri_index, float u
     return albedo.w < prim.material.alpha_cutoff;                                        // rahit:24-26
 }
 
+// closesthit.rchit:26-57 (ALPHA: closesthit_test_alpha.rchit:26-50) once the shadow ray's answer is known
+template <bool ALPHA>
+__device__ f4 raytraced_hit_payload(const DeviceScene &sc, const vhr_per_frame_data &pfd, const Hit &h, bool shadowed) {
+    const BvhTri &bt = sc.tris[h.tri_index];                                             // rchit:11-24
+    const vhr_primitive &prim = sc.primitives[bt.prim];
+    const TriAttributes at = interpolate(sc, prim, bt.tri, h.u, h.v);
+    f3 albedo;
+    if (!ALPHA && prim.material.base_color_texture == -1) {                              // rchit:26-32 (alpha variant: :26, unconditional)
+        albedo = f3{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2] };
+    } else {
+        const f4 t = sample_texture(sc, prim.material.base_color_texture, at.uvx, at.uvy);
+        albedo = f3{ t.x, t.y, t.z };
+    }
+    const f3 normal = at.normal;
+    f3 N = normal;                                                                       // rchit:34-41
+    if (prim.material.normal_map >= 0) {
+        const f4 tg = interpolate_tangent(sc, prim, bt.tri, h.u, h.v);
+        const f3 T = f3{ tg.x, tg.y, tg.z };
+        const f4 tx = sample_texture(sc, prim.material.normal_map, at.uvx, at.uvy);
+        const f3 tsn = normalize3(f3{ tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f });
+        const f3 bitangent = cross3(tsn, T) * tg.w;                                      // sic
+        const f3 tangent = normalize3(T - normal * dot3(T, normal));
+        N = (tangent * tsn.x + bitangent * tsn.y) + normal * tsn.z;
+    }
+    const f3 light_dir = -f3{ pfd.directional_light.direction[0], pfd.directional_light.direction[1], pfd.directional_light.direction[2] };
+    const f3 lc = f3{ pfd.directional_light.color[0], pfd.directional_light.color[1], pfd.directional_light.color[2] };
+    const f3 li = f3{ pfd.directional_light.intensity[0], pfd.directional_light.intensity[1], pfd.directional_light.intensity[2] };
+    const f3 albedo_lighting = ALPHA ? albedo * 0.2f : albedo * VHR_PI_INVERSE;          // alpha :39 / :46
+    f3 col = albedo_lighting;
+    if (!shadowed) {                                                                     // rchit:52-54 / alpha :45-47
+        const float nl = fmaxf(dot3(N, light_dir), 0.0f);
+        f3 lit = albedo * nl;
+        if (!ALPHA) lit = mul3(lit, li);                                                 // the alpha variant drops light_intensity
+        lit = mul3(lit, lc);
+        col = albedo_lighting + lit;
+    }
+    return f4{ col.x, col.y, col.z, 1.0f };
+}
+
 struct RaytracedArgs {
     DeviceScene scene;
     vhr_per_frame_data pfd;
@@ -1168,44 +1239,13 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
         if (traverse<false, ALPHA>(a.scene, f3{ origin.x, origin.y, origin.z }, f3{ direction.x, direction.y, direction.z }, 0.1f, 10000.0f,
                                    stack, h, overflow)) {                                // rgen:20
             hit_any = true;
-            const BvhTri &bt = a.scene.tris[h.tri_index];                                // rchit:11-24
-            const vhr_primitive &prim = a.scene.primitives[bt.prim];
-            const TriAttributes at = interpolate(a.scene, prim, bt.tri, h.u, h.v);
-            const f3 position = mat4_mul_point(prim.transform, at.object_pos);
-            f3 albedo;
-            if (!ALPHA && prim.material.base_color_texture == -1) {                      // rchit:26-32 (alpha variant: :26, unconditional)
-                albedo = f3{ prim.material.base_color[0], prim.material.base_color[1], prim.material.base_color[2] };
-            } else {
-                const f4 t = sample_texture(a.scene, prim.material.base_color_texture, at.uvx, at.uvy);
-                albedo = f3{ t.x, t.y, t.z };
-            }
-            const f3 normal = at.normal;
-            f3 N = normal;                                                               // rchit:34-41
-            if (prim.material.normal_map >= 0) {
-                const f4 tg = interpolate_tangent(a.scene, prim, bt.tri, h.u, h.v);
-                const f3 T = f3{ tg.x, tg.y, tg.z };
-                const f4 tx = sample_texture(a.scene, prim.material.normal_map, at.uvx, at.uvy);
-                const f3 tsn = normalize3(f3{ tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f });
-                const f3 bitangent = cross3(tsn, T) * tg.w;                              // sic
-                const f3 tangent = normalize3(T - normal * dot3(T, normal));
-                N = (tangent * tsn.x + bitangent * tsn.y) + normal * tsn.z;
-            }
+            f3 position, unused_normal;
+            hit_position_normal(a.scene, h, position, unused_normal);                    // rchit:24
             const f3 light_dir = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
-            const f3 lc = f3{ a.pfd.directional_light.color[0], a.pfd.directional_light.color[1], a.pfd.directional_light.color[2] };
-            const f3 li = f3{ a.pfd.directional_light.intensity[0], a.pfd.directional_light.intensity[1], a.pfd.directional_light.intensity[2] };
-            const f3 albedo_lighting = ALPHA ? albedo * 0.2f : albedo * VHR_PI_INVERSE;  // alpha :39 / :46
             Hit sh;
             // shadow ray, rchit:48-50 (alpha :41-43): shadow_payload stays true unless shadow_miss.rmiss:7 runs
             const bool shadowed = traverse<true, ALPHA>(a.scene, position, light_dir, 0.1f, 10000.0f, stack, sh, overflow);
-            f3 col = albedo_lighting;
-            if (!shadowed) {                                                             // rchit:52-54 / alpha :45-47
-                const float nl = fmaxf(dot3(N, light_dir), 0.0f);
-                f3 lit = albedo * nl;
-                if (!ALPHA) lit = mul3(lit, li);                                         // the alpha variant drops light_intensity
-                lit = mul3(lit, lc);
-                col = albedo_lighting + lit;
-            }
-            payload = f4{ col.x, col.y, col.z, 1.0f };
+            payload = raytraced_hit_payload<ALPHA>(a.scene, a.pfd, h, shadowed);
         }
         a.out[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(payload.z)), uint8_t(unorm8(payload.y)), uint8_t(unorm8(payload.x)),
                                                uint8_t(unorm8(payload.w)));             // rgen:22 imageStore, B8G8R8A8
@@ -1216,6 +1256,119 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
             if (cov) atomicAdd(&a.stats->covered_pixels, (unsigned long long)__popcll(cov));
             if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
         }
+    }
+}
+
+// Work-queue form (default, `raytraced_variant` 1): a wave owns a 16x8-pixel tile and runs wave_queue_walk twice -- the
+// primary rays (closest hit), then one shadow ray per primary hit towards the light (any hit) -- with the ray setup, the
+// shadow-ray origins (rchit:24) and closesthit.rchit's shading done by the whole wave in between and after.  Same rays, same
+// intersection arithmetic, same shader as raytraced_kernel: bit-identical output.
+template <bool SPILL, bool ALPHA>
+__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void raytraced_queue_kernel(
+    const RaytracedArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
+    const uint32_t early_exit) {
+    extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints
+    // rows 0-2: primary direction -> primary hit record (triangle, u, v); rows 3-5: shadow-ray origin -> row 3 = its answer
+    __shared__ float s_ray_all[2][6][kReflRays];
+    __shared__ uint8_t s_list_all[2][kReflRays];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 2u + wave;
+    if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
+    float (&s_ray)[6][kReflRays] = s_ray_all[wave];
+    uint8_t (&s_list)[kReflRays] = s_list_all[wave];
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    stack[0] = kStackSentinel;
+    const uint32_t W = a.width, H = a.height;
+    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const f4 origin4 = mat4_mul(a.pfd.camera_view_inverse, f4{ 0.0f, 0.0f, 0.0f, 1.0f });           // rgen:15
+    const f3 origin = f3{ origin4.x, origin4.y, origin4.z };
+    const f3 light_dir = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+
+    // ---- primary rays, whole wave (rgen:11-17) ----
+    unsigned long long in_mask[2];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const bool in_range = x < W && y < a.row_end;
+        const uint32_t p = sub * 64u + lane;
+        if (in_range) {
+            const float ux = ((float(x) + 0.5f) / float(W)) * 2.0f - 1.0f;
+            const float uy = ((float(y) + 0.5f) / float(H)) * 2.0f - 1.0f;
+            const f4 target = mat4_mul(a.pfd.camera_proj_inverse, f4{ ux, uy, 1.0f, 1.0f });
+            const f3 tn = normalize3(f3{ target.x, target.y, target.z });
+            const f4 direction = mat4_mul(a.pfd.camera_view_inverse, f4{ tn.x, tn.y, tn.z, 0.0f });
+            s_ray[0][p] = direction.x; s_ray[1][p] = direction.y; s_ray[2][p] = direction.z;
+        }
+        const unsigned long long m = __ballot(in_range);
+        in_mask[sub] = m;
+        if (in_range) s_list[total + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        total += uint32_t(__popcll(m));
+    }
+    wave_lds_sync();
+    const bool traced = a.scene.node_count != 0;
+    uint32_t overflow = 0;
+    // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
+    wave_queue_walk<SPILL, ALPHA>(
+        a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow,
+        [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
+            pix = s_list[r];
+            ro = origin;
+            rd = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+        },
+        [&](uint32_t pix, uint32_t tri, float u, float v) {
+            s_ray[0][pix] = __uint_as_float(tri); s_ray[1][pix] = u; s_ray[2][pix] = v;
+        });
+    wave_lds_sync();
+    // ---- shadow rays from the primary hits, whole wave (rchit:24,48-50) ----
+    uint32_t nhit = 0;
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        const uint32_t p = sub * 64u + lane;
+        const bool inside = traced && ((in_mask[sub] >> lane) & 1ull);
+        const uint32_t tri = inside ? __float_as_uint(s_ray[0][p]) : kNoHit;
+        const bool hit = tri != kNoHit;
+        if (hit) {
+            Hit h;
+            h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
+            f3 position, unused_normal;
+            hit_position_normal(a.scene, h, position, unused_normal);
+            s_ray[3][p] = position.x; s_ray[4][p] = position.y; s_ray[5][p] = position.z;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) s_list[nhit + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        nhit += uint32_t(__popcll(m));
+    }
+    wave_lds_sync();
+    // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
+    wave_queue_walk<SPILL, ALPHA>(
+        a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow,
+        [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
+            pix = s_list[r];
+            ro = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+            rd = light_dir;
+        },
+        [&](uint32_t pix, uint32_t tri, float, float) { s_ray[3][pix] = __uint_as_float(tri); });
+    wave_lds_sync();
+    // ---- closesthit.rchit / miss.rmiss and the image store, whole wave ----
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        if (!((in_mask[sub] >> lane) & 1ull)) continue;
+        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const uint32_t p = sub * 64u + lane;
+        f4 payload = f4{ 0.3f, 0.8f, 0.2f, 1.0f };                                       // miss.rmiss:7
+        const uint32_t tri = traced ? __float_as_uint(s_ray[0][p]) : kNoHit;
+        if (tri != kNoHit) {
+            Hit h;
+            h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
+            payload = raytraced_hit_payload<ALPHA>(a.scene, a.pfd, h, __float_as_uint(s_ray[3][p]) != kNoHit);
+        }
+        a.out[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(payload.z)), uint8_t(unorm8(payload.y)), uint8_t(unorm8(payload.x)),
+                                               uint8_t(unorm8(payload.w)));             // rgen:22 imageStore, B8G8R8A8
+    }
+    if (a.stats && lane == 0) {
+        if (nhit) atomicAdd(&a.stats->covered_pixels, (unsigned long long)nhit);
+        if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
     }
 }
 
@@ -1236,8 +1389,22 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
-    if (alpha_test) hipLaunchKernelGGL(raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(raytraced_kernel<false>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    if (ctx->options[kOptRaytracedVariant] != 0) {
+        const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
+        const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
+        const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
+        const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((a.row_end - a.row_begin + 7) / 8);
+        const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
+        const bool spill = levels < ctx->bvh_depth + 1u;
+#define VHR_LAUNCH_RT(SP, AL) hipLaunchKernelGGL((raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit)
+        if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
+        else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
+#undef VHR_LAUNCH_RT
+    } else if (alpha_test) {
+        hipLaunchKernelGGL(raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(raytraced_kernel<false>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    }
     ctx->time_end(kKernelRaygen);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raytraced kernel launch failed");
     if (a.stats && hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
