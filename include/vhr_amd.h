@@ -296,7 +296,9 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
  *                      persistent workgroups that prefetch the next tile into registers (default)
- *   "atrous_blocks_per_cu" (default 8), "atrous_xcd_aware" (default 1): launch shape of variant 4
+ *   "atrous_blocks_per_cu" (1..64, default 64: more workgroups than tiles per CU at 1080p and 4K, i.e. one tile per workgroup --
+ *                      measured faster than 8 persistent ones by 5 % at 1080p and 10 % at 4K), "atrous_xcd_aware" (default 1):
+ *                      launch shape of variant 4
  *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 4 tiles per CU (default),
  *                      0 = never, 1 = always
  *   "strip_shrink_overlap" strips only (vhr_set_strip): 1 = an a-trous launch with step s computes the owned rows extended by

@@ -773,7 +773,7 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
     const uint32_t tiles_x = (a.limit_x + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
-    const uint32_t per_cu = uint32_t(std::max(1, std::min(16, ctx->options[kOptAtrousBlocksPerCu])));
+    const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
     const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
     hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
                        uint32_t(ctx->options[kOptAtrousXcdAware]));
