@@ -580,7 +580,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
 // form above launches ~2 rounds of resident blocks that all load, then all compute: its global-load phases are
 // exposed (PMC: VALU busy 75 %).  Same arithmetic, same tile geometry; only the schedule differs.
 // ---------------------------------------------------------------------------------------------
-template <int STEP, int R>
+// ONE_TILE: the grid has a workgroup per tile (the default launch): no tile loop, and the prefetch registers die before the
+// taps start instead of carrying the next tile through them.
+template <int STEP, int R, bool ONE_TILE>
 __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total,
                                                                  const uint32_t xcd_aware) {
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
         }
         __syncthreads();
         const uint32_t vn = v + gridDim.x;
-        const bool more = vn < tiles_total;          // block-uniform
+        const bool more = !ONE_TILE && vn < tiles_total;          // block-uniform
         if (more) prefetch(vn);                      // in flight while the taps below run
 
         const int cx = x0 + tx;
@@ -775,8 +777,12 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t tiles_x = (a.limit_x + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
     const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
     const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
-    hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
-                       uint32_t(ctx->options[kOptAtrousXcdAware]));
+    if (grid == tiles_total)
+        hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R, true>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
+                           uint32_t(ctx->options[kOptAtrousXcdAware]));
+    else
+        hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R, false>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
+                           uint32_t(ctx->options[kOptAtrousXcdAware]));
 }
 
 // Thin launches (the row strip of one GPU out of 4 or 8) do not fill the chip with 8-row tiles: 195 rows x 1920 are 750
