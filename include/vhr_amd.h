@@ -309,10 +309,15 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      whole wave (default), 0 = one pixel per thread (also what two bounces use)
  *   "raytraced_variant" the raytraced render path's "Raytracing Pass": 1 = work-queue kernel (primary closest-hit walk, shadow
  *                      any-hit walk, shading with the whole wave; default), 0 = one pixel per thread
+ *   "pass_timestamps"  1 = every ray-tracing / compute pass carries begin / end timestamps for
+ *                      vhr_graph_gather_performance_statistics (default; the reference's vkCmdWriteTimestamp pair,
+ *                      render_graph.cpp:167-182; ~1.5 us per dispatch), 0 = off.  External graphics passes are not stamped.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
-/* Per-kernel timing with HIP event pairs recorded on the context stream around every launch of a kernel
+/* Per-kernel timing with HIP event pairs attached to every launch of a kernel kind on the context stream (the events ride on
+ * the dispatch packet -- hipExtLaunchKernelGGL's start / stop events, the dispatch's own begin / end timestamps -- instead of
+ * hipEventRecord, whose barrier packet costs ~4 us of stream time per record)
  * kind: 0 = raygen (K1: shadow + AO rays; with raygen_variant 0 also the mirror ray), 1 = svgf.comp (K3),
  * 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5), 4 = the mirror-ray kernel (K1's reflection ray + K2).
  * kind_mask has bit (1 << kind) set for every kind to time (0 = off).  vhr_get_kernel_time synchronises, folds

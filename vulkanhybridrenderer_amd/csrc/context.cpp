@@ -56,23 +56,35 @@ vhr::DeviceScene vhr_context::device_scene() const {
 // ---- optional per-kernel event timing -------------------------------------------------------------
 static constexpr size_t kTimerCapacity = 16384;     // events per kernel kind (8192 launches between drains)
 
-void vhr_context::time_begin(int kind) {
-    if (!(kernel_timing_mask & (1u << kind))) return;
-    KernelTimer &t = kernel_timers[kind];
-    if (t.used + 2 > kTimerCapacity) return;
-    while (t.events.size() < t.used + 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
-        t.events.push_back(e);
+// Events for the next kernel dispatch.  A kernel kind under vhr_set_kernel_timing gets its own (start, stop) pair; the pass
+// whose callback is running gets its begin stamp on its first dispatch and its end stamp on every dispatch (the last one
+// stands).  Where both want the same slot the kernel timer wins and the pass falls back to a recorded event.
+void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
+    start = stop = nullptr;
+    if (timing_kind >= 0 && (kernel_timing_mask & (1u << timing_kind))) {
+        KernelTimer &t = kernel_timers[timing_kind];
+        if (t.used + 2 <= kTimerCapacity) {
+            while (t.events.size() < t.used + 2) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) break;
+                t.events.push_back(e);
+            }
+            if (t.events.size() >= t.used + 2) {
+                start = t.events[t.used];
+                stop = t.events[t.used + 1];
+                t.used += 2;
+            }
+        }
     }
-    hipEventRecord(t.events[t.used], stream);
-}
-void vhr_context::time_end(int kind) {
-    if (!(kernel_timing_mask & (1u << kind))) return;
-    KernelTimer &t = kernel_timers[kind];
-    if (t.used + 2 > kTimerCapacity || t.events.size() < t.used + 2) return;
-    hipEventRecord(t.events[t.used + 1], stream);
-    t.used += 2;
+    if (cur_pass && options[vhr::kOptPassTimestamps] && cur_pass->ev_begin) {
+        if (!cur_pass->begin_stamped) {
+            if (!start) start = cur_pass->ev_begin;
+            else hipEventRecord(cur_pass->ev_begin, stream);
+            cur_pass->begin_stamped = true;
+        }
+        if (!stop) { stop = cur_pass->ev_end; cur_pass->end_on_last_dispatch = true; }
+        else cur_pass->end_on_last_dispatch = false;
+    }
 }
 
 extern "C" {
@@ -386,7 +398,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }

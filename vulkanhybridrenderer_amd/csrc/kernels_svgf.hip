@@ -191,7 +191,7 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
     if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
         const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
         ctx->time_begin(kKernelTemporal);
-        hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+        launch(ctx, svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
         ctx->time_end(kKernelTemporal);
         if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
     }
@@ -399,7 +399,7 @@ static void launch_atrous_tiled(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
     const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
-    hipLaunchKernelGGL((svgf_atrous_tiled_kernel<STEP, R>), grid, dim3(256), 0, ctx->stream, a);
+    launch(ctx, (svgf_atrous_tiled_kernel<STEP, R>), grid, dim3(256), 0, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,10 +778,10 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
     const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
     if (grid == tiles_total)
-        hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R, true>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
+        launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total,
                            uint32_t(ctx->options[kOptAtrousXcdAware]));
     else
-        hipLaunchKernelGGL((svgf_atrous_stream_kernel<STEP, R, false>), dim3(grid), dim3(256), 0, ctx->stream, a, tiles_x, tiles_total,
+        launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total,
                            uint32_t(ctx->options[kOptAtrousXcdAware]));
 }
 
@@ -802,7 +802,7 @@ static void launch_atrous_packed(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
     const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
-    hipLaunchKernelGGL((svgf_atrous_packed_kernel<STEP, R>), grid, dim3(256), 0, ctx->stream, a);
+    launch(ctx, (svgf_atrous_packed_kernel<STEP, R>), grid, dim3(256), 0, a);
 }
 
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in, Image &out,
@@ -867,7 +867,7 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
             default: tiled = false; break;       // other steps: the direct kernel
         }
     }
-    if (!tiled) hipLaunchKernelGGL(svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, ctx->stream, a);
+    if (!tiled) launch(ctx, svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
     ctx->time_end(kKernelAtrous);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
     return VHR_OK;
@@ -894,9 +894,9 @@ __global__ __launch_bounds__(256) void calibration_read_kernel(const T *src, siz
 int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink) {
     const size_t bytes = img.bytes();
     const dim3 grid(2048);
-    if (bytes_per_lane == 4) hipLaunchKernelGGL(calibration_read_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(img.ptr), bytes / 4, sink);
-    else if (bytes_per_lane == 8) hipLaunchKernelGGL(calibration_read_kernel<uint2>, grid, dim3(256), 0, ctx->stream, static_cast<const uint2 *>(img.ptr), bytes / 8, sink);
-    else if (bytes_per_lane == 16) hipLaunchKernelGGL(calibration_read_kernel<uint4>, grid, dim3(256), 0, ctx->stream, static_cast<const uint4 *>(img.ptr), bytes / 16, sink);
+    if (bytes_per_lane == 4) launch(ctx, calibration_read_kernel<uint32_t>, grid, dim3(256), 0, static_cast<const uint32_t *>(img.ptr), bytes / 4, sink);
+    else if (bytes_per_lane == 8) launch(ctx, calibration_read_kernel<uint2>, grid, dim3(256), 0, static_cast<const uint2 *>(img.ptr), bytes / 8, sink);
+    else if (bytes_per_lane == 16) launch(ctx, calibration_read_kernel<uint4>, grid, dim3(256), 0, static_cast<const uint4 *>(img.ptr), bytes / 16, sink);
     else return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "calibration: bytes_per_lane must be 4, 8 or 16");
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "calibration kernel launch failed");
     return VHR_OK;
@@ -933,7 +933,7 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     if (((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(d8) | bytes) & 15u) == 0) {
         const size_t count = bytes / 16;
         const uint32_t blocks = uint32_t(std::min<size_t>((count + 1023) / 1024, size_t(ctx->cu_count) * 8));
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(s8),
+        launch(ctx, copy_rows_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, reinterpret_cast<const uint4 *>(s8),
                            reinterpret_cast<uint4 *>(d8), count);
         copy_rc = hipGetLastError();
     } else {

@@ -1078,7 +1078,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
-        hipLaunchKernelGGL(raygen_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+        launch(ctx, raygen_kernel, grid, dim3(kTraceBlock), 0, a);
     } else {
         // the traversal stack is sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU
         // LDS part of the traversal stack; deeper entries spill to scratch (see the kernel)
@@ -1095,11 +1095,11 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #define VHR_LAUNCH_QUEUE(P, WV, C, SP, ST)                                                                                        \
     do {                                                                                                                          \
         if (shared_tile)                                                                                                          \
-            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
-                               ctx->stream, a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit);    \
+            launch(ctx, (raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
+                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit);    \
         else                                                                                                                      \
-            hipLaunchKernelGGL((raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-                               (stack_bytes + dir_bytes) * WV, ctx->stream, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
+            launch(ctx, (raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+                               (stack_bytes + dir_bytes) * WV, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
                                uint32_t(ctx->options[kOptXcdAware]), early_exit);                                                  \
     } while (0)
 #define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
@@ -1127,13 +1127,13 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
             const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-#define VHR_LAUNCH_REFL(SP, B) hipLaunchKernelGGL((reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit)
+#define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }
             else { if (spill) VHR_LAUNCH_REFL(true, 1); else VHR_LAUNCH_REFL(false, 1); }
 #undef VHR_LAUNCH_REFL
         } else {
-            hipLaunchKernelGGL(reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, ctx->stream, a);
+            launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, a);
         }
         ctx->time_end(kKernelReflection);
     }
@@ -1396,14 +1396,14 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((a.row_end - a.row_begin + 7) / 8);
         const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
         const bool spill = levels < ctx->bvh_depth + 1u;
-#define VHR_LAUNCH_RT(SP, AL) hipLaunchKernelGGL((raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, ctx->stream, a, levels, threshold, tiles_x, tiles_total, early_exit)
+#define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
 #undef VHR_LAUNCH_RT
     } else if (alpha_test) {
-        hipLaunchKernelGGL(raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+        launch(ctx, raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, a);
     } else {
-        hipLaunchKernelGGL(raytraced_kernel<false>, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+        launch(ctx, raytraced_kernel<false>, grid, dim3(kTraceBlock), 0, a);
     }
     ctx->time_end(kKernelRaygen);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raytraced kernel launch failed");
@@ -1527,7 +1527,7 @@ int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Imag
     a.width = depth.width;
     a.height = depth.height;
     const dim3 grid((a.width + 15) / 16, (a.height + 15) / 16);
-    hipLaunchKernelGGL(gbuffer_kernel, grid, dim3(kTraceBlock), 0, ctx->stream, a);
+    launch(ctx, gbuffer_kernel, grid, dim3(kTraceBlock), 0, a);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "gbuffer kernel launch failed");
     return VHR_OK;
 }
@@ -1627,7 +1627,7 @@ int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vh
     a.width = W; a.height = H;
     a.shadow_mode = d.shadow_mode; a.ao_mode = d.ambient_occlusion_mode; a.reflection_mode = d.reflection_mode;
     a.shadow_ao_is_rgba = shadow_ao.format == VHR_FORMAT_R16G16B16A16_SFLOAT;
-    hipLaunchKernelGGL(composition_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, ctx->stream, a);
+    launch(ctx, composition_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, a);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "composition kernel launch failed");
     return VHR_OK;
 }
@@ -1648,7 +1648,7 @@ __global__ __launch_bounds__(256) void raytraced_composition_kernel(const uchar4
 int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out) {
     if (in.width != out.width || in.height != out.height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: image extents differ");
     if (in.bpp != 4 || out.bpp != 4) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "raytraced composition: 4-byte texels expected");
-    hipLaunchKernelGGL(raytraced_composition_kernel, dim3((in.width + 63) / 64, (in.height + 3) / 4), dim3(256), 0, ctx->stream,
+    launch(ctx, raytraced_composition_kernel, dim3((in.width + 63) / 64, (in.height + 3) / 4), dim3(256), 0,
                        static_cast<const uchar4 *>(in.ptr), static_cast<uchar4 *>(out.ptr), in.width, in.height);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raytraced composition kernel launch failed");
     return VHR_OK;

@@ -294,7 +294,11 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
     ctx->error.clear();
     for (auto &name : ctx->execution_order) {
         PassDescription &p = ctx->pass_descriptions[name];
-        HIP_TRY(ctx, hipEventRecord(p.ev_begin, ctx->stream));                 // vkCmdWriteTimestamp, render_graph.cpp:167-182
+        // vkCmdWriteTimestamp x2 (render_graph.cpp:167-182): the stamps ride on the pass's first and last kernel dispatch
+        // (vhr_context::dispatch_events).  External (graphics) passes enqueue nothing here and are timed by their owner's API.
+        const bool stamps = ctx->options[vhr::kOptPassTimestamps] != 0 && p.kind != PassKind::Graphics;
+        p.begin_stamped = p.end_on_last_dispatch = false;
+        ctx->cur_pass = stamps ? &p : nullptr;
         if (p.kind == PassKind::Graphics) {
             if (p.external_cb) p.external_cb(p.user, ctx);
         } else if (p.kind == PassKind::Raytracing) {
@@ -304,8 +308,9 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
             vhr_compute_execution_context ec{ ctx, &p, resource_idx };         // ExecuteComputePass, :914-919
             p.compute_cb(p.user, &ec);
         }
-        HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
-        p.timed = true;
+        ctx->cur_pass = nullptr;
+        if (stamps && p.begin_stamped && !p.end_on_last_dispatch) HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
+        p.timed = stamps && p.begin_stamped;
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
     }

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <map>
@@ -128,6 +129,7 @@ struct PassDescription {
     void *epilogue_user = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
+    bool begin_stamped = false, end_on_last_dispatch = false;     // per Execute: see vhr_context::dispatch_events
     double ema_ms = 0.0, last_ms = 0.0;
 };
 
@@ -137,7 +139,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptCount = 19 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptCount = 20 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelKinds = 5 };
@@ -207,19 +209,34 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     uint32_t kernel_timing_mask = 0;   // bit per KernelKind
     vhr::KernelTimer kernel_timers[vhr::kKernelKinds];
-    void time_begin(int kind);
-    void time_end(int kind);
+    // Timing rides on the dispatch packets: vhr::launch() attaches (start, stop) events to a kernel launch through
+    // hipExtLaunchKernelGGL, i.e. the dispatch's own begin / end timestamps.  A hipEventRecord instead puts a barrier packet and
+    // a ~4 us bubble on the stream (measured: 33 us per frame for the eight per-pass records alone).
+    int timing_kind = -1;              // kernel kind whose launches are being issued (between time_begin and time_end)
+    vhr::PassDescription *cur_pass = nullptr;      // pass whose callback is running (vkCmdWriteTimestamp equivalents)
+    void time_begin(int kind) { timing_kind = kind; }
+    void time_end(int) { timing_kind = -1; }
+    void dispatch_events(hipEvent_t &start, hipEvent_t &stop);
 
     vhr::DeviceScene device_scene() const;
     int fail(int code, const std::string &msg) { error = msg; return code; }
 };
 
 namespace vhr {
+
+// Every kernel launch of the library goes through here (see vhr_context::dispatch_events).
+template <typename K, typename... Args>
+inline void launch(vhr_context *ctx, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+    hipEvent_t start = nullptr, stop = nullptr;
+    ctx->dispatch_events(start, stop);
+    if (start || stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, start, stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, args...);
+}
 
 uint32_t format_stride(int32_t format);   // VkUtils::FormatStride (vulkan_utils.h:128-148)
 
