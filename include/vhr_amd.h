@@ -312,6 +312,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "pass_timestamps"  1 = every ray-tracing / compute pass carries begin / end timestamps for
  *                      vhr_graph_gather_performance_statistics (default; the reference's vkCmdWriteTimestamp pair,
  *                      render_graph.cpp:167-182; ~1.5 us per dispatch), 0 = off.  External graphics passes are not stamped.
+ *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 8 (default), 4 or 2 (measured slower)
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -497,10 +497,11 @@ __device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t
 // accepts at most 16 workgroups, so single-wave blocks cap occupancy at 4 waves per SIMD: measured).  Waves of a
 // block share nothing and never synchronise with each other.
 template <int WAVES>
-__device__ __forceinline__ void tile_pixel(uint32_t block_tile, uint32_t tiles_x, uint32_t wave, uint32_t local, uint32_t row_begin, uint32_t &x, uint32_t &y) {
+__device__ __forceinline__ void tile_pixel(uint32_t block_tile, uint32_t tiles_x, uint32_t wave, uint32_t local, uint32_t row_begin, uint32_t tile_rows,
+                                           uint32_t &x, uint32_t &y) {
     const uint32_t by = block_tile / tiles_x, bx = block_tile - by * tiles_x;
     x = (bx * WAVES + wave) * 8u + (local & 7u);
-    y = row_begin + by * 8u + (local >> 3);
+    y = row_begin + by * tile_rows + (local >> 3);          // tile_rows < 8: the lanes of the tile's missing rows stay out of range
 }
 
 // orders this wave's LDS writes before its later LDS reads by other lanes (no cross-wave communication exists)
@@ -520,7 +521,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
-                                                                          const uint32_t xcd_aware, const uint32_t early_exit) {
+                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows) {
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
     extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
     const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
@@ -543,9 +544,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, x, y);
-    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, x, y);
-    const bool in_range = x < W && y < a.row_end;
+    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y);
+    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y);
+    const bool in_range = x < W && y < a.row_end && (lane >> 3) < tile_rows;
     const bool setup_wave = !SHARED || wave == 0;         // SHARED: wave 0 prepares the tile, the others join at the barrier
     bool covered = false;
     float depth = 0.0f;
@@ -1089,18 +1090,22 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const uint32_t pregen_kinds = pregen ? kinds : 0u;
         const bool shared_tile = ctx->options[kOptSharedTile] != 0;
         const size_t stack_bytes = size_t(levels + 3) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
-        const uint32_t tiles_x = (width + 7) / 8, tiles_y = (a.row_end - a.row_begin + 7) / 8;
+        // raygen_tile_rows < 8 (A-B only): 8x4- or 8x2-pixel tiles = more, shorter waves.  Measured slower everywhere, thin
+        // strips included (1080p / 8: 123 -> 131 us; full frame 452 -> 523 us): a shorter queue keeps fewer lanes busy.
+        const uint32_t rows_traced = a.row_end - a.row_begin;
+        const uint32_t tile_rows = uint32_t(std::max(1, std::min(8, ctx->options[kOptRaygenTileRows])));
+        const uint32_t tiles_x = (width + 7) / 8, tiles_y = (rows_traced + tile_rows - 1) / tile_rows;
         const int waves = ctx->options[kOptWavesPerBlock];
         const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
 #define VHR_LAUNCH_QUEUE(P, WV, C, SP, ST)                                                                                        \
     do {                                                                                                                          \
         if (shared_tile)                                                                                                          \
             launch(ctx, (raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
-                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit);    \
+                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows);    \
         else                                                                                                                      \
             launch(ctx, (raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                (stack_bytes + dir_bytes) * WV, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
-                               uint32_t(ctx->options[kOptXcdAware]), early_exit);                                                  \
+                               uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows);                                       \
     } while (0)
 #define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
     do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
