@@ -255,3 +255,30 @@ def test_gpu_kernel_variants_bit_identical(scene_name, Wv, Hv):
         ctx.set_option("lds_stack_levels", 8)
         path.destroy()
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_empty_scene_is_all_miss_colour():
+    """No geometry: every primary ray runs miss.rmiss (both kernels, both shader sets), nothing is traced towards the light."""
+    from vulkanhybridrenderer_amd import scenes
+    sc = scenes.tiny_scene()
+    sc.primitives = sc.primitives[:0]
+    ctx = lib.Context(70, 45)
+    ctx.upload_scene(sc)
+    ctx.set_ray_statistics(True)
+    path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=False)
+    path.build()
+    try:
+        ctx.update_per_frame_ubo(0, camera.dolly_frames(sc, 70, 45, 2)[1])
+        for alpha in (False, True):
+            path.rebuild(alpha)
+            for variant in (1, 0):
+                ctx.set_option("raytraced_variant", variant)
+                ctx.execute(0, 0)
+                img = ctx.download(lib.RAYTRACED_OUTPUT)
+                assert (img == SKY).all()
+                st = ctx.ray_statistics()
+                assert st["covered_pixels"] == 0 and st["unique_rays"] == 70 * 45
+    finally:
+        path.destroy()
+        ctx.close()
