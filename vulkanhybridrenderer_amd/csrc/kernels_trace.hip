@@ -474,7 +474,10 @@ __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 n
 // coordinate and classifies "parallel to the slab" correctly: inside -> (-huge, +huge), outside -> both beyond tmax.
 // (The exact direction d itself is untouched: Moeller-Trumbore never sees this value.)
 __device__ __forceinline__ float cull_reciprocal(float d) {
-    return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : __frcp_rn(d);
+    // v_rcp_f32 (1 ulp) instead of the correctly rounded division (12 instructions, three of them per ray): at scene scale
+    // (boxes reach t of a few tens) an ulp of 1/d moves a slab distance by ~1e-5, two orders below the boxes' padding
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : r;
 }
 
 constexpr int kQueueBlock = 64;
@@ -624,9 +627,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
             next += n_idle;
             if (!has && r < total) {
-                const uint32_t k = r / ncov;
+                // k = r / ncov without the integer division (~25 instructions): the queue is kind-major, k < kinds
+                uint32_t k = 0, rr = r;
+                while (rr >= ncov) { rr -= ncov; ++k; }
                 kind = k + first_kind;
-                pix = s_list[r - k * ncov];
+                pix = s_list[rr];
                 ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
                 if (PREGEN) {
                     const float *slot = s_dir + k * 3u * kQueueBlock + pix;
