@@ -12,7 +12,7 @@
 #include <cstring>
 #include <vector>
 
-#include "hybrid_render_path.hpp"     // vhr::HybridRenderPath on the facade of include/vhr_render_graph.hpp
+#include "render_paths.hpp"     // vhr::HybridRenderPath on the facade of include/vhr_render_graph.hpp
 
 namespace {
 

@@ -5,7 +5,7 @@
 //
 // Written against the vhr:: facade only (no access to library internals), i.e. exactly what a maintainer of
 // the reference would compile after swapping the Vulkan render graph for this one.
-#include "hybrid_render_path.hpp"
+#include "render_paths.hpp"
 
 #include <utility>
 

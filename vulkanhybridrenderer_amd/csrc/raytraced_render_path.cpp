@@ -3,7 +3,7 @@
 // DeregisterPath :79 (owns nothing), use_anyhit_shader toggle :81-93.
 //
 // Written against the vhr:: facade only, like hybrid_render_path.cpp.
-#include "raytraced_render_path.hpp"
+#include "render_paths.hpp"
 
 #include <string>
 #include <utility>

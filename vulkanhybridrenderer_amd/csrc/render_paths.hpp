@@ -1,0 +1,51 @@
+// The two render paths re-hosted on the vhr:: facade (include/vhr_render_graph.hpp): what an integrator instantiates.
+//   vhr::HybridRenderPath     <- src/render_paths/hybrid_render_path.{h,cpp}      (the hot path: Raytrace Pass + SVGF Denoise Pass)
+//   vhr::RaytracedRenderPath  <- src/render_paths/raytraced_render_path.{h,cpp}   
+// Settings the reference changes through ImGui radio buttons (then Rebuild()) are plain public members here.
+#pragma once
+
+#include "vhr_render_graph.hpp"
+
+namespace vhr {
+
+// mode values of hybrid_render_path.h:4-20 (also the composition shader's specialization constants)
+enum ShadowMode { SHADOW_MODE_RAYTRACED = 0, SHADOW_MODE_RASTERIZED = 1, SHADOW_MODE_OFF = 2 };
+enum AmbientOcclusionMode { AMBIENT_OCCLUSION_MODE_RAYTRACED = 0, AMBIENT_OCCLUSION_MODE_SSAO = 1, AMBIENT_OCCLUSION_MODE_OFF = 2 };
+enum ReflectionMode { REFLECTION_MODE_RAYTRACED = 0, REFLECTION_MODE_SSR = 1, REFLECTION_MODE_OFF = 2 };
+
+class HybridRenderPath : public RenderPath {
+public:
+    using RenderPath::RenderPath;
+    void RegisterPath(DeviceContext &context, RenderGraph &render_graph, ResourceManager &resource_manager) override;
+    void DeregisterPath(DeviceContext &context, RenderGraph &render_graph, ResourceManager &resource_manager) override;
+
+    // the raster stages stay with the integrator (G-buffer, composition): bodies supplied from outside
+    ExternalPassCallback gbuffer_pass;
+    ExternalPassCallback composition_pass;
+
+    // member defaults of hybrid_render_path.h:32-35
+    int shadow_mode = SHADOW_MODE_RAYTRACED;
+    int ambient_occlusion_mode = AMBIENT_OCCLUSION_MODE_OFF;
+    int reflection_mode = REFLECTION_MODE_OFF;
+    bool denoise_shadow_and_ao = false;
+    int atrous_steps = 5;                              // hybrid_render_path.cpp:299
+
+    // the five persistent SVGF images (pool indices) travel in the push constants, hybrid_render_path.cpp:247-262
+    SVGFPushConstants svgf_push_constants{};
+    bool svgf_textures_created = false;
+};
+
+class RaytracedRenderPath : public RenderPath {
+public:
+    using RenderPath::RenderPath;
+    void RegisterPath(DeviceContext &context, RenderGraph &render_graph, ResourceManager &resource_manager) override;
+    void DeregisterPath(DeviceContext &context, RenderGraph &render_graph, ResourceManager &resource_manager) override;
+
+    // the path's composition stage is a raster pass and stays with the integrator
+    ExternalPassCallback composition_pass;
+
+    // "Alpha test for shadows" (raytraced_render_path.h:15; the UI sets it at raytraced_render_path.cpp:80-93)
+    int use_anyhit_shader = 0;
+};
+
+}  // namespace vhr
