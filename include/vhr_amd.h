@@ -313,6 +313,10 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      vhr_graph_gather_performance_statistics (default; the reference's vkCmdWriteTimestamp pair,
  *                      render_graph.cpp:167-182; ~1.5 us per dispatch), 0 = off.  External graphics passes are not stamped.
  *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 8 (default), 4 or 2 (measured slower)
+ *   "fuse_blits"       1 = a compute pass records its dispatches and blits and issues them when its callback returns; a
+ *                      same-extent blit whose source is the output of a recorded a-trous dispatch (and whose destination nothing
+ *                      in between touches) becomes a second store of that launch instead of a copy kernel (default; two of the
+ *                      three blits of hybrid_render_path.cpp:310-325), 0 = every blit is a copy
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -165,3 +165,34 @@ def test_hybrid_path_sponza_quarter_res(oracle):
         assert float(np.sqrt(np.mean((den - ref) ** 2))) <= 1e-4
     finally:
         g.close()
+
+
+def test_fused_blits_equal_copies():
+    """A compute pass records its commands; two of the three blits of hybrid_render_path.cpp:310-325 become second stores of
+    the a-trous launch that produced their source ("fuse_blits", default).  Every image of the SVGF state must be the same,
+    bit for bit, as with three copy kernels -- over several frames, since the history feeds back."""
+    from vulkanhybridrenderer_amd import camera, scenes
+    from tests.helpers import GpuHybrid
+    W, H = 200, 120
+    sc = scenes.tiny_scene()
+    pfds = camera.dolly_frames(sc, W, H, 5)
+    out = {}
+    for fuse in (1, 0):
+        g = GpuHybrid(sc, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
+        try:
+            g.ctx.set_option("fuse_blits", fuse)
+            g.ctx.set_kernel_timing(["blit"])
+            pc = g.path.push_constants()
+            frames = []
+            for pfd in pfds:
+                g.frame(pfd)
+                frames.append([g.ctx.download(lib.DENOISED)] + [g.ctx.download(int(pc[k])) for k in
+                              ("prev_frame_normals_and_object_ids", "shadow_and_ao_history", "shadow_and_ao_moments_history")] +
+                              [g.ctx.download(int(pc["integrated_shadow_and_ao"][i])) for i in (0, 1)])
+            out[fuse] = (frames, g.ctx.kernel_time("blit")[1])
+        finally:
+            g.close()
+    assert out[1][1] == len(pfds) and out[0][1] == 3 * len(pfds)          # one copy kernel per frame instead of three
+    for f, (a, b) in enumerate(zip(out[1][0], out[0][0])):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), f"frame {f}, image {k}"

@@ -229,6 +229,7 @@ const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_s
 int vhr_synchronize(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return VHR_OK;
+    if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return VHR_OK;
 }
@@ -398,7 +399,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -490,6 +491,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -16,6 +16,8 @@
 
 namespace vhr {
 
+static int issue_cmd(vhr_context *ctx, const SvgfCmd &cmd);
+
 #pragma clang fp contract(off)      // K3; K4 switches contraction back on below
 
 constexpr int kSvgfBlockX = 64;    // one wave per image row segment: fully coalesced 512-byte row reads
@@ -48,16 +50,6 @@ __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1
 // No FMA contraction in K3 (the pragma sits above the shared helpers, mixf included): the kernel is bound by its
 // gathers, not by arithmetic, and with the shader's (= the oracle's) roundings its output is bit-identical to the
 // oracle's.  (A fused mix(prev, cur, 0.2) lands on the other side of an fp16 tie in ~2 % of the pixels.)
-struct TemporalArgs {
-    const uint2 *normals, *motion, *prev_normals, *history;   // RGBA16F
-    const uint32_t *raytraced, *moments_in;                   // RG16F
-    uint2 *integrated_out;                                     // RGBA16F
-    uint32_t *moments_out;                                     // RG16F
-    uint32_t width, height;       // image extent
-    uint32_t limit_x, limit_y;    // pixels covered by the dispatch (groups * 8, clamped)
-    uint32_t row_begin, row_end;  // rows this context computes
-    float display_w, display_h;   // pfd.display_size
-};
 
 // svgf.comp:16-39
 __device__ __forceinline__ bool is_valid_reprojection(const TemporalArgs &a, int px, int py, int current_object_id, f3 current_normal) {
@@ -188,29 +180,20 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
     strip_rows(ctx, H, ctx->overlap, a.row_begin, a.row_end);
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
-    if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
-        const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
-        ctx->time_begin(kKernelTemporal);
-        launch(ctx, svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
-        ctx->time_end(kKernelTemporal);
-        if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
-    }
-    // the dispatch read a snapshot (ptr) and wrote the new moments (alt): flip (oracle decision ii)
+    // the dispatch reads a snapshot (ptr) and writes the new moments (alt): flip (oracle decision ii) -- host-side state, so
+    // at record time: later commands of the pass see the flipped image
     std::swap(moments.ptr, moments.alt);
-    return VHR_OK;
+    SvgfCmd cmd{};
+    cmd.kind = SvgfCmd::Temporal;
+    cmd.t = a;
+    if (ctx->recording) { ctx->recorded.push_back(cmd); return VHR_OK; }
+    return issue_cmd(ctx, cmd);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4: svgf_atrous_filter.comp
 // ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(fast)
-struct AtrousArgs {
-    const uint2 *normals, *in;
-    uint2 *out;
-    uint32_t width, height, limit_x, limit_y, row_begin, row_end;
-    int32_t step;
-    float display_w, display_h;
-};
 
 __device__ __forceinline__ float pow128(float x) {      // max(0, pow(x, 128)); pow of x <= 0 defined as 0
     x = fmaxf(x, 0.0f);
@@ -270,7 +253,9 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(c
             s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;   // :92
         }
     const float rs = __frcp_rn(sw_s), ra = __frcp_rn(sw_a);
-    a.out[idx] = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
+    const uint2 texel = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));     // :97-101
+    a.out[idx] = texel;
+    if (a.out2) a.out2[idx] = texel;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -390,7 +375,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs
                 s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;   // :92
             }
         const float rs = __frcp_rn(sw_s), ra = __frcp_rn(sw_a);
-        a.out[size_t(cy) * W + cx] = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+        const uint2 texel = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
+        a.out[size_t(cy) * W + cx] = texel;
+        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
     }
 }
 
@@ -570,7 +557,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
             }
         }
         const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
-        a.out[size_t(cy) * W + cx] = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+        const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
+        a.out[size_t(cy) * W + cx] = texel;
+        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
     }
 }
 
@@ -762,7 +751,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                 }
             }
             const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
-            a.out[size_t(cy) * W + cx] = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));   // :97-101
+            const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
+        a.out[size_t(cy) * W + cx] = texel;
+        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
         }
         if (!more) break;
         __syncthreads();                             // every wave is done with this tile's LDS image
@@ -834,43 +825,12 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     a.step = step;
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
-    if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
-    const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
-    ctx->time_begin(kKernelAtrous);
-    const int variant = ctx->options[kOptAtrousVariant];
-    bool tiled = variant != 0;
-    if (variant == 4) {
-        switch (step) {
-            case 1: launch_atrous_stream_auto<1>(ctx, a); break;
-            case 2: launch_atrous_stream_auto<2>(ctx, a); break;
-            case 4: launch_atrous_stream_auto<4>(ctx, a); break;
-            case 8: launch_atrous_stream_auto<8>(ctx, a); break;
-            case 16: launch_atrous_stream_auto<16>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
-        }
-    } else if (variant == 3) {
-        switch (step) {
-            case 1: launch_atrous_packed<1, 8>(ctx, a); break;
-            case 2: launch_atrous_packed<2, 8>(ctx, a); break;
-            case 4: launch_atrous_packed<4, 8>(ctx, a); break;
-            case 8: launch_atrous_packed<8, 8>(ctx, a); break;
-            case 16: launch_atrous_packed<16, 8>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
-        }
-    } else if (tiled) {
-        switch (step) {
-            case 1: if (variant == 2) launch_atrous_tiled<1, 8>(ctx, a); else launch_atrous_tiled<1, 16>(ctx, a); break;
-            case 2: if (variant == 2) launch_atrous_tiled<2, 8>(ctx, a); else launch_atrous_tiled<2, 16>(ctx, a); break;
-            case 4: if (variant == 2) launch_atrous_tiled<4, 8>(ctx, a); else launch_atrous_tiled<4, 16>(ctx, a); break;
-            case 8: if (variant == 2) launch_atrous_tiled<8, 8>(ctx, a); else launch_atrous_tiled<8, 16>(ctx, a); break;
-            case 16: if (variant == 2) launch_atrous_tiled<16, 8>(ctx, a); else launch_atrous_tiled<16, 16>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
-        }
-    }
-    if (!tiled) launch(ctx, svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
-    ctx->time_end(kKernelAtrous);
-    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
-    return VHR_OK;
+    a.out2 = nullptr;
+    SvgfCmd cmd{};
+    cmd.kind = SvgfCmd::Atrous;
+    cmd.a = a;
+    if (ctx->recording) { ctx->recorded.push_back(cmd); return VHR_OK; }
+    return issue_cmd(ctx, cmd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -926,8 +886,51 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     strip_rows(ctx, src.height, ctx->halo, r0, r1);
     if (r1 <= r0 || src.ptr == dst.ptr) return VHR_OK;
     const size_t row = size_t(src.width) * src.bpp, offset = r0 * row, bytes = (r1 - r0) * row;
-    const char *s8 = static_cast<const char *>(src.ptr) + offset;
-    char *d8 = static_cast<char *>(dst.ptr) + offset;
+    SvgfCmd cmd{};
+    cmd.kind = SvgfCmd::Copy;
+    cmd.copy_src = static_cast<const char *>(src.ptr) + offset;
+    cmd.copy_dst = static_cast<char *>(dst.ptr) + offset;
+    cmd.copy_bytes = bytes;
+    cmd.src_base = src.ptr;
+    cmd.dst_base = dst.ptr;
+    if (!ctx->recording) return issue_cmd(ctx, cmd);
+    // ---- fusion: the blit becomes a second store of the recorded a-trous dispatch that produced its source ----
+    if (ctx->options[kOptFuseBlits] && src.bpp == 8) {
+        const bool whole = ctx->row_begin == 0 && ctx->row_end >= src.height;
+        auto touches = [](const SvgfCmd &c, const void *p, bool writes_only) {
+            switch (c.kind) {
+                case SvgfCmd::Temporal:
+                    return c.t.integrated_out == p || c.t.moments_out == p ||
+                           (!writes_only && (c.t.normals == p || c.t.motion == p || c.t.prev_normals == p || c.t.history == p || c.t.raytraced == p || c.t.moments_in == p));
+                case SvgfCmd::Atrous:
+                    return c.a.out == p || c.a.out2 == p || (!writes_only && (c.a.normals == p || c.a.in == p));
+                default:
+                    return c.dst_base == p || (!writes_only && c.src_base == p);
+            }
+        };
+        for (size_t k = ctx->recorded.size(); k-- > 0;) {                 // newest first
+            SvgfCmd &w = ctx->recorded[k];
+            if (touches(w, src.ptr, true)) {
+                // w wrote the source last.  Fusable iff it is an a-trous launch over whole rows that the blit covers (on a
+                // strip the blit's extra rows hold nothing valid and are refilled by the neighbour exchange, see vhr_set_strip)
+                if (w.kind == SvgfCmd::Atrous && w.a.out == src.ptr && !w.a.out2 && w.a.limit_x == w.a.width && !touches(w, dst.ptr, false) &&
+                    w.a.row_begin >= r0 && w.a.row_end <= r1 && (!whole || (w.a.row_begin == r0 && w.a.row_end == r1 && w.a.limit_y >= r1))) {
+                    w.a.out2 = static_cast<uint2 *>(dst.ptr);
+                    return VHR_OK;
+                }
+                break;
+            }
+            if (touches(w, dst.ptr, false)) break;                         // a later command uses the destination: the copy cannot move before it
+        }
+    }
+    ctx->recorded.push_back(cmd);
+    return VHR_OK;
+}
+
+static int issue_copy(vhr_context *ctx, const SvgfCmd &cmd) {
+    const char *s8 = cmd.copy_src;
+    char *d8 = cmd.copy_dst;
+    const size_t bytes = cmd.copy_bytes;
     hipError_t copy_rc = hipSuccess;
     ctx->time_begin(kKernelCopy);
     if (((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(d8) | bytes) & 15u) == 0) {
@@ -942,6 +945,79 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     ctx->time_end(kKernelCopy);
     if (copy_rc != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: device copy failed");
     return VHR_OK;
+}
+
+static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
+    if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
+        const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+        ctx->time_begin(kKernelTemporal);
+        launch(ctx, svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
+        ctx->time_end(kKernelTemporal);
+        if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
+    }
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Issue of recorded / immediate SVGF commands
+// ---------------------------------------------------------------------------------------------
+static int issue_atrous(vhr_context *ctx, const AtrousArgs &a) {
+    const int32_t step = a.step;
+    if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
+    const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+    ctx->time_begin(kKernelAtrous);
+    const int variant = ctx->options[kOptAtrousVariant];
+    bool tiled = variant != 0;
+    if (variant == 4) {
+        switch (step) {
+            case 1: launch_atrous_stream_auto<1>(ctx, a); break;
+            case 2: launch_atrous_stream_auto<2>(ctx, a); break;
+            case 4: launch_atrous_stream_auto<4>(ctx, a); break;
+            case 8: launch_atrous_stream_auto<8>(ctx, a); break;
+            case 16: launch_atrous_stream_auto<16>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    } else if (variant == 3) {
+        switch (step) {
+            case 1: launch_atrous_packed<1, 8>(ctx, a); break;
+            case 2: launch_atrous_packed<2, 8>(ctx, a); break;
+            case 4: launch_atrous_packed<4, 8>(ctx, a); break;
+            case 8: launch_atrous_packed<8, 8>(ctx, a); break;
+            case 16: launch_atrous_packed<16, 8>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    } else if (tiled) {
+        switch (step) {
+            case 1: if (variant == 2) launch_atrous_tiled<1, 8>(ctx, a); else launch_atrous_tiled<1, 16>(ctx, a); break;
+            case 2: if (variant == 2) launch_atrous_tiled<2, 8>(ctx, a); else launch_atrous_tiled<2, 16>(ctx, a); break;
+            case 4: if (variant == 2) launch_atrous_tiled<4, 8>(ctx, a); else launch_atrous_tiled<4, 16>(ctx, a); break;
+            case 8: if (variant == 2) launch_atrous_tiled<8, 8>(ctx, a); else launch_atrous_tiled<8, 16>(ctx, a); break;
+            case 16: if (variant == 2) launch_atrous_tiled<16, 8>(ctx, a); else launch_atrous_tiled<16, 16>(ctx, a); break;
+            default: tiled = false; break;       // other steps: the direct kernel
+        }
+    }
+    if (!tiled) launch(ctx, svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
+    ctx->time_end(kKernelAtrous);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
+    return VHR_OK;
+}
+
+static int issue_cmd(vhr_context *ctx, const SvgfCmd &cmd) {
+    switch (cmd.kind) {
+        case SvgfCmd::Temporal: return issue_temporal(ctx, cmd.t);
+        case SvgfCmd::Atrous: return issue_atrous(ctx, cmd.a);
+        default: return issue_copy(ctx, cmd);
+    }
+}
+
+int flush_recorded(vhr_context *ctx) {
+    int rc = VHR_OK;
+    for (const SvgfCmd &cmd : ctx->recorded) {
+        rc = issue_cmd(ctx, cmd);
+        if (rc != VHR_OK) break;
+    }
+    ctx->recorded.clear();
+    return rc;
 }
 
 }  // namespace vhr

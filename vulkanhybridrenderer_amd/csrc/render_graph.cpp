@@ -306,7 +306,11 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
             p.rt_cb(p.user, &ec);
         } else {
             vhr_compute_execution_context ec{ ctx, &p, resource_idx };         // ExecuteComputePass, :914-919
+            ctx->recording = true;                                             // the callback records, like a command buffer
             p.compute_cb(p.user, &ec);
+            ctx->recording = false;
+            const int frc = vhr::flush_recorded(ctx);                          // ... and the pass is issued when it returns
+            if (frc != VHR_OK) { ctx->cur_pass = nullptr; return frc; }
         }
         ctx->cur_pass = nullptr;
         if (stamps && p.begin_stamped && !p.end_on_last_dispatch) HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));

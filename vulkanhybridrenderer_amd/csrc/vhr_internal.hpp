@@ -133,13 +133,44 @@ struct PassDescription {
     double ema_ms = 0.0, last_ms = 0.0;
 };
 
+// Kernel arguments of the SVGF kernels (csrc/kernels_svgf.hip) and the command record of a compute pass.
+struct TemporalArgs {
+    const uint2 *normals, *motion, *prev_normals, *history;   // RGBA16F
+    const uint32_t *raytraced, *moments_in;                   // RG16F
+    uint2 *integrated_out;                                     // RGBA16F
+    uint32_t *moments_out;                                     // RG16F
+    uint32_t width, height;       // image extent
+    uint32_t limit_x, limit_y;    // pixels covered by the dispatch (groups * 8, clamped)
+    uint32_t row_begin, row_end;  // rows this context computes
+    float display_w, display_h;   // pfd.display_size
+};
+struct AtrousArgs {
+    const uint2 *normals, *in;
+    uint2 *out;
+    uint2 *out2;                  // second destination of the same texels (a blit fused into the launch), or nullptr
+    uint32_t width, height, limit_x, limit_y, row_begin, row_end;
+    int32_t step;
+    float display_w, display_h;
+};
+// A compute pass RECORDS its dispatches and blits (the reference records a command buffer, compute_execution_context.cpp)
+// and issues them when its callback returns.  That lets a same-extent blit whose source is the output of a recorded a-trous
+// dispatch -- and whose destination nothing in between touches -- become a second store of that launch instead of a copy
+// kernel of its own: two of the three blits of hybrid_render_path.cpp:310-325 (one launch, its gap and 8 B/px of reads each).
+struct SvgfCmd {
+    enum Kind { Temporal, Atrous, Copy } kind;
+    TemporalArgs t;
+    AtrousArgs a;
+    const char *copy_src; char *copy_dst; size_t copy_bytes;       // Copy: row range applied
+    const void *src_base; void *dst_base;                          // Copy: the images' base pointers (hazard checks)
+};
+
 struct RayStats {
     unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, second_bounce_rays;
     unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, pad2;   // per-wave s_memtime sums
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptCount = 21 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptCount = 22 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelKinds = 5 };
@@ -209,7 +240,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     uint32_t kernel_timing_mask = 0;   // bit per KernelKind
@@ -217,6 +248,8 @@ struct vhr_context {
     // Timing rides on the dispatch packets: vhr::launch() attaches (start, stop) events to a kernel launch through
     // hipExtLaunchKernelGGL, i.e. the dispatch's own begin / end timestamps.  A hipEventRecord instead puts a barrier packet and
     // a ~4 us bubble on the stream (measured: 33 us per frame for the eight per-pass records alone).
+    bool recording = false;            // inside a compute pass callback: SVGF commands are recorded, issued at its end
+    std::vector<vhr::SvgfCmd> recorded;
     int timing_kind = -1;              // kernel kind whose launches are being issued (between time_begin and time_end)
     vhr::PassDescription *cur_pass = nullptr;      // pass whose callback is running (vkCmdWriteTimestamp equivalents)
     void time_begin(int kind) { timing_kind = kind; }
@@ -255,6 +288,7 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in,
                        Image &out, int32_t step, uint32_t x_groups, uint32_t y_groups);
 int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst);
+int flush_recorded(vhr_context *ctx);          // issue the commands a compute pass recorded (no-op when there are none)
 int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink);
 
 }  // namespace vhr
