@@ -278,7 +278,9 @@ def main():
                 "kernel": "svgf_atrous_stream_kernel<step, 8> (svgf_atrous_filter.comp)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits)",
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits; "
+                                  "two of the five launches per frame also store the texels a blit would have copied, +8 B/px each = +6.6 MB on this average, "
+                                  "which the 24 B/px of `achieved` do not count)",
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
                 "algorithmic_bytes_per_launch": int(atrous_bytes),
             },
