@@ -269,9 +269,10 @@ int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_ou
 /* Multi-GPU row strips: this context owns rows [row_begin, row_end) of the
  * display.  Ray tracing runs on the owned rows; the SVGF kernels on the owned rows extended by `overlap`
  * rows on each side (recomputed instead of exchanged between a-trous iterations); the blits copy the owned
- * rows extended by `halo` rows (>= overlap: the rows next frame's temporal pass may read).  All ranges are
- * clamped to the image.  Default: whole image, overlap 0, halo 0.  The halo rows themselves are filled by
- * the caller's neighbour exchange (vulkanhybridrenderer_amd/tiling.py over RCCL). */
+ * rows extended by `halo` rows (>= overlap: the rows next frame's temporal pass may read) -- a blit fused into
+ * the a-trous launch that produced its source ("fuse_blits") stores that launch's rows only, which are the valid
+ * ones.  All ranges are clamped to the image.  Default: whole image, overlap 0, halo 0.  The halo rows of the
+ * history images are filled by the caller's neighbour exchange (vulkanhybridrenderer_amd/tiling.py over RCCL). */
 int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo);
 
 /* Statistics of the last vhr_trace_rays: out[0] = unique rays traced, out[1] = rays the reference would
