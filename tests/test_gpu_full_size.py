@@ -1,5 +1,5 @@
 """The hot path at BASELINE.json's full sizes (configs 2 and 3 on one GPU): oracle parity where the oracle finishes in
-seconds on the GPU box's host cores (whole 1080p frames; a 64-row band of a 4K frame), plus size-independent properties --
+seconds on the GPU box's host cores (whole 1080p and 4K frames; a band of the Bistro-sized scene), plus size-independent properties --
 every traversal variant produces the same image, sky pixels stay (1, 1), the denoised image is finite and inside [0, 1], and
 eight virtual row strips reproduce the single-context 1080p frame bit for bit."""
 import numpy as np
@@ -52,26 +52,29 @@ def test_config2_1080p_whole_frames_against_the_oracle(oracle):
         g.close()
 
 
-def test_config3_4k_band_and_properties(oracle):
-    """3840x2160 with 4 AO samples (config 3): a 64-row band of visibility against the oracle, variants identical on the whole
-    frame, denoised image finite and in range."""
+def test_config3_4k_whole_frames_against_the_oracle(oracle):
+    """3840x2160 with 4 AO samples (config 3), two whole frames: visibility bit-exact, denoised RMSE <= 1e-4, the literal
+    per-pixel kernel equal to the queue kernel (about 25 s of oracle time on the GPU box's host cores)."""
     W, H = 3840, 2160
     sc = scenes.sponza_proc()
     osc = oracle.Scene(sc)
+    svgf = oracle.SVGF(W, H)
     tp = abi.default_trace_params(ao_spp=4, reflections=False)
     g = GpuHybrid(sc, W, H, reflections=False, trace_params=tp, gbuffer="standin")
     try:
-        for pfd in camera.dolly_frames(sc, W, H, 3):
+        for i, pfd in enumerate(camera.dolly_frames(sc, W, H, 2)):
             g.frame(pfd)
-        n, m, d = _gbuffer(g)
-        got = g.ctx.download(lib.RAYTRACED)
-        r0, r1 = 1200, 1264
-        sa, _, _, _ = osc.raygen(pfd, tp, n, d, rows=(r0, r1), want_reflections=False)
-        assert np.array_equal(got[r0:r1], sa[r0:r1])
-        ao = f16(got)[..., 1][d != 0]
-        assert set(np.unique(ao).tolist()) <= {0.0, 0.25, 0.5, 0.75, 1.0}          # visible / 4
-        out = f16(g.ctx.download(lib.DENOISED))
-        assert np.isfinite(out).all() and out[..., :2].min() >= 0.0 and out[..., :2].max() <= 1.0 + 2.0 ** -10
+            n, m, d = _gbuffer(g)
+            got = g.ctx.download(lib.RAYTRACED)
+            sa, _, _, _ = osc.raygen(pfd, tp, n, d, want_reflections=False)
+            assert np.array_equal(got, sa), f"frame {i}: {(got != sa).any(-1).sum()} pixels differ"
+            ao = f16(got)[..., 1][d != 0]
+            assert set(np.unique(ao).tolist()) <= {0.0, 0.25, 0.5, 0.75, 1.0}          # visible / 4
+            den = f16(svgf.frame(pfd, n, m, sa))
+            out = f16(g.ctx.download(lib.DENOISED))
+            assert np.isfinite(out).all() and out[..., :2].min() >= 0.0 and out[..., :2].max() <= 1.0 + 2.0 ** -10
+            rmse = float(np.sqrt(np.mean((out - den) ** 2)))
+            assert rmse <= 1e-4 and np.abs(out - den).max() <= 4e-3, f"frame {i}: denoised RMSE {rmse}"
         g.ctx.set_option("raygen_variant", 0)
         g.ctx.execute(0, 0)                                          # same frame again: history differs, visibility must not
         g.ctx.synchronize()
