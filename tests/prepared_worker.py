@@ -31,6 +31,18 @@ def main():
                 bad += int((t[ra:rb] != float(100 * frame + peer)).any())
         for t in (a, b):
             bad += int((t[plan.row_begin:plan.row_end] != float(100 * frame + rank)).any())
+    # C2 with strips of unequal height (H not divisible by the world size): every rank's rows assembled on rank 0
+    img = torch.full((H, W, 4), -7.0)
+    gather = tiling.StripGather(dist, img, plan)
+    for frame in range(2):
+        img[plan.row_begin:plan.row_end] = float(10 * frame + rank + 1)
+        pending = gather.start()
+        if pending is not None:
+            pending.finish()
+        if rank == 0:
+            for r in range(world):
+                a, b = tiling.strip_bounds(H, world, r)
+                bad += int((gather.full[a:b] != float(10 * frame + r + 1)).any())
     res = torch.tensor([bad], dtype=torch.int64)
     dist.all_reduce(res)
     if rank == 0:

@@ -64,12 +64,13 @@ def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink, strip
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_prepared_exchange_replays(tmp_path, world):
-    """The P2P descriptor list the RCCL path builds once and replays every frame (tiling.PreparedExchange), on CPU over gloo."""
+    """The P2P descriptor lists the RCCL path builds once and replays every frame (tiling.PreparedExchange, tiling.StripGather),
+    on CPU over gloo, with strips of unequal height (97 rows)."""
     out = tmp_path / "prepared.txt"
     port = 29700 + world
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "prepared_worker.py"), str(out), "96", "16", "9"]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "prepared_worker.py"), str(out), "97", "16", "9"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     bad, nops = out.read_text().split()
