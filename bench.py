@@ -47,7 +47,7 @@ def parse():
     p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "tiny"])
     p.add_argument("--gltf", default=None, help="load this .gltf / .glb instead of a procedural scene (vulkanhybridrenderer_amd/gltf.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-frames", type=int, default=8, help="frames of the same workload the CPU oracle is timed on (~1.3 s each on the GPU box's 128 threads)")
+    p.add_argument("--cpu-frames", type=int, default=16, help="frames of the same workload the CPU oracle is timed on (~1.3 s each on the GPU box's 128 threads)")
     p.add_argument("--max-gbuffers", type=int, default=64, help="distinct precomputed G-buffer frames (wraps beyond)")
     p.add_argument("--verify-frames", type=int, default=3,
                    help="N > 1 only: before timing, check that the gathered strips equal a single full-frame context bit for bit")
