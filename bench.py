@@ -270,7 +270,7 @@ def main():
                 "overlap_rows_raytraced": ("recomputed locally" if getattr(loop, "trace_overlap", False) else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
                 "final_gather": ("denoised strips -> rank 0 every frame (point-to-point over RCCL, overlapped with the next frame's ray tracing, "
-                                 "finished inside the timed region)" if loop.gather else "off") if world > 1 else None,
+                                 "finished inside the timed region)" if loop.gather else ("off" + (f" (disabled at run time: {loop.gather_error})" if loop.gather_error else ""))) if world > 1 else None,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
                         "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
             },
