@@ -318,6 +318,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      same-extent blit whose source is the output of a recorded a-trous dispatch (and whose destination nothing
  *                      in between touches) becomes a second store of that launch instead of a copy kernel (default; two of the
  *                      three blits of hybrid_render_path.cpp:310-325), 0 = every blit is a copy
+ *   "raygen_cut"       1 = each tile of the queue kernel descends the BVH once from the root along the children that
+ *                      contain the box of its ray origins and keeps the siblings it passes (at most 16) in LDS; a ray tests
+ *                      those boxes when it is fetched and starts below them instead of at the root (default; same
+ *                      triangles tested in a different order, visibility bit-identical), 0 = every ray starts at the root.
+ *                      Ignored with "compact_nodes", the shared-tile variant and pre-generated rays.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

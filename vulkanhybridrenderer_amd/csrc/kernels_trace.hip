@@ -521,7 +521,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 // SHARED: the WAVES waves of a block split the queue of ONE 8x8 tile between them (queue head in LDS) instead of
 // owning a tile each: a wave then lives for about a third as long, which matters whenever few waves are in flight
 // (the end of a launch, or a thin strip of a multi-GPU run), at the price of one block-wide barrier on either side.
-template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS>
+// CUT: the rays of a tile all start within centimetres of each other, and each of them would spend most of its ~16 node
+// visits walking from the root down to the boxes around that spot -- every box on the way contains the origin, so every ray
+// hits it whatever its direction.  The wave therefore makes that descent ONCE per tile (uniformly: follow the inner child whose
+// box contains the bounding box of the tile's ray origins, keep the other child) and leaves a CUT of the tree in LDS: up to
+// kCutMax subtrees that together cover all geometry.  A ray then starts by testing the cut's boxes (a short uniform loop over
+// LDS broadcasts, every refilled lane busy) and walks only the subtrees it hits.  Box tests only cull, so results are unchanged.
+constexpr int kCutMax = 16;
+
+template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
                                                                           const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows) {
@@ -534,10 +542,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     __shared__ float s_ray_all[COPIES][7][kQueueBlock];   // per covered pixel: ray origin (3), normal (3), RNG seed (1)
     __shared__ uint8_t s_list_all[COPIES][kQueueBlock];   // compacted covered pixels
     __shared__ uint32_t s_next, s_ncov;                   // SHARED: queue head and covered-pixel count of the tile
+    __shared__ float4 s_cut_all[CUT ? COPIES : 1][CUT ? kCutMax : 1][2];   // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t (&s_vis)[kQueueBlock] = s_vis_all[SHARED ? 0 : wave];
     float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
     uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
+    float4 (&s_cut)[CUT ? kCutMax : 1][2] = s_cut_all[CUT ? (SHARED ? 0 : wave) : 0];
     // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
     // LDS stack rows: [0] = sentinel (what a pop of the empty stack returns), [1 .. stack_levels] = entries
     // 0 .. stack_levels-1, [stack_levels+1, +2] = dummies that absorb the accesses of entries living in scratch
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // CUT: bounds of the tile's ray origins
     if (covered) {
         // ---- raygen.rgen:15-29 once per pixel (shared by all of the pixel's rays) ----
         const float u = (float(x) + 0.5f) / float(W);
@@ -572,6 +583,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
         const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
+        if (CUT) { omin = origin; omax = origin; }
         if (PREGEN) {
             for (uint32_t kind = first_kind; kind <= last_kind; ++kind) {
                 const f3 d = ray_direction(a.tp, seed, kind, L, N);
@@ -594,6 +606,51 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         wave_lds_sync();
     }
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
+    uint32_t cut_n = 0;
+    if (CUT && total) {
+        // ---- bounds of the origins (wave reduction), then the shared descent; every lane computes the same thing ----
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
+            omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
+        }
+        auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+            if (lane == 0) {
+                s_cut[cut_n][0] = make_float4(lx, hx, ly, hy);
+                s_cut[cut_n][1] = make_float4(lz, hz, __int_as_float(link), 0.0f);
+            }
+            ++cut_n;
+        };
+        int node = 0;
+        float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };          // box of `node` (the root: everything)
+        bool open = true;                                                                      // `node` still waits for its entry
+        for (int it = 0; it < kCutMax - 2; ++it) {
+            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + node);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            const bool in0 = q0.x <= omin.x && omax.x <= q0.y && q0.z <= omin.y && omax.y <= q0.w && q1.x <= omin.z && omax.z <= q1.y;
+            const bool in1 = q1.z <= omin.x && omax.x <= q1.w && q2.x <= omin.y && omax.y <= q2.y && q2.z <= omin.z && omax.z <= q2.w;
+            const bool follow0 = links.x >= 0 && in0, follow1 = !follow0 && links.y >= 0 && in1;
+            if (!(follow0 || follow1)) {                                                      // the descent ends here: both children join the cut
+                add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
+                add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
+                open = false;
+                break;
+            }
+            if (follow0) {
+                add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
+                fb[0] = q0.x; fb[1] = q0.y; fb[2] = q0.z; fb[3] = q0.w; fb[4] = q1.x; fb[5] = q1.y;
+                node = links.x;
+            } else {
+                add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
+                fb[0] = q1.z; fb[1] = q1.w; fb[2] = q2.x; fb[3] = q2.y; fb[4] = q2.z; fb[5] = q2.w;
+                node = links.y;
+            }
+        }
+        if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
+        wave_lds_sync();
+    }
+    uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
@@ -645,6 +702,18 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 cur = 0; sp = 0;
+                if (CUT) {                            // the ray against the tile's cut: hit subtrees go on its stack
+                    emask = 0;
+                    for (uint32_t e = 0; e < cut_n; ++e) {
+                        const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
+                        float tnu;
+                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
+                            if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
+                            else emask |= 1u << e;
+                        }
+                    }
+                    if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
+                }
                 has = true;
             }
         }
@@ -725,6 +794,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 }
                 --sp;
             }
+        }
+        if (CUT && has && !found && cur == kStackSentinel && emask) {          // overflowed cut entries: next subtree
+            const int e = __ffs(int(emask)) - 1;
+            emask &= emask - 1u;
+            cur = __float_as_int(s_cut[e][1].z);
+            sp = 0;                                   // the pop of the empty stack left it at -1
         }
         const bool finished = found || cur == kStackSentinel;
         if (has && finished) {
@@ -1114,14 +1189,27 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     } while (0)
 #define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
     do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
+        // the shared descent ("raygen_cut", default): own-tile waves on the plain fp32 nodes
+        const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile && !ctx->options[kOptCompactNodes];
+#define VHR_LAUNCH_CUT(WV, SP, ST)                                                                                                \
+    launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+           stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows)
+#define VHR_LAUNCH_CUT_W(SP, ST) \
+    do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
         const bool compact = ctx->options[kOptCompactNodes] != 0;
         // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
         const bool spill = levels < ctx->bvh_depth + 1u;
         // A/B variants (pre-generated directions, compact nodes) exist in the diagnostic flavour only
-        if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true, true, true); else VHR_LAUNCH_QUEUE_W(true, false, true, true); }
+        if (cut) {
+            if (a.stats) { if (spill) VHR_LAUNCH_CUT_W(true, true); else VHR_LAUNCH_CUT_W(false, true); }
+            else { if (spill) VHR_LAUNCH_CUT_W(true, false); else VHR_LAUNCH_CUT_W(false, false); }
+        }
+        else if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true, true, true); else VHR_LAUNCH_QUEUE_W(true, false, true, true); }
         else if (compact) VHR_LAUNCH_QUEUE_W(false, true, true, true);
         else if (a.stats) { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, true); else VHR_LAUNCH_QUEUE_W(false, false, false, true); }
         else { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, false); else VHR_LAUNCH_QUEUE_W(false, false, false, false); }
+#undef VHR_LAUNCH_CUT_W
+#undef VHR_LAUNCH_CUT
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
