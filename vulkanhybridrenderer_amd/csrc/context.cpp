@@ -444,7 +444,7 @@ int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]) {
     if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const RayStats &r = ctx->h_ray_stats;
     out[0] = r.cycles_total; out[1] = r.cycles_setup; out[2] = r.cycles_refill; out[3] = r.cycles_nodes;
-    out[4] = r.cycles_leaves; out[5] = r.refills; out[6] = r.waves; out[7] = 0;
+    out[4] = r.cycles_leaves; out[5] = r.refills; out[6] = r.waves; out[7] = r.drain_iterations;
     return VHR_OK;
 }
 

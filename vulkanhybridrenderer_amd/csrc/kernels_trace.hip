@@ -529,6 +529,61 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS broadcasts, every refilled lane busy) and walks only the subtrees it hits.  Box tests only cull, so results are unchanged.
 constexpr int kCutMax = 16;
 
+// The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
+// origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -) --
+// and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
+__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane) {
+    // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
+        omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
+    }
+    // wave-uniform from here on, and told so: the descent then runs on scalar registers and scalar branches
+    auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
+    omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    uint32_t cut_n = 0;
+    auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+        if (lane == 0) {
+            s_cut[cut_n][0] = make_float4(lx, hx, ly, hy);
+            s_cut[cut_n][1] = make_float4(lz, hz, __int_as_float(link), 0.0f);
+        }
+        ++cut_n;
+    };
+    int node = 0;
+    float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };          // box of `node` (the root: everything)
+    bool open = true;                                                                      // `node` still waits for its entry
+    for (int it = 0; it < kCutMax - 2; ++it) {
+        const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
+        const float4 v0 = np[0], v1 = np[1], v2 = np[2];
+        const int2 vl = *reinterpret_cast<const int2 *>(np + 3);
+        const float4 q0 = make_float4(uni(v0.x), uni(v0.y), uni(v0.z), uni(v0.w)), q1 = make_float4(uni(v1.x), uni(v1.y), uni(v1.z), uni(v1.w)),
+                     q2 = make_float4(uni(v2.x), uni(v2.y), uni(v2.z), uni(v2.w));
+        const int2 links = int2{ __builtin_amdgcn_readfirstlane(vl.x), __builtin_amdgcn_readfirstlane(vl.y) };
+        const bool in0 = q0.x <= omin.x && omax.x <= q0.y && q0.z <= omin.y && omax.y <= q0.w && q1.x <= omin.z && omax.z <= q1.y;
+        const bool in1 = q1.z <= omin.x && omax.x <= q1.w && q2.x <= omin.y && omax.y <= q2.y && q2.z <= omin.z && omax.z <= q2.w;
+        const bool follow0 = links.x >= 0 && in0, follow1 = !follow0 && links.y >= 0 && in1;
+        if (!(follow0 || follow1)) {                                                      // the descent ends here: both children join the cut
+            add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
+            add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
+            open = false;
+            break;
+        }
+        if (follow0) {
+            add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
+            fb[0] = q0.x; fb[1] = q0.y; fb[2] = q0.z; fb[3] = q0.w; fb[4] = q1.x; fb[5] = q1.y;
+            node = links.x;
+        } else {
+            add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
+            fb[0] = q1.z; fb[1] = q1.w; fb[2] = q2.x; fb[3] = q2.y; fb[4] = q2.z; fb[5] = q2.w;
+            node = links.y;
+        }
+    }
+    if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
+    wave_lds_sync();
+    return cut_n;
+}
+
 template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
@@ -543,7 +598,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     __shared__ uint8_t s_list_all[COPIES][kQueueBlock];   // compacted covered pixels
     __shared__ uint32_t s_next, s_ncov;                   // SHARED: queue head and covered-pixel count of the tile
     __shared__ float4 s_cut_all[CUT ? COPIES : 1][CUT ? kCutMax : 1][2];   // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (the compiler cannot know that threadIdx.x >> 6 is the same in every lane of a wave: said explicitly, what derives
+    // from it -- the LDS bases, the wave's tile -- stays in scalar registers)
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     uint32_t (&s_vis)[kQueueBlock] = s_vis_all[SHARED ? 0 : wave];
     float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
     uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
@@ -607,49 +664,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     }
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    if (CUT && total) {
-        // ---- bounds of the origins (wave reduction), then the shared descent; every lane computes the same thing ----
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
-            omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
-        }
-        auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
-            if (lane == 0) {
-                s_cut[cut_n][0] = make_float4(lx, hx, ly, hy);
-                s_cut[cut_n][1] = make_float4(lz, hz, __int_as_float(link), 0.0f);
-            }
-            ++cut_n;
-        };
-        int node = 0;
-        float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };          // box of `node` (the root: everything)
-        bool open = true;                                                                      // `node` still waits for its entry
-        for (int it = 0; it < kCutMax - 2; ++it) {
-            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + node);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
-            const bool in0 = q0.x <= omin.x && omax.x <= q0.y && q0.z <= omin.y && omax.y <= q0.w && q1.x <= omin.z && omax.z <= q1.y;
-            const bool in1 = q1.z <= omin.x && omax.x <= q1.w && q2.x <= omin.y && omax.y <= q2.y && q2.z <= omin.z && omax.z <= q2.w;
-            const bool follow0 = links.x >= 0 && in0, follow1 = !follow0 && links.y >= 0 && in1;
-            if (!(follow0 || follow1)) {                                                      // the descent ends here: both children join the cut
-                add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
-                add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
-                open = false;
-                break;
-            }
-            if (follow0) {
-                add_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, links.y);
-                fb[0] = q0.x; fb[1] = q0.y; fb[2] = q0.z; fb[3] = q0.w; fb[4] = q1.x; fb[5] = q1.y;
-                node = links.x;
-            } else {
-                add_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, links.x);
-                fb[0] = q1.z; fb[1] = q1.w; fb[2] = q2.x; fb[3] = q2.y; fb[4] = q2.z; fb[5] = q2.w;
-                node = links.y;
-            }
-        }
-        if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
-        wave_lds_sync();
-    }
+    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane);
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0;      // statistics (only flushed when stats)
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;      // statistics (only flushed when stats)
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
@@ -813,6 +828,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
             for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
             n_wave_trips += tn + tt;
+            if (next >= total) n_drain_trips += tn + tt;    // trips made after the tile's queue ran dry (nothing left to refill with)
         }
     }
     if (SHARED) __syncthreads(); else wave_lds_sync();
@@ -829,6 +845,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             if (cov_mask) atomicAdd(&stats->covered_pixels, (unsigned long long)__popcll(cov_mask));
             if (ovf) atomicAdd(&stats->stack_overflows, (unsigned long long)__popcll(ovf));
             atomicAdd(&stats->wave_iterations, (unsigned long long)n_wave_trips);
+            atomicAdd(&stats->drain_iterations, (unsigned long long)n_drain_trips);
             atomicAdd(&stats->cycles_total, __builtin_readcyclecounter() - t_start);
             atomicAdd(&stats->cycles_setup, t_setup);
             atomicAdd(&stats->cycles_refill, t_refill);
@@ -890,12 +907,13 @@ template <bool SPILL, bool ALPHA, typename Fetch, typename Commit>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
-                                                Fetch fetch, Commit commit) {
+                                                const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit) {
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
     int cur = 0, sp = 0;
     uint32_t pix = 0, next = 0;
+    uint32_t emask = 0;                                   // cut entries this lane's ray hits that did not fit its LDS stack
     bool has = false;
     // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
     // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
@@ -914,6 +932,21 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
+                if (cut_n) {
+                    // the ray against the tile's cut (build_tile_cut): the subtrees it hits go on its stack, the deepest -- the
+                    // one closest to the origin -- on top; the (t, flat index) order of the commit makes the result independent
+                    // of the order the subtrees are walked in
+                    emask = 0;
+                    for (uint32_t e = 0; e < cut_n; ++e) {
+                        const float4 b0 = cut[e][0], b1 = cut[e][1];
+                        float tnu;
+                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
+                            if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
+                            else emask |= 1u << e;
+                        }
+                    }
+                    if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
+                }
                 has = true;
             }
         }
@@ -964,6 +997,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             }
             if (done) {
                 cur = kStackSentinel;
+                emask = 0;
             } else {
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];             // pop (the sentinel if nothing is pending)
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
@@ -971,6 +1005,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 }
                 --sp;
             }
+        }
+        if (has && cur == kStackSentinel && emask) {          // overflowed cut entries: the next subtree
+            const int e = __ffs(int(emask)) - 1;
+            emask &= emask - 1u;
+            cur = __float_as_int(cut[e][1].z);
+            sp = 0;                                           // (the pop of the empty stack left it at -1)
         }
         if (has && cur == kStackSentinel) {
             has = false;
@@ -996,14 +1036,15 @@ constexpr int kReflRays = 128;
 template <bool SPILL, int BOUNCES>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit) {
+    const uint32_t early_exit, const uint32_t use_cut) {
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
     // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
     // and rows 3-5 are rewritten with the second direction between the two walks
     constexpr int ROWS = BOUNCES > 1 ? 9 : 6;
     __shared__ float s_ray_all[2][ROWS][kReflRays];
     __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     const uint32_t tile = blockIdx.x * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[ROWS][kReflRays] = s_ray_all[wave];
@@ -1017,6 +1058,11 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // ---- phase 1: per-pixel ray setup, whole wave ----
     unsigned long long covered_mask[2];
     uint32_t ncov = 0;
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of this walk's ray origins
+    auto grow = [&](f3 o) {
+        omin = f3{ fminf(omin.x, o.x), fminf(omin.y, o.y), fminf(omin.z, o.z) };
+        omax = f3{ fmaxf(omax.x, o.x), fmaxf(omax.y, o.y), fmaxf(omax.z, o.z) };
+    };
 #pragma unroll
     for (uint32_t sub = 0; sub < 2; ++sub) {
         const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
@@ -1036,6 +1082,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             const f3 rdir = I - N * ni2;                                                     // rgen:61 reflect(I, N)
             s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
             s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
+            grow(origin);
         }
         const unsigned long long m = __ballot(covered);
         covered_mask[sub] = m;
@@ -1051,8 +1098,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 #pragma unroll 1
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
+    // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
+    const uint32_t cut_n = use_cut && total && bounce == 0 ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, false>(
-        a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow,
+        a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
             ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
@@ -1225,7 +1274,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
             const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-#define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
+#define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }
             else { if (spill) VHR_LAUNCH_REFL(true, 1); else VHR_LAUNCH_REFL(false, 1); }
@@ -1364,12 +1413,13 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
 template <bool SPILL, bool ALPHA>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void raytraced_queue_kernel(
     const RaytracedArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit) {
+    const uint32_t early_exit, const uint32_t use_cut) {
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints
     // rows 0-2: primary direction -> primary hit record (triangle, u, v); rows 3-5: shadow-ray origin -> row 3 = its answer
     __shared__ float s_ray_all[2][6][kReflRays];
     __shared__ uint8_t s_list_all[2][kReflRays];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     const uint32_t tile = blockIdx.x * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[6][kReflRays] = s_ray_all[wave];
@@ -1407,8 +1457,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const bool traced = a.scene.node_count != 0;
     uint32_t overflow = 0;
     // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
+    // (one origin for every ray: the shared descent follows the boxes around the camera)
+    uint32_t cut_n = use_cut && traced && total ? build_tile_cut(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
-        a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow,
+        a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
             ro = origin;
@@ -1420,6 +1472,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     wave_lds_sync();
     // ---- shadow rays from the primary hits, whole wave (rchit:24,48-50) ----
     uint32_t nhit = 0;
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of the shadow rays' origins
 #pragma unroll
     for (uint32_t sub = 0; sub < 2; ++sub) {
         const uint32_t p = sub * 64u + lane;
@@ -1432,6 +1485,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             f3 position, unused_normal;
             hit_position_normal(a.scene, h, position, unused_normal);
             s_ray[3][p] = position.x; s_ray[4][p] = position.y; s_ray[5][p] = position.z;
+            omin = f3{ fminf(omin.x, position.x), fminf(omin.y, position.y), fminf(omin.z, position.z) };
+            omax = f3{ fmaxf(omax.x, position.x), fmaxf(omax.y, position.y), fmaxf(omax.z, position.z) };
         }
         const unsigned long long m = __ballot(hit);
         if (hit) s_list[nhit + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
@@ -1439,8 +1494,9 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
     wave_lds_sync();
     // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
+    cut_n = use_cut && nhit ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
-        a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow,
+        a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
             ro = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
@@ -1494,7 +1550,7 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((a.row_end - a.row_begin + 7) / 8);
         const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
         const bool spill = levels < ctx->bvh_depth + 1u;
-#define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
+#define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
 #undef VHR_LAUNCH_RT

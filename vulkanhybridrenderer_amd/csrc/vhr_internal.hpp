@@ -166,7 +166,7 @@ struct SvgfCmd {
 
 struct RayStats {
     unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, second_bounce_rays;
-    unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, pad2;   // per-wave s_memtime sums
+    unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, drain_iterations;   // per-wave s_memtime sums
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results

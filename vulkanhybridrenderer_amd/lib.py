@@ -453,7 +453,7 @@ class Context:
     def traversal_cycles(self):
         out = (C.c_uint64 * 8)()
         self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
-        return dict(total=out[0], setup=out[1], refill=out[2], nodes=out[3], leaves=out[4], refills=out[5], waves=out[6])
+        return dict(total=out[0], setup=out[1], refill=out[2], nodes=out[3], leaves=out[4], refills=out[5], waves=out[6], drain_iterations=out[7])
 
     def bvh_statistics(self):
         out = (C.c_uint64 * 5)()
