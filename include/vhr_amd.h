@@ -119,7 +119,14 @@ int vhr_graph_add_raytracing_pass(vhr_context *ctx, const char *render_pass_name
                                   const vhr_raytracing_pipeline_description *pipeline,
                                   vhr_raytracing_pass_callback callback, void *user);
 /* AddComputePass (render_graph.h:16-18, .cpp:103-116).  Known kernels:
- * "hybrid_render_path/svgf.comp", "hybrid_render_path/svgf_atrous_filter.comp".  A shader name is a
+ * "hybrid_render_path/svgf.comp", "hybrid_render_path/svgf_atrous_filter.comp" (SVGFPushConstants, 24 bytes), and the
+ * screen-space alternatives of hybrid_render_path.cpp:138-243: "hybrid_render_path/ssao.comp" (bindings 0 normals, 1 depth,
+ * 2 output; dispatched WITHOUT push constants, as the reference does although the shader reads SSAOPushConstants.radius --
+ * the kernel uses the SSAOPushConstants last pushed on this context by any dispatch, 0.75 before the first),
+ * "hybrid_render_path/ssao_blur.comp" (0 input, 1 output; SSAOPushConstants, 4 bytes, which the shader ignores) and
+ * "hybrid_render_path/ssr.comp" (0 albedo, 1 normals, 2 motion / metallic-roughness, 3 depth, 4 output; SSRPushConstants,
+ * 16 bytes).  Their inputs must be whole images (they sample anywhere on screen, REPEAT-wrapped); with row strips only the
+ * owned output rows are computed (ssao.comp six more on either side for the blur).  A shader name is a
  * global key: registering it in two passes fails (render_graph.cpp:677). */
 int vhr_graph_add_compute_pass(vhr_context *ctx, const char *render_pass_name,
                                const vhr_transient_resource *dependencies, uint32_t dependency_count,
@@ -242,15 +249,17 @@ int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, con
                                     const char *motion_image, const char *depth_image);
 
 /* Next row: stand-in for the untouched composition stage -- composition.vert:5-8 +
- * composition.frag:60-161 for the ray-traced modes (0) and off (2); the raster alternatives (shadow map PCF, SSAO,
- * SSR; mode 1) stay outside.  Reads the named transient images, writes swapchain-format texels (B8G8R8A8_SRGB, bytes
+ * composition.frag:60-161: shadows ray traced (0) or off (2) -- the rasterised shadow map with PCF (1) stays outside --,
+ * ambient occlusion and reflections ray traced (0), screen space (1: ssao.comp + ssao_blur.comp / ssr.comp, row f4) or
+ * off (2).  Reads the named transient images, writes swapchain-format texels (B8G8R8A8_SRGB, bytes
  * b g r a, presentation orientation: row 0 = top) into a storage image of 4-byte texels. */
 typedef struct vhr_composition_desc {
     int32_t shadow_mode, ambient_occlusion_mode, reflection_mode;      /* the three specialization constants, :6-8 */
     const char *albedo_image, *normals_image, *motion_image, *depth_image;
     const char *shadow_ao_image;      /* "Denoised Raytraced Shadows and Ambient Occlusion" or the raw RG16F image (:353-355) */
-    const char *reflections_image;    /* may be NULL when reflection_mode != 0 */
+    const char *reflections_image;    /* "Raytraced Reflections" (mode 0) / "Screen Space Reflections" (mode 1); may be NULL for mode 2 */
     int32_t output_storage_image;
+    const char *ssao_image;           /* "Screen Space Ambient Occlusion" for ambient_occlusion_mode 1, else may be NULL */
 } vhr_composition_desc;
 int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_composition_desc *desc);
 

@@ -78,6 +78,17 @@ typedef struct vhr_svgf_push_constants {
     int32_t atrous_step;
 } vhr_svgf_push_constants;
 
+/* ---- glsl_common.h:41-50: push constants of the screen-space alternatives ---- */
+typedef struct vhr_ssr_push_constants {
+    float   ray_distance;     /* 25.0  (hybrid_render_path.cpp:203-208) */
+    float   step_size;        /* 0.1 */
+    float   thickness;        /* 0.5 */
+    int32_t bsearch_steps;    /* 10 */
+} vhr_ssr_push_constants;
+typedef struct vhr_ssao_push_constants {
+    float radius;             /* 0.75 (hybrid_render_path.cpp:139-141) */
+} vhr_ssao_push_constants;
+
 /* Constants raygen.rgen hard-codes (data/shaders/hybrid_render_path/raygen.rgen:29-65).  Defaults
  * (vhr_default_trace_params) reproduce the shader; other values are documented extensions used by
  * BASELINE.json configs 3 and 5 (ao_spp 4 / 16). */
@@ -165,6 +176,7 @@ static_assert(sizeof(vhr_primitive) == 120, "Primitive");
 static_assert(sizeof(vhr_directional_light) == 112, "DirectionalLight");
 static_assert(sizeof(vhr_per_frame_data) == 584, "PerFrameData");
 static_assert(sizeof(vhr_svgf_push_constants) == 24, "SVGFPushConstants");
+static_assert(sizeof(vhr_ssr_push_constants) == 16 && sizeof(vhr_ssao_push_constants) == 4, "SSRPushConstants / SSAOPushConstants");
 static_assert(sizeof(vhr_trace_params) == 32, "vhr_trace_params");
 #else
 _Static_assert(sizeof(vhr_vertex) == 56, "Vertex");
@@ -173,6 +185,7 @@ _Static_assert(sizeof(vhr_primitive) == 120, "Primitive");
 _Static_assert(sizeof(vhr_directional_light) == 112, "DirectionalLight");
 _Static_assert(sizeof(vhr_per_frame_data) == 584, "PerFrameData");
 _Static_assert(sizeof(vhr_svgf_push_constants) == 24, "SVGFPushConstants");
+_Static_assert(sizeof(vhr_ssr_push_constants) == 16 && sizeof(vhr_ssao_push_constants) == 4, "SSRPushConstants / SSAOPushConstants");
 _Static_assert(sizeof(vhr_trace_params) == 32, "vhr_trace_params");
 #endif
 

@@ -68,10 +68,14 @@ def lib():
                                         C.POINTER(u32), C.POINTER(u32)]
         L.orc_gbuffer.argtypes = [vp, vp, u32, u32, vp, vp, vp]
         L.orc_gbuffer_albedo.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
-        L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
         L.orc_raygen.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, i32]
         L.orc_raytraced.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, vp, i32]
         L.orc_raytraced_composition.argtypes = [u32, u32, vp, vp]
+        L.orc_sample_linear_repeat.argtypes = [i32, vp, u32, u32, f32, f32, vp]
+        L.orc_ssao.argtypes = [vp, u32, u32, u32, u32, vp, vp, f32, vp]
+        L.orc_ssao_blur.argtypes = [vp, u32, u32, u32, u32, vp, vp]
+        L.orc_ssr.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, f32, f32, f32, C.c_int32, vp]
         L.orc_svgf_temporal.argtypes = [vp, u32, u32] + [vp] * 8
         L.orc_svgf_atrous.argtypes = [vp, u32, u32, vp, vp, vp, C.c_int32]
         L.orc_svgf_create.restype = vp
@@ -191,7 +195,7 @@ def raytraced_composition(raytraced_bgra8):
     return out
 
 
-def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections):
+def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections, ssao=None):
     """composition.frag with (shadow_mode, ao_mode, reflection_mode); returns B8G8R8A8_SRGB texels (H, W, 4)."""
     H, W = depth.shape
     out = np.zeros((H, W, 4), np.uint8)
@@ -200,7 +204,53 @@ def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflectio
     depth, shadow_ao = _c(depth, np.float32), _c(shadow_ao, np.uint16)
     reflections = _c(reflections, np.uint16) if reflections is not None else np.zeros((H, W, 4), np.uint16)
     lib().orc_composition(_p(pfd), W, H, modes[0], modes[1], modes[2], _p(albedo), _p(normals), _p(motion), _p(depth), _p(shadow_ao),
-                          shadow_ao.shape[-1], _p(reflections), _p(out))
+                          shadow_ao.shape[-1], _p(reflections), _p(_c(ssao, np.uint16)) if ssao is not None else None, _p(out))
+    return out
+
+
+def sample_linear_repeat(img, u, v):
+    """texture() through the default sampler (decision x) on an RGBA16F (H, W, 4) uint16, D32F (H, W) float32 or
+    B8G8R8A8 (H, W, 4) uint8 image -> 4 floats."""
+    img = _c(img)
+    kind = {np.dtype(np.uint16): 0, np.dtype(np.float32): 1, np.dtype(np.uint8): 2}[img.dtype]
+    H, W = img.shape[:2]
+    out = np.zeros(4, np.float32)
+    lib().orc_sample_linear_repeat(kind, _p(img), W, H, float(np.float32(u)), float(np.float32(v)), _p(out))
+    return out
+
+
+def _rows(rows, H):
+    return (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+
+
+def ssao(pfd, normals, depth, radius=0.75, rows=None):
+    """ssao.comp -> "Screen Space Ambient Occlusion Raw" (H, W, 4) uint16 (RGBA16F bits)."""
+    H, W = depth.shape
+    out = np.zeros((H, W, 4), np.uint16)
+    pfd, normals, depth = _c(pfd), _c(normals, np.uint16), _c(depth, np.float32)
+    r0, r1 = _rows(rows, H)
+    lib().orc_ssao(_p(pfd), W, H, r0, r1, _p(normals), _p(depth), float(radius), _p(out))
+    return out
+
+
+def ssao_blur(pfd, ssao_raw, rows=None):
+    """ssao_blur.comp -> "Screen Space Ambient Occlusion"."""
+    H, W = ssao_raw.shape[:2]
+    out = np.zeros((H, W, 4), np.uint16)
+    pfd, ssao_raw = _c(pfd), _c(ssao_raw, np.uint16)
+    r0, r1 = _rows(rows, H)
+    lib().orc_ssao_blur(_p(pfd), W, H, r0, r1, _p(ssao_raw), _p(out))
+    return out
+
+
+def ssr(pfd, albedo, normals, motion, depth, ray_distance=25.0, step_size=0.1, thickness=0.5, bsearch_steps=10, rows=None):
+    """ssr.comp -> "Screen Space Reflections" (defaults: hybrid_render_path.cpp:203-208)."""
+    H, W = depth.shape
+    out = np.zeros((H, W, 4), np.uint16)
+    pfd, albedo, normals, motion, depth = _c(pfd), _c(albedo, np.uint8), _c(normals, np.uint16), _c(motion, np.uint16), _c(depth, np.float32)
+    r0, r1 = _rows(rows, H)
+    lib().orc_ssr(_p(pfd), W, H, r0, r1, _p(albedo), _p(normals), _p(motion), _p(depth), float(ray_distance), float(step_size),
+                  float(thickness), int(bsearch_steps), _p(out))
     return out
 
 

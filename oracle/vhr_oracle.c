@@ -1059,7 +1059,7 @@ static inline uint8_t srgb8(float c) {          /* B8G8R8A8_SRGB store: NaN -> 0
 
 void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
                      const uint8_t *albedo_img, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
-                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, uint8_t *out) {
+                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, const uint16_t *ssao, uint8_t *out) {
 #pragma omp parallel for schedule(static)
     for (int64_t jj = 0; jj < (int64_t)H; ++jj) {
         int j = (int)jj;
@@ -1083,7 +1083,8 @@ void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int 
             v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
             v3 Hh = normalize3(v3add(L, Vv));
             float shadow = shadow_mode == 0 ? rs : 1.0f;                                       /* :77-80 */
-            float ao = ao_mode == 0 ? ra : 1.0f;                                               /* :115-121 */
+            float ao = ao_mode == 0 ? ra : 1.0f;                                               /* :114-121 */
+            if (ao_mode == 1) ao = load_rgba16f(ssao, W, x, gy).x;                             /* :117-119: texture() at a texel centre */
             float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f);                                   /* :123-125 */
             float roughness = fminf(fmaxf(mm.w, 0.04f), 1.0f);
             v3 li = V3(pfd->directional_light.intensity[0], pfd->directional_light.intensity[1], pfd->directional_light.intensity[2]);
@@ -1095,7 +1096,7 @@ void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int 
             v3 ambient = v3scale(albedo, ao * ORC_PI_INVERSE);                                 /* :137 */
             v3 diff = v3scale(v3mul(v3mul(v3scale(diffuse_brdf(metallic, albedo, F), ndl), li), lc), shadow);   /* :138 */
             v3 spec = v3scale(v3mul(v3mul(v3scale(specular_brdf(roughness, F, Vv, L, N, Hh), ndl), li), lc), shadow);   /* :139 */
-            if (reflection_mode == 0) {                                                        /* :141-149 */
+            if (reflection_mode == 0 || reflection_mode == 1) {                                /* :139-156, ray traced or screen space */
                 v4 r = load_rgba16f(reflections, W, x, gy);
                 v3 refl = v3scale(V3(r.x, r.y, r.z), shadow);
                 if (metallic == 1.0f) spec = refl;
@@ -1104,6 +1105,197 @@ void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int 
             v3 lighting = v3add(v3add(ambient, diff), spec);                                   /* :160-162 */
             uint8_t *o = out + ((size_t)j * W + x) * 4;
             o[0] = srgb8(lighting.z); o[1] = srgb8(lighting.y); o[2] = srgb8(lighting.x); o[3] = 255;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * next row f4 (second half): the screen-space alternatives of the hybrid render path
+ *   data/shaders/hybrid_render_path/ssao.comp:14-53, ssao_blur.comp:11-26, ssr.comp:16-137
+ * Decisions (the reference leaves them to the Vulkan implementation):
+ *  (x)   texture() on a transient image goes through the default sampler (LINEAR mag / min, REPEAT,
+ *        resource_manager.cpp:58-69) at LOD 0: unnormalised coordinate u * W - 0.5, floor, the four texels wrapped,
+ *        weights in full fp32 (hardware uses 8 fractional bits), blended x first then y;
+ *  (xi)  the shaders declare their output images r16f, the images are R16G16B16A16_SFLOAT (hybrid_render_path.cpp:149,
+ *        176,219): all four components of the stored vec4 land in the texel;
+ *  (xii) min / max / clamp drop a NaN operand (IEEE minNum / maxNum, what the author's hardware does; GLSL leaves it
+ *        undefined) -- sky samples produce inf and NaN view-space positions, which then contribute 0;
+ *  (xiii) float -> int of the coordinates saturates and maps NaN to 0 (f2i above).
+ * ---------------------------------------------------------------------------------------- */
+static inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+typedef v4 (*orc_texel_fn)(const void *img, uint32_t W, int x, int y);
+static v4 texel_rgba16f(const void *img, uint32_t W, int x, int y) { return load_rgba16f((const uint16_t *)img, W, x, y); }
+static v4 texel_d32f(const void *img, uint32_t W, int x, int y) {
+    v4 r = { ((const float *)img)[(size_t)y * W + x], 0.0f, 0.0f, 1.0f };
+    return r;
+}
+static v4 texel_bgra8(const void *img, uint32_t W, int x, int y) {      /* B8G8R8A8_UNORM sampled as (r, g, b, a) */
+    const uint8_t *p = (const uint8_t *)img + ((size_t)y * W + x) * 4;
+    v4 r = { p[2] * (1.0f / 255.0f), p[1] * (1.0f / 255.0f), p[0] * (1.0f / 255.0f), p[3] * (1.0f / 255.0f) };
+    return r;
+}
+/* decision (x) */
+static v4 sample_linear_repeat(orc_texel_fn fetch, const void *img, uint32_t W, uint32_t H, float u, float v) {
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    int x0 = wrap_repeat(f2i(x0f), (int)W), y0 = wrap_repeat(f2i(y0f), (int)H);
+    int x1 = x0 + 1 == (int)W ? 0 : x0 + 1, y1 = y0 + 1 == (int)H ? 0 : y0 + 1;
+    v4 t00 = fetch(img, W, x0, y0), t10 = fetch(img, W, x1, y0), t01 = fetch(img, W, x0, y1), t11 = fetch(img, W, x1, y1);
+    float bx = 1.0f - ax, by = 1.0f - ay;
+    v4 r;
+    r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
+    r.y = (t00.y * bx + t10.y * ax) * by + (t01.y * bx + t11.y * ax) * ay;
+    r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
+    r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
+    return r;
+}
+void orc_sample_linear_repeat(int kind, const void *img, uint32_t W, uint32_t H, float u, float v, float out[4]) {
+    v4 r = sample_linear_repeat(kind == 0 ? texel_rgba16f : kind == 1 ? texel_d32f : texel_bgra8, img, W, H, u, v);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+/* glsl_common.h:111-115 */
+static v3 get_view_space_position(const orc_per_frame_data *pfd, float depth, float u, float v) {
+    v4 ndc = { u * 2.0f - 1.0f, v * 2.0f - 1.0f, depth, 1.0f };
+    v4 r = mat4_mul_v4(pfd->camera_proj_inverse, ndc);
+    return V3(r.x / r.w, r.y / r.w, r.z / r.w);
+}
+
+/* ssao.comp:14-53.  radius: SSAOPushConstants.radius (see the note on orc_ssao in the header). */
+void orc_ssao(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+              const uint16_t *normals_ids, const float *depth, float radius, uint16_t *ssao_raw) {
+    const float *cv = pfd->camera_view;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; ++yy) {
+        int y = (int)yy;
+        for (int x = 0; x < (int)W; ++x) {
+            float cu = (float)x * pfd->display_size_inverse[0], cvv = (float)y * pfd->display_size_inverse[1];      /* :15 */
+            float current_depth = sample_linear_repeat(texel_d32f, depth, W, H, cu, cvv).x;                         /* :16 */
+            if (current_depth == 0.0f) { store_rgba16f(ssao_raw, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f); continue; }      /* :17-24 */
+            v3 P = get_view_space_position(pfd, current_depth, cu, cvv);                                            /* :25 */
+            v4 n4 = sample_linear_repeat(texel_rgba16f, normals_ids, W, H, cu, cvv);
+            v3 N = V3((cv[0] * n4.x + cv[4] * n4.y) + cv[8] * n4.z, (cv[1] * n4.x + cv[5] * n4.y) + cv[9] * n4.z,
+                      (cv[2] * n4.x + cv[6] * n4.y) + cv[10] * n4.z);                                               /* :26 mat3(view) * n */
+            float perspective_radius = radius / P.z;                                                                /* :28-29 */
+            const float beta = 1e-4f;                                                                               /* :30-31 */
+            uint32_t rng = orc_seed_thread(((uint32_t)y * (uint32_t)pfd->display_size[1] + (uint32_t)x) * pfd->frame_index);   /* :32 */
+            float sum = 0.0f;
+            for (int i = 0; i < 16; ++i) {                                                                          /* :33-45 */
+                float ang = (orc_random01(&rng) * 2.0f) * ORC_PI;
+                float dist = orc_random01(&rng) * perspective_radius;
+                float sn, cs;
+                orc_sincos(ang, &sn, &cs);
+                float su = cu + cs * dist, sv = cvv + sn * dist;
+                v3 Q = get_view_space_position(pfd, sample_linear_repeat(texel_d32f, depth, W, H, su, sv).x, su, sv);
+                v3 V = v3sub(Q, P);
+                sum += fmaxf(dot3(V, N) - beta, 0.0f) / (dot3(V, V) + 1e-4f);
+            }
+            float ao = fmaxf(1.0f - ((2.0f * 1.0f) / 16.0f) * sum, 0.0f);                                           /* :47 */
+            store_rgba16f(ssao_raw, W, x, y, ao, ao, ao, ao);                                                       /* :49-53, decision (xi) */
+        }
+    }
+}
+
+/* ssao_blur.comp:11-26: 13x13 box over the texels inside the display, always divided by 169 */
+void orc_ssao_blur(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                   const uint16_t *ssao_raw, uint16_t *ssao_blurred) {
+#pragma omp parallel for schedule(static)
+    for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; ++yy) {
+        int cy = (int)yy;
+        for (int cx = 0; cx < (int)W; ++cx) {
+            float ao = 0.0f;
+            for (int y = -6; y <= 6; ++y)
+                for (int x = -6; x <= 6; ++x) {
+                    int sx = cx + x, sy = cy + y;
+                    if (sx < 0 || (float)sx >= pfd->display_size[0] || sy < 0 || (float)sy >= pfd->display_size[1]) continue;
+                    if ((uint32_t)sx >= W || (uint32_t)sy >= H) continue;                     /* imageLoad outside the image returns 0 */
+                    ao += load_rgba16f(ssao_raw, W, sx, sy).x;
+                }
+            float r = ao / (13.0f * 13.0f);
+            store_rgba16f(ssao_blurred, W, cx, cy, r, r, r, r);
+        }
+    }
+}
+
+static inline float distance3(v3 a, v3 b) { v3 d = v3sub(a, b); return sqrtf(dot3(d, d)); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* ssr.comp:16-137.  albedo: B8G8R8A8_UNORM; output RGBA16F = (lighting, 1) or 0 */
+void orc_ssr(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+             const uint8_t *albedo_bgra8, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
+             float ray_distance, float step_size, float thickness, int32_t bsearch_steps, uint16_t *ssr_out) {
+    float projview[16];
+    orc_mat4_mul(pfd->camera_proj, pfd->camera_view, projview);                               /* :23 proj * view, then * vec4 */
+    const v3 cam = V3(pfd->camera_view_inverse[12], pfd->camera_view_inverse[13], pfd->camera_view_inverse[14]);
+    const int n_steps = f2i(ray_distance / step_size);                                        /* :83 */
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int64_t yy = (int64_t)row_begin; yy < (int64_t)row_end; ++yy) {
+        int y = (int)yy;
+        for (int x = 0; x < (int)W; ++x) {
+            float cu = (float)x * pfd->display_size_inverse[0], cvv = (float)y * pfd->display_size_inverse[1];      /* :68 */
+            float fragment_depth = sample_linear_repeat(texel_d32f, depth, W, H, cu, cvv).x;
+            v3 P = get_world_space_position(pfd, fragment_depth, cu, cvv);                                          /* :72 */
+            v4 n4 = sample_linear_repeat(texel_rgba16f, normals_ids, W, H, cu, cvv);
+            v3 N = V3(n4.x, n4.y, n4.z);
+            v3 I = normalize3(v3sub(P, cam));                                                                       /* :74 */
+            float ni2 = 2.0f * dot3(N, I);
+            v3 rdir = normalize3(v3sub(I, v3scale(N, ni2)));                                                        /* :75 */
+            int found = 0;
+            float prev_step = 0.0f, final_step = 0.0f;
+            float fu = 0.0f, fv = 0.0f;
+            for (int i = 0; i < n_steps; ++i) {                                                                     /* :83-101 */
+                float offset = step_size * (float)i;
+                v3 rp = v3add(P, v3scale(rdir, offset));
+                float d_ray = distance3(cam, rp);
+                v4 clip = mat4_mul_v4(projview, (v4){ rp.x, rp.y, rp.z, 1.0f });                                    /* :22-26 */
+                float su = (clip.x / clip.w) * 0.5f + 0.5f, sv = (clip.y / clip.w) * 0.5f + 0.5f;
+                v3 sp = get_world_space_position(pfd, sample_linear_repeat(texel_d32f, depth, W, H, su, sv).x, su, sv);
+                float delta = d_ray - distance3(cam, sp);
+                if (delta > 0.3f && delta < thickness) { final_step = offset; found = 1; break; }
+                prev_step = offset;
+            }
+            if (!found) { store_rgba16f(ssr_out, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f); continue; }                      /* :62-66, 103-105 */
+            float mid_step = (prev_step + final_step) * 0.5f;                                                       /* :108 */
+            for (int i = 0; i < bsearch_steps; ++i) {                                                               /* :110-128 */
+                v3 rp = v3add(P, v3scale(rdir, mid_step));
+                float d_ray = distance3(cam, rp);
+                v4 clip = mat4_mul_v4(projview, (v4){ rp.x, rp.y, rp.z, 1.0f });
+                fu = (clip.x / clip.w) * 0.5f + 0.5f; fv = (clip.y / clip.w) * 0.5f + 0.5f;
+                v3 sp = get_world_space_position(pfd, sample_linear_repeat(texel_d32f, depth, W, H, fu, fv).x, fu, fv);
+                float delta = d_ray - distance3(cam, sp);
+                if (delta > 0.3f && delta < thickness) {
+                    mid_step = (prev_step + mid_step) * 0.5f;
+                } else {
+                    float tmp = mid_step;
+                    mid_step = mid_step + (mid_step - prev_step);
+                    prev_step = tmp;
+                }
+            }
+            /* compute_lighting(final_uv), :28-59 */
+            v4 a4 = sample_linear_repeat(texel_bgra8, albedo_bgra8, W, H, fu, fv);
+            v3 albedo = V3(a4.x, a4.y, a4.z);
+            v3 position = get_world_space_position(pfd, sample_linear_repeat(texel_d32f, depth, W, H, fu, fv).x, fu, fv);
+            v4 mm = sample_linear_repeat(texel_rgba16f, motion_mr, W, H, fu, fv);
+            v3 Vv = normalize3(v3sub(cam, position));
+            v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
+            v4 ln = sample_linear_repeat(texel_rgba16f, normals_ids, W, H, fu, fv);
+            v3 Nl = V3(ln.x, ln.y, ln.z);
+            v3 Hh = normalize3(v3add(L, Vv));
+            float metallic = clampf(mm.z, 0.0f, 1.0f);
+            float roughness = clampf(mm.w, 0.04f, 1.0f);
+            float ambient_factor = ORC_PI_INVERSE * 0.2f;
+            v3 li = V3(pfd->directional_light.intensity[0], pfd->directional_light.intensity[1], pfd->directional_light.intensity[2]);
+            v3 lc = V3(pfd->directional_light.color[0], pfd->directional_light.color[1], pfd->directional_light.color[2]);
+            v3 f0 = V3(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+            v3 F = fresnel_schlick(f0, Hh, Vv);
+            v3 ambient = v3scale(albedo, ambient_factor);
+            v3 diff = diffuse_brdf(metallic, albedo, F);
+            v3 spec = specular_brdf(roughness, F, Vv, L, Nl, Hh);
+            float ndl = fmaxf(dot3(Nl, L), 0.0f);
+            v3 lit = v3add(ambient, v3mul(v3mul(v3scale(v3add(diff, spec), ndl), li), lc));
+            store_rgba16f(ssr_out, W, x, y, lit.x, lit.y, lit.z, 1.0f);                                             /* :131-135 */
         }
     }
 }

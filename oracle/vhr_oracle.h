@@ -101,13 +101,14 @@ void orc_gbuffer(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, 
 void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W, uint32_t H,
                         uint16_t *normals_ids, uint16_t *motion_mr, float *depth, uint8_t *albedo_bgra8);
 
-/* ---- next row f3: composition.vert:5-8 + composition.frag:60-161 (ray-traced modes only) ----
- * modes: 0 ray traced, 2 off (1 = the raster alternatives, not restated).  shadow_ao: RGBA16F (denoised) if
+/* ---- next row f3: composition.vert:5-8 + composition.frag:60-161 ----
+ * modes: 0 ray traced, 1 screen space (ambient occlusion and reflections only; the shadow map is not restated), 2 off.  shadow_ao: RGBA16F (denoised) if
  * shadow_ao_channels == 4 else RG16F.  Output: B8G8R8A8_SRGB swapchain texels (bytes b, g, r, a), row 0 = top of the
  * presented image = G-buffer row H-1 (the composition viewport is flipped, pipeline.cpp:175-178). */
 void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
                      const uint8_t *albedo_bgra8, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
-                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, uint8_t *out_bgra8_srgb);
+                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections /* mode 0: ray traced, 1: SSR */,
+                     const uint16_t *ssao /* "Screen Space Ambient Occlusion" for ao_mode 1, else may be NULL */, uint8_t *out_bgra8_srgb);
 
 /* ---- K1 + K2: raygen.rgen:14-66, miss.rmiss, reflection_miss.rmiss, reflection_hit.rchit ---- */
 /* vis_mask (optional, may be NULL): per pixel bit0 = shadow ray missed (lit), bit(1+i) = AO ray i missed,
@@ -126,6 +127,22 @@ void orc_raytraced(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t W
                    int use_anyhit_shader, uint8_t *out_bgra8, uint64_t *rays_out, int use_bvh);
 /* raytraced_render_path/composition.frag:11-13 through the flipped presentation viewport -> B8G8R8A8_SRGB */
 void orc_raytraced_composition(uint32_t W, uint32_t H, const uint8_t *raytraced_bgra8, uint8_t *out_bgra8_srgb);
+
+/* ---- next row f4, second half: the screen-space alternatives (hybrid_render_path.cpp:138-243) ----
+ * ssao.comp:14-53 -> "Screen Space Ambient Occlusion Raw"; ssao_blur.comp:11-26 -> "Screen Space Ambient Occlusion";
+ * ssr.comp:16-137 -> "Screen Space Reflections" (all RGBA16F although the shaders say r16f: every component is stored).
+ * radius: the reference never pushes SSAOPushConstants to ssao.comp (the SSAO Pass declares no push constants and
+ * dispatches without them, hybrid_render_path.cpp:151-167; the blur pass gets them instead, :182-197), so what the shader
+ * reads is undefined in Vulkan; the oracle takes the value as a parameter (0.75 = the value the host initialises, :139-141).
+ * kind for orc_sample_linear_repeat: 0 RGBA16F, 1 D32F, 2 B8G8R8A8_UNORM. */
+void orc_sample_linear_repeat(int kind, const void *img, uint32_t W, uint32_t H, float u, float v, float out[4]);
+void orc_ssao(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+              const uint16_t *normals_ids, const float *depth, float radius, uint16_t *ssao_raw /*RGBA16F*/);
+void orc_ssao_blur(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+                   const uint16_t *ssao_raw, uint16_t *ssao_blurred /*RGBA16F*/);
+void orc_ssr(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, uint32_t row_begin, uint32_t row_end,
+             const uint8_t *albedo_bgra8, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
+             float ray_distance, float step_size, float thickness, int32_t bsearch_steps, uint16_t *ssr_out /*RGBA16F*/);
 
 /* ---- K3: svgf.comp:41-145 ---- */
 void orc_svgf_temporal(const orc_per_frame_data *pfd, uint32_t W, uint32_t H,

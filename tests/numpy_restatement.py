@@ -235,3 +235,171 @@ def reflection_hit(scene, pfd, prim_index, tri, u, v):                  # reflec
     L = -np.asarray(light["direction"], np.float64)[:3]
     diffuse, specular, nl = brdf_terms(albedo, metallic, roughness, N, V, L)
     return albedo * (0.2 / np.pi) + (diffuse + specular) * nl * np.asarray(light["intensity"], np.float64)[:3] * np.asarray(light["color"], np.float64)[:3]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Screen-space alternatives in float64, vectorised over the image, written from the GLSL (ssao.comp:14-53,
+# ssao_blur.comp:11-26, ssr.comp:16-137, glsl_common.h:111-122, common.glsl:116-150): a second derivation compared with
+# the oracle at a tolerance (float64 here, fp32 there; np.sin / np.cos instead of the shared polynomial).
+# ---------------------------------------------------------------------------------------------------------
+def seed_thread_v(seed):
+    seed = np.asarray(seed, np.uint64) & 0xffffffff
+    seed = ((seed ^ 61) ^ (seed >> 16)) & 0xffffffff
+    seed = (seed * 9) & 0xffffffff
+    seed = (seed ^ (seed >> 4)) & 0xffffffff
+    seed = (seed * 0x27d4eb2d) & 0xffffffff
+    seed = (seed ^ (seed >> 15)) & 0xffffffff
+    return seed
+
+
+def random01_v(state):
+    state = state ^ ((state << 13) & 0xffffffff)
+    state = state ^ (state >> 17)
+    state = state ^ ((state << 5) & 0xffffffff)
+    state &= 0xffffffff
+    bits = (0x3f800000 | (state >> 9)).astype(np.uint32)
+    return state, bits.view(np.float32).astype(np.float64) - 1.0
+
+
+def sample_linear_repeat(img, u, v):
+    """texture() with the default sampler (LINEAR, REPEAT, resource_manager.cpp:58-69) on an (H, W[, C]) float array."""
+    H, W = img.shape[:2]
+    with np.errstate(invalid="ignore"):
+        fx, fy = u * W - 0.5, v * H - 0.5
+        x0f, y0f = np.floor(fx), np.floor(fy)
+        ax, ay = fx - x0f, fy - y0f
+        bad = ~(np.isfinite(x0f) & np.isfinite(y0f))
+        x0 = np.mod(np.where(bad, 0, np.clip(x0f, -2**31, 2**31 - 1)).astype(np.int64), W)
+        y0 = np.mod(np.where(bad, 0, np.clip(y0f, -2**31, 2**31 - 1)).astype(np.int64), H)
+    x1, y1 = (x0 + 1) % W, (y0 + 1) % H
+    if img.ndim == 3:
+        ax, ay = ax[..., None], ay[..., None]
+    return (img[y0, x0] * (1 - ax) + img[y0, x1] * ax) * (1 - ay) + (img[y1, x0] * (1 - ax) + img[y1, x1] * ax) * ay
+
+
+def _unproject(M, depth, u, v):
+    p = np.stack([u * 2.0 - 1.0, v * 2.0 - 1.0, depth, np.ones_like(depth)], -1) @ M.T
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return p[..., :3] / p[..., 3:4]
+
+
+def _fmax(a, b):          # IEEE maxNum: a NaN operand loses (oracle decision xii)
+    return np.fmax(a, b)
+
+
+def ssao(pfd, normals_bits, depth, radius=0.75):
+    H, W = depth.shape
+    depth = depth.astype(np.float64)
+    nrm = h2f(normals_bits).astype(np.float64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    inv = np.asarray(pfd["display_size_inverse"], np.float64)
+    cu, cv = xs * inv[0], ys * inv[1]
+    cur = sample_linear_repeat(depth, cu, cv)
+    Pinv = _mat(pfd, "camera_proj_inverse")
+    P = _unproject(Pinv, cur, cu, cv)
+    N = sample_linear_repeat(nrm, cu, cv)[..., :3] @ _mat(pfd, "camera_view")[:3, :3].T
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pr = radius / P[..., 2]
+    rng = seed_thread_v((ys.astype(np.uint64) * np.uint64(int(pfd["display_size"][1])) + xs.astype(np.uint64)) * np.uint64(int(pfd["frame_index"])))
+    total = np.zeros((H, W))
+    for _ in range(16):
+        rng, r1 = random01_v(rng)
+        rng, r2 = random01_v(rng)
+        ang, dist = r1 * 2 * np.pi, r2 * pr
+        su, sv = cu + np.cos(ang) * dist, cv + np.sin(ang) * dist
+        V = _unproject(Pinv, sample_linear_repeat(depth, su, sv), su, sv) - P
+        with np.errstate(invalid="ignore", over="ignore"):
+            total = total + _fmax((V * N).sum(-1) - 1e-4, 0.0) / ((V * V).sum(-1) + 1e-4)
+    ao = _fmax(1.0 - (2.0 / 16.0) * total, 0.0)
+    return np.where(cur == 0.0, 0.0, ao)
+
+
+def ssao_blur_f32(raw_bits, display_w, display_h):
+    """ssao_blur.comp in fp32 with the shader's summation order (rows top to bottom, taps left to right): bit-comparable."""
+    H, W = raw_bits.shape[:2]
+    src = h2f(raw_bits[..., 0])
+    acc = np.zeros((H, W), np.float32)
+    for dy in range(-6, 7):
+        for dx in range(-6, 7):
+            tap, mask = _shift(src, dx, dy)
+            ys, xs = np.mgrid[0:H, 0:W]
+            mask &= ((xs + dx) < display_w) & ((ys + dy) < display_h)
+            acc = np.where(mask, (acc + tap).astype(np.float32), acc)
+    return (acc / np.float32(13.0 * 13.0)).astype(np.float32)
+
+
+def ssr(pfd, albedo_bgra8, normals_bits, motion_bits, depth, ray_distance=25.0, step_size=0.1, thickness=0.5, bsearch_steps=10):
+    """Returns (found mask, lighting (H, W, 3), final step offset) in float64."""
+    H, W = depth.shape
+    depth = depth.astype(np.float64)
+    nrm = h2f(normals_bits).astype(np.float64)
+    mot = h2f(motion_bits).astype(np.float64)
+    alb = albedo_bgra8[..., [2, 1, 0]].astype(np.float64) / 255.0
+    ys, xs = np.mgrid[0:H, 0:W]
+    inv = np.asarray(pfd["display_size_inverse"], np.float64)
+    cu, cv = xs * inv[0], ys * inv[1]
+    VPinv = _mat(pfd, "camera_viewproj_inverse")
+    PV = _mat(pfd, "camera_proj") @ _mat(pfd, "camera_view")
+    cam = _mat(pfd, "camera_view_inverse")[:3, 3]
+    P = _unproject(VPinv, sample_linear_repeat(depth, cu, cv), cu, cv)
+    N = sample_linear_repeat(nrm, cu, cv)[..., :3]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        I = (P - cam) / np.linalg.norm(P - cam, axis=-1, keepdims=True)
+        R = I - 2.0 * (N * I).sum(-1, keepdims=True) * N
+        R = R / np.linalg.norm(R, axis=-1, keepdims=True)
+
+    def probe(offset):
+        rp = P + R * offset[..., None]
+        clip = np.concatenate([rp, np.ones((H, W, 1))], -1) @ PV.T
+        with np.errstate(invalid="ignore", divide="ignore"):
+            uv = clip[..., :2] / clip[..., 3:4] * 0.5 + 0.5
+            sp = _unproject(VPinv, sample_linear_repeat(depth, uv[..., 0], uv[..., 1]), uv[..., 0], uv[..., 1])
+            delta = np.linalg.norm(cam - rp, axis=-1) - np.linalg.norm(cam - sp, axis=-1)
+        return delta, uv
+
+    found = np.zeros((H, W), bool)
+    prev = np.zeros((H, W))
+    final = np.zeros((H, W))
+    for i in range(int(np.float32(ray_distance) / np.float32(step_size))):
+        off = np.full((H, W), float(np.float32(step_size) * np.float32(i)))
+        with np.errstate(invalid="ignore"):
+            delta, _ = probe(off)
+            hit = ~found & (delta > 0.3) & (delta < thickness)
+        final = np.where(hit, off, final)
+        prev = np.where(~found & ~hit, off, prev)
+        found |= hit
+    mid = (prev + final) * 0.5
+    uv = np.zeros((H, W, 2))
+    for _ in range(bsearch_steps):
+        with np.errstate(invalid="ignore"):
+            delta, uv = probe(mid)
+            inside = (delta > 0.3) & (delta < thickness)
+        new_mid = np.where(inside, (prev + mid) * 0.5, mid + (mid - prev))
+        prev = np.where(inside, prev, mid)
+        mid = new_mid
+    fu, fv = uv[..., 0], uv[..., 1]
+    albedo = sample_linear_repeat(alb, fu, fv)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        position = _unproject(VPinv, sample_linear_repeat(depth, fu, fv), fu, fv)
+        mr = sample_linear_repeat(mot, fu, fv)[..., 2:4]
+        V = (cam - position) / np.linalg.norm(cam - position, axis=-1, keepdims=True)
+        light = pfd["directional_light"]
+        L = -np.asarray(light["direction"], np.float64)[:3]
+        Nl = sample_linear_repeat(nrm, fu, fv)[..., :3]
+        Hh = (L + V) / np.linalg.norm(L + V, axis=-1, keepdims=True)
+        metallic = np.clip(mr[..., 0:1], 0.0, 1.0)
+        rough = np.clip(mr[..., 1:2], 0.04, 1.0)
+        f0 = 0.04 * (1.0 - metallic) + albedo * metallic
+        hv = np.fmax((Hh * V).sum(-1, keepdims=True), 0.0)
+        F = f0 + (1.0 - f0) * (1.0 - hv) ** 5
+        a2 = rough * rough
+        nh = np.fmax((Nl * Hh).sum(-1, keepdims=True), 0.0)
+        f = nh * nh * (a2 - 1.0) + 1.0
+        D = a2 / (np.pi * f * f)
+        k = (rough + 1.0) ** 2 * 0.125
+        nv, nl = np.fmax((Nl * V).sum(-1, keepdims=True), 0.0), np.fmax((Nl * L).sum(-1, keepdims=True), 0.0)
+        G = (nv / (nv * (1.0 - k) + k)) * (nl / (nl * (1.0 - k) + k))
+        spec = D * G * F / np.fmax(4.0 * nv * nl, 1e-6)
+        diff = (1.0 - F) * (1.0 - metallic) * albedo / np.pi
+        lit = albedo * (0.2 / np.pi) + (diff + spec) * nl * np.asarray(light["intensity"], np.float64)[:3] * np.asarray(light["color"], np.float64)[:3]
+    return found, np.where(found[..., None], lit, 0.0), np.where(found, final, -1.0)

@@ -48,8 +48,8 @@ def test_hybrid_mode_matrix(ctx):
     assert "Raytrace Pass" not in ctx.execution_order() and "Shadow Map Pass" in ctx.execution_order()
     p.rebuild(shadow_mode=2, reflection_mode=0, denoise_shadow_and_ao=1)
     assert ctx.execution_order() == ["G-Buffer Pass", "Raytrace Pass", "SVGF Denoise Pass", "Composition Pass"]
-    with pytest.raises(lib.VhrError, match="SSAO"):
-        p.rebuild(ambient_occlusion_mode=1)
+    p.rebuild(ambient_occlusion_mode=1, reflection_mode=1)                # the screen-space alternatives (:138-243), tests/test_screen_space.py
+    assert {"SSAO Pass", "SSAO Blur Pass", "SSR Pass"} <= set(ctx.execution_order())
     p.destroy()
 
 
@@ -66,7 +66,7 @@ def test_registration_rules(ctx):
     with pytest.raises(lib.VhrError, match="already registered by pass"):  # shader name is a global key (:677)
         ctx.add_compute_pass("C2", [], [], [lib.ATROUS_SHADER], 24, noop)
     with pytest.raises(lib.VhrError, match="no HIP kernel"):
-        ctx.add_compute_pass("C3", [], [], ["hybrid_render_path/ssao.comp"], 4, noop)
+        ctx.add_compute_pass("C3", [], [], ["hybrid_render_path/depth_prepass.comp"], 4, noop)
     with pytest.raises(lib.VhrError, match="no HIP kernel"):
         ctx.add_raytracing_pass("R", [], [], noop, raygen="rayquery_render_path/anything.rgen")
     with pytest.raises(lib.VhrError, match="shadow_miss"):              # the raytraced path's raygen with the hybrid path's shader set

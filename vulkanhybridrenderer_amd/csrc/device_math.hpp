@@ -123,6 +123,36 @@ __device__ __forceinline__ f3 onb_transform(f3 n, f3 v) {
                (c0.z * v.x + c1.z * v.y) + n.z * v.z };
 }
 
+// common.glsl:116-150
+__device__ __forceinline__ f3 fresnel_schlick(f3 f0, f3 H, f3 V) {
+    const float hv = fmaxf(dot3(H, V), 0.0f);
+    const float om = 1.0f - hv;
+    const float p5 = om * om * om * om * om;
+    return f3{ f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5 };
+}
+__device__ __forceinline__ float D_GGX(float roughness, f3 N, f3 H) {
+    const float a2 = roughness * roughness;
+    const float nh = fmaxf(dot3(N, H), 0.0f);
+    const float f = nh * nh * (a2 - 1.0f) + 1.0f;
+    return a2 / (VHR_PI * f * f);
+}
+__device__ __forceinline__ float G_GGX(float roughness, f3 N, f3 V, f3 L) {
+    const float k = ((roughness + 1.0f) * (roughness + 1.0f)) * 0.125f;
+    const float nv = fmaxf(dot3(N, V), 0.0f), nl = fmaxf(dot3(N, L), 0.0f);
+    return (nv / (nv * (1.0f - k) + k)) * (nl / (nl * (1.0f - k) + k));
+}
+// common.glsl:140-150
+__device__ __forceinline__ f3 specular_brdf(float roughness, f3 F, f3 V, f3 L, f3 N, f3 H) {
+    const float dg = D_GGX(roughness, N, H) * G_GGX(roughness, N, V, L);
+    const float denom = 4.0f * fmaxf(dot3(N, V), 0.0f) * fmaxf(dot3(N, L), 0.0f);
+    const float invd = 1.0f / fmaxf(denom, 1e-6f);
+    return f3{ dg * F.x * invd, dg * F.y * invd, dg * F.z * invd };
+}
+__device__ __forceinline__ f3 diffuse_brdf(float metallic, f3 albedo, f3 F) {
+    const f3 dp = f3{ (1.0f - F.x) * (1.0f - metallic), (1.0f - F.y) * (1.0f - metallic), (1.0f - F.z) * (1.0f - metallic) };
+    return f3{ dp.x * albedo.x / VHR_PI, dp.y * albedo.y / VHR_PI, dp.z * albedo.z / VHR_PI };
+}
+
 // XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one),
 // and each XCD has its own 4 MiB L2.  With the natural order every XCD would walk tiles from all over the screen
 // and pull the whole visible BVH / triangle set (> 4 MiB) through its L2; instead the blocks that share an XCD get

@@ -1,6 +1,6 @@
 // Host side of the hot path: which passes the hybrid path registers, what they read and
 // write, which persistent SVGF images it owns, and the per-frame SVGF dispatch schedule.
-// Reference: src/render_paths/hybrid_render_path.cpp -- RT pass :101-136, SVGF images :245-262, SVGF pass and
+// Reference: src/render_paths/hybrid_render_path.cpp -- RT pass :101-136, SSAO / SSR passes :138-243, SVGF images :245-262, SVGF pass and
 // schedule :264-331, composition inputs :333-351, DeregisterPath :383-392.
 //
 // Written against the vhr:: facade only (no access to library internals), i.e. exactly what a maintainer of
@@ -19,6 +19,12 @@ constexpr const char *kAlbedo = "Albedo";
 constexpr const char *kRaytraced = "Raytraced Shadows and Ambient Occlusion";
 constexpr const char *kReflections = "Raytraced Reflections";
 constexpr const char *kDenoised = "Denoised Raytraced Shadows and Ambient Occlusion";
+constexpr const char *kSsaoRaw = "Screen Space Ambient Occlusion Raw";
+constexpr const char *kSsao = "Screen Space Ambient Occlusion";
+constexpr const char *kSsr = "Screen Space Reflections";
+constexpr const char *kSsaoShader = "hybrid_render_path/ssao.comp";
+constexpr const char *kSsaoBlurShader = "hybrid_render_path/ssao_blur.comp";
+constexpr const char *kSsrShader = "hybrid_render_path/ssr.comp";
 constexpr const char *kSvgfShader = "hybrid_render_path/svgf.comp";
 constexpr const char *kAtrousShader = "hybrid_render_path/svgf_atrous_filter.comp";
 
@@ -65,8 +71,52 @@ void HybridRenderPath::RegisterPath(DeviceContext &context, RenderGraph &render_
             });
     }
 
-    if (ambient_occlusion_mode == AMBIENT_OCCLUSION_MODE_SSAO || reflection_mode == REFLECTION_MODE_SSR)
-        throw std::runtime_error("HybridRenderPath: SSAO / SSR are raster-side alternatives outside the ray-traced hot path (SURVEY.md row 27)");
+    if (ambient_occlusion_mode == AMBIENT_OCCLUSION_MODE_SSAO) {              // :138-200
+        ssao_push_constants = vhr_ssao_push_constants{ 0.75f };
+        ComputePipelineDescription ssao;                                      // no push constant description (:151-157) ...
+        ssao.kernels = { ComputeKernel{ kSsaoShader } };
+        render_graph.AddComputePass(
+            "SSAO Pass",
+            { VkUtils::CreateTransientSampledImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 0),
+              VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 1) },
+            { VkUtils::CreateTransientStorageImage(kSsaoRaw, VHR_FORMAT_R16G16B16A16_SFLOAT, 2) },
+            ssao,
+            [](ComputeExecutionContext &execution_context) {
+                const uvec2 display_size = execution_context.GetDisplaySize();
+                execution_context.Dispatch(kSsaoShader, groups_of_8(display_size.x), groups_of_8(display_size.y), 1);   // ... and none pushed (:161-166)
+            });
+        ComputePipelineDescription blur;                                      // :177-188: the blur gets the SSAO constants it does not read
+        blur.kernels = { ComputeKernel{ kSsaoBlurShader } };
+        blur.push_constant_description.size = sizeof(vhr_ssao_push_constants);
+        render_graph.AddComputePass(
+            "SSAO Blur Pass",
+            { VkUtils::CreateTransientStorageImage(kSsaoRaw, VHR_FORMAT_R16G16B16A16_SFLOAT, 0) },
+            { VkUtils::CreateTransientStorageImage(kSsao, VHR_FORMAT_R16G16B16A16_SFLOAT, 1) },
+            blur,
+            [this](ComputeExecutionContext &execution_context) {
+                const uvec2 display_size = execution_context.GetDisplaySize();
+                execution_context.Dispatch(kSsaoBlurShader, groups_of_8(display_size.x), groups_of_8(display_size.y), 1, ssao_push_constants);
+            });
+    }
+
+    if (reflection_mode == REFLECTION_MODE_SSR) {                             // :202-243
+        ssr_push_constants = vhr_ssr_push_constants{ 25.0f, 0.1f, 0.5f, 10 };
+        ComputePipelineDescription ssr;
+        ssr.kernels = { ComputeKernel{ kSsrShader } };
+        ssr.push_constant_description.size = sizeof(vhr_ssr_push_constants);
+        render_graph.AddComputePass(
+            "SSR Pass",
+            { VkUtils::CreateTransientSampledImage(kAlbedo, VHR_FORMAT_B8G8R8A8_UNORM, 0),
+              VkUtils::CreateTransientSampledImage(kNormals, VHR_FORMAT_R16G16B16A16_SFLOAT, 1),
+              VkUtils::CreateTransientSampledImage(kMotion, VHR_FORMAT_R16G16B16A16_SFLOAT, 2),
+              VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 3) },
+            { VkUtils::CreateTransientStorageImage(kSsr, VHR_FORMAT_R16G16B16A16_SFLOAT, 4) },
+            ssr,
+            [this](ComputeExecutionContext &execution_context) {
+                const uvec2 display_size = execution_context.GetDisplaySize();
+                execution_context.Dispatch(kSsrShader, groups_of_8(display_size.x), groups_of_8(display_size.y), 1, ssr_push_constants);
+            });
+    }
 
     if (denoise_shadow_and_ao && any_raytraced) {
         // five persistent images, :247-262 (the moments history really is allocated R16G16)
@@ -121,8 +171,8 @@ void HybridRenderPath::RegisterPath(DeviceContext &context, RenderGraph &render_
           VkUtils::CreateTransientSampledImage(kMotion, VHR_FORMAT_R16G16B16A16_SFLOAT, 2),
           VkUtils::CreateTransientSampledImage(kDepth, VHR_FORMAT_D32_SFLOAT, 3),
           VkUtils::CreateTransientSampledImage("Shadow Map", 4096, 4096, VHR_FORMAT_D32_SFLOAT, 4),
-          VkUtils::CreateTransientSampledImage("Screen Space Ambient Occlusion", VHR_FORMAT_R16G16B16A16_SFLOAT, 5),
-          VkUtils::CreateTransientSampledImage("Screen Space Reflections", VHR_FORMAT_R16G16B16A16_SFLOAT, 6),
+          VkUtils::CreateTransientSampledImage(kSsao, VHR_FORMAT_R16G16B16A16_SFLOAT, 5),
+          VkUtils::CreateTransientSampledImage(kSsr, VHR_FORMAT_R16G16B16A16_SFLOAT, 6),
           denoise_shadow_and_ao ? VkUtils::CreateTransientSampledImage(kDenoised, VHR_FORMAT_R16G16B16A16_SFLOAT, 7)
                                 : VkUtils::CreateTransientSampledImage(kRaytraced, VHR_FORMAT_R16G16_SFLOAT, 7),
           VkUtils::CreateTransientSampledImage(kReflections, VHR_FORMAT_R16G16B16A16_SFLOAT, 8) },

@@ -191,25 +191,6 @@ __device__ f4 sample_texture(const DeviceScene &sc, int idx, float u, float v) {
 // ---------------------------------------------------------------------------------------------
 // K2: reflection_hit.rchit:10-72
 // ---------------------------------------------------------------------------------------------
-// common.glsl:116-150
-__device__ __forceinline__ f3 fresnel_schlick(f3 f0, f3 H, f3 V) {
-    const float hv = fmaxf(dot3(H, V), 0.0f);
-    const float om = 1.0f - hv;
-    const float p5 = om * om * om * om * om;
-    return f3{ f0.x + (1.0f - f0.x) * p5, f0.y + (1.0f - f0.y) * p5, f0.z + (1.0f - f0.z) * p5 };
-}
-__device__ __forceinline__ float D_GGX(float roughness, f3 N, f3 H) {
-    const float a2 = roughness * roughness;
-    const float nh = fmaxf(dot3(N, H), 0.0f);
-    const float f = nh * nh * (a2 - 1.0f) + 1.0f;
-    return a2 / (VHR_PI * f * f);
-}
-__device__ __forceinline__ float G_GGX(float roughness, f3 N, f3 V, f3 L) {
-    const float k = ((roughness + 1.0f) * (roughness + 1.0f)) * 0.125f;
-    const float nv = fmaxf(dot3(N, V), 0.0f), nl = fmaxf(dot3(N, L), 0.0f);
-    return (nv / (nv * (1.0f - k) + k)) * (nl / (nl * (1.0f - k) + k));
-}
-
 struct TriAttributes { float uvx, uvy; f3 normal; f3 object_pos; };
 
 __device__ __forceinline__ TriAttributes interpolate(const DeviceScene &sc, const vhr_primitive &prim, uint32_t tri, float u, float v) {
@@ -1695,7 +1676,8 @@ struct CompositionArgs {
     const void *normals, *motion;
     const float *depth;
     const void *shadow_ao;       // RGBA16F (denoised) or RG16F (raw)
-    const void *reflections;     // RGBA16F or nullptr
+    const void *reflections;     // RGBA16F or nullptr: "Raytraced Reflections" (mode 0) / "Screen Space Reflections" (mode 1)
+    const void *ssao;            // RGBA16F or nullptr: "Screen Space Ambient Occlusion" (ambient occlusion mode 1)
     uchar4 *out;                 // B8G8R8A8_SRGB
     uint32_t width, height;
     int shadow_mode, ao_mode, reflection_mode, shadow_ao_is_rgba;
@@ -1733,7 +1715,8 @@ __global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs 
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     const f3 Hh = normalize3(L + V);
     const float shadow = a.shadow_mode == 0 ? rs : 1.0f;                                                           // :77-80
-    const float ao = a.ao_mode == 0 ? ra : 1.0f;                                                                   // :115-121
+    float ao = a.ao_mode == 0 ? ra : 1.0f;                                                                         // :114-121
+    if (a.ao_mode == 1) ao = load_rgba16f(a.ssao, W, x, gy).x;                                                     // :117-119 (in_uv is the texel centre)
     const float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f), roughness = fminf(fmaxf(mm.w, 0.04f), 1.0f);            // :123-125
     const f3 li = f3{ a.pfd.directional_light.intensity[0], a.pfd.directional_light.intensity[1], a.pfd.directional_light.intensity[2] };
     const f3 lc = f3{ a.pfd.directional_light.color[0], a.pfd.directional_light.color[1], a.pfd.directional_light.color[2] };
@@ -1747,7 +1730,7 @@ __global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs 
     const float dg = D_GGX(roughness, N, Hh) * G_GGX(roughness, N, V, L);
     const float invd = 1.0f / fmaxf(4.0f * fmaxf(dot3(N, V), 0.0f) * fmaxf(dot3(N, L), 0.0f), 1e-6f);
     f3 spec = mul3(mul3(f3{ dg * F.x * invd, dg * F.y * invd, dg * F.z * invd } * ndl, li), lc) * shadow;          // :139
-    if (a.reflection_mode == 0 && a.reflections) {                                                                 // :141-149
+    if ((a.reflection_mode == 0 || a.reflection_mode == 1) && a.reflections) {                                     // :139-156 (the same blend for both sources)
         const f4 r = load_rgba16f(a.reflections, W, x, gy);
         const f3 refl = f3{ r.x, r.y, r.z } * shadow;
         if (metallic == 1.0f) spec = refl;
@@ -1759,7 +1742,7 @@ __global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs 
 }
 
 int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
-                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, Image &out) {
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao, Image &out) {
     const uint32_t W = depth.width, H = depth.height;
     const Image *all[] = { &albedo, &normals, &motion, &shadow_ao, &out };
     for (const Image *im : all)
@@ -1768,9 +1751,14 @@ int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vh
     if (albedo.bpp != 4 || out.bpp != 4 || normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || motion.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
         depth.format != VHR_FORMAT_D32_SFLOAT || (shadow_ao.format != VHR_FORMAT_R16G16B16A16_SFLOAT && shadow_ao.format != VHR_FORMAT_R16G16_SFLOAT))
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: unexpected image format");
-    for (int m : { d.shadow_mode, d.ambient_occlusion_mode, d.reflection_mode })
-        if (m != 0 && m != 2) return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: only the ray-traced (0) and off (2) modes exist here; shadow map / SSAO / SSR are raster-side");
+    if (d.shadow_mode != 0 && d.shadow_mode != 2)
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: shadow_mode 1 (the rasterised shadow map with PCF) stays with the raster side");
+    for (int m : { d.ambient_occlusion_mode, d.reflection_mode })
+        if (m < 0 || m > 2) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: modes are 0 (ray traced), 1 (screen space) or 2 (off)");
+    if (d.ambient_occlusion_mode == 1 && (!ssao || ssao->width != W || ssao->height != H || ssao->format != VHR_FORMAT_R16G16B16A16_SFLOAT))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: ambient_occlusion_mode 1 needs the R16G16B16A16 \"Screen Space Ambient Occlusion\" image");
     CompositionArgs a;
+    a.ssao = ssao ? ssao->ptr : nullptr;
     a.pfd = pfd;
     a.albedo = static_cast<const uchar4 *>(albedo.ptr);
     a.normals = normals.ptr; a.motion = motion.ptr;

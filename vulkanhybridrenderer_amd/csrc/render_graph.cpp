@@ -35,6 +35,13 @@ static const char *kRtClosestHitAlpha = "raytraced_render_path/closesthit_test_a
 static const char *kRtShadowAnyHit = "raytraced_render_path/shadow_anyhit.rahit";
 static const char *kSvgf = "hybrid_render_path/svgf.comp";
 static const char *kAtrous = "hybrid_render_path/svgf_atrous_filter.comp";
+// the screen-space alternatives (hybrid_render_path.cpp:138-243), SURVEY.md section 8 row f4
+static const char *kSsao = "hybrid_render_path/ssao.comp";
+static const char *kSsaoBlur = "hybrid_render_path/ssao_blur.comp";
+static const char *kSsr = "hybrid_render_path/ssr.comp";
+static bool known_compute_shader(const char *k) {
+    return !std::strcmp(k, kSvgf) || !std::strcmp(k, kAtrous) || !std::strcmp(k, kSsao) || !std::strcmp(k, kSsaoBlur) || !std::strcmp(k, kSsr);
+}
 
 static void free_pass_events(PassDescription &p) {
     if (p.ev_begin) hipEventDestroy(p.ev_begin);
@@ -184,7 +191,7 @@ int vhr_graph_add_compute_pass(vhr_context *ctx, const char *name, const vhr_tra
     if (rc) return rc;
     for (uint32_t i = 0; i < pipeline->kernel_count; ++i) {
         const char *k = pipeline->kernels[i];
-        if (!k || (std::strcmp(k, kSvgf) != 0 && std::strcmp(k, kAtrous) != 0))
+        if (!k || !known_compute_shader(k))
             return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no HIP kernel for compute shader '") + (k ? k : "(null)") + "'");
         if (ctx->compute_kernel_owner.count(k))       // assert(!compute_pipelines.contains(kernel.shader)), render_graph.cpp:677
             return ctx->fail(VHR_ERROR_GRAPH, std::string("compute shader '") + k + "' is already registered by pass '" + ctx->compute_kernel_owner[k] + "'");
@@ -425,12 +432,52 @@ int vhr_compute_dispatch(vhr_compute_execution_context *exec, const char *shader
         return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("compute shader '") + shader + "' is not part of pass '" + p.name + "'");
     if (push_constants_size != p.push_constant_size || (push_constants_size && !push_constants))     // assert, compute_execution_context.h:23
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: push constant size differs from the pipeline's declaration");
+    if (z_groups != 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: z_groups must be 1");
+    const vhr_per_frame_data &pfd = ctx->per_frame[exec->resource_idx];
+    // ---- the screen-space alternatives.  Bindings: ssao.comp:8-10, ssao_blur.comp:8-9, ssr.comp:8-12 ----
+    // (issued at once: anything the pass has recorded so far goes first, in order)
+    if (std::strcmp(shader, kSvgf) != 0 && std::strcmp(shader, kAtrous) != 0 && !ctx->recorded.empty()) {
+        const int frc = vhr::flush_recorded(ctx);
+        if (frc != VHR_OK) return frc;
+    }
+    if (!std::strcmp(shader, kSsao)) {
+        // The reference dispatches ssao.comp WITHOUT push constants (its pass declares none, hybrid_render_path.cpp:151-167) although
+        // the shader reads pc.radius; a caller that does push SSAOPushConstants here is accepted too.
+        if (push_constants_size != 0 && push_constants_size != sizeof(vhr_ssao_push_constants))
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: ssao.comp takes no push constants (as the reference dispatches it) or SSAOPushConstants (4 bytes)");
+        if (push_constants_size) std::memcpy(&ctx->ssao_radius, push_constants, sizeof(float));
+        Image *normals = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
+        Image *depth = pass_image(ctx, p, 1, VHR_FORMAT_D32_SFLOAT, "depth");
+        Image *out = pass_image(ctx, p, 2, VHR_FORMAT_R16G16B16A16_SFLOAT, "screen_space_ambient_occlusion");
+        if (!normals || !depth || !out) return VHR_ERROR_GRAPH;
+        return launch_ssao(ctx, pfd, *normals, *depth, *out, ctx->ssao_radius, x_groups, y_groups);
+    }
+    if (!std::strcmp(shader, kSsaoBlur)) {
+        if (push_constants_size != sizeof(vhr_ssao_push_constants))
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: ssao_blur.comp is dispatched with SSAOPushConstants (4 bytes, hybrid_render_path.cpp:182-197)");
+        std::memcpy(&ctx->ssao_radius, push_constants, sizeof(float));     // the shader ignores it; the next ssao.comp dispatch sees it
+        Image *in = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "screen_space_ambient_occlusion");
+        Image *out = pass_image(ctx, p, 1, VHR_FORMAT_R16G16B16A16_SFLOAT, "screen_space_ambient_occlusion_blurred");
+        if (!in || !out) return VHR_ERROR_GRAPH;
+        return launch_ssao_blur(ctx, pfd, *in, *out, x_groups, y_groups);
+    }
+    if (!std::strcmp(shader, kSsr)) {
+        if (push_constants_size != sizeof(vhr_ssr_push_constants))
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: ssr.comp takes SSRPushConstants (16 bytes)");
+        vhr_ssr_push_constants spc;
+        std::memcpy(&spc, push_constants, sizeof spc);
+        Image *albedo = pass_image(ctx, p, 0, VHR_FORMAT_B8G8R8A8_UNORM, "albedo");
+        Image *normals = pass_image(ctx, p, 1, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
+        Image *motion = pass_image(ctx, p, 2, VHR_FORMAT_R16G16B16A16_SFLOAT, "motion_vectors_and_metallic_roughness");
+        Image *depth = pass_image(ctx, p, 3, VHR_FORMAT_D32_SFLOAT, "depth");
+        Image *out = pass_image(ctx, p, 4, VHR_FORMAT_R16G16B16A16_SFLOAT, "screen_space_reflections");
+        if (!albedo || !normals || !motion || !depth || !out) return VHR_ERROR_GRAPH;
+        return launch_ssr(ctx, pfd, *albedo, *normals, *motion, *depth, *out, spc, x_groups, y_groups);
+    }
     if (push_constants_size != sizeof(vhr_svgf_push_constants))
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: the SVGF kernels take SVGFPushConstants (24 bytes)");
-    if (z_groups != 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "Dispatch: z_groups must be 1");
     vhr_svgf_push_constants pc;
     std::memcpy(&pc, push_constants, sizeof pc);              // copied at call time, like vkCmdPushConstants
-    const vhr_per_frame_data &pfd = ctx->per_frame[exec->resource_idx];
     // set 3 bindings of svgf.comp:8-12 / svgf_atrous_filter.comp:8-12
     Image *normals = pass_image(ctx, p, 0, VHR_FORMAT_R16G16B16A16_SFLOAT, "world_space_normals_and_object_ids");
     if (!normals) return VHR_ERROR_GRAPH;

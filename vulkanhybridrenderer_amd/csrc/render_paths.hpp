@@ -30,6 +30,11 @@ public:
     bool denoise_shadow_and_ao = false;
     int atrous_steps = 5;                              // hybrid_render_path.cpp:299
 
+    // settings of the screen-space alternatives (the ImGui sliders of hybrid_render_path.cpp:422-433); (re)initialised by
+    // RegisterPath like the reference does (:139-141, :203-208)
+    vhr_ssao_push_constants ssao_push_constants{ 0.75f };
+    vhr_ssr_push_constants ssr_push_constants{ 25.0f, 0.1f, 0.5f, 10 };
+
     // the five persistent SVGF images (pool indices) travel in the push constants, hybrid_render_path.cpp:247-262
     SVGFPushConstants svgf_push_constants{};
     bool svgf_textures_created = false;

@@ -173,7 +173,7 @@ struct RayStats {
 enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptCount = 23 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
-enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelKinds = 5 };
+enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelKinds = 8 };
 struct KernelTimer {
     std::vector<hipEvent_t> events;     // begin/end pairs
     size_t used = 0;                    // events recorded since the last drain
@@ -243,6 +243,9 @@ struct vhr_context {
     int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
+    // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
+    // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
+    float ssao_radius = 0.75f;
     uint32_t kernel_timing_mask = 0;   // bit per KernelKind
     vhr::KernelTimer kernel_timers[vhr::kKernelKinds];
     // Timing rides on the dispatch packets: vhr::launch() attaches (start, stop) events to a kernel launch through
@@ -281,13 +284,19 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
 int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out);
 int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth, Image *albedo);
 int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
-                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, Image &out);
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao, Image &out);
 int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
                          const Image &raytraced, const Image &prev_normals, const Image &history,
                          Image &moments, Image &integrated_out, uint32_t x_groups, uint32_t y_groups);
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in,
                        Image &out, int32_t step, uint32_t x_groups, uint32_t y_groups);
 int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst);
+// csrc/kernels_screen.hip: ssao.comp, ssao_blur.comp, ssr.comp
+int launch_ssao(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &depth, Image &out, float radius,
+                uint32_t x_groups, uint32_t y_groups);
+int launch_ssao_blur(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &in, Image &out, uint32_t x_groups, uint32_t y_groups);
+int launch_ssr(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &albedo, const Image &normals, const Image &motion,
+               const Image &depth, Image &out, const vhr_ssr_push_constants &pc, uint32_t x_groups, uint32_t y_groups);
 int flush_recorded(vhr_context *ctx);          // issue the commands a compute pass recorded (no-op when there are none)
 int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink);
 

@@ -77,7 +77,8 @@ class ImageInfo(C.Structure):
 class CompositionDesc(C.Structure):
     _fields_ = [("shadow_mode", C.c_int32), ("ambient_occlusion_mode", C.c_int32), ("reflection_mode", C.c_int32),
                 ("albedo_image", C.c_char_p), ("normals_image", C.c_char_p), ("motion_image", C.c_char_p), ("depth_image", C.c_char_p),
-                ("shadow_ao_image", C.c_char_p), ("reflections_image", C.c_char_p), ("output_storage_image", C.c_int32)]
+                ("shadow_ao_image", C.c_char_p), ("reflections_image", C.c_char_p), ("output_storage_image", C.c_int32),
+                ("ssao_image", C.c_char_p)]
 
 
 class HybridSettings(C.Structure):
@@ -193,6 +194,12 @@ ALBEDO = "Albedo"
 SVGF_SHADER = "hybrid_render_path/svgf.comp"
 ATROUS_SHADER = "hybrid_render_path/svgf_atrous_filter.comp"
 RAYTRACED_OUTPUT = "RaytracedOutput"        # raytraced_render_path.cpp:15
+SSAO_RAW = "Screen Space Ambient Occlusion Raw"     # hybrid_render_path.cpp:149
+SSAO = "Screen Space Ambient Occlusion"             # :176
+SSR = "Screen Space Reflections"                    # :219
+SSAO_SHADER = "hybrid_render_path/ssao.comp"
+SSAO_BLUR_SHADER = "hybrid_render_path/ssao_blur.comp"
+SSR_SHADER = "hybrid_render_path/ssr.comp"
 
 ATTACHMENT_IMAGE, SAMPLED_IMAGE, STORAGE_IMAGE = 0, 1, 2
 
@@ -423,9 +430,13 @@ class Context:
                                                           depth.encode()), "standin_gbuffer_with_albedo")
 
     def standin_composition(self, output_storage_image, shadow_mode=0, ao_mode=0, reflection_mode=0, shadow_ao=DENOISED,
-                            reflections=REFLECTIONS, resource_idx=0):
+                            reflections=REFLECTIONS, resource_idx=0, ssao=None):
+        """composition.frag stand-in.  ao_mode 1 reads `ssao` (default SSAO), reflection_mode 1 expects `reflections` = SSR."""
+        if ao_mode == 1 and ssao is None:
+            ssao = SSAO
         d = CompositionDesc(shadow_mode, ao_mode, reflection_mode, ALBEDO.encode(), NORMALS.encode(), MOTION.encode(), DEPTH.encode(),
-                            shadow_ao.encode(), reflections.encode() if reflections else None, output_storage_image)
+                            shadow_ao.encode(), reflections.encode() if reflections else None, output_storage_image,
+                            ssao.encode() if ssao else None)
         self.check(self.L.vhr_standin_composition(self.handle, resource_idx, C.byref(d)), "standin_composition")
 
     def standin_raytraced_composition(self, output_storage_image, raytraced_output=RAYTRACED_OUTPUT):
@@ -460,7 +471,7 @@ class Context:
         self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
 
-    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4}
+    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4, "ssao": 5, "ssao_blur": 6, "ssr": 7}
 
     def set_option(self, key, value):
         self.check(self.L.vhr_set_option(self.handle, key.encode(), int(value)), "set_option")
@@ -468,7 +479,7 @@ class Context:
     def set_kernel_timing(self, kinds):
         """kinds: True (all), False (off) or an iterable of kind names from KERNEL_KINDS."""
         if kinds is True:
-            mask = 0xF
+            mask = 0xFF
         elif not kinds:
             mask = 0
         else:
