@@ -288,6 +288,32 @@ def test_gpu_strips_compose_the_whole_frame(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_config0_512_square_screen_space_whole_frame(oracle):
+    """BASELINE.json configs[0] ("Sponza 512x512, raster-only path: shadow map + Alchemy SSAO", the reference's CPU-runnable
+    plumbing case) as far as this build reaches: sponza_proc at 512x512 with SSAO + blur (+ SSR) and nothing ray traced --
+    whole frames against the oracle; the shadow map is raster work and stays outside (composition with shadows off)."""
+    scene = scenes.sponza_proc()
+    W = H = 512
+    osc = oracle.Scene(scene)
+    g = ScreenSpacePath(scene, W, H)
+    try:
+        assert "Raytrace Pass" not in g.ctx.execution_order()
+        for pfd in camera.dolly_frames(scene, W, H, 2):
+            gbuf = osc.gbuffer(pfd, W, H, with_albedo=True)
+            n, m, d, al = gbuf
+            g.frame(pfd, gbuf)
+            raw = g.ctx.download(lib.SSAO_RAW)
+            _bits_close(raw, oracle.ssao(pfd, n, d), "ssao.comp")
+            assert np.array_equal(g.ctx.download(lib.SSAO), oracle.ssao_blur(pfd, raw))
+            _bits_close(g.ctx.download(lib.SSR), oracle.ssr(pfd, al, n, m, d), "ssr.comp")
+            ref = oracle.composition(pfd, (2, 1, 1), al, n, m, d, np.zeros((H, W, 2), np.uint16), g.ctx.download(lib.SSR), ssao=g.ctx.download(lib.SSAO))
+            diff = np.abs(g.ctx.download(g.out_img).astype(np.int32) - ref.astype(np.int32))
+            assert diff.max() <= 1 and (diff == 0).mean() > 0.99
+    finally:
+        g.close()
+
+
+@pytest.mark.gpu
 def test_gpu_1080p_with_raytraced_shadows_and_svgf(oracle):
     """Full size, mixed modes (ray-traced shadows + SVGF, SSAO, SSR): a band of every image against the oracle, properties
     on the rest, and the kernel times."""

@@ -19,7 +19,13 @@ namespace vhr {
 constexpr int kScreenBlockX = 64;   // one wave per row segment: 512-byte coalesced RGBA16F rows
 constexpr int kScreenBlockY = 4;
 
-__device__ __forceinline__ int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+// REPEAT addressing.  Nearly every coordinate is on screen: the integer modulo (~20 instructions for a run-time divisor, two per
+// sample) sits behind a test that whole waves usually skip.
+__device__ __forceinline__ int wrap_repeat(int i, int n) {
+    if (__builtin_expect(uint32_t(i) < uint32_t(n), 1)) return i;
+    const int m = i % n;
+    return m < 0 ? m + n : m;
+}
 
 struct Taps { int x0, x1, y0, y1; float ax, ay, bx, by; };
 // oracle decision (x): u * W - 0.5, floor, wrapped texels, fp32 weights
@@ -134,34 +140,70 @@ struct BlurArgs {
 constexpr int kBlurR = 6;
 constexpr int kBlurTileX = 64, kBlurTileY = 16;
 constexpr int kBlurLdsW = kBlurTileX + 2 * kBlurR, kBlurLdsH = kBlurTileY + 2 * kBlurR;
+constexpr int kBlurLdsStride = 80;                  // floats per LDS row: a multiple of 4, so every thread's 16-float window is 16-byte aligned
 
 __global__ __launch_bounds__(256) void ssao_blur_kernel(const BlurArgs a) {
     // .x of the raw image as fp32; texels the shader skips (outside the display or the image) are stored as -0.0f, whose
     // addition leaves every partial sum unchanged (x + -0 == x, and the sum starts at +0)
-    __shared__ float tile[kBlurLdsH][kBlurLdsW + 1];
+    __shared__ __attribute__((aligned(16))) float tile[kBlurLdsH][kBlurLdsStride];
     const int tx0 = int(blockIdx.x) * kBlurTileX, ty0 = int(a.row_begin) + int(blockIdx.y) * kBlurTileY;
-    for (int i = int(threadIdx.x); i < kBlurLdsW * kBlurLdsH; i += 256) {
+    // (constant trip count, unrolled: the nine loads of a thread are in flight together instead of one round trip each)
+    constexpr int kFill = (kBlurLdsW * kBlurLdsH + 255) / 256;
+    uint32_t raw[kFill];
+#pragma unroll
+    for (int it = 0; it < kFill; ++it) {
+        const int i = int(threadIdx.x) + it * 256;
         const int ly = i / kBlurLdsW, lx = i - ly * kBlurLdsW;
         const int sx = tx0 + lx - kBlurR, sy = ty0 + ly - kBlurR;
-        const bool inside = sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h && uint32_t(sx) < a.width && uint32_t(sy) < a.height;
-        float v = -0.0f;
-        if (inside) {
-            const uint32_t raw = a.in[size_t(sy) * a.width + sx].x;
-            v = __half2float(__ushort_as_half(uint16_t(raw & 0xffffu)));
+        const bool inside = i < kBlurLdsW * kBlurLdsH && sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h &&
+                            uint32_t(sx) < a.width && uint32_t(sy) < a.height;
+        raw[it] = inside ? a.in[size_t(sy) * a.width + sx].x & 0xffffu : 0x8000u;        // fp16 -0.0
+    }
+#pragma unroll
+    for (int it = 0; it < kFill; ++it) {
+        const int i = int(threadIdx.x) + it * 256;
+        if (i < kBlurLdsW * kBlurLdsH) {
+            const int ly = i / kBlurLdsW, lx = i - ly * kBlurLdsW;
+            tile[ly][lx] = __half2float(__ushort_as_half(uint16_t(raw[it])));
         }
-        tile[ly][lx] = v;
     }
     __syncthreads();
-    const int lx = int(threadIdx.x) & 63;
-    for (int ly = int(threadIdx.x) >> 6; ly < kBlurTileY; ly += 4) {
-        const uint32_t cx = uint32_t(tx0 + lx), cy = uint32_t(ty0 + ly);
-        if (cx >= a.limit_x || cy >= a.row_end || cy >= a.limit_y) continue;
-        float ao = 0.0f;
+    // A thread owns four pixels next to each other: per tile row it reads one 16-float window (four ds_read_b128) that holds
+    // the 13 taps of each of them, and feeds four accumulators -- each in the shader's order (rows top to bottom, taps left to
+    // right), so every sum has the shader's roundings while the LDS traffic per pixel drops from 169 to 52 words.
+    const int gx = (int(threadIdx.x) & 15) * 4, ly = int(threadIdx.x) >> 4;
+    float ao[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    float4 nxt[4];
+    {
+        const float4 *row = reinterpret_cast<const float4 *>(&tile[ly][gx]);
 #pragma unroll
-        for (int y = 0; y <= 2 * kBlurR; ++y)
+        for (int q = 0; q < 4; ++q) nxt[q] = row[q];
+    }
+    // one row per trip with the next row's window already on its way (fully unrolled, the compiler hoists all 52 reads:
+    // 216 VGPRs, 2 waves per SIMD)
+#pragma unroll 1
+    for (int y = 0; y <= 2 * kBlurR; ++y) {
+        float w[16];
 #pragma unroll
-            for (int x = 0; x <= 2 * kBlurR; ++x) ao += tile[ly + y][lx + x];
-        const float r = ao / (13.0f * 13.0f);
+        for (int q = 0; q < 4; ++q) { w[4 * q] = nxt[q].x; w[4 * q + 1] = nxt[q].y; w[4 * q + 2] = nxt[q].z; w[4 * q + 3] = nxt[q].w; }
+        if (y < 2 * kBlurR) {
+            const float4 *row = reinterpret_cast<const float4 *>(&tile[ly + y + 1][gx]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = row[q];
+        }
+#pragma unroll
+        for (int x = 0; x <= 2 * kBlurR; ++x) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ao[k] += w[k + x];
+        }
+    }
+    const uint32_t cy = uint32_t(ty0 + ly);
+    if (cy >= a.row_end || cy >= a.limit_y) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t cx = uint32_t(tx0 + gx + k);
+        if (cx >= a.limit_x) continue;
+        const float r = ao[k] / (13.0f * 13.0f);
         a.out[size_t(cy) * a.width + cx] = pack_half4(r, r, r, r);
     }
 }
