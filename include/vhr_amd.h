@@ -332,6 +332,9 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      those boxes when it is fetched and starts below them instead of at the root (default; same
  *                      triangles tested in a different order, visibility bit-identical), 0 = every ray starts at the root.
  *                      Ignored with "compact_nodes", the shared-tile variant and pre-generated rays.
+ *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair
+ *                      (default 1 = every launch).  A timed dispatch costs ~6 us that the next kernel waits for; bench.py samples
+ *                      the a-trous launches with stride 6 (coprime with the 5 launches of a frame, so every step size is sampled).
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

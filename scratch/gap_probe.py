@@ -1,0 +1,20 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from vulkanhybridrenderer_amd import scenes, lib
+from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+W, H = 1920, 1080
+loop = HybridFrameLoop(scenes.sponza_proc(), W, H, 40)
+ctx = loop.ctx
+def run(label):
+    for i in range(4): loop.frame(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(4, 36): loop.frame(i)
+    torch.cuda.synchronize()
+    print(f"{label}: {(time.perf_counter() - t0) / 32 * 1e3:.4f} ms/frame", flush=True)
+ctx.set_kernel_timing(["svgf_atrous"]); run("a-trous event pairs, pass timestamps on (bench)")
+ctx.set_kernel_timing(False); run("no kernel event pairs, pass timestamps on")
+ctx.set_option("pass_timestamps", 0); run("no event pairs, no pass timestamps")
+ctx.set_kernel_timing(["svgf_atrous"]); run("a-trous event pairs, no pass timestamps")
+loop.close()

@@ -196,3 +196,26 @@ def test_fused_blits_equal_copies():
     for f, (a, b) in enumerate(zip(out[1][0], out[0][0])):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), f"frame {f}, image {k}"
+
+
+def test_kernel_timing_stride_samples_every_nth_launch():
+    """kernel_timing_stride n: with kernel timing on, every n-th launch of a kind carries the event pair (bench.py times the
+    a-trous launches with stride 6: the sample walks through the five step sizes)."""
+    from tests.helpers import GpuHybrid
+    W, H = 128, 72
+    sc = scenes.tiny_scene()
+    pfds = camera.dolly_frames(sc, W, H, 6)
+    g = GpuHybrid(sc, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
+    try:
+        g.ctx.set_kernel_timing(["svgf_atrous", "svgf_temporal"])
+        for pfd in pfds:
+            g.frame(pfd)
+        assert g.ctx.kernel_time("svgf_atrous", reset=True)[1] == 30 and g.ctx.kernel_time("svgf_temporal", reset=True)[1] == 6
+        g.ctx.set_option("kernel_timing_stride", 6)
+        for pfd in pfds:
+            g.frame(pfd)
+        ms, n = g.ctx.kernel_time("svgf_atrous", reset=True)
+        assert n == 5 and ms > 0.0                                        # launches 30, 36, ... 54 of the kind since timing went on
+        assert g.ctx.kernel_time("svgf_temporal", reset=True)[1] == 1
+    finally:
+        g.close()

@@ -63,7 +63,10 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
     start = stop = nullptr;
     if (timing_kind >= 0 && (kernel_timing_mask & (1u << timing_kind))) {
         KernelTimer &t = kernel_timers[timing_kind];
-        if (t.used + 2 <= kTimerCapacity) {
+        // "kernel_timing_stride" n: only every n-th launch of the kind carries an event pair (a profiled dispatch costs ~6 us of
+        // completion-signal and release-fence handling that the next kernel waits for; sampling keeps the measured loop honest)
+        const uint64_t stride = uint64_t(std::max(1, options[vhr::kOptKernelTimingStride]));
+        if ((t.seen++ % stride) == 0 && t.used + 2 <= kTimerCapacity) {
             while (t.events.size() < t.used + 2) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) != hipSuccess) break;
@@ -399,7 +402,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
