@@ -248,6 +248,17 @@ def main():
     for name in ("Raytrace Pass", "SVGF Denoise Pass"):
         ema, last = ctx.pass_time_ms(name)
         passes[name] = round(last, 4)
+    # distribution of the per-pass GPU times (the reference's timestamp pairs, render_graph.cpp:167-199) over 12 more frames,
+    # gathered frame by frame outside the timed region: median and p95
+    samples = {name: [] for name in passes}
+    for i in range(args.warmup, args.warmup + 12):
+        loop.frame(i)
+        ctx.gather_performance_statistics()
+        for name in samples:
+            samples[name].append(ctx.pass_time_ms(name)[1])
+    barrier()
+    passes_median = {k: round(float(np.median(v)), 4) for k, v in samples.items()}
+    passes_p95 = {k: round(float(np.percentile(v, 95)), 4) for k, v in samples.items()}
 
     if rank == 0:
         bvh = ctx.bvh_statistics()
@@ -307,7 +318,7 @@ def main():
                            "svgf_atrous": round(atrous_us, 2),
                            "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2),
                            "reflection": round(kt["reflection"][0] / max(1, kt["reflection"][1]) * 1e3, 2) if kt["reflection"][1] else None},
-            "passes_ms": passes,
+            "passes_ms": passes, "passes_ms_median": passes_median, "passes_ms_p95": passes_p95,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, loop.tp, args.cpu_frames, loop.rays_per_pixel)
