@@ -201,7 +201,7 @@ def test_fused_blits_equal_copies():
 def test_kernel_timing_stride_samples_every_nth_launch():
     """kernel_timing_stride n: with kernel timing on, every n-th launch of a kind carries the event pair (bench.py times the
     a-trous launches with stride 6: the sample walks through the five step sizes)."""
-    from tests.helpers import GpuHybrid
+    from vulkanhybridrenderer_amd import camera
     W, H = 128, 72
     sc = scenes.tiny_scene()
     pfds = camera.dolly_frames(sc, W, H, 6)
