@@ -56,3 +56,8 @@ n4, m4, d4, al4 = osc.gbuffer(pfd, TW, TH, with_albedo=True)
 comp = ob.composition(pfd, (0, 0, 0), al4, n4, m4, d4, sa, refl)
 np.savez_compressed(os.path.join(HERE, "composition_tiny.npz"), albedo=al4, composition=comp)
 print("golden fixtures written")
+# row f4, screen-space alternatives: ssao.comp / ssao_blur.comp / ssr.comp of the same tiny frame (its G-buffer incl. albedo)
+raw = ob.ssao(pfd, n4, d4)
+np.savez_compressed(os.path.join(HERE, "screen_space_tiny.npz"), ssao_raw=raw, ssao=ob.ssao_blur(pfd, raw),
+                    ssr=ob.ssr(pfd, al4, n4, m4, d4))
+print("screen-space fixture written")

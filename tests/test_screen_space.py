@@ -97,6 +97,23 @@ def test_oracle_matches_the_numpy_restatement(oracle):
     assert (refl[~(refl[..., 3] == 1.0)] == 0.0).all()       # ssr.comp:62-66: misses keep the cleared texel
 
 
+def _golden():
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    t, c, s = (np.load(os.path.join(g, f)) for f in ("trace_tiny.npz", "composition_tiny.npz", "screen_space_tiny.npz"))
+    pfd = np.frombuffer(t["pfd"].tobytes(), abi.per_frame_dtype)[0]
+    return pfd, (t["normals"], t["motion"], t["depth"], c["albedo"]), s
+
+
+def test_golden_fixture(oracle):
+    """tests/golden/screen_space_tiny.npz (make_golden.py) keeps the restatement from drifting."""
+    pfd, (n, m, d, al), s = _golden()
+    raw = oracle.ssao(pfd, n, d)
+    assert np.array_equal(raw, s["ssao_raw"]) and np.array_equal(oracle.ssao_blur(pfd, raw), s["ssao"])
+    assert np.array_equal(oracle.ssr(pfd, al, n, m, d), s["ssr"])
+    assert 0.05 < (f16(s["ssr"])[..., 3] == 1.0).mean() < 0.95 and 0.2 < f16(s["ssao"])[..., 0].mean() < 1.0
+
+
 def test_oracle_rows_are_independent(oracle):
     scene = _small_scene()
     W, H = 64, 40
@@ -215,6 +232,20 @@ def test_gpu_kernels_match_the_oracle(oracle, scene_name, W, H):
             assert diff.max() <= 1 and (diff == 0).mean() > 0.99
         refl = f16(g.ctx.download(lib.SSR))
         assert 0.05 < (refl[..., 3] == 1.0).mean() < 0.95 and f16(g.ctx.download(lib.SSAO))[..., 0].mean() > 0.3
+    finally:
+        g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_golden_fixture():
+    """The committed fixture through the C ABI (no oracle at run time): every texel of the three images."""
+    pfd, gbuf, s = _golden()
+    H, W = gbuf[2].shape
+    g = ScreenSpacePath(scenes.tiny_scene(), W, H, composition=False)
+    try:
+        g.frame(pfd, gbuf)
+        for name, key in ((lib.SSAO_RAW, "ssao_raw"), (lib.SSAO, "ssao"), (lib.SSR, "ssr")):
+            assert np.array_equal(g.ctx.download(name), s[key]), name
     finally:
         g.close()
 
