@@ -34,12 +34,40 @@ def yaw_pitch_roll(yaw, pitch, roll):
     return ry @ rx @ rz
 
 
+def light_projview(direction):
+    """scene_loader.cpp:85-94: glm::ortho(-8, 8, -8, 8, 12, 0.1) * glm::lookAt(-direction * 12, origin, +y) under the
+    reference's GLM_FORCE_DEPTH_ZERO_TO_ONE (pch.h:37), right-handed: the shadow map's reverse-Z orthographic frustum
+    (depth 1 at 0.1 m from the light's eye point, 0 at 12 m).  Only the rasterised shadow map and composition.frag's PCF
+    read it -- the ray-traced path never does -- but the scene host fills it like the reference."""
+    d = np.asarray(direction, dtype=np.float64)
+    d = d / np.linalg.norm(d)
+    left, right, bottom, top, z_near, z_far = -8.0, 8.0, -8.0, 8.0, 12.0, 0.1
+    ortho = np.eye(4)
+    ortho[0, 0] = 2.0 / (right - left)
+    ortho[1, 1] = 2.0 / (top - bottom)
+    ortho[2, 2] = -1.0 / (z_far - z_near)
+    ortho[0, 3] = -(right + left) / (right - left)
+    ortho[1, 3] = -(top + bottom) / (top - bottom)
+    ortho[2, 3] = -z_near / (z_far - z_near)
+    eye = -d * 12.0
+    f = -eye / np.linalg.norm(eye)                       # normalize(center - eye), center = origin
+    s_ = np.cross(f, [0.0, 1.0, 0.0])
+    s_ = s_ / np.linalg.norm(s_)                         # a light straight down the y axis is degenerate here as in glm::lookAt
+    u = np.cross(s_, f)
+    view = np.eye(4)
+    view[0, :3], view[1, :3], view[2, :3] = s_, u, -f
+    view[0, 3], view[1, 3], view[2, 3] = -np.dot(s_, eye), -np.dot(u, eye), np.dot(f, eye)
+    return ortho @ view
+
+
 def directional_light(direction, color=(1.0, 1.0, 1.0), intensity=30.0):
-    """scene_loader.cpp:73-99: direction vec4(w=0), colour vec4(w=1), intensity vec4(30)."""
+    """scene_loader.cpp:73-99: projview (light_projview), direction vec4(w=0), colour vec4(w=1), intensity vec4(30)."""
     d = np.asarray(direction, dtype=np.float64)
     d = d / np.linalg.norm(d)
     light = np.zeros((), abi.directional_light_dtype)
-    light["projview"] = abi.mat_to_glm(np.eye(4))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pv = light_projview(d)
+    light["projview"] = abi.mat_to_glm(pv if np.isfinite(pv).all() else np.eye(4))
     light["direction"] = [d[0], d[1], d[2], 0.0]
     light["color"] = [color[0], color[1], color[2], 1.0]
     light["intensity"] = [intensity] * 4
