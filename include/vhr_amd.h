@@ -248,8 +248,14 @@ int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *nor
 int vhr_standin_gbuffer_with_albedo(vhr_context *ctx, uint32_t resource_idx, const char *albedo_image, const char *normals_image,
                                     const char *motion_image, const char *depth_image);
 
+/* Stand-in for the rasterised "Shadow Map Pass" (hybrid_render_path.cpp:58-99, depth_prepass.vert:16-19; BASELINE configs[0]'s
+ * shadow map): fills the named square D32_SFLOAT transient image ("Shadow Map", 4096 x 4096) with the depth of the closest hit of
+ * the orthographic ray through every texel centre of PerFrameData.directional_light.projview's frustum (reverse Z: 1 on the near
+ * plane, clear value 0 where nothing is hit).  A ray caster on the path's own BVH, not a rasteriser. */
+int vhr_standin_shadow_map(vhr_context *ctx, uint32_t resource_idx, const char *shadow_map_image);
+
 /* Next row: stand-in for the untouched composition stage -- composition.vert:5-8 +
- * composition.frag:60-161: shadows ray traced (0) or off (2) -- the rasterised shadow map with PCF (1) stays outside --,
+ * composition.frag:60-161: shadows ray traced (0), from the shadow map with the shader's 16-tap PCF (1, :81-107) or off (2);
  * ambient occlusion and reflections ray traced (0), screen space (1: ssao.comp + ssao_blur.comp / ssr.comp, row f4) or
  * off (2).  Reads the named transient images, writes swapchain-format texels (B8G8R8A8_SRGB, bytes
  * b g r a, presentation orientation: row 0 = top) into a storage image of 4-byte texels. */
@@ -260,6 +266,7 @@ typedef struct vhr_composition_desc {
     const char *reflections_image;    /* "Raytraced Reflections" (mode 0) / "Screen Space Reflections" (mode 1); may be NULL for mode 2 */
     int32_t output_storage_image;
     const char *ssao_image;           /* "Screen Space Ambient Occlusion" for ambient_occlusion_mode 1, else may be NULL */
+    const char *shadow_map_image;     /* "Shadow Map" (square D32_SFLOAT) for shadow_mode 1, else may be NULL */
 } vhr_composition_desc;
 int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_composition_desc *desc);
 

@@ -68,7 +68,8 @@ def lib():
                                         C.POINTER(u32), C.POINTER(u32)]
         L.orc_gbuffer.argtypes = [vp, vp, u32, u32, vp, vp, vp]
         L.orc_gbuffer_albedo.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
-        L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+        L.orc_composition.argtypes = [vp, u32, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, u32, vp]
+        L.orc_shadow_map.argtypes = [vp, vp, u32, u32, u32, vp, i32]
         L.orc_raygen.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, i32]
         L.orc_raytraced.argtypes = [vp, vp, u32, u32, u32, u32, i32, vp, vp, i32]
         L.orc_raytraced_composition.argtypes = [u32, u32, vp, vp]
@@ -163,6 +164,14 @@ class Scene:
                                       C.byref(v), C.byref(pr), C.byref(tr))
         return (np.float32(t.value), np.float32(u.value), np.float32(v.value), pr.value, tr.value) if hit else None
 
+    def shadow_map(self, pfd, size=4096, rows=None, use_bvh=True):
+        """Stand-in for the rasterised Shadow Map Pass (decision xiv): (size, size) float32."""
+        out = np.zeros((size, size), np.float32)
+        pfd = _c(pfd)
+        r0, r1 = (0, size) if rows is None else rows
+        lib().orc_shadow_map(self.handle, _p(pfd), size, r0, r1, _p(out), int(use_bvh))
+        return out
+
     def gbuffer(self, pfd, W, H, with_albedo=False):
         normals = np.zeros((H, W, 4), np.uint16)
         motion = np.zeros((H, W, 4), np.uint16)
@@ -195,7 +204,7 @@ def raytraced_composition(raytraced_bgra8):
     return out
 
 
-def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections, ssao=None):
+def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflections, ssao=None, shadow_map=None):
     """composition.frag with (shadow_mode, ao_mode, reflection_mode); returns B8G8R8A8_SRGB texels (H, W, 4)."""
     H, W = depth.shape
     out = np.zeros((H, W, 4), np.uint8)
@@ -204,7 +213,8 @@ def composition(pfd, modes, albedo, normals, motion, depth, shadow_ao, reflectio
     depth, shadow_ao = _c(depth, np.float32), _c(shadow_ao, np.uint16)
     reflections = _c(reflections, np.uint16) if reflections is not None else np.zeros((H, W, 4), np.uint16)
     lib().orc_composition(_p(pfd), W, H, modes[0], modes[1], modes[2], _p(albedo), _p(normals), _p(motion), _p(depth), _p(shadow_ao),
-                          shadow_ao.shape[-1], _p(reflections), _p(_c(ssao, np.uint16)) if ssao is not None else None, _p(out))
+                          shadow_ao.shape[-1], _p(reflections), _p(_c(ssao, np.uint16)) if ssao is not None else None,
+                          _p(_c(shadow_map, np.float32)) if shadow_map is not None else None, 0 if shadow_map is None else shadow_map.shape[0], _p(out))
     return out
 
 

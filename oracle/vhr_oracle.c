@@ -1057,9 +1057,40 @@ static inline uint8_t srgb8(float c) {          /* B8G8R8A8_SRGB store: NaN -> 0
     return (uint8_t)(e * 255.0 + 0.5);
 }
 
+/* the default sampler (decision x), defined with the screen-space shaders below */
+typedef v4 (*orc_texel_fn)(const void *img, uint32_t W, int x, int y);
+static v4 texel_d32f(const void *img, uint32_t W, int x, int y);
+static v4 sample_linear_repeat(orc_texel_fn fetch, const void *img, uint32_t W, uint32_t H, float u, float v);
+
+/* Stand-in for the "Shadow Map Pass" (hybrid_render_path.cpp:58-99, depth_prepass.vert:16-19): the reference rasterises the scene
+ * with directional_light.projview into a 4096 x 4096 D32 image, cleared to 0, depth test GREATER_OR_EQUAL (reverse Z: 1 on the near
+ * plane).  Decision (xiv): texel (i, j) holds the depth of the closest hit of the orthographic ray through its centre -- from
+ * the near plane (NDC z = 1) to the far plane (z = 0), depth = 1 - t with t the ray parameter in (0, 1) -- or the clear value. */
+void orc_shadow_map(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t size, uint32_t row_begin, uint32_t row_end, float *shadow_map,
+                    int use_bvh) {
+    float inv[16];
+    orc_mat4_inverse(pfd->directional_light.projview, inv);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t jj = (int64_t)row_begin; jj < (int64_t)row_end; ++jj) {
+        int j = (int)jj;
+        for (int i = 0; i < (int)size; ++i) {
+            float nx = (((float)i + 0.5f) / (float)size) * 2.0f - 1.0f, ny = (((float)j + 0.5f) / (float)size) * 2.0f - 1.0f;
+            v4 a = mat4_mul_v4(inv, (v4){ nx, ny, 1.0f, 1.0f }), b = mat4_mul_v4(inv, (v4){ nx, ny, 0.0f, 1.0f });
+            v3 o = V3(a.x / a.w, a.y / a.w, a.z / a.w), f = V3(b.x / b.w, b.y / b.w, b.z / b.w);
+            orc_hit h = trace(s, o, v3sub(f, o), 0.0f, 1.0f, 0, use_bvh);
+            shadow_map[(size_t)j * size + i] = h.hit ? 1.0f - h.t : 0.0f;
+        }
+    }
+}
+
 void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
                      const uint8_t *albedo_img, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
-                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, const uint16_t *ssao, uint8_t *out) {
+                     const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections, const uint16_t *ssao,
+                     const float *shadow_map, uint32_t shadow_map_size, uint8_t *out) {
+    /* composition.frag:82 `SHADOW_BIAS_MATRIX * pfd.directional_light.projview * vec4(P, 1)`: the matrix product first */
+    static const float bias[16] = { 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f };   /* common.glsl:6-11 */
+    float bias_projview[16];
+    orc_mat4_mul(bias, pfd->directional_light.projview, bias_projview);
 #pragma omp parallel for schedule(static)
     for (int64_t jj = 0; jj < (int64_t)H; ++jj) {
         int j = (int)jj;
@@ -1083,6 +1114,18 @@ void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int 
             v3 L = v3neg(V3(pfd->directional_light.direction[0], pfd->directional_light.direction[1], pfd->directional_light.direction[2]));
             v3 Hh = normalize3(v3add(L, Vv));
             float shadow = shadow_mode == 0 ? rs : 1.0f;                                       /* :77-80 */
+            if (shadow_mode == 1) {                                                            /* :81-107: 16-tap PCF on the shadow map */
+                v4 pl = mat4_mul_v4(bias_projview, (v4){ P.x, P.y, P.z, 1.0f });
+                float sx = pl.x / pl.w, sy = pl.y / pl.w, sz = pl.z / pl.w;
+                const float scale = 1.0f / 4096.0f;
+                float lit = 0.0f;
+                for (int i = 0; i < 16; ++i) {
+                    float ox = ((float)(i >> 2) - 1.5f) * scale, oy = ((float)(i & 3) - 1.5f) * scale;    /* offsets[i], :88-93 */
+                    float ds = sample_linear_repeat(texel_d32f, shadow_map, shadow_map_size, shadow_map_size, sx + ox, sy + oy).x;
+                    lit += (sz < ds - 1e-4f) ? 0.0f : 1.0f;
+                }
+                shadow = lit / 16.0f;
+            }
             float ao = ao_mode == 0 ? ra : 1.0f;                                               /* :114-121 */
             if (ao_mode == 1) ao = load_rgba16f(ssao, W, x, gy).x;                             /* :117-119: texture() at a texel centre */
             float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f);                                   /* :123-125 */
@@ -1124,7 +1167,6 @@ void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int 
  * ---------------------------------------------------------------------------------------- */
 static inline int wrap_repeat(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 
-typedef v4 (*orc_texel_fn)(const void *img, uint32_t W, int x, int y);
 static v4 texel_rgba16f(const void *img, uint32_t W, int x, int y) { return load_rgba16f((const uint16_t *)img, W, x, y); }
 static v4 texel_d32f(const void *img, uint32_t W, int x, int y) {
     v4 r = { ((const float *)img)[(size_t)y * W + x], 0.0f, 0.0f, 1.0f };

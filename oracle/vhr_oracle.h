@@ -102,13 +102,19 @@ void orc_gbuffer_albedo(const orc_scene *s, const orc_per_frame_data *pfd, uint3
                         uint16_t *normals_ids, uint16_t *motion_mr, float *depth, uint8_t *albedo_bgra8);
 
 /* ---- next row f3: composition.vert:5-8 + composition.frag:60-161 ----
- * modes: 0 ray traced, 1 screen space (ambient occlusion and reflections only; the shadow map is not restated), 2 off.  shadow_ao: RGBA16F (denoised) if
+ * modes: 0 ray traced, 1 the raster-side alternative (shadow map with the 16-tap PCF of :81-107 / SSAO / SSR), 2 off.  shadow_ao: RGBA16F (denoised) if
  * shadow_ao_channels == 4 else RG16F.  Output: B8G8R8A8_SRGB swapchain texels (bytes b, g, r, a), row 0 = top of the
  * presented image = G-buffer row H-1 (the composition viewport is flipped, pipeline.cpp:175-178). */
 void orc_composition(const orc_per_frame_data *pfd, uint32_t W, uint32_t H, int shadow_mode, int ao_mode, int reflection_mode,
                      const uint8_t *albedo_bgra8, const uint16_t *normals_ids, const uint16_t *motion_mr, const float *depth,
                      const uint16_t *shadow_ao, int shadow_ao_channels, const uint16_t *reflections /* mode 0: ray traced, 1: SSR */,
-                     const uint16_t *ssao /* "Screen Space Ambient Occlusion" for ao_mode 1, else may be NULL */, uint8_t *out_bgra8_srgb);
+                     const uint16_t *ssao /* "Screen Space Ambient Occlusion" for ao_mode 1, else may be NULL */,
+                     const float *shadow_map /* D32F, shadow_map_size^2, for shadow_mode 1, else may be NULL */, uint32_t shadow_map_size,
+                     uint8_t *out_bgra8_srgb);
+/* Stand-in for the rasterised "Shadow Map Pass" (hybrid_render_path.cpp:58-99): decision (xiv), orthographic closest-hit rays
+ * through the texel centres of directional_light.projview's frustum, depth = 1 - t (reverse Z), clear value 0. */
+void orc_shadow_map(const orc_scene *s, const orc_per_frame_data *pfd, uint32_t size, uint32_t row_begin, uint32_t row_end,
+                    float *shadow_map, int use_bvh);
 
 /* ---- K1 + K2: raygen.rgen:14-66, miss.rmiss, reflection_miss.rmiss, reflection_hit.rchit ---- */
 /* vis_mask (optional, may be NULL): per pixel bit0 = shadow ray missed (lit), bit(1+i) = AO ray i missed,

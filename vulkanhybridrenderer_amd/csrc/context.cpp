@@ -536,12 +536,23 @@ int vhr_standin_composition(vhr_context *ctx, uint32_t resource_idx, const vhr_c
     Image *al = find(d->albedo_image), *no = find(d->normals_image), *mo = find(d->motion_image), *de = find(d->depth_image), *sa = find(d->shadow_ao_image);
     Image *re = d->reflections_image ? find(d->reflections_image) : nullptr;
     Image *ss = d->ssao_image ? find(d->ssao_image) : nullptr;
-    if (!al || !no || !mo || !de || !sa || (d->reflections_image && !re) || (d->ssao_image && !ss)) return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: unknown transient image");
+    Image *sm = d->shadow_map_image ? find(d->shadow_map_image) : nullptr;
+    if (!al || !no || !mo || !de || !sa || (d->reflections_image && !re) || (d->ssao_image && !ss) || (d->shadow_map_image && !sm))
+        return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: unknown transient image");
     if ((d->reflection_mode == 0 || d->reflection_mode == 1) && !re) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: reflection_mode 0 / 1 needs a reflections image");
     if (d->output_storage_image < 0 || uint32_t(d->output_storage_image) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[d->output_storage_image].used)
         return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: output storage image is not allocated");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_composition(ctx, ctx->per_frame[resource_idx], *d, *al, *no, *mo, *de, *sa, re, ss, ctx->storage_images[d->output_storage_image]);
+    return launch_composition(ctx, ctx->per_frame[resource_idx], *d, *al, *no, *mo, *de, *sa, re, ss, sm, ctx->storage_images[d->output_storage_image]);
+}
+
+int vhr_standin_shadow_map(vhr_context *ctx, uint32_t resource_idx, const char *shadow_map_image) {
+    if (!ctx || !shadow_map_image || resource_idx >= 3) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_shadow_map: bad argument") : VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    auto it = ctx->images.find(shadow_map_image);
+    if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, "standin_shadow_map: unknown transient image");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_standin_shadow_map(ctx, ctx->per_frame[resource_idx], it->second);
 }
 
 int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_output_image, int32_t output_storage_image) {

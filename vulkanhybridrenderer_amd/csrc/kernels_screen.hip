@@ -19,37 +19,6 @@ namespace vhr {
 constexpr int kScreenBlockX = 64;   // one wave per row segment: 512-byte coalesced RGBA16F rows
 constexpr int kScreenBlockY = 4;
 
-// REPEAT addressing.  Nearly every coordinate is on screen: the integer modulo (~20 instructions for a run-time divisor, two per
-// sample) sits behind a test that whole waves usually skip.
-__device__ __forceinline__ int wrap_repeat(int i, int n) {
-    if (__builtin_expect(uint32_t(i) < uint32_t(n), 1)) return i;
-    const int m = i % n;
-    return m < 0 ? m + n : m;
-}
-
-struct Taps { int x0, x1, y0, y1; float ax, ay, bx, by; };
-// oracle decision (x): u * W - 0.5, floor, wrapped texels, fp32 weights
-__device__ __forceinline__ Taps bilinear_taps(uint32_t W, uint32_t H, float u, float v) {
-    const float fx = u * float(W) - 0.5f, fy = v * float(H) - 0.5f;
-    const float x0f = floorf(fx), y0f = floorf(fy);
-    Taps t;
-    t.ax = fx - x0f; t.ay = fy - y0f;
-    t.bx = 1.0f - t.ax; t.by = 1.0f - t.ay;
-    t.x0 = wrap_repeat(int(x0f), int(W));          // v_cvt_i32_f32: saturates, NaN -> 0 (decision xiii)
-    t.y0 = wrap_repeat(int(y0f), int(H));
-    t.x1 = t.x0 + 1 == int(W) ? 0 : t.x0 + 1;
-    t.y1 = t.y0 + 1 == int(H) ? 0 : t.y0 + 1;
-    return t;
-}
-__device__ __forceinline__ float blend(const Taps &t, float t00, float t10, float t01, float t11) {
-    return (t00 * t.bx + t10 * t.ax) * t.by + (t01 * t.bx + t11 * t.ax) * t.ay;
-}
-__device__ __forceinline__ float sample_depth(const float *img, uint32_t W, uint32_t H, float u, float v) {
-    const Taps t = bilinear_taps(W, H, u, v);
-    const float *r0 = img + size_t(t.y0) * W, *r1 = img + size_t(t.y1) * W;
-    const float t00 = r0[t.x0], t10 = r0[t.x1], t01 = r1[t.x0], t11 = r1[t.x1];
-    return blend(t, t00, t10, t01, t11);
-}
 __device__ __forceinline__ f4 unpack_half4(uint2 raw) {
     const float2 lo = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
     const float2 hi = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));

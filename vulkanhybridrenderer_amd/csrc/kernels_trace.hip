@@ -1668,7 +1668,77 @@ int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Imag
 }
 
 // ---------------------------------------------------------------------------------------------
-// next row f3: stand-in for the composition stage (composition.vert:5-8, composition.frag:60-161), ray-traced modes
+// Stand-in for the rasterised "Shadow Map Pass" (hybrid_render_path.cpp:58-99, depth_prepass.vert:16-19; BASELINE configs[0]):
+// the closest hit of the orthographic ray through every texel centre of directional_light.projview's frustum, from the near
+// plane (NDC z = 1, reverse Z) to the far plane; depth = 1 - t, misses keep the clear value 0 (oracle decision xiv).
+// ---------------------------------------------------------------------------------------------
+struct ShadowMapArgs {
+    DeviceScene scene;
+    float inv_projview[16];
+    float *out;
+    uint32_t size, row_begin, row_end;
+};
+
+__global__ __launch_bounds__(kTraceBlock) void shadow_map_kernel(const ShadowMapArgs a) {
+    __shared__ int s_stack[kTraceStack * kTraceBlock];
+    int *stack = s_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, a.row_begin);
+    if (x >= a.size || y >= a.row_end) return;
+    const float nx = ((float(x) + 0.5f) / float(a.size)) * 2.0f - 1.0f, ny = ((float(y) + 0.5f) / float(a.size)) * 2.0f - 1.0f;
+    const f4 pa = mat4_mul(a.inv_projview, f4{ nx, ny, 1.0f, 1.0f }), pb = mat4_mul(a.inv_projview, f4{ nx, ny, 0.0f, 1.0f });
+    const f3 o = f3{ pa.x / pa.w, pa.y / pa.w, pa.z / pa.w }, f = f3{ pb.x / pb.w, pb.y / pb.w, pb.z / pb.w };
+    Hit h;
+    uint32_t overflow = 0;
+    float depth = 0.0f;
+    if (a.scene.node_count != 0 && traverse<false>(a.scene, o, f - o, 0.0f, 1.0f, stack, h, overflow)) depth = 1.0f - h.t;
+    a.out[size_t(y) * a.size + x] = depth;
+}
+
+// general 4x4 inverse by cofactors in double, rounded once (the light's projview has no inverse in PerFrameData)
+static bool host_mat4_inverse(const float *m, float *out) {
+    double a[16], inv[16];
+    for (int i = 0; i < 16; ++i) a[i] = double(m[i]);
+    inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+    if (det == 0.0) return false;
+    for (int i = 0; i < 16; ++i) out[i] = float(inv[i] / det);
+    return true;
+}
+
+int launch_standin_shadow_map(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &shadow_map) {
+    if (shadow_map.format != VHR_FORMAT_D32_SFLOAT || shadow_map.width != shadow_map.height)
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_shadow_map: a square D32_SFLOAT image is expected (4096 x 4096, hybrid_render_path.cpp:62)");
+    ShadowMapArgs a;
+    a.scene = ctx->device_scene();
+    if (!host_mat4_inverse(pfd.directional_light.projview, a.inv_projview))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "standin_shadow_map: directional_light.projview is singular");
+    a.out = static_cast<float *>(shadow_map.ptr);
+    a.size = shadow_map.width;
+    a.row_begin = 0;
+    a.row_end = shadow_map.height;
+    launch(ctx, shadow_map_kernel, dim3((a.size + 15) / 16, (a.row_end - a.row_begin + 15) / 16), dim3(kTraceBlock), 0, a);
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "shadow map kernel launch failed");
+    return VHR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// next row f3: stand-in for the composition stage (composition.vert:5-8, composition.frag:60-161)
 // ---------------------------------------------------------------------------------------------
 struct CompositionArgs {
     vhr_per_frame_data pfd;
@@ -1678,6 +1748,9 @@ struct CompositionArgs {
     const void *shadow_ao;       // RGBA16F (denoised) or RG16F (raw)
     const void *reflections;     // RGBA16F or nullptr: "Raytraced Reflections" (mode 0) / "Screen Space Reflections" (mode 1)
     const void *ssao;            // RGBA16F or nullptr: "Screen Space Ambient Occlusion" (ambient occlusion mode 1)
+    const float *shadow_map;     // D32F, shadow_size^2, or nullptr: "Shadow Map" (shadow mode 1)
+    float bias_projview[16];     // SHADOW_BIAS_MATRIX * directional_light.projview (composition.frag:82, the matrix product first)
+    uint32_t shadow_size;
     uchar4 *out;                 // B8G8R8A8_SRGB
     uint32_t width, height;
     int shadow_mode, ao_mode, reflection_mode, shadow_ao_is_rgba;
@@ -1714,7 +1787,19 @@ __global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs 
     const f3 V = normalize3(cam - P);                                                                              // :72-75
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     const f3 Hh = normalize3(L + V);
-    const float shadow = a.shadow_mode == 0 ? rs : 1.0f;                                                           // :77-80
+    float shadow = a.shadow_mode == 0 ? rs : 1.0f;                                                                 // :77-80
+    if (a.shadow_mode == 1) {                                                                                      // :81-107: 16-tap PCF
+        const f4 pl = mat4_mul(a.bias_projview, f4{ P.x, P.y, P.z, 1.0f });
+        const float sx = pl.x / pl.w, sy = pl.y / pl.w, sz = pl.z / pl.w;
+        const float scale = 1.0f / 4096.0f;
+        float lit = 0.0f;
+        for (int i = 0; i < 16; ++i) {
+            const float ox = (float(i >> 2) - 1.5f) * scale, oy = (float(i & 3) - 1.5f) * scale;                  // offsets[i], :88-93
+            const float ds = sample_depth(a.shadow_map, a.shadow_size, a.shadow_size, sx + ox, sy + oy);
+            lit += (sz < ds - 1e-4f) ? 0.0f : 1.0f;
+        }
+        shadow = lit / 16.0f;
+    }
     float ao = a.ao_mode == 0 ? ra : 1.0f;                                                                         // :114-121
     if (a.ao_mode == 1) ao = load_rgba16f(a.ssao, W, x, gy).x;                                                     // :117-119 (in_uv is the texel centre)
     const float metallic = fminf(fmaxf(mm.z, 0.0f), 1.0f), roughness = fminf(fmaxf(mm.w, 0.04f), 1.0f);            // :123-125
@@ -1742,7 +1827,8 @@ __global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs 
 }
 
 int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
-                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao, Image &out) {
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao,
+                       const Image *shadow_map, Image &out) {
     const uint32_t W = depth.width, H = depth.height;
     const Image *all[] = { &albedo, &normals, &motion, &shadow_ao, &out };
     for (const Image *im : all)
@@ -1751,14 +1837,18 @@ int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vh
     if (albedo.bpp != 4 || out.bpp != 4 || normals.format != VHR_FORMAT_R16G16B16A16_SFLOAT || motion.format != VHR_FORMAT_R16G16B16A16_SFLOAT ||
         depth.format != VHR_FORMAT_D32_SFLOAT || (shadow_ao.format != VHR_FORMAT_R16G16B16A16_SFLOAT && shadow_ao.format != VHR_FORMAT_R16G16_SFLOAT))
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: unexpected image format");
-    if (d.shadow_mode != 0 && d.shadow_mode != 2)
-        return ctx->fail(VHR_ERROR_NOT_FOUND, "composition: shadow_mode 1 (the rasterised shadow map with PCF) stays with the raster side");
-    for (int m : { d.ambient_occlusion_mode, d.reflection_mode })
+    if (d.shadow_mode == 1 && (!shadow_map || shadow_map->format != VHR_FORMAT_D32_SFLOAT || shadow_map->width != shadow_map->height))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: shadow_mode 1 needs the square D32 \"Shadow Map\" image");
+    for (int m : { d.shadow_mode, d.ambient_occlusion_mode, d.reflection_mode })
         if (m < 0 || m > 2) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: modes are 0 (ray traced), 1 (screen space) or 2 (off)");
     if (d.ambient_occlusion_mode == 1 && (!ssao || ssao->width != W || ssao->height != H || ssao->format != VHR_FORMAT_R16G16B16A16_SFLOAT))
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "composition: ambient_occlusion_mode 1 needs the R16G16B16A16 \"Screen Space Ambient Occlusion\" image");
     CompositionArgs a;
     a.ssao = ssao ? ssao->ptr : nullptr;
+    a.shadow_map = shadow_map ? static_cast<const float *>(shadow_map->ptr) : nullptr;
+    a.shadow_size = shadow_map ? shadow_map->width : 0;
+    static const float kShadowBias[16] = { 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f };   // common.glsl:6-11
+    host_mat4_mul(kShadowBias, pfd.directional_light.projview, a.bias_projview);
     a.pfd = pfd;
     a.albedo = static_cast<const uchar4 *>(albedo.ptr);
     a.normals = normals.ptr; a.motion = motion.ptr;

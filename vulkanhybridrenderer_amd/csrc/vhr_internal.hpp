@@ -285,7 +285,8 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
 int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out);
 int launch_standin_gbuffer(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &normals, Image &motion, Image &depth, Image *albedo);
 int launch_composition(vhr_context *ctx, const vhr_per_frame_data &pfd, const vhr_composition_desc &d, const Image &albedo, const Image &normals,
-                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao, Image &out);
+                       const Image &motion, const Image &depth, const Image &shadow_ao, const Image *reflections, const Image *ssao, const Image *shadow_map, Image &out);
+int launch_standin_shadow_map(vhr_context *ctx, const vhr_per_frame_data &pfd, Image &shadow_map);
 int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
                          const Image &raytraced, const Image &prev_normals, const Image &history,
                          Image &moments, Image &integrated_out, uint32_t x_groups, uint32_t y_groups);

@@ -29,7 +29,7 @@ EXPORTS = [
     "vhr_compute_blit_image_storage_to_storage", "vhr_hybrid_create", "vhr_hybrid_destroy", "vhr_hybrid_build",
     "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
-    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_set_strip",
+    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
@@ -78,7 +78,7 @@ class CompositionDesc(C.Structure):
     _fields_ = [("shadow_mode", C.c_int32), ("ambient_occlusion_mode", C.c_int32), ("reflection_mode", C.c_int32),
                 ("albedo_image", C.c_char_p), ("normals_image", C.c_char_p), ("motion_image", C.c_char_p), ("depth_image", C.c_char_p),
                 ("shadow_ao_image", C.c_char_p), ("reflections_image", C.c_char_p), ("output_storage_image", C.c_int32),
-                ("ssao_image", C.c_char_p)]
+                ("ssao_image", C.c_char_p), ("shadow_map_image", C.c_char_p)]
 
 
 class HybridSettings(C.Structure):
@@ -162,6 +162,7 @@ def load():
     L.vhr_standin_gbuffer_with_albedo.argtypes = [vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
     L.vhr_standin_composition.argtypes = [vp, u32, C.POINTER(CompositionDesc)]
     L.vhr_standin_raytraced_composition.argtypes = [vp, C.c_char_p, i32]
+    L.vhr_standin_shadow_map.argtypes = [vp, u32, C.c_char_p]
     L.vhr_raytraced_create.argtypes = [vp, i32, EXTERNAL_CB, vp, C.POINTER(vp)]
     L.vhr_raytraced_destroy.argtypes = [vp]
     L.vhr_raytraced_destroy.restype = None
@@ -194,6 +195,7 @@ ALBEDO = "Albedo"
 SVGF_SHADER = "hybrid_render_path/svgf.comp"
 ATROUS_SHADER = "hybrid_render_path/svgf_atrous_filter.comp"
 RAYTRACED_OUTPUT = "RaytracedOutput"        # raytraced_render_path.cpp:15
+SHADOW_MAP = "Shadow Map"                           # hybrid_render_path.cpp:62
 SSAO_RAW = "Screen Space Ambient Occlusion Raw"     # hybrid_render_path.cpp:149
 SSAO = "Screen Space Ambient Occlusion"             # :176
 SSR = "Screen Space Reflections"                    # :219
@@ -430,14 +432,19 @@ class Context:
                                                           depth.encode()), "standin_gbuffer_with_albedo")
 
     def standin_composition(self, output_storage_image, shadow_mode=0, ao_mode=0, reflection_mode=0, shadow_ao=DENOISED,
-                            reflections=REFLECTIONS, resource_idx=0, ssao=None):
+                            reflections=REFLECTIONS, resource_idx=0, ssao=None, shadow_map=None):
         """composition.frag stand-in.  ao_mode 1 reads `ssao` (default SSAO), reflection_mode 1 expects `reflections` = SSR."""
         if ao_mode == 1 and ssao is None:
             ssao = SSAO
+        if shadow_mode == 1 and shadow_map is None:
+            shadow_map = SHADOW_MAP
         d = CompositionDesc(shadow_mode, ao_mode, reflection_mode, ALBEDO.encode(), NORMALS.encode(), MOTION.encode(), DEPTH.encode(),
                             shadow_ao.encode(), reflections.encode() if reflections else None, output_storage_image,
-                            ssao.encode() if ssao else None)
+                            ssao.encode() if ssao else None, shadow_map.encode() if shadow_map else None)
         self.check(self.L.vhr_standin_composition(self.handle, resource_idx, C.byref(d)), "standin_composition")
+
+    def standin_shadow_map(self, resource_idx=0, shadow_map=SHADOW_MAP):
+        self.check(self.L.vhr_standin_shadow_map(self.handle, resource_idx, shadow_map.encode()), "standin_shadow_map")
 
     def standin_raytraced_composition(self, output_storage_image, raytraced_output=RAYTRACED_OUTPUT):
         self.check(self.L.vhr_standin_raytraced_composition(self.handle, raytraced_output.encode(), output_storage_image),
