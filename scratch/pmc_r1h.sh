@@ -1,8 +1,8 @@
 #!/bin/bash
 # r1h PMC passes (each in its own run, --kernel-trace only): hardware lane utilisation of the traversal kernels and the
-# SVGF traffic (tools/profile_traffic.sh).  Usage on the GPU box: scratch/pmc_r1h.sh
+# SVGF traffic (tools/profile_traffic.sh).  Usage on the GPU box: scratch/pmc_${TAG:-r1j}.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc_r1h
+OUT=$R/gpurun_out/pmc_${TAG:-r1j}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3-avail list 2>/dev/null | grep -i -o "SQ_THREAD_CYCLES_VALU\|SQ_ACTIVE_INST_VALU\b" | sort | uniq -c > $OUT/avail.txt
