@@ -2,13 +2,17 @@
 texture list, camera and directional light that SceneLoader::ParseglTF / ParseNode hand to
 ResourceManager::UpdateGeometry and UploadTextureFromData (/root/reference/src/scene/scene_loader.cpp:40-332), so that
 a real Sponza / Bistro file drops into the hot path the moment the asset is supplied (none ships with the reference:
-.gitignore:3).  The reference parses with cgltf and decodes with stb_image; here: json + numpy, Pillow for images.
+.gitignore:3).  The reference parses with cgltf and decodes with stb_image; here: json + numpy; PNG through Pillow's inflate,
+JPEG through a restatement of stb_image's decoder (stb_jpeg.py).  Pinned against cgltf 1.9, glm 0.9.9.8 and stb_image 2.26
+themselves -- the reference's vendored copies, compiled in the build container -- by tests/test_reference_pins.py.
 
 Semantics kept from the reference (file:line = scene_loader.cpp):
   * nodes are visited in ARRAY order, each with its WORLD transform (cgltf_node_transform_world, :58,:75,:108);
   * a camera node sets the reverse-Z infinite projection from yfov / aspectRatio / znear and the transform
-    T * yawPitchRoll(extractEulerAngleYXZ(world)) (:43-71) -- scale and shear of the node are dropped this way;
-  * a KHR_lights_punctual directional light gives direction = normalize(rot * (0, 0, -1)), its colour, and the
+    T * yawPitchRoll(extractEulerAngleYXZ(world)) (:43-71) -- the angles are taken from the world matrix as it stands, so
+    a scaled or sheared camera node bends them exactly as in the reference (camera_from_world);
+  * a KHR_lights_punctual directional light gives direction = normalize(rot * (0, 0, -1)) with rot from glm::decompose
+    (Gram-Schmidt on the world matrix' axes, light_direction_from_world), its colour, and the
     hard-wired intensity 30 (2 for "Pica.glb") (:73-99); without one: direction (0, -1, 0.01), colour (1, 1, 1, 0),
     intensity 0 (:324-329);
   * every mesh primitive becomes one Primitive {world transform, material, vertex_offset, index_offset, index_count};
@@ -95,8 +99,9 @@ def _accessor(doc, buffers, index):
     arr = np.ndarray((count, ncomp), dt, buffer=data, offset=start, strides=(stride, dt.itemsize))
     if acc.get("normalized") and dt.kind in "iu":
         info = np.iinfo(dt)
-        f = arr.astype(np.float32) / np.float32(info.max)
-        return np.maximum(f, -1.0) if dt.kind == "i" else f
+        # cgltf 1.9's cgltf_component_read_float: value / max as it stands -- the most negative integer maps to just below
+        # -1 (-32768 / 32767), unlike the glTF specification's max(c / max, -1); pinned by tests/golden/ref_gltf/nested.gltf
+        return arr.astype(np.float32) / np.float32(info.max)
     return np.array(arr)
 
 
@@ -144,12 +149,28 @@ def extract_euler_yxz(m):
     return float(t1), float(t2), float(t3)
 
 
-def _decode_image(doc, buffers, base_dir, image_index):
+def decode_image_bytes(data):
+    """stbi_load_from_memory(..., STBI_rgb_alpha) (scene_loader.cpp:277-290): encoded PNG / JPEG bytes -> RGBA8 [h, w, 4].
+    PNG goes through Pillow's inflate + unfilter and stb_image's own colour-type expansion rules (16-bit samples keep their
+    high byte, grey replicates, missing alpha = 255); JPEG through the restatement of stb_image's decoder in stb_jpeg.py --
+    JPEG decoders differ in IDCT, chroma upsampling and colour conversion, and the reference's textures are what stb makes of
+    them.  tests/test_reference_pins.py compares both with stb_image 2.26 itself, texel for texel."""
+    if data[:2] == b"\xff\xd8":
+        from . import stb_jpeg
+        return stb_jpeg.decode_rgba(data)
     try:
         from PIL import Image
     except ImportError as e:                                   # no silent stand-in pixels
         raise GltfError("decoding glTF images needs Pillow (PIL)") from e
     import io
+    im = Image.open(io.BytesIO(data))
+    if im.mode in ("I;16", "I;16B", "I;16L", "I"):             # 16-bit grey: stbi__convert_16_to_8 keeps the high byte
+        g = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
+        return np.stack([g, g, g, np.full_like(g, 255)], -1)
+    return np.array(im.convert("RGBA"), np.uint8)
+
+
+def _decode_image(doc, buffers, base_dir, image_index):
     img = doc["images"][image_index]
     if "uri" in img:
         uri = img["uri"]
@@ -162,7 +183,35 @@ def _decode_image(doc, buffers, base_dir, image_index):
         view = doc["bufferViews"][img["bufferView"]]
         off = view.get("byteOffset", 0)
         data = buffers[view["buffer"]][off: off + view["byteLength"]]
-    return np.array(Image.open(io.BytesIO(data)).convert("RGBA"), np.uint8)          # stbi_load(..., STBI_rgb_alpha)
+    return decode_image_bytes(bytes(data))
+
+
+def camera_from_world(m):
+    """scene_loader.cpp:58-66 on the camera node's WORLD matrix m[row, col]: the Euler angles are extracted from the matrix
+    as it stands (scale and shear included -- glm::extractEulerAngleYXZ does not normalise), the camera transform is
+    T(translation) * yawPitchRoll(angles), the view its inverse.  -> (yaw, pitch, roll, transform, view)."""
+    from .camera import yaw_pitch_roll
+    yaw, pitch, roll = extract_euler_yxz(np.asarray(m, np.float64))
+    t = np.eye(4)
+    t[:3, 3] = np.asarray(m, np.float64)[:3, 3]
+    transform = t @ yaw_pitch_roll(yaw, pitch, roll)
+    return yaw, pitch, roll, transform, np.linalg.inv(transform)
+
+
+def light_direction_from_world(m):
+    """scene_loader.cpp:74-86: glm::decompose(world) -> rotation quaternion -> normalize(rot * (0, 0, -1)).  decompose
+    orthonormalises the three axes in order (x; y minus its x part; z minus its x and y parts: Gram-Schmidt, i.e. shear
+    is removed from the LATER axes) and flips all three if the basis is left-handed; the direction is minus the third."""
+    a = np.asarray(m, np.float64)[:3, :3] / np.asarray(m, np.float64)[3, 3]
+    x = a[:, 0] / np.linalg.norm(a[:, 0])
+    y = a[:, 1] - x * np.dot(x, a[:, 1])
+    y /= np.linalg.norm(y)
+    z = a[:, 2] - x * np.dot(x, a[:, 2])
+    z = z - y * np.dot(y, z)
+    z /= np.linalg.norm(z)
+    if np.dot(x, np.cross(y, z)) < 0:
+        z = -z
+    return -z
 
 
 def load(path, dolly_step=0.05):
@@ -219,9 +268,8 @@ def load(path, dolly_step=0.05):
             if cam.get("type") != "perspective":
                 raise GltfError("only perspective cameras are supported (scene_loader.cpp:44)")
             p = cam["perspective"]
-            rot = m[:3, :3] / np.maximum(np.linalg.norm(m[:3, :3], axis=0, keepdims=True), 1e-30)
-            yaw, pitch, roll = extract_euler_yxz(np.block([[rot, np.zeros((3, 1))], [np.zeros((1, 3)), np.ones((1, 1))]]))
-            forward = -(rot[:, 2])
+            yaw, pitch, roll, transform, _ = camera_from_world(m)
+            forward = -(transform[:3, 2])
             camera = dict(position=[float(v) for v in m[:3, 3]], yaw=yaw, pitch=pitch, roll=roll, yfov=float(p["yfov"]),
                           znear=float(p["znear"]), aspect=(float(p["aspectRatio"]) if "aspectRatio" in p else None),
                           dolly=[float(v) * dolly_step for v in forward])
@@ -229,8 +277,7 @@ def load(path, dolly_step=0.05):
         ext = node.get("extensions", {}).get("KHR_lights_punctual")
         if ext is not None and lights[ext["light"]].get("type") == "directional":               # :73-99
             lt = lights[ext["light"]]
-            rot = m[:3, :3] / np.maximum(np.linalg.norm(m[:3, :3], axis=0, keepdims=True), 1e-30)
-            d = rot @ np.array([0.0, 0.0, -1.0])
+            d = light_direction_from_world(m)
             from .camera import directional_light
             light = directional_light(d, tuple(lt.get("color", [1.0, 1.0, 1.0])), 2.0 if name == "Pica.glb" else 30.0)
             continue
