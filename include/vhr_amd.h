@@ -342,6 +342,25 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair
  *                      (default 1 = every launch).  A timed dispatch costs ~6 us that the next kernel waits for; bench.py samples
  *                      the a-trous launches with stride 6 (coprime with the 5 launches of a frame, so every step size is sampled).
+ *   "shadow_packet"    with "raygen_cut": 1 = the shadow rays of a tile (one per pixel, within 0.18 degrees of the light direction,
+ *                      raygen.rgen:32-35) are walked as ONE wave-uniform packet before the tile's queue starts -- the node arrives
+ *                      through scalar loads, every lane tests its own ray, the stack is wave-uniform -- and the queue carries the
+ *                      AO rays only; 0 = shadow rays share the per-ray queue.  Visibility bit-identical (any hit = OR over triangles).
+ *   "cut_reach"        with "raygen_cut", whenever the queue holds AO rays only (shadow rays off or walked as a packet): 1 = a
+ *                      subtree whose box lies farther from the bounds of the tile's ray origins than any of its AO rays can
+ *                      reach (ao_tmax * an upper bound of |d|: the G-buffer normal is not a unit vector) is left out of the
+ *                      tile's cut (default), 0 = all siblings kept.  Box tests only cull: bit-identical.
+ *   "raygen_tile_pixels" pixels per wave of the work-queue raygen kernel: 64 = one 8x8 tile (default), 128 / 256 = 16x8 / 16x16 pixels
+ *                      with ONE ray queue over all of them (raygen_wide_kernel: fewer lanes idle while a queue drains -- 45 / 50 %
+ *                      instead of 37 % active lanes -- but half / a quarter as many waves per launch; measured -2 % at 4K, +4 % at
+ *                      1080p).  Bit-identical.
+ *   "frames_in_flight" 1 (default), 2 or 3; read by vhr_graph_build.  n > 1: frame f uses resource index f mod n (as the
+ *                      reference's frame loop does, vulkan_common.h:9 / renderer.cpp:103-146); the passes up to and including the
+ *                      last ray-tracing pass are issued on a second stream beside the previous frame's remaining passes, every
+ *                      graph-owned transient image exists once per index, an external binding (vhr_graph_bind_external_image)
+ *                      belongs to the index being executed, and the two streams are ordered by events derived from the pass
+ *                      declarations.  External graphics passes before the ray-tracing pass must enqueue on the stream current
+ *                      during their callback.  Images bit-identical to n = 1.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
@@ -365,6 +384,13 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
  * over waves): out[0] = whole kernel, out[1] = per-tile pixel setup, out[2] = queue refills (ray generation),
  * out[3] = inner-node loop, out[4] = leaf (triangle) stage, out[5] = refills, out[6] = waves, out[7] = 0. */
 int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]);
+
+/* Shadow packets of the last work-queue raygen launch (option "shadow_packet", statistics enabled): out[0] = waves that walked
+ * one (tiles with covered pixels), out[1] = wave-level inner-node visits, out[2] = wave-level triangle tests, out[3] = still
+ * undecided lanes summed over those steps (active-lane utilisation of the packets = out[3] / (64 * (out[1] + out[2]))),
+ * out[4] = s_memtime ticks spent in the packets; out[5] = entries of the tiles' tree cuts ("raygen_cut"), summed over the
+ * waves of the launch (traversal cycles out[6]): what "cut_reach" prunes. */
+int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[6]);
 
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */

@@ -90,6 +90,13 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
     }
 }
 
+int vhr_context::sync_streams() {
+    if (host_only) return VHR_OK;
+    if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
+    if (hipStreamSynchronize(stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize failed");     // (a null handle is the default stream)
+    return VHR_OK;
+}
+
 extern "C" {
 
 int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask) {
@@ -100,7 +107,7 @@ int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask) {
 
 int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64_t *launches, int32_t reset) {
     if (!ctx || kind < 0 || kind >= kKernelKinds) return VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     KernelTimer &t = ctx->kernel_timers[kind];
     for (size_t i = 0; i + 1 < t.used; i += 2) {
         float ms = 0.0f;
@@ -209,8 +216,9 @@ void vhr_destroy(vhr_context *ctx) {
         return;
     }
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    ctx->sync_streams();
     vhr_graph_destroy_resources(ctx);
+    if (ctx->front_stream) hipStreamDestroy(ctx->front_stream);
     for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
         if (!im.used) continue;
         hipFree(im.ptr);
@@ -233,7 +241,7 @@ int vhr_synchronize(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return VHR_OK;
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     return VHR_OK;
 }
 
@@ -268,7 +276,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
             if (t < -1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: negative texture index other than -1");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     free_scene(ctx);
 
     HostBvh bvh;
@@ -322,7 +330,7 @@ int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t 
         const auto &s = ctx->textures[i];
         table[i] = DeviceTexture{ static_cast<const uint8_t *>(s.texels), s.w, s.h, s.format, s.sampler.mag_filter, s.sampler.address_mode_u, s.sampler.address_mode_v, 0 };
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     hipFree(ctx->d_textures);
     ctx->d_textures = nullptr;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_textures), sizeof(DeviceTexture) * table.size()));
@@ -361,7 +369,7 @@ int vhr_destroy_storage_image(vhr_context *ctx, int32_t id) {
     if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "DestroyStorageImage: no such image") : VHR_ERROR_INVALID_ARGUMENT;   // assert at resource_manager.cpp:266
     if (ctx->host_only) { ctx->storage_images[id] = Image{}; return VHR_OK; }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     Image &im = ctx->storage_images[id];
     // ptr/alt may have been flipped: free both distinct allocations
     void *a = im.ptr, *b = im.alt;
@@ -402,7 +410,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -417,7 +425,7 @@ int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable) {
 
 int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     const vhr_trace_params &tp = ctx->trace_params;
     const uint64_t covered = ctx->h_ray_stats.covered_pixels;
     if (ctx->raytraced_pixels) {          // raytraced render path: one primary ray per pixel + one shadow ray per primary hit
@@ -436,7 +444,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]) {
 
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     out[0] = ctx->h_ray_stats.node_visits; out[1] = ctx->h_ray_stats.leaf_visits;
     out[2] = ctx->h_ray_stats.triangle_tests; out[3] = ctx->h_ray_stats.wave_iterations;
     return VHR_OK;
@@ -444,10 +452,18 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
 
 int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->host_only) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     const RayStats &r = ctx->h_ray_stats;
     out[0] = r.cycles_total; out[1] = r.cycles_setup; out[2] = r.cycles_refill; out[3] = r.cycles_nodes;
     out[4] = r.cycles_leaves; out[5] = r.refills; out[6] = r.waves; out[7] = r.drain_iterations;
+    return VHR_OK;
+}
+
+int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[6]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
+    const RayStats &r = ctx->h_ray_stats;
+    out[0] = r.packets; out[1] = r.packet_nodes; out[2] = r.packet_triangles; out[3] = r.packet_lane_tests; out[4] = r.cycles_packet; out[5] = r.cut_entries;
     return VHR_OK;
 }
 
@@ -497,7 +513,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     return VHR_OK;
 }
 

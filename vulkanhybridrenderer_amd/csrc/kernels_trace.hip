@@ -509,22 +509,56 @@ __device__ __forceinline__ void wave_lds_sync() {
 // kCutMax subtrees that together cover all geometry.  A ray then starts by testing the cut's boxes (a short uniform loop over
 // LDS broadcasts, every refilled lane busy) and walks only the subtrees it hits.  Box tests only cull, so results are unchanged.
 constexpr int kCutMax = 16;
+constexpr int kWideCutMax = 12;      // raygen_wide_kernel (LDS budget; 12 and 24 entries measured flat around 16 on the 8x8 kernel)
+
+// An upper bound of |onb_transform(n, v)| / |v|, i.e. of the largest singular value of the Frisvad basis (c0, c1, n) that
+// common.glsl:80-93 builds around the G-buffer normal.  The normal is a rounded half vector, not a unit vector, and near
+// n.z = -1 the basis amplifies that error by 1 / (1 + n.z): AO directions are NOT unit vectors, so the reach of an AO ray is
+// tmax * |d|, not tmax.  Gershgorin on the Gram matrix of the three columns, 2 % of slack for this function's own rounding
+// and for |v| of the cosine-hemisphere sample (1 within a few ulp).
+__device__ __forceinline__ float onb_norm_bound(f3 n) {
+    f3 c0, c1;
+    if (n.z < -0.9999999f) {
+        c0 = f3{ 0.0f, -1.0f, 0.0f };
+        c1 = f3{ -1.0f, 0.0f, 0.0f };
+    } else {
+        const float a = 1.0f / (1.0f + n.z);
+        const float b = ((-n.x) * n.y) * a;
+        c0 = f3{ 1.0f - (n.x * n.x) * a, b, -n.x };
+        c1 = f3{ b, 1.0f - (n.y * n.y) * a, -n.y };
+    }
+    const float g00 = dot3(c0, c0), g11 = dot3(c1, c1), g22 = dot3(n, n);
+    const float g01 = fabsf(dot3(c0, c1)), g02 = fabsf(dot3(c0, n)), g12 = fabsf(dot3(c1, n));
+    const float row = fmaxf(fmaxf(g00 + g01 + g02, g01 + g11 + g12), g02 + g12 + g22);
+    const float bound = sqrtf(row) * 1.02f;
+    return bound == bound ? bound : 3.0e38f;            // a NaN normal prunes nothing
+}
 
 // The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
 // origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -) --
 // and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
-__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane) {
+// `reach` (this lane's contribution, 0 for lanes without rays; +inf = no pruning): an upper bound of how far any of the tile's
+// rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
+// hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
+__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
+                                                   const int max_entries = kCutMax) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
         omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
+        reach = fmaxf(reach, __shfl_xor(reach, off));
     }
     // wave-uniform from here on, and told so: the descent then runs on scalar registers and scalar branches
     auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    reach = uni(reach);
+    const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
     uint32_t cut_n = 0;
     auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+        const float gx = fmaxf(fmaxf(lx - omax.x, omin.x - hx), 0.0f), gy = fmaxf(fmaxf(ly - omax.y, omin.y - hy), 0.0f),
+                    gz = fmaxf(fmaxf(lz - omax.z, omin.z - hz), 0.0f);
+        if ((gx * gx + gy * gy) + gz * gz > reach2) return;                                  // out of every ray's reach
         if (lane == 0) {
             s_cut[cut_n][0] = make_float4(lx, hx, ly, hy);
             s_cut[cut_n][1] = make_float4(lz, hz, __int_as_float(link), 0.0f);
@@ -534,7 +568,7 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     int node = 0;
     float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };          // box of `node` (the root: everything)
     bool open = true;                                                                      // `node` still waits for its entry
-    for (int it = 0; it < kCutMax - 2; ++it) {
+    for (int it = 0; it < max_entries - 2; ++it) {
         const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
         const float4 v0 = np[0], v1 = np[1], v2 = np[2];
         const int2 vl = *reinterpret_cast<const int2 *>(np + 3);
@@ -565,10 +599,95 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     return cut_n;
 }
 
-template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false>
+// ---------------------------------------------------------------------------------------------
+// Shadow rays as a PACKET (option "shadow_packet").  The shadow rays of an 8x8-pixel tile leave from origins centimetres
+// apart in directions that differ by less than 0.18 degrees (one cone sample around the light direction, raygen.rgen:32-35):
+// walking the tree once per RAY repeats the same node sequence 64 times at whatever lane occupancy divergence leaves.  Here
+// the WAVE walks the tree once for its tile: the current node is wave-uniform and arrives through scalar loads (s_load_dwordx8
+// x 2 per node, the boxes then sit in SGPR pairs that v_pk_fma_f32 takes directly), every lane tests ITS ray against both
+// child boxes, a child is entered when any still-undecided lane hits it (the near one by majority first), the traversal
+// stack is wave-uniform (one VGPR: lane i holds entry i), leaves test their triangles against all lanes at once with a
+// branch-free Moeller-Trumbore, and a lane leaves the packet at its first accepted triangle (terminateOnFirstHit).  No LDS,
+// no vector memory, no divergence.  Results are those of the per-ray walk bit for bit: box tests only cull (padded boxes,
+// the per-ray arithmetic of box_test_pk), a lane whose ray meets a triangle passes the tests of every box above it, so the
+// packet visits that leaf, and any-hit visibility is an OR over triangles in any order.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f *uniform_f4_ptr;         // constant address space + uniform address = SMEM loads
+typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
+
+struct PacketCounters { uint32_t nodes, triangles, lane_tests; };
+
+template <bool STATS>
+__device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &sc, unsigned long long active, const f3 ro, const f3 rd, const float tmin,
+                                                            const float tmax, const uint32_t lane, PacketCounters &pc) {
+    const f3 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+    const f3 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+    float tmin_v = tmin, tmax_v = tmax;               // VGPR copies for the asm-operand min / max of the slab test
+    asm volatile("" : "+v"(tmin_v), "+v"(tmax_v));
+    unsigned long long occluded = 0;
+    int stackv = 0;                                   // wave-uniform stack: lane i holds entry i (depth <= kMaxBvhDepth < 64)
+    uint32_t sp = 0;
+    int node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(sc.nodes + node);
+            const v4f q0 = np[0], q1 = np[1], q2 = np[2];
+            const v4i links = *(uniform_i4_ptr)(np + 3);
+            float tn0, tn1;
+            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax_v, tn0);
+            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax_v, tn1);
+            const unsigned long long m0 = __ballot(h0) & active, m1 = __ballot(h1) & active;
+            if (STATS) { ++pc.nodes; pc.lane_tests += uint32_t(__popcll(active)); }
+            if (m0 != 0 && m1 != 0) {
+                // both children hold work: the one most undecided lanes meet first goes first, the other waits on the stack
+                const unsigned long long zero_nearer = __ballot(tn0 <= tn1) & m0;
+                const bool first0 = uint32_t(__popcll(zero_nearer | (m0 & ~m1))) * 2u >= uint32_t(__popcll(m0 | m1));
+                const int farc = first0 ? links.y : links.x;
+                stackv = (lane == sp) ? farc : stackv;
+                ++sp;
+                node = first0 ? links.x : links.y;
+                continue;
+            }
+            if (m0 != 0) { node = links.x; continue; }
+            if (m1 != 0) { node = links.y; continue; }
+        } else {
+            const uint32_t vv = ~uint32_t(node);
+            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const uniform_f4_ptr tp = (uniform_f4_ptr)(uintptr_t)(sc.tris + first + i);
+                const v4f ta = tp[0], tb = tp[1], tc = tp[2];
+                if (STATS) { ++pc.triangles; pc.lane_tests += uint32_t(__popcll(active)); }
+                // ray_triangle() without its early returns (same operations in the same order on the same operands; a lane
+                // the branching form would have sent home early computes on and fails the same comparison at the end)
+                const f3 e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
+                const f3 pvec = cross3(rd, e2);
+                const float det = dot3(e1, pvec);
+                const float inv = 1.0f / det;
+                const f3 tvec = ro - f3{ ta.x, ta.y, ta.z };
+                const float uu = dot3(tvec, pvec) * inv;
+                const f3 qvec = cross3(tvec, e1);
+                const float vv2 = dot3(rd, qvec) * inv;
+                const float tt = dot3(e2, qvec) * inv;
+                const bool hit = det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv2 >= 0.0f && !(uu + vv2 > 1.0f) && tt > tmin && tt < tmax;
+                const unsigned long long hm = __ballot(hit) & active;
+                occluded |= hm;
+                active &= ~hm;
+            }
+            if (active == 0) break;                   // every ray of the tile has met an occluder
+        }
+        if (sp == 0) break;
+        --sp;
+        node = __builtin_amdgcn_readlane(stackv, int(sp));
+    }
+    return occluded;
+}
+
+template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
-                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows) {
+                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t cut_reach) {
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
     extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
     const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
@@ -607,10 +726,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                         // rgen:20-21
     }
     if (setup_wave) s_vis[lane] = 0;
-    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
+    const uint32_t first_kind = (a.tp.shadow_enable && !PACKET) ? 0u : 1u;       // PACKET: the shadow rays never enter the queue
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // CUT: bounds of the tile's ray origins
+    f3 pk_origin = f3{ 0.0f, 0.0f, 0.0f }, pk_dir = f3{ 0.0f, 0.0f, 1.0f };              // PACKET: this pixel's shadow ray
+    float ao_reach = 0.0f;                                                                   // CUT: bound of tmax * |d| over this pixel's AO rays
     if (covered) {
         // ---- raygen.rgen:15-29 once per pixel (shared by all of the pixel's rays) ----
         const float u = (float(x) + 0.5f) / float(W);
@@ -621,6 +742,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
         const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
+        if (PACKET && a.tp.shadow_enable) { pk_origin = origin; pk_dir = ray_direction(a.tp, seed, 0u, L, N); }   // rgen:32-35, whole wave
+        if (CUT) ao_reach = a.tp.ao_tmax * onb_norm_bound(N);
         if (CUT) { omin = origin; omax = origin; }
         if (PREGEN) {
             for (uint32_t kind = first_kind; kind <= last_kind; ++kind) {
@@ -644,8 +767,21 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         wave_lds_sync();
     }
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
+    PacketCounters pkc = { 0u, 0u, 0u };
+    uint32_t n_cut_entries = 0;
+    unsigned long long t_packet = 0;
+    if (PACKET && a.tp.shadow_enable && a.scene.node_count != 0 && cov_mask != 0) {
+        const unsigned long long tp0 = stats ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long occluded = shadow_packet<STATS>(a.scene, cov_mask, pk_origin, pk_dir, a.tp.tmin, a.tp.tmax, lane, pkc);
+        if ((occluded >> lane) & 1ull) s_vis[lane] = 1u;                                     // miss.rmiss:7 leaves 1.0 for the others
+        wave_lds_sync();
+        if (stats) t_packet = __builtin_readcyclecounter() - tp0;
+    }
     uint32_t cut_n = 0;
-    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane);
+    // the queue holds AO rays only (shadow rays off, or walked as a packet above): the cut is pruned to their reach
+    const bool ao_only = first_kind != 0u && cut_reach != 0u;
+    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f);
+    if (STATS) n_cut_entries = cut_n;
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
@@ -834,10 +970,264 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             atomicAdd(&stats->cycles_leaves, t_leaves);
             atomicAdd(&stats->refills, n_refills);
             atomicAdd(&stats->waves, 1ull);
+            atomicAdd(&stats->cut_entries, (unsigned long long)n_cut_entries);
+            if (PACKET && pkc.nodes) {
+                atomicAdd(&stats->packets, 1ull);
+                atomicAdd(&stats->packet_nodes, (unsigned long long)pkc.nodes);
+                atomicAdd(&stats->packet_triangles, (unsigned long long)pkc.triangles);
+                atomicAdd(&stats->packet_lane_tests, (unsigned long long)pkc.lane_tests);
+                atomicAdd(&stats->cycles_packet, t_packet);
+            }
         }
         atomicAdd(&stats->node_visits, (unsigned long long)n_nodes);
         atomicAdd(&stats->leaf_visits, (unsigned long long)n_leaves);
         atomicAdd(&stats->triangle_tests, (unsigned long long)n_tris);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1, work-queue form with WIDE tiles (option "raygen_tile_pixels" 128 / 256): the kernel above with SUB 8x8-pixel sub-tiles
+// per wave (16x8 or 16x16 pixels) and ONE queue over all of their rays.  What the lanes of a wave lose is set by the length
+// of the queue they share: a wave works through its rays greedily, and when the queue has run dry the slowest rays finish
+// with ever fewer lanes (PMC / in-kernel counters on the 8x8 kernel: 47 % of the wave trips after the drain began, AO rays
+// alone at 27 % of the lanes).  Twice or four times the rays per queue halve / quarter the share of that drain.  Per-pixel
+// set-up (raygen.rgen:15-29) runs SUB times with the whole wave; the tree cut is built once over all origins.  Same rays,
+// same arithmetic, integer visibility accumulated in LDS: bit-identical to the 8x8 form.
+// ---------------------------------------------------------------------------------------------
+template <int SUB, int WAVES, bool SPILL, bool STATS>
+__global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_wide_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
+                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t cut_reach) {
+    static_assert(SUB == 2 || SUB == 4, "16x8 or 16x16 pixels per wave");
+    constexpr int PIX = kQueueBlock * SUB;
+    constexpr uint32_t TW = 16u, TH = SUB == 4 ? 16u : 8u;
+    RayStats *const stats = STATS ? a.stats : nullptr;
+    extern __shared__ int s_dyn[];                    // per wave: (stack_levels + 3) x 64 ints (see raygen_queue_kernel)
+    const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
+    // LDS per wave is what decides the waves per SIMD here (7 need <= 5.7 KB): two pixels share a visibility word, the normal
+    // stays in the G-buffer's own half bits (2 words), the RNG seed is recomputed from the pixel at refill, 12 cut entries
+    __shared__ uint32_t s_vis_all[WAVES][PIX / 2];    // per pixel 16 bits: bit 0 shadow ray occluded, bits 4..: AO rays that escaped
+    __shared__ float s_ray_all[WAVES][5][PIX];        // per covered pixel: ray origin (3), normal as stored in the G-buffer (2)
+    __shared__ uint8_t s_list_all[WAVES][PIX];        // compacted covered pixels
+    __shared__ float4 s_cut_all[WAVES][kWideCutMax][2];
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    uint32_t (&s_vis)[PIX / 2] = s_vis_all[wave];
+    float (&s_ray)[5][PIX] = s_ray_all[wave];
+    uint8_t (&s_list)[PIX] = s_list_all[wave];
+    float4 (&s_cut)[kWideCutMax][2] = s_cut_all[wave];
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    stack[0] = kStackSentinel;
+    const uint32_t W = a.width, H = a.height;
+    const uint32_t by = blockIdx.x / block_tiles_x, bx = blockIdx.x - by * block_tiles_x;
+    const uint32_t tile_x0 = (bx * WAVES + wave) * TW, tile_y0 = a.row_begin + by * TH;
+    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
+    const uint32_t last_kind = a.tp.ao_spp;
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
+    float ao_reach = 0.0f;
+    unsigned long long cov_masks[SUB];
+    uint32_t ncov = 0;
+#pragma unroll
+    for (uint32_t sub = 0; sub < uint32_t(SUB); ++sub) {
+        const uint32_t x = tile_x0 + (sub & 1u) * 8u + (lane & 7u), y = tile_y0 + (sub >> 1) * 8u + (lane >> 3);
+        const uint32_t p = sub * kQueueBlock + lane;
+        bool covered = false;
+        float depth = 0.0f;
+        if (x < W && y < a.row_end) {
+            depth = a.depth[size_t(y) * W + x];                                              // rgen:19
+            covered = depth != 0.0f;
+            if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                     // rgen:20-21
+        }
+        if ((sub & 1u) == 0u) s_vis[(sub >> 1) * kQueueBlock + lane] = 0;
+        if (covered) {
+            // ---- raygen.rgen:15-29 once per pixel ----
+            const float u = (float(x) + 0.5f) / float(W);
+            const float v = (float(y) + 0.5f) / float(H);
+            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
+            const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];  // rgen:28
+            const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
+            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
+            s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
+            s_ray[3][p] = __uint_as_float(nraw.x); s_ray[4][p] = __uint_as_float(nraw.y);
+            omin = f3{ fminf(omin.x, origin.x), fminf(omin.y, origin.y), fminf(omin.z, origin.z) };
+            omax = f3{ fmaxf(omax.x, origin.x), fmaxf(omax.y, origin.y), fmaxf(omax.z, origin.z) };
+            ao_reach = fmaxf(ao_reach, a.tp.ao_tmax * onb_norm_bound(N));
+        }
+        const unsigned long long m = __ballot(covered);
+        cov_masks[sub] = m;
+        if (covered) s_list[ncov + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        ncov += uint32_t(__popcll(m));
+    }
+    wave_lds_sync();
+    const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
+    uint32_t cut_n = 0;
+    const bool ao_only = first_kind != 0u && cut_reach != 0u;
+    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kWideCutMax);
+    uint32_t emask = 0;
+    if (stats) t_setup = __builtin_readcyclecounter() - t_start;
+
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    float tmax = 0.0f;
+    int cur = 0, sp = 0;
+    uint32_t pix = 0, kind = 0;
+    bool has = false;
+    uint32_t next = 0;
+    uint32_t overflow = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;
+    volatile int spill[SPILL ? kTraceStack : 1];     // volatile: stays in scratch (see wave_queue_walk)
+    const float tmin = a.tp.tmin;
+    float tmin_v = tmin;
+    asm volatile("" : "+v"(tmin_v));
+    for (;;) {
+        // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        const unsigned long long t0 = stats ? __builtin_readcyclecounter() : 0ull;
+        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
+            ++n_refills;
+            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            next += n_idle;
+            if (!has && r < total) {
+                uint32_t k = 0, rr = r;
+                while (rr >= ncov) { rr -= ncov; ++k; }                                      // kind-major queue, k < kinds
+                kind = k + first_kind;
+                pix = s_list[rr];
+                ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+                const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nz = __float_as_uint(s_ray[4][pix]);
+                const uint32_t px = tile_x0 + ((pix >> 6) & 1u) * 8u + (pix & 7u), py = tile_y0 + (pix >> 7) * 8u + ((pix >> 3) & 7u);
+                rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                        // rgen:17
+                                   f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nz & 0xffffu)) });
+                tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
+                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                cur = 0; sp = 0;
+                emask = 0;
+                for (uint32_t e = 0; e < cut_n; ++e) {                                       // the ray against the tile's cut
+                    const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
+                    float tnu;
+                    if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
+                        if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
+                        else emask |= 1u << e;
+                    }
+                }
+                if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
+                has = true;
+            }
+        }
+        if (!__any(has)) break;
+        const unsigned long long t1 = stats ? __builtin_readcyclecounter() : 0ull;
+        // ---- inner nodes (the node step of raygen_queue_kernel) ----
+        bool found = false;
+        const uint32_t nodes_before = n_nodes, tris_before = n_tris;
+        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
+        while (has && cur >= 0) {
+            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
+            ++n_nodes;
+            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            float tn0, tn1;
+            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax, tn0);
+            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax, tn1);
+            const bool both = h0 && h1, none = !(h0 || h1);
+            const bool first0 = tn0 <= tn1;
+            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
+            int top = row[0];
+            row[kQueueBlock] = farc;
+            if (__any(uint32_t(sp) >= stack_levels)) {
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (uint32_t(sp) >= stack_levels) {
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    else overflow |= both ? 1u : 0u;
+                }
+            }
+            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
+            sp += (both ? 1 : 0) - (none ? 1 : 0);
+        }
+        const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
+        // ---- leaf ----
+        if (has && cur < 0 && cur != kStackSentinel) {
+            const uint32_t vv = ~uint32_t(cur);
+            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
+            ++n_leaves;
+            for (uint32_t i = 0; i < count; ++i) {
+                ++n_tris;
+                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
+                const float4 ta = tp[0], tb = tp[1];
+                const float tcx = reinterpret_cast<const float *>(tp)[8];
+                float t, uu, ww;
+                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax, t, uu, ww)) {
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) {
+                cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
+                if (SPILL && __any(uint32_t(sp) > stack_levels)) {
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                }
+                --sp;
+            }
+        }
+        if (has && !found && cur == kStackSentinel && emask) {                 // overflowed cut entries: next subtree
+            const int e = __ffs(int(emask)) - 1;
+            emask &= emask - 1u;
+            cur = __float_as_int(s_cut[e][1].z);
+            sp = 0;
+        }
+        const bool finished = found || cur == kStackSentinel;
+        if (has && finished) {
+            has = false;
+            // pixel p = 64 * sub + l lives in word 64 * (sub >> 1) + l, half (sub & 1)
+            uint32_t *const word = &s_vis[(pix >> 7) * kQueueBlock + (pix & 63u)];
+            const uint32_t shift = ((pix >> 6) & 1u) * 16u;
+            if (kind == 0) { if (found) atomicOr(word, 1u << shift); }                       // miss.rmiss:7 leaves 1.0
+            else if (!found) atomicAdd(word, 16u << shift);
+        }
+        if (stats) {
+            const unsigned long long t3 = __builtin_readcyclecounter();
+            t_refill += t1 - t0; t_nodes += t2 - t1; t_leaves += t3 - t2;
+            uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
+            for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
+            n_wave_trips += tn + tt;
+            if (next >= total) n_drain_trips += tn + tt;
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (uint32_t sub = 0; sub < uint32_t(SUB); ++sub) {
+        if (!((cov_masks[sub] >> lane) & 1ull)) continue;
+        const uint32_t x = tile_x0 + (sub & 1u) * 8u + (lane & 7u), y = tile_y0 + (sub >> 1) * 8u + (lane >> 3);
+        const uint32_t vis = (s_vis[(sub >> 1) * kQueueBlock + lane] >> ((sub & 1u) * 16u)) & 0xffffu;
+        const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
+        float ao_payload = 1.0f;
+        if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 4)) / float(a.tp.ao_spp);   // rgen:55
+        store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
+    }
+    if (stats) {
+        const unsigned long long ovf = __ballot(overflow != 0);
+        if (lane == 0) {
+            if (ncov) atomicAdd(&stats->covered_pixels, (unsigned long long)ncov);
+            if (ovf) atomicAdd(&stats->stack_overflows, (unsigned long long)__popcll(ovf));
+            atomicAdd(&stats->wave_iterations, (unsigned long long)n_wave_trips);
+            atomicAdd(&stats->drain_iterations, (unsigned long long)n_drain_trips);
+            atomicAdd(&stats->cycles_total, __builtin_readcyclecounter() - t_start);
+            atomicAdd(&stats->cycles_setup, t_setup);
+            atomicAdd(&stats->cycles_refill, t_refill);
+            atomicAdd(&stats->cycles_nodes, t_nodes);
+            atomicAdd(&stats->cycles_leaves, t_leaves);
+            atomicAdd(&stats->refills, n_refills);
+            atomicAdd(&stats->waves, 1ull);
+            atomicAdd(&stats->cut_entries, (unsigned long long)cut_n);
+        }
+        // wave-reduced before the atomics (64 same-address atomics per wave serialise at the memory side)
+        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
+        if (lane == 0) {
+            atomicAdd(&stats->node_visits, (unsigned long long)n_nodes);
+            atomicAdd(&stats->leaf_visits, (unsigned long long)n_leaves);
+            atomicAdd(&stats->triangle_tests, (unsigned long long)n_tris);
+        }
     }
 }
 
@@ -1211,26 +1601,51 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     do {                                                                                                                          \
         if (shared_tile)                                                                                                          \
             launch(ctx, (raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
-                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows);    \
+                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, 0u);    \
         else                                                                                                                      \
             launch(ctx, (raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                (stack_bytes + dir_bytes) * WV, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
-                               uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows);                                       \
+                               uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, 0u);                                   \
     } while (0)
 #define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
     do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
         // the shared descent ("raygen_cut", default): own-tile waves on the plain fp32 nodes
         const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile && !ctx->options[kOptCompactNodes];
-#define VHR_LAUNCH_CUT(WV, SP, ST)                                                                                                \
-    launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-           stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows)
+        const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
+#define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
+    launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+           stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
+           uint32_t(ctx->options[kOptCutReach] != 0))
+#define VHR_LAUNCH_CUT(WV, SP, ST) do { if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
 #define VHR_LAUNCH_CUT_W(SP, ST) \
     do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
         const bool compact = ctx->options[kOptCompactNodes] != 0;
         // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
         const bool spill = levels < ctx->bvh_depth + 1u;
         // A/B variants (pre-generated directions, compact nodes) exist in the diagnostic flavour only
-        if (cut) {
+        const int tile_pixels = ctx->options[kOptRaygenTilePixels];
+        if (cut && tile_rows == 8u && (tile_pixels == 128 || tile_pixels == 256)) {
+            // wide tiles: 16x8 / 16x16 pixels per wave, one queue over all their rays (raygen_wide_kernel)
+            const uint32_t th = tile_pixels == 256 ? 16u : 8u;
+            const uint32_t wtiles_x = (width + 15u) / 16u, wtiles_y = (rows_traced + th - 1u) / th;
+            const int wv = waves >= 2 ? 2 : 1;
+            const uint32_t blocks_x = (wtiles_x + wv - 1) / wv;
+            // 6 LDS stack levels at most: with 5.6 KB of LDS per wave 7 waves per SIMD stay resident (deeper entries spill)
+            const uint32_t wlevels = std::min<uint32_t>(levels, 6u);
+            const size_t wstack_bytes = size_t(wlevels + 3) * kQueueBlock * sizeof(int);
+            const bool wspill = wlevels < ctx->bvh_depth + 1u;
+#define VHR_LAUNCH_WIDE(SUBT, WV, SP, ST) \
+    launch(ctx, (raygen_wide_kernel<SUBT, WV, SP, ST>), dim3(blocks_x * wtiles_y), dim3(kQueueBlock * WV), wstack_bytes * WV, a, wlevels, threshold, blocks_x, \
+           early_exit, uint32_t(ctx->options[kOptCutReach] != 0))
+#define VHR_LAUNCH_WIDE_S(SUBT, WV) \
+    do { if (a.stats) { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, true); else VHR_LAUNCH_WIDE(SUBT, WV, false, true); } \
+         else { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, false); else VHR_LAUNCH_WIDE(SUBT, WV, false, false); } } while (0)
+            if (tile_pixels == 256) { if (wv == 2) VHR_LAUNCH_WIDE_S(4, 2); else VHR_LAUNCH_WIDE_S(4, 1); }
+            else { if (wv == 2) VHR_LAUNCH_WIDE_S(2, 2); else VHR_LAUNCH_WIDE_S(2, 1); }
+#undef VHR_LAUNCH_WIDE_S
+#undef VHR_LAUNCH_WIDE
+        }
+        else if (cut) {
             if (a.stats) { if (spill) VHR_LAUNCH_CUT_W(true, true); else VHR_LAUNCH_CUT_W(false, true); }
             else { if (spill) VHR_LAUNCH_CUT_W(true, false); else VHR_LAUNCH_CUT_W(false, false); }
         }
@@ -1240,6 +1655,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         else { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, false); else VHR_LAUNCH_QUEUE_W(false, false, false, false); }
 #undef VHR_LAUNCH_CUT_W
 #undef VHR_LAUNCH_CUT
+#undef VHR_LAUNCH_CUT_P
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)

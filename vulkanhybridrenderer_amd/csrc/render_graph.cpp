@@ -111,10 +111,22 @@ int vhr_graph_destroy_resources(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (!ctx->host_only) {
         hipSetDevice(ctx->device);
-        if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        ctx->sync_streams();
         for (auto &kv : ctx->pass_descriptions) free_pass_events(kv.second);
-        for (auto &kv : ctx->images) hipFree(kv.second.owned);
+        for (auto &kv : ctx->images) {
+            Image &im = kv.second;
+            if (im.slot_owned[0]) { for (void *q : im.slot_owned) hipFree(q); }      // one instance per frame slot
+            else hipFree(im.owned);
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (ctx->front_done[i]) hipEventDestroy(ctx->front_done[i]);
+            if (ctx->back_done[i]) hipEventDestroy(ctx->back_done[i]);
+            ctx->front_done[i] = ctx->back_done[i] = nullptr;
+            ctx->back_pending[i] = false;
+        }
     }
+    ctx->front_passes = 0;
+    ctx->cur_slot = 0;
     ctx->pass_descriptions.clear();
     ctx->registration_order.clear();
     ctx->execution_order.clear();
@@ -218,6 +230,13 @@ static int actualize(vhr_context *ctx, const vhr_transient_resource &r) {
     if (!ctx->host_only) {
         HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
         HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
+        if (ctx->frames_in_flight > 1) {                      // one instance per frame slot
+            im.slot_owned[0] = im.owned;
+            for (int i = 1; i < ctx->frames_in_flight; ++i) {
+                HIP_TRY(ctx, hipMalloc(&im.slot_owned[i], im.bytes()));
+                HIP_TRY(ctx, hipMemsetAsync(im.slot_owned[i], 0, im.bytes(), ctx->stream));
+            }
+        }
     }
     im.ptr = im.owned;
     im.used = true;
@@ -272,6 +291,8 @@ static int sanity_check(vhr_context *ctx) {
 int vhr_graph_build(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (!ctx->host_only) HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->images.empty())                                  // the slot count of existing images stands (Build after DestroyResources changes it)
+        ctx->frames_in_flight = ctx->host_only ? 1 : std::max(1, std::min(3, ctx->options[vhr::kOptFramesInFlight]));
     std::map<std::string, std::vector<std::string>> writers;
     // the reference iterates an unordered_map; registration order is the deterministic choice here
     for (auto &name : ctx->registration_order) {
@@ -287,6 +308,21 @@ int vhr_graph_build(vhr_context *ctx) {
     if (rc) return rc;
     rc = sanity_check(ctx);
     if (rc) return rc;
+    // frames in flight: the front of the frame = everything up to and including the last ray-tracing pass
+    ctx->front_passes = 0;
+    if (ctx->frames_in_flight > 1) {
+        for (size_t i = 0; i < ctx->execution_order.size(); ++i)
+            if (ctx->pass_descriptions[ctx->execution_order[i]].kind == PassKind::Raytracing) ctx->front_passes = i + 1;
+        if (ctx->front_passes == ctx->execution_order.size()) ctx->front_passes = 0;       // nothing behind it to overlap with
+        if (ctx->front_passes) {
+            if (!ctx->front_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->front_stream, hipStreamNonBlocking));
+            for (int i = 0; i < ctx->frames_in_flight; ++i) {
+                if (!ctx->front_done[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->front_done[i], hipEventDisableTiming));
+                if (!ctx->back_done[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->back_done[i], hipEventDisableTiming));
+            }
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the instances' clears, before another stream may touch them
+    }
     ctx->built = true;
     return VHR_OK;
 }
@@ -299,8 +335,19 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
     if (resource_idx >= 3) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "resource_idx >= MAX_FRAMES_IN_FLIGHT");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->error.clear();
-    for (auto &name : ctx->execution_order) {
-        PassDescription &p = ctx->pass_descriptions[name];
+    const bool split = ctx->frames_in_flight > 1 && ctx->front_passes != 0;
+    const uint32_t slot = ctx->frames_in_flight > 1 ? resource_idx % uint32_t(ctx->frames_in_flight) : 0u;
+    hipStream_t const back = ctx->stream;
+    if (ctx->frames_in_flight > 1) {
+        ctx->cur_slot = slot;
+        for (auto &kv : ctx->images) kv.second.select_slot(slot);
+        // this frame's front rewrites the slot's images: the back of the frame that used the slot last has to be through with them
+        if (split && ctx->back_pending[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->front_stream, ctx->back_done[slot], 0));
+    }
+    struct RestoreStream { vhr_context *c; hipStream_t s; ~RestoreStream() { c->stream = s; } } restore{ ctx, back };
+    for (size_t pi = 0; pi < ctx->execution_order.size(); ++pi) {
+        PassDescription &p = ctx->pass_descriptions[ctx->execution_order[pi]];
+        ctx->stream = (split && pi < ctx->front_passes) ? ctx->front_stream : back;
         // vkCmdWriteTimestamp x2 (render_graph.cpp:167-182): the stamps ride on the pass's first and last kernel dispatch
         // (vhr_context::dispatch_events).  External (graphics) passes enqueue nothing here and are timed by their owner's API.
         const bool stamps = ctx->options[vhr::kOptPassTimestamps] != 0 && p.kind != PassKind::Graphics;
@@ -322,8 +369,17 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         ctx->cur_pass = nullptr;
         if (stamps && p.begin_stamped && !p.end_on_last_dispatch) HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
         p.timed = stamps && p.begin_stamped;
+        if (split && pi + 1 == ctx->front_passes) {                            // the back of the frame consumes what its front produced
+            HIP_TRY(ctx, hipEventRecord(ctx->front_done[slot], ctx->front_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->front_done[slot], 0));
+        }
+        ctx->stream = back;                                                    // epilogues (the caller's exchanges) belong to the caller's stream
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
+    }
+    if (split) {
+        HIP_TRY(ctx, hipEventRecord(ctx->back_done[slot], back));
+        ctx->back_pending[slot] = true;
     }
     return VHR_OK;
 }
@@ -331,7 +387,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
 int vhr_graph_gather_performance_statistics(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return VHR_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                           // VK_QUERY_RESULT_WAIT_BIT, render_graph.cpp:192-193
+    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }  // VK_QUERY_RESULT_WAIT_BIT, render_graph.cpp:192-193
     for (auto &name : ctx->execution_order) {
         PassDescription &p = ctx->pass_descriptions[name];
         if (!p.timed) continue;
@@ -382,6 +438,7 @@ int vhr_graph_bind_external_image(vhr_context *ctx, const char *image_name, void
     if (!ctx || !image_name) return VHR_ERROR_INVALID_ARGUMENT;
     auto it = ctx->images.find(image_name);
     if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + image_name + "'");
+    it->second.slot_external[ctx->cur_slot] = device_ptr;       // belongs to the frame slot being recorded (slot 0 without frames in flight)
     it->second.ptr = device_ptr ? device_ptr : it->second.owned;
     return VHR_OK;
 }

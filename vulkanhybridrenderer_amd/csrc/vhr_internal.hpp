@@ -89,6 +89,11 @@ struct Image {
     void *ptr = nullptr;          // active device pointer (owned or external)
     void *owned = nullptr;        // context-owned allocation (may differ from ptr when bound externally)
     void *alt = nullptr;          // second buffer for images a kernel reads and rewrites in one dispatch
+    // frames in flight ("frames_in_flight" n > 1): a graph-owned transient image has one instance per frame slot (slot 0 is
+    // `owned`), and an external binding belongs to the slot it was made in; select_slot() points ptr / owned at the slot's
+    void *slot_owned[3] = { nullptr, nullptr, nullptr };
+    void *slot_external[3] = { nullptr, nullptr, nullptr };
+    void select_slot(uint32_t s) { if (slot_owned[s]) owned = slot_owned[s]; ptr = slot_external[s] ? slot_external[s] : owned; }
     uint32_t width = 0, height = 0;
     int32_t format = 0;
     uint32_t bpp = 0;
@@ -167,10 +172,13 @@ struct SvgfCmd {
 struct RayStats {
     unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, second_bounce_rays;
     unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, drain_iterations;   // per-wave s_memtime sums
+    // shadow packets ("shadow_packet"): waves that walked one, wave-level node visits and triangle tests, undecided lanes summed
+    // over those steps (lane utilisation = packet_lane_tests / (64 * (packet_nodes + packet_triangles))), s_memtime ticks
+    unsigned long long packets, packet_nodes, packet_triangles, packet_lane_tests, cycles_packet, cut_entries;
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptCount = 24 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCount = 28 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelKinds = 8 };
@@ -235,13 +243,28 @@ struct vhr_context {
     // strips
     uint32_t row_begin = 0, row_end = 0, overlap = 0, halo = 0;
 
+    // Frames in flight (vulkan_common.h:9 MAX_FRAMES_IN_FLIGHT, renderer.cpp:103-146: the reference's CPU runs up to three
+    // frames ahead and its queue overlaps whatever the barriers allow).  With "frames_in_flight" n > 1 (read at vhr_graph_build)
+    // the passes up to and including the last ray-tracing pass of the execution order -- the FRONT of the frame: G-buffer,
+    // shadow map, Raytrace Pass -- are issued on `front_stream`, the rest (SVGF, composition, ...) on `stream`; every transient
+    // image exists once per frame slot (resource_idx mod n).  Dependencies, derived from that split: the back of frame f waits
+    // for its front (front_done[slot]); the front of frame f + n, which rewrites slot f mod n, waits for the back of frame f
+    // (back_done[slot]).  Persistent storage images (the SVGF history) are touched by back passes only, which stay in order.
+    int frames_in_flight = 1;
+    hipStream_t front_stream = nullptr;
+    hipEvent_t front_done[3] = { nullptr, nullptr, nullptr }, back_done[3] = { nullptr, nullptr, nullptr };
+    bool back_pending[3] = { false, false, false };
+    size_t front_passes = 0;           // passes [0, front_passes) of execution_order run on front_stream
+    uint32_t cur_slot = 0;
+    int sync_streams();                // waits for both streams
+
     // statistics
     bool ray_stats_enabled = false;
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never

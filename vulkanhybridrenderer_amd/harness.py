@@ -32,7 +32,8 @@ def alias_tensor(info):
 
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
-                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True):
+                 atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True,
+                 frames_in_flight=1, allow_degraded=False):
         import torch
         self.torch = torch
         self.scene, self.W, self.H = scene, width, height
@@ -41,6 +42,10 @@ class HybridFrameLoop:
         self.stream = torch.cuda.current_stream()
         self.ctx = lib.Context(width, height, device=device, stream=self.stream.cuda_stream)
         self.ctx.upload_scene(scene)
+        # frames in flight (vulkan_common.h:9, renderer.cpp:103-146): frame i uses resource index i mod n; the library then
+        # issues the front of a frame (G-buffer, Raytrace Pass) on a second stream beside the previous frame's SVGF pass
+        self.frames_in_flight = max(1, min(3, int(frames_in_flight)))
+        self.ctx.set_option("frames_in_flight", self.frames_in_flight)          # read by the graph build below
         self.tp = abi.default_trace_params(shadow=shadow, ao_spp=ao_spp, reflections=reflections)
         self.ctx.set_trace_params(self.tp)
         # `reflections` = mirror bounces (True / 1 = the reference, 2 = the two-bounce extension).  Second-bounce rays exist
@@ -52,7 +57,10 @@ class HybridFrameLoop:
         self._aliases = {}
         self._prepared = {}
         self._pending = None
-        self._gather = None               # tiling.StripGather of the denoised image (C2), built on first use
+        self._gather = None               # tiling.StripGather of the denoised image (C2), built on first use ...
+        self._gathers = {}                # ... per instance of the image (one per frame slot with frames in flight)
+        self.allow_degraded = bool(allow_degraded)
+        self.degraded = []                # fall-backs taken (only ever non-empty with allow_degraded)
         self._pending_gather = None
         self.gather = bool(gather) and world > 1 and denoise
         self.gather_error = None
@@ -140,13 +148,24 @@ class HybridFrameLoop:
         tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
 
     def _exchange_history(self, ctx):
-        if self.gather:                                   # C2: this frame's denoised rows -> rank 0, behind the next frame's ray tracing
+        """Epilogue of the SVGF pass: start C2 (this frame's denoised rows -> rank 0) and exchange #2 (history + moments halo rows
+        for the NEXT frame's svgf.comp), both behind the next frame's ray tracing.  A transport failure is an error: a frame loop
+        that quietly dropped the gather or fell back to per-frame descriptors would report a different (and faster-looking)
+        measurement.  `allow_degraded` restores the old fall-backs for bring-up on a new transport; they are then recorded in
+        `degraded` and bench.py prints them."""
+        if self.gather:                                   # C2
+            den = ctx.transient_info(lib.DENOISED)        # one instance per frame slot with frames in flight
             try:
-                if self._gather is None:
-                    self._gather = tiling.StripGather(self.dist, self._alias(ctx.transient_info(lib.DENOISED)), self.plan)
-                self._pending_gather = self._gather.start()
-            except Exception as e:   # noqa: BLE001 -- a transport that refuses the replayed descriptors must not take the frame loop down
+                g = self._gathers.get(int(den.device_ptr))
+                if g is None:
+                    g = self._gathers[int(den.device_ptr)] = tiling.StripGather(self.dist, self._alias(den), self.plan)
+                self._gather = g
+                self._pending_gather = g.start()
+            except Exception as e:   # noqa: BLE001
+                if not self.allow_degraded:
+                    raise
                 self.gather, self._gather, self.gather_error = False, None, repr(e)
+                self.degraded.append(f"strip gather disabled: {e!r}")
                 print(f"[harness] strip gather disabled: {e!r}", file=sys.stderr, flush=True)
         hist_info = ctx.storage_info(int(self.pc["shadow_and_ao_history"]))
         mom_info = ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"]))            # current (just written) buffer
@@ -164,16 +183,20 @@ class HybridFrameLoop:
                     prepared = self._prepared[key] = tiling.PreparedExchange(self.dist, [hist, mom], self.plan, self.plan.halo)
                 self._pending = prepared.start()          # consumed by the NEXT frame
                 return
-            except Exception as e:   # noqa: BLE001 -- fall back to building the descriptors every frame
+            except Exception as e:   # noqa: BLE001
+                if not self.allow_degraded:
+                    raise
                 self._use_prepared = False
+                self.degraded.append(f"prepared exchange disabled: {e!r}")
                 print(f"[harness] prepared exchange disabled: {e!r}", file=sys.stderr, flush=True)
         self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)
 
     # ---- one frame of the hot path ----
     def frame(self, i):
         self.current = i
-        self.ctx.update_per_frame_ubo(0, self.pfds[i % len(self.pfds)])
-        self.ctx.execute(0, 0)
+        idx = i % self.frames_in_flight
+        self.ctx.update_per_frame_ubo(idx, self.pfds[i % len(self.pfds)])
+        self.ctx.execute(idx, 0)
 
     def owned_rows(self):
         return self.plan.row_begin, self.plan.row_end

@@ -33,7 +33,7 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics",
     "vhr_calibration_stream_read",
 ]
 
@@ -177,6 +177,7 @@ def load():
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
@@ -472,6 +473,13 @@ class Context:
         out = (C.c_uint64 * 8)()
         self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
         return dict(total=out[0], setup=out[1], refill=out[2], nodes=out[3], leaves=out[4], refills=out[5], waves=out[6], drain_iterations=out[7])
+
+    def packet_statistics(self):
+        out = (C.c_uint64 * 6)()
+        self.check(self.L.vhr_get_packet_statistics(self.handle, out), "packet_statistics")
+        d = dict(packets=out[0], node_visits=out[1], triangle_tests=out[2], lane_tests=out[3], cycles=out[4], cut_entries=out[5])
+        d["active_lane_utilisation"] = out[3] / (64.0 * (out[1] + out[2])) if out[1] + out[2] else 0.0
+        return d
 
     def bvh_statistics(self):
         out = (C.c_uint64 * 5)()
