@@ -60,6 +60,14 @@ def parse():
                    help="N > 1: leave the denoised strips on their GPUs (default: gathered to rank 0 every frame, asynchronously, "
                         "inside the timed region -- the frame the composition stage of the display GPU consumes)")
     p.add_argument("--share-device", action="store_true", default=bool(os.environ.get("VHR_BENCH_SHARE_DEVICE")))
+    p.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
+                   help="frames in flight of the timed region (vhr_set_option frames_in_flight; 1 = the single-stream contract). "
+                        "At N = 1 the line carries the 2-frames-in-flight figures as extra fields either way")
+    p.add_argument("--min-seconds", type=float, default=1.0,
+                   help="the timed block of --steps frames is repeated until this much time has been measured; value = the median block")
+    p.add_argument("--no-extras", action="store_true", help="skip the extra blocks (mirror-ray frame, frames in flight) of the N = 1 line")
+    p.add_argument("--allow-degraded", action="store_true",
+                   help="N > 1: fall back (per-frame descriptors / no gather) instead of failing when the transport refuses the replayed exchanges")
     return p.parse_args()
 
 
@@ -94,7 +102,7 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     from vulkanhybridrenderer_amd import lib
     from vulkanhybridrenderer_amd.harness import HybridFrameLoop, alias_tensor
     W, H, V = args.width, args.height, args.verify_frames
-    ref = HybridFrameLoop(scene, W, H, V, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True, device=device) if rank == 0 else None
+    ref = HybridFrameLoop(scene, W, H, V, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True, device=device) if rank == 0 else None   # single stream
     ok = True
     cpu = args.backend == "gloo"
     for i in range(V):
@@ -127,6 +135,40 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     flag = torch.tensor([1 if ok else 0], device="cpu" if cpu else "cuda")
     dist.broadcast(flag, src=0)
     return "bit-identical" if int(flag[0]) else "MISMATCH"
+
+
+SIMDS, CLOCK_HZ = 1024, 2.4e9     # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2400 MHz max clock
+
+
+def pmc_valu(args):
+    """Wave-level VALU instructions per a-trous launch from the committed PMC run (SQ_INSTS_VALU, profiles/atrous_valu.json).  A
+    wave64 VALU instruction occupies its SIMD for 4 cycles, so insts x 4 / (SIMDs x clock) is the time the launch needs at 100 %
+    issue: the floor of THIS formulation of the shader's arithmetic (the kernel is arithmetic bound, not HBM bound)."""
+    if (args.width, args.height, args.scene, args.gpus) != (1920, 1080, "sponza_proc", 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "atrous_valu.json")) as f:
+            return int(json.load(f)["svgf_atrous_valu_insts_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
+    """Blocks of exactly `steps` frames, each bracketed by barrier + synchronize, until `min_seconds` have been measured.
+    Returns (block seconds, next frame index)."""
+    times, f, total = [], first_frame, 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(f, f + steps):
+            loop.frame(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        total += dt
+        f += steps
+        if total >= min_seconds or len(times) >= max_blocks:
+            return times, f
 
 
 def pmc_traffic(args):
@@ -171,25 +213,42 @@ def main():
     else:
         scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
     W, H = args.width, args.height
-    n_frames = min(args.steps + args.warmup, args.max_gbuffers)
-    loop = HybridFrameLoop(scene, W, H, n_frames, shadow=True, ao_spp=args.ao_spp, reflections=_bounces(args), denoise=True,
-                           device=local_rank, rank=rank, world=world, dist=dist if world > 1 else None, trace_overlap=not args.exchange_raytraced,
-                           gather=not args.no_gather)
+    n_frames = min(args.steps + args.warmup + (args.verify_frames if world > 1 else 0), args.max_gbuffers)
+    common = dict(shadow=True, ao_spp=args.ao_spp, denoise=True, device=local_rank)
+    loop = HybridFrameLoop(scene, W, H, n_frames, reflections=_bounces(args), rank=rank, world=world, dist=dist if world > 1 else None,
+                           trace_overlap=not args.exchange_raytraced, gather=not args.no_gather, frames_in_flight=args.frames_in_flight,
+                           allow_degraded=args.allow_degraded, **common)
     ctx = loop.ctx
+    build_ms, upload_ms = ctx.build_times_ms()
 
     def barrier():
         loop.finish_pending_exchange()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        ctx.synchronize()                          # both streams of a context with frames in flight
 
+    # The frame counter only ever moves forward: the dolly's frame 0 (zero previous matrices, NaN motion) is rendered once, on the
+    # clean history it is meant for; beyond the precomputed frames the sequence wraps to frame 1 (HybridFrameLoop.frame_slot).
+    f = 0
     strip_check = None
     if world > 1 and args.verify_frames > 0:
         strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
+        f = args.verify_frames
         barrier()
+        if strip_check != "bit-identical":
+            # a decomposition that does not reproduce the single-context frame measures something else: no value is printed
+            if rank == 0:
+                print(json.dumps({"error": "row strips differ from the single-context frame", "strips_vs_single_context": strip_check,
+                                  "n_gpus": world}), flush=True)
+            loop.close()
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
-    for i in range(args.warmup):
+    for i in range(f, f + args.warmup):
         loop.frame(i)
+    f += args.warmup
     barrier()
     # Only the roofline kernel (a-trous) carries event pairs inside the timed region, and only every 6th of its launches
     # (a dispatch with an event pair costs ~6 us that the next kernel waits for: all five launches of a frame timed = +30 us on
@@ -200,37 +259,37 @@ def main():
     ctx.set_kernel_timing(["svgf_atrous"])
     for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit", "reflection"):
         ctx.kernel_time(k, reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loop.frame(i)
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- the timed region: blocks of exactly --steps frames, repeated until --min-seconds have been measured (a single 20-frame
+    # block lasts 14 ms); every block is bracketed by barrier + synchronize, the MEDIAN block is reported ----
+    first_timed = f
+    block_s, f = time_blocks(loop, barrier, f, args.steps, args.min_seconds)
     ctx.gather_performance_statistics()
     atrous_timed = ctx.kernel_time("svgf_atrous")
     ctx.set_option("kernel_timing_stride", 1)
     ctx.set_kernel_timing(["raygen", "svgf_temporal", "blit", "reflection"])
-    for i in range(args.warmup, args.warmup + min(args.steps, 8)):
+    for i in range(f, f + min(args.steps, 8)):
         loop.frame(i)
+    f += min(args.steps, 8)
     barrier()
 
-    my_rays = sum(loop.rays_in_frame(i) for i in range(args.warmup, args.warmup + args.steps))
-    stats = torch.tensor([dt, float(my_rays)], dtype=torch.float64, device="cpu" if (world > 1 and args.backend == "gloo") else "cuda")
+    rays_per_block = [sum(loop.rays_in_frame(i) for i in range(first_timed + b * args.steps, first_timed + (b + 1) * args.steps)) for b in range(len(block_s))]
+    cpu_dev = "cpu" if (world > 1 and args.backend == "gloo") else "cuda"
+    t_blocks = torch.tensor(block_s, dtype=torch.float64, device=cpu_dev)
+    r_blocks = torch.tensor(rays_per_block, dtype=torch.float64, device=cpu_dev)
     if world > 1:
-        tmax = stats.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, total_rays = float(tmax[0]), float(tsum[1])
-    else:
-        dt_max, total_rays = dt, float(my_rays)
+        dist.all_reduce(t_blocks, op=dist.ReduceOp.MAX)        # a block lasts as long as its slowest rank
+        dist.all_reduce(r_blocks, op=dist.ReduceOp.SUM)
+    t_blocks, r_blocks = t_blocks.cpu().numpy(), r_blocks.cpu().numpy()
+    mid = int(np.argsort(t_blocks)[len(t_blocks) // 2])         # the median block
+    dt_max, total_rays = float(t_blocks[mid]), float(r_blocks[mid])
 
     kt = {k: ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "blit", "reflection")}
     kt["svgf_atrous"] = atrous_timed
     ctx.set_kernel_timing(False)
     # traversal work counters (one extra, untimed frame with the in-kernel statistics enabled)
     ctx.set_ray_statistics(True)
-    loop.frame(args.warmup)
+    loop.frame(f)
+    f += 1
     barrier()
     ray_stats, trav_stats = ctx.ray_statistics(), ctx.traversal_statistics()
     ctx.set_ray_statistics(False)
@@ -251,17 +310,52 @@ def main():
     # distribution of the per-pass GPU times (the reference's timestamp pairs, render_graph.cpp:167-199) over 12 more frames,
     # gathered frame by frame outside the timed region: median and p95
     samples = {name: [] for name in passes}
-    for i in range(args.warmup, args.warmup + 12):
+    for i in range(f, f + 12):
         loop.frame(i)
         ctx.gather_performance_statistics()
         for name in samples:
             samples[name].append(ctx.pass_time_ms(name)[1])
+    f += 12
     barrier()
     passes_median = {k: round(float(np.median(v)), 4) for k, v in samples.items()}
     passes_p95 = {k: round(float(np.percentile(v, 95)), 4) for k, v in samples.items()}
+    rays_one_frame = loop.rays_in_frame(first_timed)
+    bvh = ctx.bvh_statistics()
+    degraded = list(loop.degraded)
+    gather_on, gather_error, plan, tp, rpp, rrpp = loop.gather, loop.gather_error, loop.plan, loop.tp, loop.rays_per_pixel, loop.reference_rays_per_pixel
+    trace_overlap = getattr(loop, "trace_overlap", False)
+    loop.close()
+
+    # ---- extra blocks of the N = 1 line (each its own context, after the timed region): what raygen.rgen's pass costs with its
+    # always-on mirror ray, and the same workload with two frames in flight ----
+    extras = {}
+    if world == 1 and not args.no_extras:
+        def one(**kw):
+            lp = HybridFrameLoop(scene, W, H, n_frames, **common, **kw)
+
+            def sync():
+                torch.cuda.synchronize()
+                lp.ctx.synchronize()
+            for i in range(args.warmup + 1):
+                lp.frame(i)
+            first = args.warmup + 1
+            ts, _ = time_blocks(lp, sync, first, args.steps, min(args.min_seconds, 0.5))
+            b = int(np.argsort(ts)[len(ts) // 2])                        # the median block and its own rays
+            rays = sum(lp.rays_in_frame(i) for i in range(first + b * args.steps, first + (b + 1) * args.steps))
+            lp.close()
+            return round(ts[b] / args.steps * 1e3, 4), round(rays / ts[b] / 1e6, 2)
+        if not _bounces(args):
+            ms, mr = one(reflections=1, frames_in_flight=args.frames_in_flight)
+            extras["ms_per_step_with_mirror_ray"] = ms                   # raygen.rgen:59-65 always traces it
+            extras["value_with_mirror_ray"] = mr
+        other = 2 if args.frames_in_flight == 1 else 1
+        ms, mr = one(reflections=_bounces(args), frames_in_flight=other)
+        extras[f"ms_per_step_frames_in_flight_{other}"] = ms
+        extras[f"value_frames_in_flight_{other}"] = mr
 
     if rank == 0:
-        bvh = ctx.bvh_statistics()
+        valu = pmc_valu(args)
+        valu_floor_us = valu * 4.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
         out = {
             "metric": "Mrays/s (unique rays) + ms/frame, Sponza 1080p RT shadows+AO+SVGF",
             "value": round(total_rays / dt_max / 1e6, 2),
@@ -275,20 +369,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "timed_blocks": {"blocks": len(t_blocks), "steps_per_block": args.steps, "seconds_measured": round(float(t_blocks.sum()), 3),
+                             "ms_per_step_min": round(float(t_blocks.min()) / args.steps * 1e3, 4), "ms_per_step_max": round(float(t_blocks.max()) / args.steps * 1e3, 4),
+                             "reported": "median block"},
             "config": {
                 "workload": f"{scene.name} {W}x{H}: 1 shadow + {args.ao_spp} AO" + ({0: "", 1: " + 1 mirror", 2: " + 1 mirror with a second bounce (second-bounce rays not counted)"}[_bounces(args)]) +
                             " unique rays/px + SVGF (1 temporal + 5 a-trous + 3 blits), 0.05 m/frame dolly",
                 "triangles": scene.triangle_count, "primitives": int(len(scene.primitives)),
-                "rays_per_covered_pixel": loop.rays_per_pixel,
-                "reference_issued_rays_per_covered_pixel": loop.reference_rays_per_pixel,
+                "rays_per_covered_pixel": rpp,
+                "reference_issued_rays_per_covered_pixel": rrpp,
                 "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
-                "strip_overlap_rows": loop.plan.overlap, "history_halo_rows": loop.plan.halo,
-                "overlap_rows_raytraced": ("recomputed locally" if getattr(loop, "trace_overlap", False) else "exchanged") if world > 1 else None,
+                "frames_in_flight": args.frames_in_flight,
+                "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo,
+                "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
+                "multi_gpu_on_hardware": None if world == 1 else "this line IS the measurement; the repository holds no earlier multi-GPU run (rounds 1-2 had one GPU)",
                 "final_gather": ("denoised strips -> rank 0 every frame (point-to-point over RCCL, overlapped with the next frame's ray tracing, "
-                                 "finished inside the timed region)" if loop.gather else ("off" + (f" (disabled at run time: {loop.gather_error})" if loop.gather_error else ""))) if world > 1 else None,
+                                 "finished inside the timed region)" if gather_on else ("off" + (f" (disabled at run time: {gather_error})" if gather_error else ""))) if world > 1 else None,
+                "degraded": degraded or None,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
-                        "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode)",
+                        "raygen.rgen's always-on mirror ray is off unless --reflections (composition discards it in this mode): "
+                        "ms_per_step_with_mirror_ray is the frame with it",
             },
             "roofline": {
                 "kernel": "svgf_atrous_stream_kernel<step, 8> (svgf_atrous_filter.comp)",
@@ -298,14 +399,18 @@ def main():
                                   "two of the five launches per frame also store the texels a blit would have copied, +8 B/px each = +6.6 MB on this average, "
                                   "which the 24 B/px of `achieved` do not count)",
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
-                "launches_note": f"HIP event pairs on every {ATROUS_TIMING_STRIDE}th of the {5 * args.steps} a-trous launches of the timed region (all five step sizes sampled evenly); "
+                "launches_note": f"HIP event pairs on every {ATROUS_TIMING_STRIDE}th a-trous launch of the timed region ({5 * args.steps * len(t_blocks)} launches, all five step sizes sampled evenly); "
                                  "profiles/*kernel_stats* hold rocprofv3's average over all launches",
                 "algorithmic_bytes_per_launch": int(atrous_bytes),
+                # what actually bounds the kernel: issue of its vector instructions (PMC: lanes 96-97 % active, traffic 1.2-1.3 x algorithmic)
+                "valu": None if not valu else {
+                    "insts_per_launch": valu, "floor_us": round(valu_floor_us, 2), "frac": round(valu_floor_us / atrous_us, 4) if atrous_us > 0 else None,
+                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 4 cycles / (1024 SIMDs x 2.4 GHz)"},
             },
             "traversal": {
                 "kernel": "raygen_queue_kernel (raygen.rgen's shadow + AO rays + miss.rmiss); the mirror ray runs in reflection_kernel (kernels_us.reflection)",
                 "avg_launch_ms": round(raygen_ms, 4),
-                "mrays_per_s": round(loop.rays_in_frame(args.warmup) * (1 + args.ao_spp) / max(1, loop.rays_per_pixel) / max(raygen_ms, 1e-9) / 1e3, 1),
+                "mrays_per_s": round(rays_one_frame * (1 + args.ao_spp) / max(1, rpp) / max(raygen_ms, 1e-9) / 1e3, 1),
                 "bvh_nodes": int(bvh["nodes"]), "bvh_bytes": int(bvh["node_bytes"] + bvh["triangle_bytes"]), "bvh_max_depth": int(bvh["max_depth"]),
                 "active_lane_utilisation": round(trav_stats["active_lane_utilisation"], 3),
                 "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
@@ -314,16 +419,19 @@ def main():
                 "stack_overflows": int(ray_stats["stack_overflows"]),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
             },
+            # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); here a host
+            # binned-SAH build + upload, once per scene, outside the frame
+            "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1),
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),
                            "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2),
                            "reflection": round(kt["reflection"][0] / max(1, kt["reflection"][1]) * 1e3, 2) if kt["reflection"][1] else None},
             "passes_ms": passes, "passes_ms_median": passes_median, "passes_ms_p95": passes_p95,
         }
+        out.update(extras)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, loop.tp, args.cpu_frames, loop.rays_per_pixel)
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, tp, args.cpu_frames, rpp)
         print(json.dumps(out), flush=True)
-    loop.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

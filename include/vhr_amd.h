@@ -33,7 +33,8 @@ enum {
     VHR_ERROR_NOT_FOUND = -3,
     VHR_ERROR_OUT_OF_SLOTS = -4,
     VHR_ERROR_GRAPH = -5,
-    VHR_ERROR_NO_DEVICE = -6
+    VHR_ERROR_NO_DEVICE = -6,
+    VHR_ERROR_UNSUPPORTED = -7      /* what the index-returning calls use for invalid arguments: their -1 is the reference's "exhausted" sentinel */
 };
 
 /* ---------------------------------------------------------------------------------------------
@@ -395,6 +396,10 @@ int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[6]);
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */
 int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_t bytes_per_lane);
+
+/* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792;
+ * here the binned-SAH build runs on the host): out[0] = build, out[1] = upload of scene + tree, in milliseconds of host time. */
+int vhr_get_build_times(vhr_context *ctx, double out[2]);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

@@ -110,6 +110,7 @@ def test_shadows_disabled_extension(oracle):
 
 @pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)), ("compact_nodes", (0, 1)),
                                            ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)), ("raygen_shared_tile", (0, 1)), ("raygen_pregen", (0, 1)), ("raygen_early_exit", (0, 8, 15)), ("raygen_cut", (0, 1)),
+                                           ("shadow_packet", (0, 1)), ("cut_reach", (0, 1)), ("raygen_tile_pixels", (64, 128, 256)),
                                            ("atrous_variant", (0, 1, 2, 3, 4)), ("atrous_blocks_per_cu", (1, 3)), ("atrous_xcd_aware", (0, 1)), ("atrous_small_tiles", (0, 1))])
 def test_every_tuning_option_is_result_neutral(oracle, option, values):
     scene = scenes.tiny_scene()
@@ -125,7 +126,7 @@ def test_every_tuning_option_is_result_neutral(oracle, option, values):
                 g.frame(fr["pfd"], fr["gbuf"])
                 assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), (option, v)
             outs.append(g.ctx.download(lib.DENOISED))
-            if option in ("lds_stack_levels", "compact_nodes", "raygen_cut"):
+            if option in ("lds_stack_levels", "compact_nodes", "raygen_cut", "shadow_packet", "raygen_tile_pixels"):
                 g.ctx.set_ray_statistics(True)
                 g.frame(frames[-1]["pfd"], frames[-1]["gbuf"])
                 assert g.ctx.ray_statistics()["stack_overflows"] == 0
@@ -156,3 +157,48 @@ def test_scene_through_the_gltf_host(oracle, tmp_path):
     scene = gltf.load(path)
     assert np.array_equal(scene.vertices, src.vertices) and len(scene.textures) == 4
     _check(oracle, scene, 96, 64, 2, abi.default_trace_params())
+
+
+def test_packet_and_wide_tiles_on_odd_sizes_and_ao_only(oracle):
+    """The shadow-packet stage (with the AO-only queue's reach-pruned cut) and the 16x8 / 16x16 wide-tile kernel on image sizes
+    that leave partial tiles, with and without shadow rays, 1 and 4 AO samples: visibility bit-identical to the oracle."""
+    scene = scenes.sponza_proc(detail=0.25) if hasattr(scenes, "sponza_proc") else scenes.tiny_scene()
+    W, H = 150, 93
+    for shadow, ao in ((True, 1), (False, 4), (True, 0)):
+        tp = abi.default_trace_params(shadow=shadow, ao_spp=ao, reflections=False)
+        frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+        g = GpuHybrid(scene, W, H, shadow=shadow, ao=bool(ao), trace_params=tp, reflections=False, denoise=False)
+        try:
+            for key, val in (("shadow_packet", 1), ("raygen_tile_pixels", 128), ("raygen_tile_pixels", 256)):
+                g.ctx.set_option("shadow_packet", 0)
+                g.ctx.set_option("raygen_tile_pixels", 64)
+                g.ctx.set_option(key, val)
+                for fr in frames:
+                    g.frame(fr["pfd"], fr["gbuf"])
+                    got = g.ctx.download(lib.RAYTRACED)
+                    assert np.array_equal(got, fr["shadow_ao"]), (shadow, ao, key, val, int((got != fr["shadow_ao"]).any(-1).sum()))
+        finally:
+            g.close()
+
+
+def test_non_finite_geometry_is_rejected():
+    """vhr_update_geometry refuses NaN / Inf positions and transforms (they would reach the builder's bin index and comparators)."""
+    import copy
+    scene = scenes.tiny_scene()
+    c = lib.Context(32, 32)
+    try:
+        bad = copy.copy(scene)
+        bad.vertices = scene.vertices.copy()
+        bad.vertices["pos"][3, 1] = np.nan
+        with pytest.raises(lib.VhrError, match="non-finite position"):
+            c.upload_scene(bad)
+        bad = copy.copy(scene)
+        bad.primitives = scene.primitives.copy()
+        bad.primitives["transform"][0, 5] = np.inf
+        with pytest.raises(lib.VhrError, match="non-finite transform"):
+            c.upload_scene(bad)
+        c.upload_scene(scene)                                   # the context is still usable
+        build_ms, upload_ms = c.build_times_ms()
+        assert build_ms > 0 and upload_ms > 0
+    finally:
+        c.close()

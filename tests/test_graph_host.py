@@ -104,6 +104,24 @@ def test_storage_image_pool(ctx):
     rest = [ctx.upload_new_storage_image(1, 1, F2) for _ in range(2048 - 4)]
     assert rest[0] == 3 and rest[-1] == 2047
     assert ctx.upload_new_storage_image(1, 1, F2) == -1                    # pool exhausted -> uint32_t(-1) (:876-877)
+    # ... and -1 means nothing else: an unsupported format or an empty extent is an error, not a "no slot" id
+    ctx.destroy_storage_image(7)
+    with pytest.raises(lib.VhrError, match="unsupported format or empty extent"):
+        ctx.upload_new_storage_image(4, 4, 12345)
+    with pytest.raises(lib.VhrError, match="unsupported format or empty extent"):
+        ctx.upload_new_storage_image(0, 4, F4)
+    assert ctx.upload_new_storage_image(2, 2, F4) == 7                     # the failed calls left the slot free
+
+
+def test_leaf_size_option_is_per_context(vhr):
+    a, b = lib.Context(8, 8, host_only=True), lib.Context(8, 8, host_only=True)
+    try:
+        a.set_option("bvh_leaf_triangles", 1)
+        with pytest.raises(lib.VhrError):
+            a.set_option("bvh_leaf_triangles", 5)
+        b.set_option("bvh_leaf_triangles", 4)                              # no shared state between the two
+    finally:
+        a.close(); b.close()
 
 
 def test_host_only_context_cannot_compute(ctx):

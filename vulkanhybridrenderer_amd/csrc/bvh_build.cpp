@@ -21,7 +21,6 @@
 #include "vhr_internal.hpp"
 
 namespace vhr {
-int g_leaf_tris = kMaxLeafTris;
 namespace {
 
 struct Box {
@@ -56,9 +55,10 @@ struct Builder {
     std::vector<uint32_t> order;
     std::vector<TmpNode> nodes;
     uint32_t max_depth = 0;
+    int leaf_tris = kMaxLeafTris;      // per build (vhr_set_option "bvh_leaf_triangles" of the context that builds)
 
-    static uint32_t levels_needed(uint32_t count) {
-        uint32_t leaves = (count + g_leaf_tris - 1) / g_leaf_tris;
+    uint32_t levels_needed(uint32_t count) const {
+        uint32_t leaves = (count + leaf_tris - 1) / leaf_tris;
         uint32_t l = 0;
         while ((1u << l) < leaves) ++l;
         return l;
@@ -79,7 +79,7 @@ struct Builder {
         n.count = count;
         n.depth = depth;
         max_depth = std::max(max_depth, depth);
-        if (count <= uint32_t(g_leaf_tris)) {
+        if (count <= uint32_t(leaf_tris)) {
             nodes[id] = n;
             return id;
         }
@@ -142,7 +142,7 @@ struct Builder {
             std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                              [&](uint32_t a, uint32_t b) {
                                  float ca = centroid[size_t(a) * 3 + axis], cb2 = centroid[size_t(b) * 3 + axis];
-                                 return ca < cb2 || (ca == cb2 && a < b);
+                                 return ca < cb2 || (!(cb2 < ca) && a < b);      // a strict weak order whatever the values (inputs are validated finite)
                              });
         }
         n.count = 0;
@@ -213,8 +213,9 @@ inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((firs
 }  // namespace
 
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out) {
+               uint32_t primitive_count, HostBvh &out, int leaf_tris) {
     Builder b;
+    b.leaf_tris = std::max(1, std::min(kMaxLeafTris, leaf_tris));
     size_t total = 0;
     for (uint32_t p = 0; p < primitive_count; ++p) total += primitives[p].index_count / 3;
     b.tris.reserve(total);

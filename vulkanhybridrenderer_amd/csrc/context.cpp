@@ -2,6 +2,8 @@
 // buffers, the bindless texture table, the storage-image pool and the per-frame uniform data.
 // Reference: src/rendering_backend/resource_manager.{h,cpp}, vulkan_context.cpp.
 #include <cmath>
+#include <chrono>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -26,7 +28,7 @@ uint32_t format_stride(int32_t format) {      // VkUtils::FormatStride, vulkan_u
 
 using namespace vhr;
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;     // vhr_create has no context to carry its message: per thread
 
 #define HIP_TRY(ctx, expr)                                                                                  \
     do {                                                                                                    \
@@ -264,6 +266,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: null array") : VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     // Validate every offset the kernels will dereference (an out-of-range index would fault the GPU).
+    uint64_t total_triangles = 0;
     for (uint32_t p = 0; p < primitive_count; ++p) {
         const vhr_primitive &pr = primitives[p];
         if (uint64_t(pr.index_offset) + pr.index_count > index_count)
@@ -274,13 +277,24 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         const int32_t tex[2] = { pr.material.base_color_texture, pr.material.metallic_roughness_texture };
         for (int32_t t : tex)
             if (t < -1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: negative texture index other than -1");
+        // a NaN / Inf coordinate would reach the builder's bin index (float -> int of a NaN is undefined) and its comparators
+        for (int k = 0; k < 16; ++k)
+            if (!std::isfinite(pr.transform[k])) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: primitive " + std::to_string(p) + " has a non-finite transform");
+        total_triangles += pr.index_count / 3;
     }
+    for (uint32_t v = 0; v < vertex_count; ++v)
+        if (!std::isfinite(vertices[v].pos[0]) || !std::isfinite(vertices[v].pos[1]) || !std::isfinite(vertices[v].pos[2]))
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: vertex " + std::to_string(v) + " has a non-finite position");
+    if (total_triangles >= (1ull << 29))            // a leaf link packs (first triangle << 2 | count - 1) into 31 bits
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: 2^29 triangles or more");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     free_scene(ctx);
 
     HostBvh bvh;
-    build_bvh(vertices, indices, primitives, primitive_count, bvh);          // UpdateBLAS + UpdateTLAS
+    const auto t_build0 = std::chrono::steady_clock::now();
+    build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris);          // UpdateBLAS + UpdateTLAS
+    const auto t_build1 = std::chrono::steady_clock::now();
     std::vector<float> nm(size_t(primitive_count) * 9);
     for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
 
@@ -305,14 +319,24 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     ctx->node_count = uint32_t(bvh.nodes.size());
     ctx->tri_count = uint32_t(bvh.tris.size());
     ctx->bvh_depth = bvh.max_depth;
+    ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
+    ctx->geometry_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
+    return VHR_OK;
+}
+
+int vhr_get_build_times(vhr_context *ctx, double out[2]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    out[0] = ctx->bvh_build_ms;
+    out[1] = ctx->geometry_upload_ms;
     return VHR_OK;
 }
 
 int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t height, const uint8_t *data, int32_t format,
                                      const vhr_sampler_info *sampler_info) {
-    if (!ctx || !data || !width || !height) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
+    // (-1 is the reference's "table exhausted" sentinel, resource_manager.cpp:847-848, and nothing else)
+    if (!ctx || !data || !width || !height) return ctx ? ctx->fail(VHR_ERROR_UNSUPPORTED, "UploadTextureFromData: invalid arguments") : VHR_ERROR_UNSUPPORTED;
     if (format != VHR_FORMAT_R8G8B8A8_SRGB && format != VHR_FORMAT_R8G8B8A8_UNORM)
-        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadTextureFromData: format must be R8G8B8A8_SRGB or R8G8B8A8_UNORM");
+        return ctx->fail(VHR_ERROR_UNSUPPORTED, "UploadTextureFromData: format must be R8G8B8A8_SRGB or R8G8B8A8_UNORM");
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (ctx->textures.size() >= vhr_context::kMaxGlobalResources) { ctx->error = "texture table exhausted"; return -1; }   // resource_manager.cpp:847-848
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -339,9 +363,10 @@ int32_t vhr_upload_texture_from_data(vhr_context *ctx, uint32_t width, uint32_t 
 }
 
 int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t height, int32_t format) {
-    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    // -1 is the reference's "pool exhausted" sentinel (resource_manager.cpp:876-877) and nothing else: every failure is < -1
+    if (!ctx) return VHR_ERROR_UNSUPPORTED;
     const uint32_t bpp = format_stride(format);
-    if (!bpp || !width || !height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UploadNewStorageImage: unsupported format or empty extent");
+    if (!bpp || !width || !height) return ctx->fail(VHR_ERROR_UNSUPPORTED, "UploadNewStorageImage: unsupported format or empty extent");
     if (!ctx->host_only) HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (uint32_t i = 0; i < vhr_context::kMaxGlobalResources; ++i) {         // first free slot, resource_manager.cpp:866-878
         Image &im = ctx->storage_images[i];
@@ -349,15 +374,20 @@ int32_t vhr_upload_new_storage_image(vhr_context *ctx, uint32_t width, uint32_t 
         im = Image{};
         im.width = width; im.height = height; im.format = format; im.bpp = bpp;
         if (ctx->host_only) { im.used = true; return int32_t(i); }
-        HIP_TRY(ctx, hipMalloc(&im.owned, im.bytes()));
-        HIP_TRY(ctx, hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream));
-        im.ptr = im.owned;
-        if (format == VHR_FORMAT_R16G16_SFLOAT) {
-            // svgf.comp reads neighbours of, and rewrites, the moments history in one dispatch
-            // (svgf.comp:72,140-144): keep a second buffer so the dispatch reads a snapshot
-            HIP_TRY(ctx, hipMalloc(&im.alt, im.bytes()));
-            HIP_TRY(ctx, hipMemsetAsync(im.alt, 0, im.bytes(), ctx->stream));
+        // svgf.comp reads neighbours of, and rewrites, the moments history in one dispatch (svgf.comp:72,140-144): an RG16F image
+        // keeps a second buffer so that the dispatch reads a snapshot
+        const bool twin = format == VHR_FORMAT_R16G16_SFLOAT;
+        hipError_t e = hipMalloc(&im.owned, im.bytes());
+        if (e == hipSuccess) e = hipMemsetAsync(im.owned, 0, im.bytes(), ctx->stream);
+        if (e == hipSuccess && twin) e = hipMalloc(&im.alt, im.bytes());
+        if (e == hipSuccess && twin) e = hipMemsetAsync(im.alt, 0, im.bytes(), ctx->stream);
+        if (e != hipSuccess) {                        // nothing half-made stays behind
+            hipFree(im.owned);
+            hipFree(im.alt);
+            im = Image{};
+            return ctx->fail(VHR_ERROR_DEVICE, std::string("UploadNewStorageImage: ") + hipGetErrorString(e));
         }
+        im.ptr = im.owned;
         im.used = true;
         return int32_t(i);
     }
@@ -406,7 +436,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!ctx || !key) return VHR_ERROR_INVALID_ARGUMENT;
     if (!std::strcmp(key, "bvh_leaf_triangles")) {          // applies to the next vhr_update_geometry
         if (value < 1 || value > kMaxLeafTris) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_leaf_triangles must be 1..4");
-        g_leaf_tris = value;
+        ctx->bvh_leaf_tris = value;
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",

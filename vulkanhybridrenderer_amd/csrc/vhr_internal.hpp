@@ -56,7 +56,6 @@ struct BvhTri {
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 
 constexpr int kMaxLeafTris = 4;      // encoding limit of a leaf link
-extern int g_leaf_tris;               // builder's leaf size (<= kMaxLeafTris); tunable for experiments
 constexpr int kMaxBvhDepth = 32;     // builder guarantee == traversal stack capacity
 constexpr int kTraceStack = 32;
 
@@ -111,7 +110,7 @@ struct HostBvh {
 
 // builds the BVH2 (csrc/bvh_build.cpp)
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out);
+               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris);
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
@@ -231,6 +230,8 @@ struct vhr_context {
     float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
+    int bvh_leaf_tris = vhr::kMaxLeafTris;       // "bvh_leaf_triangles": leaf size of this context's next build
+    double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
 
     // RenderGraph state
     std::map<std::string, vhr::PassDescription> pass_descriptions;

@@ -109,10 +109,17 @@ class HybridFrameLoop:
         self.max_motion_rows = int(np.ceil(max_mv))
         self._binding = True
 
+    def frame_slot(self, i):
+        """Which precomputed frame (per-frame data + G-buffer) step i replays.  Beyond the last one the sequence wraps to frame 1,
+        not 0: frame 0 carries the reference's zero previous matrices (renderer.cpp:188), i.e. NaN motion vectors, which
+        svgf.comp maps to texel (0, 0) -- meaningful on the very first frame only (and row 0 is outside every strip but the first)."""
+        n = len(self.pfds)
+        return i if i < n else (1 + (i - 1) % (n - 1) if n > 1 else 0)
+
     def _gbuffer_pass(self, ctx):
         if not self._binding:
             return
-        n, m, d = self.gbuffers[self.current % len(self.gbuffers)]
+        n, m, d = self.gbuffers[self.frame_slot(self.current)]
         ctx.bind_external_image(lib.NORMALS, n.data_ptr())
         ctx.bind_external_image(lib.MOTION, m.data_ptr())
         ctx.bind_external_image(lib.DEPTH, d.data_ptr())
@@ -195,7 +202,7 @@ class HybridFrameLoop:
     def frame(self, i):
         self.current = i
         idx = i % self.frames_in_flight
-        self.ctx.update_per_frame_ubo(idx, self.pfds[i % len(self.pfds)])
+        self.ctx.update_per_frame_ubo(idx, self.pfds[self.frame_slot(i)])
         self.ctx.execute(idx, 0)
 
     def owned_rows(self):
@@ -204,8 +211,8 @@ class HybridFrameLoop:
     def rays_in_frame(self, i, owned_only=True):
         """Unique rays traced by this rank in frame i."""
         if self.world == 1 or not owned_only:
-            return self.covered_pixels[i % len(self.gbuffers)] * self.rays_per_pixel
-        d = self.gbuffers[i % len(self.gbuffers)][2][self.plan.row_begin:self.plan.row_end]
+            return self.covered_pixels[self.frame_slot(i)] * self.rays_per_pixel
+        d = self.gbuffers[self.frame_slot(i)][2][self.plan.row_begin:self.plan.row_end]
         return int(self.torch.count_nonzero(d).item()) * self.rays_per_pixel
 
     def close(self):

@@ -33,7 +33,7 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times",
     "vhr_calibration_stream_read",
 ]
 
@@ -178,6 +178,7 @@ def load():
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_build_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
@@ -290,7 +291,7 @@ class Context:
 
     def upload_new_storage_image(self, width, height, fmt):
         r = self.L.vhr_upload_new_storage_image(self.handle, width, height, fmt)
-        if r < -1:
+        if r < -1:        # -1 = the reference's "pool exhausted" sentinel, returned as is; every failure is below it
             self.check(r, "UploadNewStorageImage")
         return r
 
@@ -473,6 +474,12 @@ class Context:
         out = (C.c_uint64 * 8)()
         self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
         return dict(total=out[0], setup=out[1], refill=out[2], nodes=out[3], leaves=out[4], refills=out[5], waves=out[6], drain_iterations=out[7])
+
+    def build_times_ms(self):
+        """K0: (host BVH build, upload of scene + tree) of the last upload_scene, milliseconds."""
+        out = (C.c_double * 2)()
+        self.check(self.L.vhr_get_build_times(self.handle, out), "build_times")
+        return float(out[0]), float(out[1])
 
     def packet_statistics(self):
         out = (C.c_uint64 * 6)()
