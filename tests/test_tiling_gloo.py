@@ -76,3 +76,22 @@ def test_prepared_exchange_replays(tmp_path, world):
     bad, nops = out.read_text().split()
     assert int(bad) == 0
     assert int(nops) == 4                      # rank 0: one neighbour x two tensors x (send + recv)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_loop_ordering_with_replayed_exchanges(oracle, tmp_path, world):
+    """harness.HybridFrameLoop's per-frame ordering (tiling.StripExchanges: epilogue -> deferred exchange -> next frame's wait)
+    over 6 frames with the replayed descriptor lists, the double-buffered moments history and the deferred gather, on CPU:
+    every rank's owned rows and every gathered frame equal the single-process result bit for bit."""
+    out = tmp_path / "loop.txt"
+    port = 29750 + world
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "frame_exchange_worker.py"), str(out), "64", "120", "6"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    bad, gathers_checked, n_prepared, n_gathers, degraded = (int(v) for v in out.read_text().split())
+    assert bad == 0, f"{bad} frames differ from the single-process result"
+    assert gathers_checked == 5                       # frames 0..4, each checked once its gather had landed
+    assert n_prepared == 2 and n_gathers == 1         # one descriptor list per moments buffer, replayed; one gather
+    assert degraded == 0

@@ -7,8 +7,6 @@ loop contains only the hot path (Raytrace Pass + SVGF Denoise Pass) and, for N >
 PyTorch is plumbing here: device memory for the precomputed G-buffers, the HIP stream, and torch.distributed
 (backend "nccl" == RCCL) for the neighbour exchanges.
 """
-import sys
-
 import numpy as np
 
 from . import abi, camera, lib, tiling
@@ -55,16 +53,8 @@ class HybridFrameLoop:
         self.pfds = camera.dolly_frames(scene, width, height, n_frames, start_frame_index)
         self.current = 0
         self._aliases = {}
-        self._prepared = {}
-        self._pending = None
-        self._gather = None               # tiling.StripGather of the denoised image (C2), built on first use ...
-        self._gathers = {}                # ... per instance of the image (one per frame slot with frames in flight)
-        self.allow_degraded = bool(allow_degraded)
-        self.degraded = []                # fall-backs taken (only ever non-empty with allow_degraded)
-        self._pending_gather = None
-        self.gather = bool(gather) and world > 1 and denoise
-        self.gather_error = None
-        self._use_prepared = True
+        self._gather_requested, self._allow_degraded = bool(gather), bool(allow_degraded)
+        self.exchanges = None             # tiling.StripExchanges, once the strip plan exists (N > 1)
         self.path = lib.HybridRenderPath(self.ctx, shadow_mode=0 if shadow else 2, ambient_occlusion_mode=0 if ao_spp else 2,
                                          reflection_mode=0 if reflections else 2, denoise=denoise, atrous_steps=atrous_steps,
                                          gbuffer_pass=self._gbuffer_pass)
@@ -81,6 +71,8 @@ class HybridFrameLoop:
             self.ctx.set_option("trace_overlap", 1 if self.trace_overlap else 0)
             # the path's own host driver runs the doubling a-trous schedule, so later iterations may compute fewer overlap rows
             self.ctx.set_option("strip_shrink_overlap", 1)
+            self.exchanges = tiling.StripExchanges(dist, self.plan, trace_overlap=self.trace_overlap, denoise=denoise, gather=self._gather_requested,
+                                                   allow_degraded=self._allow_degraded)
             self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
             if denoise:
                 self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)
@@ -133,70 +125,35 @@ class HybridFrameLoop:
             t = self._aliases[key] = alias_tensor(info)
         return t
 
+    # the per-frame communication itself lives in tiling.StripExchanges (shared with the CPU gloo test); these are the hooks
+    @property
+    def gather(self):
+        return self.exchanges.gather if self.exchanges else False
+
+    @property
+    def gather_error(self):
+        return self.exchanges.gather_error if self.exchanges else None
+
+    @property
+    def degraded(self):
+        return self.exchanges.degraded if self.exchanges else []
+
     def finish_pending_exchange(self):
-        if self._pending is not None:
-            self._pending.finish()
-            self._pending = None
-        if self._pending_gather is not None:
-            self._pending_gather.finish()
-            self._pending_gather = None
+        if self.exchanges:
+            self.exchanges.finish_pending()
 
     def gathered_frame(self):
         """Rank 0: the full denoised frame assembled by the last finished gather (a torch tensor), else None."""
-        return self._gather.full if self._gather is not None else None
+        return self.exchanges.gathered_frame() if self.exchanges else None
 
-    def _exchange_raytraced(self, ctx):
-        # exchange #2 of the previous frame (history + moments) was left in flight behind this frame's ray tracing;
-        # it has to land before svgf.comp, which runs right after this epilogue
-        self.finish_pending_exchange()
-        if self.trace_overlap or not self.denoise:
-            return
-        t = self._alias(ctx.transient_info(lib.RAYTRACED))
-        tiling.exchange_rows(self.dist, [t], self.plan, self.plan.overlap)          # exchange #1: on the critical path
+    def _exchange_raytraced(self, ctx):           # epilogue of the Raytrace Pass
+        self.exchanges.after_raytrace(lambda: self._alias(ctx.transient_info(lib.RAYTRACED)))
 
-    def _exchange_history(self, ctx):
-        """Epilogue of the SVGF pass: start C2 (this frame's denoised rows -> rank 0) and exchange #2 (history + moments halo rows
-        for the NEXT frame's svgf.comp), both behind the next frame's ray tracing.  A transport failure is an error: a frame loop
-        that quietly dropped the gather or fell back to per-frame descriptors would report a different (and faster-looking)
-        measurement.  `allow_degraded` restores the old fall-backs for bring-up on a new transport; they are then recorded in
-        `degraded` and bench.py prints them."""
-        if self.gather:                                   # C2
-            den = ctx.transient_info(lib.DENOISED)        # one instance per frame slot with frames in flight
-            try:
-                g = self._gathers.get(int(den.device_ptr))
-                if g is None:
-                    g = self._gathers[int(den.device_ptr)] = tiling.StripGather(self.dist, self._alias(den), self.plan)
-                self._gather = g
-                self._pending_gather = g.start()
-            except Exception as e:   # noqa: BLE001
-                if not self.allow_degraded:
-                    raise
-                self.gather, self._gather, self.gather_error = False, None, repr(e)
-                self.degraded.append(f"strip gather disabled: {e!r}")
-                print(f"[harness] strip gather disabled: {e!r}", file=sys.stderr, flush=True)
-        hist_info = ctx.storage_info(int(self.pc["shadow_and_ao_history"]))
-        mom_info = ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"]))            # current (just written) buffer
-        hist, mom = self._alias(hist_info), self._alias(mom_info)
-        if self.dist.get_backend() == "gloo":             # CPU transport (CI route): staged through host memory every frame
-            self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)
-            return
-        # RCCL: the descriptors of this exchange are built once per (history, moments) buffer pair -- the moments history
-        # alternates between two buffers -- and replayed every frame
-        if self._use_prepared:
-            try:
-                key = (int(hist_info.device_ptr), int(mom_info.device_ptr))
-                prepared = self._prepared.get(key)
-                if prepared is None:
-                    prepared = self._prepared[key] = tiling.PreparedExchange(self.dist, [hist, mom], self.plan, self.plan.halo)
-                self._pending = prepared.start()          # consumed by the NEXT frame
-                return
-            except Exception as e:   # noqa: BLE001
-                if not self.allow_degraded:
-                    raise
-                self._use_prepared = False
-                self.degraded.append(f"prepared exchange disabled: {e!r}")
-                print(f"[harness] prepared exchange disabled: {e!r}", file=sys.stderr, flush=True)
-        self._pending = tiling.start_exchange(self.dist, [hist, mom], self.plan, self.plan.halo)
+    def _exchange_history(self, ctx):             # epilogue of the SVGF Denoise Pass
+        den = self._alias(ctx.transient_info(lib.DENOISED))                                   # one instance per frame slot
+        hist = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_history"])))
+        mom = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))    # the buffer just written
+        self.exchanges.after_svgf(den, hist, mom)
 
     # ---- one frame of the hot path ----
     def frame(self, i):

@@ -221,3 +221,82 @@ def exchange_rows(dist, tensors, plan, n_rows, group=None):
     pending = start_exchange(dist, tensors, plan, n_rows, group)
     if pending is not None:
         pending.finish()
+
+
+class StripExchanges:
+    """One rank's per-frame communication, as hooked into the two pass epilogues of the render graph (harness.HybridFrameLoop) --
+    kept here, transport-agnostic, so that tests/test_tiling_gloo.py drives the very same ordering on CPU tensors over gloo:
+
+        Raytrace Pass epilogue   after_raytrace():  the PREVIOUS frame's exchange #2 and gather have been in flight behind this
+                                 frame's ray tracing; they land now (stream wait), before svgf.comp reads the history halo.
+                                 With trace_overlap off, exchange #1 (E rows of raw visibility) happens here, blocking.
+        SVGF pass epilogue       after_svgf():  start the gather (C2) of this frame's denoised rows and exchange #2 (history +
+                                 moments halo rows for the NEXT frame's svgf.comp); neither is waited for.
+
+    Descriptors are built once per distinct buffer set and replayed (PreparedExchange / StripGather, keyed by data pointers: the
+    moments history alternates between two buffers, and with frames in flight the denoised image has one instance per slot).
+    Device tensors under gloo (several ranks sharing one GPU in CI) are staged through the host every frame instead.
+    A transport failure is an error unless `allow_degraded`, in which case the fall-back taken is listed in `degraded`."""
+
+    def __init__(self, dist, plan, trace_overlap=True, denoise=True, gather=True, allow_degraded=False, group=None):
+        self.dist, self.plan, self.group = dist, plan, group
+        self.trace_overlap, self.denoise = bool(trace_overlap), bool(denoise)
+        self.gather = bool(gather) and plan.world > 1 and self.denoise
+        self.allow_degraded = bool(allow_degraded)
+        self.degraded, self.gather_error = [], None
+        self._prepared, self._gathers = {}, {}
+        self._use_prepared = True
+        self._pending = self._pending_gather = None
+        self._last_gather = None
+
+    def finish_pending(self):
+        if self._pending is not None:
+            self._pending.finish()
+            self._pending = None
+        if self._pending_gather is not None:
+            self._pending_gather.finish()
+            self._pending_gather = None
+
+    def gathered_frame(self):
+        """Root rank: the full frame assembled by the last finished gather, else None."""
+        return self._last_gather.full if self._last_gather is not None else None
+
+    def after_raytrace(self, raytraced=None):
+        self.finish_pending()
+        if self.trace_overlap or not self.denoise or self.plan.world == 1:
+            return
+        exchange_rows(self.dist, [raytraced() if callable(raytraced) else raytraced], self.plan, self.plan.overlap, self.group)   # exchange #1
+
+    def _fallback(self, what, e):
+        if not self.allow_degraded:
+            raise e
+        self.degraded.append(f"{what}: {e!r}")
+        import sys
+        print(f"[strips] {what}: {e!r}", file=sys.stderr, flush=True)
+
+    def after_svgf(self, denoised, history, moments):
+        if self.plan.world == 1 or not self.denoise:
+            return
+        staged = self.dist.get_backend(self.group) == "gloo" and history.is_cuda
+        if self.gather:                                   # C2
+            try:
+                g = self._gathers.get(denoised.data_ptr())
+                if g is None:
+                    g = self._gathers[denoised.data_ptr()] = StripGather(self.dist, denoised, self.plan, group=self.group)
+                self._last_gather = g
+                self._pending_gather = g.start()
+            except Exception as e:   # noqa: BLE001
+                self.gather, self._last_gather, self.gather_error = False, None, repr(e)
+                self._fallback("strip gather disabled", e)
+        if self._use_prepared and not staged:             # exchange #2, replayed descriptors
+            try:
+                key = (history.data_ptr(), moments.data_ptr())
+                prepared = self._prepared.get(key)
+                if prepared is None:
+                    prepared = self._prepared[key] = PreparedExchange(self.dist, [history, moments], self.plan, self.plan.halo, self.group)
+                self._pending = prepared.start()          # consumed by the NEXT frame
+                return
+            except Exception as e:   # noqa: BLE001
+                self._use_prepared = False
+                self._fallback("prepared exchange disabled (descriptors rebuilt every frame)", e)
+        self._pending = start_exchange(self.dist, [history, moments], self.plan, self.plan.halo, self.group)
