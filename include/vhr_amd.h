@@ -292,6 +292,46 @@ int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_ou
  * history images are filled by the caller's neighbour exchange (vulkanhybridrenderer_amd/tiling.py over RCCL). */
 int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo);
 
+/* ---- C1 / C2: the row-strip decomposition's exchanges inside the library (RCCL point-to-point, one process per GPU) ----------
+ * The reference is single-GPU (one queue, renderer.cpp:135); these calls exist for an integrator that shards the framebuffer by
+ * row strips.  The row arithmetic follows the reference's SVGF schedule (hybrid_render_path.cpp:288-329:
+ * the published image is the output of a-trous iteration n-2, iteration i reads +-2*2^i rows) and is the one
+ * vulkanhybridrenderer_amd/tiling.py uses (tests/test_comm_plan.py compares the two).  RCCL is loaded on first use.
+ * N > 1 has not run on hardware yet (rounds 1-2 had one GPU): world size 1 is smoke-tested, the planner is tested on the CPU. */
+typedef struct vhr_strip_plan {
+    uint32_t rank, world, height;
+    uint32_t row_begin, row_end;     /* owned rows [g*H/N, (g+1)*H/N) */
+    uint32_t overlap;                /* E: rows the SVGF kernels recompute beyond the strip (30 for the reference's 5 iterations) */
+    uint32_t halo;                   /* Hh = E + ceil(max |motion.y| * H) + 2: rows of history / moments fetched from each neighbour */
+} vhr_strip_plan;
+typedef struct vhr_row_exchange { int32_t peer; uint32_t send_begin, send_end, recv_begin, recv_end; } vhr_row_exchange;
+#define VHR_COMM_UNIQUE_ID_BYTES 128
+typedef struct vhr_comm vhr_comm;
+
+uint32_t vhr_atrous_overlap(uint32_t atrous_steps);
+uint32_t vhr_atrous_output_extent(uint32_t overlap, uint32_t step);     /* what "strip_shrink_overlap" makes an a-trous launch compute */
+/* VHR_ERROR_OUT_OF_SLOTS when the thinnest strip is thinner than the history halo (use fewer GPUs or a taller image) */
+int vhr_strip_plan_make(uint32_t height, uint32_t world, uint32_t rank, uint32_t max_motion_rows, uint32_t atrous_steps, vhr_strip_plan *out);
+/* the neighbours' row ranges of an n_rows-deep halo; returns their number (0..2) */
+int vhr_strip_plan_exchanges(const vhr_strip_plan *plan, uint32_t n_rows, vhr_row_exchange out[2]);
+
+int vhr_comm_get_unique_id(uint8_t out[VHR_COMM_UNIQUE_ID_BYTES]);      /* ncclGetUniqueId on one rank; the caller hands it to the others */
+/* ncclCommInitRank + vhr_set_strip(plan): collective over the `world` processes of the plan */
+int vhr_comm_create(vhr_context *ctx, const vhr_strip_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out);
+void vhr_comm_destroy(vhr_comm *comm);
+const char *vhr_comm_last_error(const vhr_comm *comm);
+/* Raytrace Pass epilogue, only with "trace_overlap" off: the overlap rows of the raw shadow / AO image from the neighbours, in the
+ * context's stream order (exchange #1). */
+int vhr_comm_exchange_raytraced(vhr_comm *comm, const char *raytraced_image);
+/* SVGF pass epilogue: exchange #2 (halo rows of the history and of the moments history just written, for the NEXT frame's
+ * svgf.comp) and, if denoised_image != NULL, the gather of every rank's owned rows into `gathered_frame` on `root` (a device
+ * buffer of the whole image there).  Issued on the communicator's own stream behind the context's work so far -- beside the next
+ * frame's ray tracing -- and not waited for. */
+int vhr_comm_start_frame_exchanges(vhr_comm *comm, int32_t history_storage_image, int32_t moments_storage_image, const char *denoised_image,
+                                   int32_t root, void *gathered_frame);
+/* Raytrace Pass epilogue of the next frame: the context's stream waits for them (no host synchronisation). */
+int vhr_comm_finish_frame_exchanges(vhr_comm *comm);
+
 /* Statistics of the last vhr_trace_rays: out[0] = unique rays traced, out[1] = rays the reference would
  * issue (4x duplicate shadow ray, raygen.rgen:38-40), out[2] = covered (non-sky) pixels, out[3] = traversal
  * stack overflows (must be 0).  Requires vhr_set_ray_statistics(ctx, 1) (costs one counter flush per pass). */

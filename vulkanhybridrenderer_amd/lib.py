@@ -33,7 +33,9 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
+    "vhr_strip_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
 
@@ -81,6 +83,16 @@ class CompositionDesc(C.Structure):
                 ("ssao_image", C.c_char_p), ("shadow_map_image", C.c_char_p)]
 
 
+class StripPlanC(C.Structure):
+    """vhr_strip_plan (include/vhr_amd.h): the C planner's row strip, field for field tiling.StripPlan."""
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
+                ("overlap", C.c_uint32), ("halo", C.c_uint32)]
+
+
+class RowExchangeC(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("send_begin", C.c_uint32), ("send_end", C.c_uint32), ("recv_begin", C.c_uint32), ("recv_end", C.c_uint32)]
+
+
 class HybridSettings(C.Structure):
     _fields_ = [("shadow_mode", C.c_int32), ("ambient_occlusion_mode", C.c_int32), ("reflection_mode", C.c_int32),
                 ("denoise_shadow_and_ao", C.c_int32), ("atrous_steps", C.c_int32)]
@@ -101,6 +113,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VhrError(f"{LIB_PATH} is missing: build it with `make -C vulkanhybridrenderer_amd/csrc` "
                        "(there is no CPU or pure-Python fallback)")
+    # One HIP runtime (and one RCCL) per process.  PyTorch's wheel bundles its own libamdhip64 / librccl; libvhr_amd.so links
+    # the ROCm installation's.  The loader merges them by soname only when torch's copies are loaded FIRST -- the other way round
+    # the process ends up with two HIP runtimes, of which the second finds no device (measured: ncclCommInitRank fails with "no
+    # ROCm-capable device", and the process aborts at exit).  torch is this package's plumbing for device memory and
+    # torch.distributed anyway, so it goes first whenever it is installed; a C / C++ host without torch has one runtime by itself.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
     L.vhr_create.argtypes = [C.POINTER(CreateInfo), C.POINTER(vp)]
@@ -179,6 +200,21 @@ def load():
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_build_times.argtypes = [vp, C.POINTER(C.c_double)]
+    L.vhr_atrous_overlap.restype = u32
+    L.vhr_atrous_overlap.argtypes = [u32]
+    L.vhr_atrous_output_extent.restype = u32
+    L.vhr_atrous_output_extent.argtypes = [u32, u32]
+    L.vhr_strip_plan_make.argtypes = [u32, u32, u32, u32, u32, C.POINTER(StripPlanC)]
+    L.vhr_strip_plan_exchanges.argtypes = [C.POINTER(StripPlanC), u32, C.POINTER(RowExchangeC)]
+    L.vhr_comm_get_unique_id.argtypes = [C.c_char_p]
+    L.vhr_comm_create.argtypes = [vp, C.POINTER(StripPlanC), C.c_char_p, C.POINTER(vp)]
+    L.vhr_comm_destroy.argtypes = [vp]
+    L.vhr_comm_destroy.restype = None
+    L.vhr_comm_last_error.argtypes = [vp]
+    L.vhr_comm_last_error.restype = C.c_char_p
+    L.vhr_comm_exchange_raytraced.argtypes = [vp, C.c_char_p]
+    L.vhr_comm_start_frame_exchanges.argtypes = [vp, i32, i32, C.c_char_p, i32, vp]
+    L.vhr_comm_finish_frame_exchanges.argtypes = [vp]
     L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
@@ -618,4 +654,57 @@ class RaytracedRenderPath:
     def destroy(self):
         if self.handle:
             self.ctx.L.vhr_raytraced_destroy(self.handle)
+            self.handle = None
+
+
+def strip_plan(height, world, rank, max_motion_rows, atrous_steps=5):
+    """vhr_strip_plan_make: the C planner (csrc/comm.cpp).  None when the strips are thinner than the history halo."""
+    p = StripPlanC()
+    rc = load().vhr_strip_plan_make(height, world, rank, max_motion_rows, atrous_steps, C.byref(p))
+    if rc == -4:                      # VHR_ERROR_OUT_OF_SLOTS
+        return None
+    if rc != 0:
+        raise VhrError(f"vhr_strip_plan_make: {rc}")
+    return p
+
+
+def strip_plan_exchanges(plan, n_rows):
+    out = (RowExchangeC * 2)()
+    n = load().vhr_strip_plan_exchanges(C.byref(plan), n_rows, out)
+    return [(out[i].peer, (out[i].send_begin, out[i].send_end), (out[i].recv_begin, out[i].recv_end)) for i in range(n)]
+
+
+class Comm:
+    """vhr_comm_*: the strip exchanges inside the library (RCCL).  One per context and process."""
+
+    def __init__(self, ctx, plan, unique_id):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        ctx.check(ctx.L.vhr_comm_create(ctx.handle, C.byref(plan), unique_id, C.byref(self.handle)), "vhr_comm_create")
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load().vhr_comm_get_unique_id(buf)
+        if rc != 0:
+            raise VhrError(f"vhr_comm_get_unique_id: {rc} (RCCL not available?)")
+        return buf.raw
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VhrError(f"{what}: {self.ctx.L.vhr_comm_last_error(self.handle).decode()}")
+
+    def exchange_raytraced(self, image=RAYTRACED):
+        self._check(self.ctx.L.vhr_comm_exchange_raytraced(self.handle, image.encode()), "vhr_comm_exchange_raytraced")
+
+    def start_frame_exchanges(self, history, moments, denoised=None, root=0, gathered_frame_ptr=None):
+        self._check(self.ctx.L.vhr_comm_start_frame_exchanges(self.handle, history, moments, denoised.encode() if denoised else None, root,
+                                                              gathered_frame_ptr), "vhr_comm_start_frame_exchanges")
+
+    def finish_frame_exchanges(self):
+        self._check(self.ctx.L.vhr_comm_finish_frame_exchanges(self.handle), "vhr_comm_finish_frame_exchanges")
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.L.vhr_comm_destroy(self.handle)
             self.handle = None
