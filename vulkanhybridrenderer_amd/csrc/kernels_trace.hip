@@ -728,6 +728,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     if (setup_wave) s_vis[lane] = 0;
     const uint32_t first_kind = (a.tp.shadow_enable && !PACKET) ? 0u : 1u;       // PACKET: the shadow rays never enter the queue
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
+    // the queue holds AO rays only (shadow rays off, or walked as a packet): the cut is pruned to their reach ("cut_reach")
+    const bool ao_only = first_kind != 0u && cut_reach != 0u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // CUT: bounds of the tile's ray origins
     f3 pk_origin = f3{ 0.0f, 0.0f, 0.0f }, pk_dir = f3{ 0.0f, 0.0f, 1.0f };              // PACKET: this pixel's shadow ray
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
         if (PACKET && a.tp.shadow_enable) { pk_origin = origin; pk_dir = ray_direction(a.tp, seed, 0u, L, N); }   // rgen:32-35, whole wave
-        if (CUT) ao_reach = a.tp.ao_tmax * onb_norm_bound(N);
+        if (CUT && ao_only) ao_reach = a.tp.ao_tmax * onb_norm_bound(N);      // (wave-uniform condition)
         if (CUT) { omin = origin; omax = origin; }
         if (PREGEN) {
             for (uint32_t kind = first_kind; kind <= last_kind; ++kind) {
@@ -778,8 +780,6 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (stats) t_packet = __builtin_readcyclecounter() - tp0;
     }
     uint32_t cut_n = 0;
-    // the queue holds AO rays only (shadow rays off, or walked as a packet above): the cut is pruned to their reach
-    const bool ao_only = first_kind != 0u && cut_reach != 0u;
     if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f);
     if (STATS) n_cut_entries = cut_n;
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t tile_x0 = (bx * WAVES + wave) * TW, tile_y0 = a.row_begin + by * TH;
     const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;
+    const bool ao_only = first_kind != 0u && cut_reach != 0u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
     float ao_reach = 0.0f;
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             s_ray[3][p] = __uint_as_float(nraw.x); s_ray[4][p] = __uint_as_float(nraw.y);
             omin = f3{ fminf(omin.x, origin.x), fminf(omin.y, origin.y), fminf(omin.z, origin.z) };
             omax = f3{ fmaxf(omax.x, origin.x), fmaxf(omax.y, origin.y), fmaxf(omax.z, origin.z) };
-            ao_reach = fmaxf(ao_reach, a.tp.ao_tmax * onb_norm_bound(N));
+            if (ao_only) ao_reach = fmaxf(ao_reach, a.tp.ao_tmax * onb_norm_bound(N));
         }
         const unsigned long long m = __ballot(covered);
         cov_masks[sub] = m;
@@ -1065,7 +1066,6 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    const bool ao_only = first_kind != 0u && cut_reach != 0u;
     if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kWideCutMax);
     uint32_t emask = 0;
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
