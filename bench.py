@@ -405,7 +405,12 @@ def main():
                 # what actually bounds the kernel: issue of its vector instructions (PMC: lanes 96-97 % active, traffic 1.2-1.3 x algorithmic)
                 "valu": None if not valu else {
                     "insts_per_launch": valu, "floor_us": round(valu_floor_us, 2), "frac": round(valu_floor_us / atrous_us, 4) if atrous_us > 0 else None,
-                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 4 cycles / (1024 SIMDs x 2.4 GHz)"},
+                    # measured on this chip (scratch/issue_rates.hip, profiles/r2_issue_rates.txt): with 8 waves resident a SIMD issues a vector
+                    # instruction every ~2 cycles, not every 4 (4-5 is what ONE wave alone gets)
+                    "floor_us_at_measured_issue_rate": round(valu_floor_us / 2.0, 2),
+                    "frac_at_measured_issue_rate": round(valu_floor_us / 2.0 / atrous_us, 4) if atrous_us > 0 else None,
+                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 4 cycles / (1024 SIMDs x 2.4 GHz) "
+                              "as VERDICT r1 defines it; profiles/r2_pmc_stalls.txt: 59 % of the waves' cycles are issue stalls, 20 % memory / LDS waits"},
             },
             "traversal": {
                 "kernel": "raygen_queue_kernel (raygen.rgen's shadow + AO rays + miss.rmiss); the mirror ray runs in reflection_kernel (kernels_us.reflection)",

@@ -246,6 +246,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     const uint32_t n = uint32_t(b.tris.size());
     out.nodes.clear();
     out.nodes16.clear();
+    out.nodes_ch.clear();
     out.tris.clear();
     out.max_depth = 0;
     if (n == 0) return;
@@ -282,7 +283,36 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         (which == 0 ? node.child0 : node.child1) = link;
     };
 
+    // centre / half-extent twin of every node (BvhNodeCH): c +- h must contain [lo, hi] in exact arithmetic
+    auto finalize_ch = [&]() {
+        out.nodes_ch.resize(out.nodes.size());
+        for (size_t k = 0; k < out.nodes.size(); ++k) {
+            const BvhNode &nd = out.nodes[k];
+            BvhNodeCH c{};
+            for (int which = 0; which < 2; ++which) {
+                const float *box = which == 0 ? nd.box0 : nd.box1;
+                float *hdst = which == 0 ? c.h0 : c.h1;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = box[2 * a], hi = box[2 * a + 1];
+                    float cc = 0.0f, hh = -1.0f;                   // absent child: never entered
+                    if (lo <= hi) {
+                        cc = 0.5f * lo + 0.5f * hi;
+                        hh = std::max(hi - cc, cc - lo);
+                        hh += (std::fabs(cc) + hh) * 2.4e-7f;      // 4 ulp of the magnitudes involved
+                        while (double(cc) - double(hh) > double(lo) || double(cc) + double(hh) < double(hi)) hh = std::nextafter(hh, inf);
+                    }
+                    (a == 0 ? c.cx : a == 1 ? c.cy : c.cz)[which] = cc;
+                    hdst[a] = hh;
+                }
+            }
+            c.child0 = nd.child0;
+            c.child1 = nd.child1;
+            out.nodes_ch[k] = c;
+        }
+    };
+
     auto finalize16 = [&]() {
+        finalize_ch();
         float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
         for (const BvhNode &nd : out.nodes)
             for (int a = 0; a < 3; ++a) {

@@ -40,6 +40,7 @@ vhr::DeviceScene vhr_context::device_scene() const {
     DeviceScene s;
     s.nodes = d_nodes;
     s.nodes16 = d_nodes16;
+    s.nodes_ch = d_nodes_ch;
     s.centre[0] = bvh_centre[0]; s.centre[1] = bvh_centre[1]; s.centre[2] = bvh_centre[2];
     s.pad0 = 0.0f;
     s.tris = d_tris;
@@ -204,9 +205,9 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
 
 static void free_scene(vhr_context *ctx) {
     hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
-    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_tris);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_tris);
     ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_tris = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_tris = nullptr;
     ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
 }
 
@@ -311,6 +312,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_normal_matrices), nm.data(), sizeof(float) * nm.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
     for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
     ctx->vertex_count = vertex_count;

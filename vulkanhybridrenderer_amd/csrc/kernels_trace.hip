@@ -450,6 +450,29 @@ __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 n
     return tn <= tf;
 }
 
+// Both child boxes of a centre / half-extent node (BvhNodeCH) against one ray: `ainv` = |1/d|.  The centre terms of the two boxes
+// share one packed FMA per axis; a box's (near, far) pair of an axis is ONE packed FMA (-h and +h through neg_lo on the same
+// register), so no per-axis min / max is needed: 9 FMAs + 8 min / max per node instead of 6 + 20.  Culling only (see BvhNodeCH).
+template <typename V4>
+__device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q2, f3 inv, f3 ainv, f3 noi, float tmin, float tlimit,
+                                            bool &h0, bool &h1, float &tn0, float &tn1) {
+    const f2v cix = __builtin_elementwise_fma(f2v{ q0.x, q0.y }, f2v{ inv.x, inv.x }, f2v{ noi.x, noi.x });
+    const f2v ciy = __builtin_elementwise_fma(f2v{ q0.z, q0.w }, f2v{ inv.y, inv.y }, f2v{ noi.y, noi.y });
+    const f2v ciz = __builtin_elementwise_fma(f2v{ q1.x, q1.y }, f2v{ inv.z, inv.z }, f2v{ noi.z, noi.z });
+    const f2v x0 = __builtin_elementwise_fma(f2v{ -q1.z, q1.z }, f2v{ ainv.x, ainv.x }, f2v{ cix.x, cix.x });
+    const f2v y0 = __builtin_elementwise_fma(f2v{ -q1.w, q1.w }, f2v{ ainv.y, ainv.y }, f2v{ ciy.x, ciy.x });
+    const f2v z0 = __builtin_elementwise_fma(f2v{ -q2.x, q2.x }, f2v{ ainv.z, ainv.z }, f2v{ ciz.x, ciz.x });
+    const f2v x1 = __builtin_elementwise_fma(f2v{ -q2.y, q2.y }, f2v{ ainv.x, ainv.x }, f2v{ cix.y, cix.y });
+    const f2v y1 = __builtin_elementwise_fma(f2v{ -q2.z, q2.z }, f2v{ ainv.y, ainv.y }, f2v{ ciy.y, ciy.y });
+    const f2v z1 = __builtin_elementwise_fma(f2v{ -q2.w, q2.w }, f2v{ ainv.z, ainv.z }, f2v{ ciz.y, ciz.y });
+    tn0 = hw_max3(x0.x, y0.x, hw_max(z0.x, tmin));
+    tn1 = hw_max3(x1.x, y1.x, hw_max(z1.x, tmin));
+    const float tf0 = hw_min3(x0.y, y0.y, hw_min(z0.y, tlimit));
+    const float tf1 = hw_min3(x1.y, y1.y, hw_min(z1.y, tlimit));
+    h0 = tn0 <= tf0;
+    h1 = tn1 <= tf1;
+}
+
 // 1/d for the slab test.  A zero (or denormal) component must not become inf: fma(lo, inf, -o*inf) is NaN on one
 // side of the slab only, which would cull boxes the ray is inside of.  1e30 keeps lo * inv finite for any scene
 // coordinate and classifies "parallel to the slab" correctly: inside -> (-huge, +huge), outside -> both beyond tmax.
@@ -624,6 +647,7 @@ __device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &s
                                                             const float tmax, const uint32_t lane, PacketCounters &pc) {
     const f3 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
     const f3 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+    const f3 ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
     float tmin_v = tmin, tmax_v = tmax;               // VGPR copies for the asm-operand min / max of the slab test
     asm volatile("" : "+v"(tmin_v), "+v"(tmax_v));
     unsigned long long occluded = 0;
@@ -632,12 +656,12 @@ __device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &s
     int node = 0;
     for (;;) {
         if (node >= 0) {
-            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(sc.nodes + node);
+            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(sc.nodes_ch + node);
             const v4f q0 = np[0], q1 = np[1], q2 = np[2];
             const v4i links = *(uniform_i4_ptr)(np + 3);
             float tn0, tn1;
-            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax_v, tn0);
-            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax_v, tn1);
+            bool h0, h1;
+            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax_v, h0, h1, tn0, tn1);
             const unsigned long long m0 = __ballot(h0) & active, m1 = __ballot(h1) & active;
             if (STATS) { ++pc.nodes; pc.lane_tests += uint32_t(__popcll(active)); }
             if (m0 != 0 && m1 != 0) {
@@ -785,7 +809,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
-    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tmax = 0.0f;
     int cur = 0, sp = 0;
     uint32_t pix = 0, kind = 0;
@@ -833,13 +857,16 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 // COMPACT boxes are relative to the scene centre: shift the origin used by the slab test (only)
                 const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
+                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 cur = 0; sp = 0;
                 if (CUT) {                            // the ray against the tile's cut: hit subtrees go on its stack
                     emask = 0;
+                    // (the cut's boxes are absolute fp32 boxes whatever the node format)
+                    const f3 noi_cut = COMPACT ? f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) } : noi;
                     for (uint32_t e = 0; e < cut_n; ++e) {
                         const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
                         float tnu;
-                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
+                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
                             if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
                             else emask |= 1u << e;
                         }
@@ -876,11 +903,10 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin_v, tmax, tn1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
-                const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+                const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes_ch + cur);
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2];
                 links = *reinterpret_cast<const int2 *>(np + 3);
-                h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax, tn0);
-                h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax, tn1);
+                box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
             }
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
@@ -1070,7 +1096,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t emask = 0;
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
-    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tmax = 0.0f;
     int cur = 0, sp = 0;
     uint32_t pix = 0, kind = 0;
@@ -1104,6 +1130,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 cur = 0; sp = 0;
                 emask = 0;
                 for (uint32_t e = 0; e < cut_n; ++e) {                                       // the ray against the tile's cut
@@ -1127,12 +1154,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
             ++n_nodes;
-            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes + cur);
+            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes_ch + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const int2 links = *reinterpret_cast<const int2 *>(np + 3);
             float tn0, tn1;
-            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tmax, tn0);
-            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tmax, tn1);
+            bool h0, h1;
+            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
@@ -1283,7 +1310,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
                                                 const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit) {
-    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 };
+    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
     int cur = 0, sp = 0;
@@ -1305,6 +1332,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 fetch(r, pix, ro, rd);
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
                 if (cut_n) {
@@ -1330,12 +1358,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes_ch + cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const int2 links = *reinterpret_cast<const int2 *>(np + 3);
             float tn0, tn1;
-            const bool h0 = box_test_pk(f2v{ q0.x, q0.y }, f2v{ q0.z, q0.w }, f2v{ q1.x, q1.y }, rinv, noi, tmin_v, tbest, tn0);
-            const bool h1 = box_test_pk(f2v{ q1.z, q1.w }, f2v{ q2.x, q2.y }, f2v{ q2.z, q2.w }, rinv, noi, tmin_v, tbest, tn1);
+            bool h0, h1;
+            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
@@ -1614,7 +1642,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
     do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
         // the shared descent ("raygen_cut", default): own-tile waves on the plain fp32 nodes
-        const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile && !ctx->options[kOptCompactNodes];
+        const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile;
+        const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0;
         const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
 #define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
     launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
@@ -1648,6 +1677,11 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             else { if (wv == 2) VHR_LAUNCH_WIDE_S(2, 2); else VHR_LAUNCH_WIDE_S(2, 1); }
 #undef VHR_LAUNCH_WIDE_S
 #undef VHR_LAUNCH_WIDE
+        }
+        else if (compact_cut && tile_rows == 8u && !a.stats) {     // A-B: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of four)
+            const uint32_t bx = (tiles_x + 1) / 2;
+            if (spill) launch(ctx, (raygen_queue_kernel<false, 2, true, false, true, false, true, false>), dim3(bx * tiles_y), dim3(kQueueBlock * 2), stack_bytes * 2, a, levels, threshold, 0u, bx, 0u, early_exit, tile_rows, 0u);
+            else launch(ctx, (raygen_queue_kernel<false, 2, true, false, false, false, true, false>), dim3(bx * tiles_y), dim3(kQueueBlock * 2), stack_bytes * 2, a, levels, threshold, 0u, bx, 0u, early_exit, tile_rows, 0u);
         }
         else if (cut) {
             if (a.stats) { if (spill) VHR_LAUNCH_CUT_W(true, true); else VHR_LAUNCH_CUT_W(false, true); }

@@ -43,6 +43,21 @@ struct BvhNode16 {
 };
 static_assert(sizeof(BvhNode16) == 32, "BvhNode16");
 
+// The node the queue kernels walk (r2): the same two boxes as CENTRE and HALF EXTENT, 64 B.  With c and h the slab distances of an
+// axis are near = c*inv + (-o*inv) - h*|inv|, far = ... + h*|inv|: one packed FMA for the centre term of BOTH boxes, then one
+// packed FMA per box whose two halves are (near, far) directly (neg_lo on the half extent) -- the per-axis min / max pair of the
+// (lo, hi) form disappears: 9 + 8 instead of 6 + 12 + 8 vector instructions per node.  c +- h contains the padded (lo, hi) box
+// (h is widened until it does in exact arithmetic, plus 4 ulp of the coordinates' magnitude), and boxes only cull.
+//   q0 = (c0.x, c1.x, c0.y, c1.y)  q1 = (c0.z, c1.z, h0.x, h0.y)  q2 = (h0.z, h1.x, h1.y, h1.z)  q3 = (child0, child1, 0, 0)
+// An absent child has h = -1 (near > far on every axis).
+struct BvhNodeCH {
+    float cx[2], cy[2], cz[2];
+    float h0[3], h1[3];
+    int32_t child0, child1;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNodeCH) == 64, "BvhNodeCH");
+
 // Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
 // (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
 struct BvhTri {
@@ -70,6 +85,7 @@ struct DeviceTexture {
 struct DeviceScene {
     const BvhNode *nodes;
     const BvhNode16 *nodes16;
+    const BvhNodeCH *nodes_ch;       // centre / half-extent form of `nodes` (same indices, same links)
     float centre[3];                 // origin of the half-precision boxes
     float pad0;
     const BvhTri *tris;
@@ -103,6 +119,7 @@ struct Image {
 struct HostBvh {
     std::vector<BvhNode> nodes;
     std::vector<BvhNode16> nodes16;
+    std::vector<BvhNodeCH> nodes_ch;
     float centre[3] = { 0, 0, 0 };
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
@@ -227,6 +244,7 @@ struct vhr_context {
     float *d_normal_matrices = nullptr;
     vhr::BvhNode *d_nodes = nullptr;
     vhr::BvhNode16 *d_nodes16 = nullptr;
+    vhr::BvhNodeCH *d_nodes_ch = nullptr;
     float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
