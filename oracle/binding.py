@@ -1,8 +1,9 @@
 """ctypes binding of oracle/libvhr_oracle.so (TEST INFRASTRUCTURE ONLY -- see oracle/vhr_oracle.h).
 
-PARITY UNPINNED: the oracle is pinned only by hand-derived known-answer values (tests/golden/) and an
-independent numpy restatement (tests/numpy_restatement.py), because the reference ships no tests and
-cannot be built in this image.
+PARITY UNPINNED for the shaders' arithmetic: the oracle is pinned only by hand-derived known-answer values
+(tests/golden/) and an independent numpy restatement (tests/numpy_restatement.py), because the reference ships no
+tests and cannot be built in this image.  Its struct layouts are pinned against the reference's own glsl_common.h
+(tests/test_reference_pins.py, oracle/ref_probes/).
 """
 import ctypes as C
 import os

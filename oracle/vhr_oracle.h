@@ -11,6 +11,12 @@
  * ray/triangle + BVH arithmetic lives in the Vulkan driver).  The restatement is
  * pinned only by known-answer values derived by hand from the reference's
  * formulas (tests/golden/kat_*.json) and by an independent numpy restatement.
+ * What IS pinned against the reference (round 2, tests/test_reference_pins.py): the
+ * struct layouts below against src/rendering_backend/glsl_common.h itself (compiled
+ * with the reference's glm by oracle/ref_probes/, `make -C oracle ref`, outputs in
+ * tests/golden/ref_abi_layout.json) -- orc_struct_sizes() is part of that test -- and,
+ * on the scene-host side, glm / cgltf / stb_image outputs.  The arithmetic of the
+ * shaders restated in vhr_oracle.c stays unpinned.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference).

@@ -74,6 +74,32 @@ def test_c_header_matches_the_reference_header_field_by_field(tmp_path):
             assert got[f"{name}.{field}"] == want, (name, field)
 
 
+def test_oracle_header_matches_the_reference_header_field_by_field(tmp_path):
+    """oracle/vhr_oracle.h's own copies of the structs (the checker must read the same bytes the product does)."""
+    ref = _layout()
+    names = {"Vertex": "orc_vertex", "Material": "orc_material", "Primitive": "orc_primitive", "DirectionalLight": "orc_directional_light",
+             "PerFrameData": "orc_per_frame_data"}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "vhr_oracle.h"', 'int main(void) {']
+    for name, cname in names.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({cname}));')
+        for field in ref[name]["fields"]:
+            lines.append(f'printf("{name}.{field} %zu %zu\\n", offsetof({cname}, {field}), sizeof((({cname} *)0)->{field}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "orc_abi_probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "orc_abi_probe"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "oracle"), str(src), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n"):
+        if line:
+            k, *v = line.split()
+            got[k] = [int(x) for x in v]
+    for name in names:
+        assert got[name] == [ref[name]["size"]], name
+        for field, want in ref[name]["fields"].items():
+            assert got[f"{name}.{field}"] == want, (name, field)
+
+
 def _glm_cases():
     with open(os.path.join(GOLD, "ref_glm_cases.json")) as f:
         return json.load(f)
