@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1
 mkdir -p $OUT
-run() { name=$1; shift; timeout -k 10 400 python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/cfg_$name.json 2> $OUT/cfg_$name.err || echo "FAILED $name"; }
+run() { name=$1; shift; timeout -k 10 400 python3 $R/bench.py --no-cpu-baseline --no-extras --min-seconds 0.3 "$@" > $OUT/cfg_$name.json 2> $OUT/cfg_$name.err || echo "FAILED $name"; }
 run cfg2_1080p_shadows_only --ao-spp 0 --steps 16
 run cfg3_4k_4spp --width 3840 --height 2160 --ao-spp 4 --steps 16 --max-gbuffers 20
 run cfg4_bistro_1080p_full_hybrid --scene bistro_proc --reflections --steps 16
