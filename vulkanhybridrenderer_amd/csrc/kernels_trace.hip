@@ -44,6 +44,37 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, fl
     return true;
 }
 
+// ray_triangle() without its early returns: the same operations in the same order on the same operands (a lane the branching
+// form would have sent home early computes on and fails the same comparison at the end; det == 0 gives inf / NaN quotients, which
+// fail every comparison, and is tested explicitly as well).  Used by the queue kernels' leaf stage, where the early returns buy
+// nothing (some lane of the wave always goes on) and cost a second memory round trip: the compiler sinks the load of v0 behind
+// the `det == 0` return, so every triangle test waited for memory twice.
+__device__ __forceinline__ bool ray_triangle_any(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax) {
+    const f3 pvec = cross3(d, e2);
+    const float det = dot3(e1, pvec);
+    const float inv = 1.0f / det;
+    const f3 tvec = o - v0;
+    const float uu = dot3(tvec, pvec) * inv;
+    const f3 qvec = cross3(tvec, e1);
+    const float vv = dot3(d, qvec) * inv;
+    const float tt = dot3(e2, qvec) * inv;
+    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
+}
+
+// the same for closest-hit walks: t, u, v of the candidate come back too
+__device__ __forceinline__ bool ray_triangle_nb(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
+    const f3 pvec = cross3(d, e2);
+    const float det = dot3(e1, pvec);
+    const float inv = 1.0f / det;
+    const f3 tvec = o - v0;
+    const float uu = dot3(tvec, pvec) * inv;
+    const f3 qvec = cross3(tvec, e1);
+    const float vv = dot3(d, qvec) * inv;
+    const float tt = dot3(e2, qvec) * inv;
+    t = tt; u = uu; v = vv;
+    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
+}
+
 // Slab test of one child box against [tmin, tlimit]; NaNs from 0 * inf drop out of fminf/fmaxf
 // (IEEE minNum/maxNum), which can only enlarge the interval, i.e. stays conservative.
 __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv,
@@ -934,13 +965,14 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             const uint32_t vv = ~uint32_t(cur);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
+            // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
+            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
             for (uint32_t i = 0; i < count; ++i) {
                 ++n_tris;
                 const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
                 const float4 ta = tp[0], tb = tp[1];
                 const float tcx = reinterpret_cast<const float *>(tp)[8];
-                float t, uu, ww;
-                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax, t, uu, ww)) {
+                if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
                     found = true;
                     break;
                 }
@@ -1182,13 +1214,14 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             const uint32_t vv = ~uint32_t(cur);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
+            // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
+            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
             for (uint32_t i = 0; i < count; ++i) {
                 ++n_tris;
                 const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
                 const float4 ta = tp[0], tb = tp[1];
                 const float tcx = reinterpret_cast<const float *>(tp)[8];
-                float t, uu, ww;
-                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax, t, uu, ww)) {
+                if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
                     found = true;
                     break;
                 }
@@ -1389,7 +1422,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 float t, uu, ww;
-                if (ray_triangle(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
+                if (ray_triangle_nb(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
                     const uint32_t flat = __float_as_uint(tc.w);
                     if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
