@@ -352,6 +352,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)
+ *   "bvh_build_threads" host threads of the next build: 0 = up to 16 of the machine's (default), 1 = the serial build; subtrees below
+ *                      the top of the tree are built by a pool and spliced in -- the tree is the same whatever the count
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
  *                      persistent workgroups that prefetch the next tile into registers (default)
  *   "atrous_blocks_per_cu" (1..64, default 64: more workgroups than tiles per CU at 1080p and 4K, i.e. one tile per workgroup --

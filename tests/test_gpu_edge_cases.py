@@ -202,3 +202,31 @@ def test_non_finite_geometry_is_rejected():
         assert build_ms > 0 and upload_ms > 0
     finally:
         c.close()
+
+
+def test_parallel_bvh_build_makes_the_same_tree():
+    """The host builder's thread pool ("bvh_build_threads"): same node / triangle counts and depth, and the same image bit for bit,
+    with 1, 3 and the default number of threads on a scene large enough to be split (sponza_proc, 257 k triangles)."""
+    scene = scenes.sponza_proc()
+    W, H = 256, 144
+    tp = abi.default_trace_params(reflections=False)
+    pfd = camera.dolly_frames(scene, W, H, 2)[1]
+    ref = None
+    for threads in (1, 3, 0):
+        c = lib.Context(W, H)
+        try:
+            c.set_option("bvh_build_threads", threads)
+            c.upload_scene(scene)
+            c.set_trace_params(tp)
+            path = lib.HybridRenderPath(c, 0, 0, 2, False, 5, lambda ctx: ctx.standin_gbuffer(0))
+            path.build()
+            c.update_per_frame_ubo(0, pfd)
+            c.execute(0, 0)
+            c.synchronize()
+            got = (c.bvh_statistics(), c.download(lib.RAYTRACED))
+            path.destroy()
+        finally:
+            c.close()
+        if ref is None:
+            ref = got
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), threads

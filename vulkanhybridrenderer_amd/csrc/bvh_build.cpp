@@ -15,8 +15,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <limits>
 #include <queue>
+#include <thread>
 
 #include "vhr_internal.hpp"
 
@@ -64,7 +66,19 @@ struct Builder {
         return l;
     }
 
-    int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+    // Subtrees of at most `defer_below` triangles are not built here but recorded in `tasks` (their link is the code
+    // kDeferred - task index): the top of the tree is built by one thread, the subtrees below it by a pool, each into a node
+    // vector of its own, and spliced in afterwards (build_parallel).  `order` is partitioned in place on disjoint ranges, so the
+    // workers share it without locks; the result is the tree the one-thread build makes (same splits: nothing depends on node ids).
+    struct Task { uint32_t first, count, depth; };
+    static constexpr int32_t kDeferred = -1000000000;
+
+    int32_t build(std::vector<TmpNode> &nodes, uint32_t &max_depth, uint32_t first, uint32_t count, uint32_t depth, uint32_t defer_below = 0,
+                  std::vector<Task> *tasks = nullptr) {
+        if (tasks && count <= defer_below && count > uint32_t(leaf_tris)) {
+            tasks->push_back(Task{ first, count, depth });
+            return kDeferred - int32_t(tasks->size() - 1);
+        }
         int32_t id = int32_t(nodes.size());
         nodes.emplace_back();
         TmpNode n;
@@ -147,11 +161,51 @@ struct Builder {
         }
         n.count = 0;
         nodes[id] = n;
-        int32_t l = build(first, mid - first, depth + 1);
-        int32_t r = build(mid, first + count - mid, depth + 1);
+        int32_t l = build(nodes, max_depth, first, mid - first, depth + 1, defer_below, tasks);
+        int32_t r = build(nodes, max_depth, mid, first + count - mid, depth + 1, defer_below, tasks);
         nodes[id].left = l;
         nodes[id].right = r;
         return id;
+    }
+
+    void build_parallel(uint32_t n, int threads) {
+        const unsigned hw = threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (hw == 1 || n < 32768u) {                     // small scenes: one thread
+            build(nodes, max_depth, 0, n, 0);
+            return;
+        }
+        std::vector<Task> tasks;
+        build(nodes, max_depth, 0, n, 0, std::max<uint32_t>(4096u, n / (8u * hw)), &tasks);
+        std::vector<std::vector<TmpNode>> sub(tasks.size());
+        std::vector<uint32_t> sub_depth(tasks.size(), 0);
+        std::atomic<size_t> next{ 0 };
+        auto worker = [&]() {
+            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+                sub[k].reserve(size_t(tasks[k].count));
+                build(sub[k], sub_depth[k], tasks[k].first, tasks[k].count, tasks[k].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < hw; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        // splice: a subtree's nodes keep their relative links, its root replaces the deferred code in the top tree
+        std::vector<int32_t> root_of(tasks.size());
+        const size_t top = nodes.size();
+        for (size_t k = 0; k < tasks.size(); ++k) {
+            const int32_t offset = int32_t(nodes.size());
+            root_of[k] = offset;
+            for (TmpNode t : sub[k]) {
+                if (t.left >= 0) { t.left += offset; t.right += offset; }
+                nodes.push_back(t);
+            }
+            max_depth = std::max(max_depth, sub_depth[k]);
+        }
+        for (size_t i = 0; i < top; ++i) {
+            TmpNode &t = nodes[i];
+            if (t.left <= kDeferred) t.left = root_of[size_t(kDeferred - t.left)];
+            if (t.right <= kDeferred) t.right = root_of[size_t(kDeferred - t.right)];
+        }
     }
 };
 
@@ -213,7 +267,7 @@ inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((firs
 }  // namespace
 
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris) {
+               uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads) {
     Builder b;
     b.leaf_tris = std::max(1, std::min(kMaxLeafTris, leaf_tris));
     size_t total = 0;
@@ -268,7 +322,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         b.order[i] = i;
     }
     b.nodes.reserve(size_t(n));
-    b.build(0, n, 0);
+    b.build_parallel(n, threads);
     out.max_depth = b.max_depth;
 
     out.tris.resize(n);

@@ -294,7 +294,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
 
     HostBvh bvh;
     const auto t_build0 = std::chrono::steady_clock::now();
-    build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris);          // UpdateBLAS + UpdateTLAS
+    build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
     const auto t_build1 = std::chrono::steady_clock::now();
     std::vector<float> nm(size_t(primitive_count) * 9);
     for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
@@ -439,6 +439,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!std::strcmp(key, "bvh_leaf_triangles")) {          // applies to the next vhr_update_geometry
         if (value < 1 || value > kMaxLeafTris) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_leaf_triangles must be 1..4");
         ctx->bvh_leaf_tris = value;
+        return VHR_OK;
+    }
+    if (!std::strcmp(key, "bvh_build_threads")) {            // applies to the next vhr_update_geometry; the tree does not depend on it
+        if (value < 0 || value > 64) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_build_threads must be 0..64");
+        ctx->bvh_build_threads = value;
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",

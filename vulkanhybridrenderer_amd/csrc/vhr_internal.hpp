@@ -127,7 +127,7 @@ struct HostBvh {
 
 // builds the BVH2 (csrc/bvh_build.cpp)
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris);
+               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
@@ -249,6 +249,7 @@ struct vhr_context {
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
     int bvh_leaf_tris = vhr::kMaxLeafTris;       // "bvh_leaf_triangles": leaf size of this context's next build
+    int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
     double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
 
     // RenderGraph state
