@@ -432,8 +432,9 @@ int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]);
  * one (tiles with covered pixels), out[1] = wave-level inner-node visits, out[2] = wave-level triangle tests, out[3] = still
  * undecided lanes summed over those steps (active-lane utilisation of the packets = out[3] / (64 * (out[1] + out[2]))),
  * out[4] = s_memtime ticks spent in the packets; out[5] = entries of the tiles' tree cuts ("raygen_cut"), summed over the
- * waves of the launch (traversal cycles out[6]): what "cut_reach" prunes. */
-int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[6]);
+ * waves of the launch (traversal cycles out[6]): what "cut_reach" prunes; out[6..8] = wave-level trips made after the tile's queue
+ * had run dry with at most 4 / 8 / 16 of the wave's rays still in flight (the tail of the drain). */
+int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[9]);
 
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */

@@ -301,6 +301,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     out.nodes.clear();
     out.nodes16.clear();
     out.nodes_ch.clear();
+    out.nodes48.clear();
     out.tris.clear();
     out.max_depth = 0;
     if (n == 0) return;
@@ -362,6 +363,26 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             c.child0 = nd.child0;
             c.child1 = nd.child1;
             out.nodes_ch[k] = c;
+        }
+        // the 48-byte form: half extents as the upper half of their fp32 pattern, rounded up (away from zero for the -1 of an
+        // absent child, which is exact anyway)
+        auto upper16 = [](float h) -> uint32_t {
+            uint32_t bits;
+            std::memcpy(&bits, &h, 4);
+            if (h > 0.0f && (bits & 0xffffu)) bits += 0x10000u;      // next value with 16 zero bits below (an overflow would give +inf: no finite h gets there)
+            return bits >> 16;
+        };
+        out.nodes48.resize(out.nodes_ch.size());
+        for (size_t k = 0; k < out.nodes_ch.size(); ++k) {
+            const BvhNodeCH &c = out.nodes_ch[k];
+            BvhNode48 n{};
+            for (int w = 0; w < 2; ++w) { n.cx[w] = c.cx[w]; n.cy[w] = c.cy[w]; n.cz[w] = c.cz[w]; }
+            n.hp[0] = (upper16(c.h0[0]) << 16) | upper16(c.h0[1]);
+            n.hp[1] = (upper16(c.h0[2]) << 16) | upper16(c.h1[0]);
+            n.hp[2] = (upper16(c.h1[1]) << 16) | upper16(c.h1[2]);
+            n.child0 = c.child0;
+            n.child1 = c.child1;
+            out.nodes48[k] = n;
         }
     };
 

@@ -41,6 +41,7 @@ vhr::DeviceScene vhr_context::device_scene() const {
     s.nodes = d_nodes;
     s.nodes16 = d_nodes16;
     s.nodes_ch = d_nodes_ch;
+    s.nodes48 = d_nodes48;
     s.centre[0] = bvh_centre[0]; s.centre[1] = bvh_centre[1]; s.centre[2] = bvh_centre[2];
     s.pad0 = 0.0f;
     s.tris = d_tris;
@@ -205,9 +206,9 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
 
 static void free_scene(vhr_context *ctx) {
     hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
-    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_tris);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
     ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_tris = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_tris = nullptr;
     ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
 }
 
@@ -313,6 +314,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes48), bvh.nodes48.data(), sizeof(BvhNode48) * bvh.nodes48.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
     for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
     ctx->vertex_count = vertex_count;
@@ -496,11 +498,12 @@ int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]) {
     return VHR_OK;
 }
 
-int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[6]) {
+int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[9]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     const RayStats &r = ctx->h_ray_stats;
     out[0] = r.packets; out[1] = r.packet_nodes; out[2] = r.packet_triangles; out[3] = r.packet_lane_tests; out[4] = r.cycles_packet; out[5] = r.cut_entries;
+    out[6] = r.drain_le4; out[7] = r.drain_le8; out[8] = r.drain_le16;
     return VHR_OK;
 }
 

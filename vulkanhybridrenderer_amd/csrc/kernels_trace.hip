@@ -504,6 +504,20 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
     h1 = tn1 <= tf1;
 }
 
+// One visit's worth of a 48-byte node (BvhNode48): three 16-byte loads, the half extents widened back to fp32 words (first of a
+// pair = the word itself, second = one shift), links from the third load.  Feeds box_pair_ch unchanged.
+struct Node48Words { float4 q0, q1, q2; int2 links; };
+__device__ __forceinline__ Node48Words load_node48(const BvhNode48 *nodes, int cur) {
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + uint32_t(cur) * uint32_t(sizeof(BvhNode48)));
+    const float4 r0 = np[0], r1 = np[1], r2 = np[2];
+    Node48Words n;
+    n.q0 = r0;
+    n.q1 = make_float4(r1.x, r1.y, r1.z, __uint_as_float(__float_as_uint(r1.z) << 16));
+    n.q2 = make_float4(r1.w, __uint_as_float(__float_as_uint(r1.w) << 16), r2.x, __uint_as_float(__float_as_uint(r2.x) << 16));
+    n.links = int2{ __float_as_int(r2.y), __float_as_int(r2.z) };
+    return n;
+}
+
 // 1/d for the slab test.  A zero (or denormal) component must not become inf: fma(lo, inf, -o*inf) is NaN on one
 // side of the slab only, which would cull boxes the ray is inside of.  1e30 keeps lo * inv finite for any scene
 // coordinate and classifies "parallel to the slab" correctly: inside -> (-huge, +huge), outside -> both beyond tmax.
@@ -848,6 +862,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
     uint32_t overflow = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;      // statistics (only flushed when stats)
+    uint32_t n_drain_le4 = 0, n_drain_le8 = 0, n_drain_le16 = 0;
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
@@ -934,10 +949,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin_v, tmax, tn1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
-                const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes_ch + cur);
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-                links = *reinterpret_cast<const int2 *>(np + 3);
-                box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
+                const Node48Words nw = load_node48(a.scene.nodes48, cur);
+                links = nw.links;
+                box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
             }
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
@@ -1003,7 +1017,13 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
             for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
             n_wave_trips += tn + tt;
-            if (next >= total) n_drain_trips += tn + tt;    // trips made after the tile's queue ran dry (nothing left to refill with)
+            if (next >= total) {
+                n_drain_trips += tn + tt;    // trips made after the tile's queue ran dry (nothing left to refill with)
+                const uint32_t live = uint32_t(__popcll(__ballot(has)));   // rays still in flight after this round of trips
+                if (live <= 4u) n_drain_le4 += tn + tt;
+                if (live <= 8u) n_drain_le8 += tn + tt;
+                if (live <= 16u) n_drain_le16 += tn + tt;
+            }
         }
     }
     if (SHARED) __syncthreads(); else wave_lds_sync();
@@ -1021,6 +1041,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             if (ovf) atomicAdd(&stats->stack_overflows, (unsigned long long)__popcll(ovf));
             atomicAdd(&stats->wave_iterations, (unsigned long long)n_wave_trips);
             atomicAdd(&stats->drain_iterations, (unsigned long long)n_drain_trips);
+            atomicAdd(&stats->drain_le4, (unsigned long long)n_drain_le4);
+            atomicAdd(&stats->drain_le8, (unsigned long long)n_drain_le8);
+            atomicAdd(&stats->drain_le16, (unsigned long long)n_drain_le16);
             atomicAdd(&stats->cycles_total, __builtin_readcyclecounter() - t_start);
             atomicAdd(&stats->cycles_setup, t_setup);
             atomicAdd(&stats->cycles_refill, t_refill);
@@ -1186,9 +1209,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
             ++n_nodes;
-            const float4 *np = reinterpret_cast<const float4 *>(a.scene.nodes_ch + cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            const Node48Words nw = load_node48(a.scene.nodes48, cur);
+            const float4 q0 = nw.q0, q1 = nw.q1, q2 = nw.q2;
+            const int2 links = nw.links;
             float tn0, tn1;
             bool h0, h1;
             box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
@@ -1391,9 +1414,9 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes_ch + cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            const int2 links = *reinterpret_cast<const int2 *>(np + 3);
+            const Node48Words nw = load_node48(sc.nodes48, cur);
+            const float4 q0 = nw.q0, q1 = nw.q1, q2 = nw.q2;
+            const int2 links = nw.links;
             float tn0, tn1;
             bool h0, h1;
             box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);

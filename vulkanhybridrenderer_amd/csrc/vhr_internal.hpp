@@ -58,6 +58,21 @@ struct BvhNodeCH {
 };
 static_assert(sizeof(BvhNodeCH) == 64, "BvhNodeCH");
 
+// BvhNodeCH in 48 bytes = THREE 16-byte loads per visit instead of four (the any-hit queue kernel is bound by the number of vector
+// memory instructions its waves issue: ~20 cycles of the CU's address unit each, whatever their width -- profiles/r2_pmc_memory.txt).
+// Centres stay fp32; the six half extents are stored as the UPPER 16 BITS of their fp32 pattern, rounded up, two per word:
+//   hp[0] = (h0.x, h0.y)  hp[1] = (h0.z, h1.x)  hp[2] = (h1.y, h1.z)     (first in bits 31..16, second in bits 15..0)
+// A kernel reads the first of a pair by using the word as the fp32 it is (the second's bits only enlarge the mantissa: a still
+// larger half extent) and the second with one shift.  Larger half extents only cull less; results are unchanged.
+//   q0 = (c0.x, c1.x, c0.y, c1.y)  q1 = (c0.z, c1.z, hp[0], hp[1])  q2 = (hp[2], child0, child1, 0)
+struct BvhNode48 {
+    float cx[2], cy[2], cz[2];
+    uint32_t hp[3];
+    int32_t child0, child1;
+    int32_t pad;
+};
+static_assert(sizeof(BvhNode48) == 48, "BvhNode48");
+
 // Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
 // (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
 struct BvhTri {
@@ -86,6 +101,7 @@ struct DeviceScene {
     const BvhNode *nodes;
     const BvhNode16 *nodes16;
     const BvhNodeCH *nodes_ch;       // centre / half-extent form of `nodes` (same indices, same links)
+    const BvhNode48 *nodes48;        // the same in 48 bytes (same indices, same links)
     float centre[3];                 // origin of the half-precision boxes
     float pad0;
     const BvhTri *tris;
@@ -120,6 +136,7 @@ struct HostBvh {
     std::vector<BvhNode> nodes;
     std::vector<BvhNode16> nodes16;
     std::vector<BvhNodeCH> nodes_ch;
+    std::vector<BvhNode48> nodes48;
     float centre[3] = { 0, 0, 0 };
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
@@ -191,6 +208,7 @@ struct RayStats {
     // shadow packets ("shadow_packet"): waves that walked one, wave-level node visits and triangle tests, undecided lanes summed
     // over those steps (lane utilisation = packet_lane_tests / (64 * (packet_nodes + packet_triangles))), s_memtime ticks
     unsigned long long packets, packet_nodes, packet_triangles, packet_lane_tests, cycles_packet, cut_entries;
+    unsigned long long drain_le4, drain_le8, drain_le16;     // drain trips made with at most 4 / 8 / 16 rays of the wave still in flight
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
@@ -245,6 +263,7 @@ struct vhr_context {
     vhr::BvhNode *d_nodes = nullptr;
     vhr::BvhNode16 *d_nodes16 = nullptr;
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
+    vhr::BvhNode48 *d_nodes48 = nullptr;
     float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;

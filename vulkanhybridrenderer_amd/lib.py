@@ -518,9 +518,10 @@ class Context:
         return float(out[0]), float(out[1])
 
     def packet_statistics(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 9)()
         self.check(self.L.vhr_get_packet_statistics(self.handle, out), "packet_statistics")
-        d = dict(packets=out[0], node_visits=out[1], triangle_tests=out[2], lane_tests=out[3], cycles=out[4], cut_entries=out[5])
+        d = dict(packets=out[0], node_visits=out[1], triangle_tests=out[2], lane_tests=out[3], cycles=out[4], cut_entries=out[5],
+                 drain_trips_le4=out[6], drain_trips_le8=out[7], drain_trips_le16=out[8])
         d["active_lane_utilisation"] = out[3] / (64.0 * (out[1] + out[2])) if out[1] + out[2] else 0.0
         return d
 
