@@ -529,6 +529,11 @@ __device__ __forceinline__ float cull_reciprocal(float d) {
     return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : r;
 }
 
+// Rank of this lane among the set bits of a wave mask: v_mbcnt_lo / v_mbcnt_hi (no per-lane (1 << lane) - 1 mask to keep in registers)
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+}
+
 constexpr int kQueueBlock = 64;
 constexpr int kStackSentinel = int(0x80000000u);   // not a node (>= 0) and not a leaf code the builder can emit
 constexpr uint32_t kMaxPregenKinds = 17;       // 1 shadow + up to 16 AO samples pre-generated into LDS (13 KB)
@@ -602,6 +607,11 @@ __device__ __forceinline__ float onb_norm_bound(f3 n) {
     return bound == bound ? bound : 3.0e38f;            // a NaN normal prunes nothing
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f *uniform_f4_ptr;         // constant address space + uniform address = SMEM loads
+typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
+
 // The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
 // origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -) --
 // and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
@@ -637,12 +647,12 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };          // box of `node` (the root: everything)
     bool open = true;                                                                      // `node` still waits for its entry
     for (int it = 0; it < max_entries - 2; ++it) {
-        const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
-        const float4 v0 = np[0], v1 = np[1], v2 = np[2];
-        const int2 vl = *reinterpret_cast<const int2 *>(np + 3);
-        const float4 q0 = make_float4(uni(v0.x), uni(v0.y), uni(v0.z), uni(v0.w)), q1 = make_float4(uni(v1.x), uni(v1.y), uni(v1.z), uni(v1.w)),
-                     q2 = make_float4(uni(v2.x), uni(v2.y), uni(v2.z), uni(v2.w));
-        const int2 links = int2{ __builtin_amdgcn_readfirstlane(vl.x), __builtin_amdgcn_readfirstlane(vl.y) };
+        // a uniform address in the constant address space: the node arrives through the scalar cache (s_load), not through the
+        // vector memory path the walk itself is bound by
+        const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(nodes + node);
+        const v4f q0 = np[0], q1 = np[1], q2 = np[2];
+        const v4i vl = ((uniform_i4_ptr)np)[3];
+        const int2 links = int2{ vl.x, vl.y };
         const bool in0 = q0.x <= omin.x && omax.x <= q0.y && q0.z <= omin.y && omax.y <= q0.w && q1.x <= omin.z && omax.z <= q1.y;
         const bool in1 = q1.z <= omin.x && omax.x <= q1.w && q2.x <= omin.y && omax.y <= q2.y && q2.z <= omin.z && omax.z <= q2.w;
         const bool follow0 = links.x >= 0 && in0, follow1 = !follow0 && links.y >= 0 && in1;
@@ -680,10 +690,6 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
 // the per-ray arithmetic of box_test_pk), a lane whose ray meets a triangle passes the tests of every box above it, so the
 // packet visits that leaf, and any-hit visibility is an OR over triangles in any order.
 // ---------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) v4f *uniform_f4_ptr;         // constant address space + uniform address = SMEM loads
-typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 
 struct PacketCounters { uint32_t nodes, triangles, lane_tests; };
 
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     }
     const unsigned long long cov_mask = __ballot(covered);
     uint32_t ncov = uint32_t(__popcll(cov_mask));
-    if (covered) s_list[__popcll(cov_mask & ((1ull << lane) - 1ull))] = uint8_t(lane);
+    if (covered) s_list[lane_rank(cov_mask)] = uint8_t(lane);
     if (SHARED) {
         if (threadIdx.x == 0) { s_ncov = ncov; s_next = 0; }
         __syncthreads();
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 if (int(lane) == leader) base = atomicAdd(&s_next, n_idle);
                 next = __shfl(base, leader);
             }
-            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            const uint32_t r = next + lane_rank(idle);
             next += n_idle;
             if (!has && r < total) {
                 // k = r / ncov without the integer division (~25 instructions): the queue is kind-major, k < kinds
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         }
         const unsigned long long m = __ballot(covered);
         cov_masks[sub] = m;
-        if (covered) s_list[ncov + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        if (covered) s_list[ncov + lane_rank(m)] = uint8_t(p);
         ncov += uint32_t(__popcll(m));
     }
     wave_lds_sync();
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const unsigned long long t0 = stats ? __builtin_readcyclecounter() : 0ull;
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
             ++n_refills;
-            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            const uint32_t r = next + lane_rank(idle);
             next += n_idle;
             if (!has && r < total) {
                 uint32_t k = 0, rr = r;
@@ -1382,7 +1388,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = uint32_t(__popcll(idle));
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {                 // wave-uniform
-            const uint32_t r = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+            const uint32_t r = next + lane_rank(idle);
             next += n_idle;
             if (!has && r < total) {
                 fetch(r, pix, ro, rd);
@@ -1545,7 +1551,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         }
         const unsigned long long m = __ballot(covered);
         covered_mask[sub] = m;
-        if (covered) s_list[ncov + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        if (covered) s_list[ncov + lane_rank(m)] = uint8_t(p);
         ncov += uint32_t(__popcll(m));
     }
     wave_lds_sync();
@@ -1594,7 +1600,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
                 s_ray[3][p] = d2.x; s_ray[4][p] = d2.y; s_ray[5][p] = d2.z;
             }
             const unsigned long long m = __ballot(hit1);
-            if (hit1) s_list[n2 + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+            if (hit1) s_list[n2 + lane_rank(m)] = uint8_t(p);
             n2 += uint32_t(__popcll(m));
         }
         wave_lds_sync();
@@ -1941,7 +1947,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         }
         const unsigned long long m = __ballot(in_range);
         in_mask[sub] = m;
-        if (in_range) s_list[total + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        if (in_range) s_list[total + lane_rank(m)] = uint8_t(p);
         total += uint32_t(__popcll(m));
     }
     wave_lds_sync();
@@ -1980,7 +1986,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             omax = f3{ fmaxf(omax.x, position.x), fmaxf(omax.y, position.y), fmaxf(omax.z, position.z) };
         }
         const unsigned long long m = __ballot(hit);
-        if (hit) s_list[nhit + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = uint8_t(p);
+        if (hit) s_list[nhit + lane_rank(m)] = uint8_t(p);
         nhit += uint32_t(__popcll(m));
     }
     wave_lds_sync();
