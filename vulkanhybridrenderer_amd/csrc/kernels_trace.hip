@@ -619,7 +619,7 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
 __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
-                                                   const int max_entries = kCutMax) {
+                                                   const int max_entries = kCutMax, const uint32_t expand = 0u) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -632,15 +632,25 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
     reach = uni(reach);
     const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
+    // The cut while it is being built: entry e lives in lane e (box, link, and a key: the half area of an inner node's box that
+    // overlaps the bounds of the origins -- what the expansion below picks by -- or 0).
+    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f, e_key = 0.0f;
+    int e_link = 0;
     uint32_t cut_n = 0;
-    auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+    auto gap2_of = [&](float lx, float hx, float ly, float hy, float lz, float hz) {
         const float gx = fmaxf(fmaxf(lx - omax.x, omin.x - hx), 0.0f), gy = fmaxf(fmaxf(ly - omax.y, omin.y - hy), 0.0f),
                     gz = fmaxf(fmaxf(lz - omax.z, omin.z - hz), 0.0f);
-        if ((gx * gx + gy * gy) + gz * gz > reach2) return;                                  // out of every ray's reach
-        if (lane == 0) {
-            s_cut[cut_n][0] = make_float4(lx, hx, ly, hy);
-            s_cut[cut_n][1] = make_float4(lz, hz, __int_as_float(link), 0.0f);
-        }
+        return (gx * gx + gy * gy) + gz * gz;
+    };
+    auto put = [&](uint32_t slot, float lx, float hx, float ly, float hy, float lz, float hz, int link, float gap2) {
+        const float dx = hx - lx, dy = hy - ly, dz = hz - lz;
+        const float key = (link >= 0 && gap2 == 0.0f) ? fmaxf((dx * dy + dy * dz) + dz * dx, 1.0e-30f) : 0.0f;
+        if (lane == slot) { e_lx = lx; e_hx = hx; e_ly = ly; e_hy = hy; e_lz = lz; e_hz = hz; e_link = link; e_key = key; }
+    };
+    auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+        const float g2 = gap2_of(lx, hx, ly, hy, lz, hz);
+        if (g2 > reach2) return;                                                             // out of every ray's reach
+        put(cut_n, lx, hx, ly, hy, lz, hz, link, g2);
         ++cut_n;
     };
     int node = 0;
@@ -673,6 +683,39 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
         }
     }
     if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
+    // ---- expansion ("cut_expand"): the descent stops where the origins straddle both children, usually with half the entries
+    // unused.  Every ray that STARTS inside an entry's box enters it, so an inner entry overlapping the origins' bounds costs most
+    // rays a node visit in memory; replacing it by its two children trades that visit for one more box test out of LDS at refill.
+    // Largest overlapping box first, until the entries are used up.  The cut still covers everything within reach.
+    if (expand) {
+        for (int it = 0; it < max_entries && int(cut_n) < max_entries; ++it) {
+            uint32_t k = (lane < cut_n && e_key > 0.0f) ? ((__float_as_uint(e_key) & ~63u) | lane) : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) k = max(k, uint32_t(__shfl_xor(int(k), off)));
+            k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+            if (k == 0u) break;
+            const uint32_t e = k & 63u;
+            const int link = __builtin_amdgcn_readlane(e_link, e);
+            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(nodes + link);
+            const v4f q0 = np[0], q1 = np[1], q2 = np[2];
+            const v4i vl = ((uniform_i4_ptr)np)[3];
+            const float g0 = gap2_of(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y), g1 = gap2_of(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            const bool keep0 = !(g0 > reach2), keep1 = !(g1 > reach2);
+            if (keep0) put(e, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, vl.x, g0);
+            if (keep1) { put(keep0 ? cut_n : e, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, vl.y, g1); if (keep0) ++cut_n; }
+            if (!keep0 && !keep1) {                                                        // nothing of it within reach: the last entry takes its place
+                --cut_n;
+                const float mlx = __shfl(e_lx, int(cut_n)), mhx = __shfl(e_hx, int(cut_n)), mly = __shfl(e_ly, int(cut_n)), mhy = __shfl(e_hy, int(cut_n)),
+                            mlz = __shfl(e_lz, int(cut_n)), mhz = __shfl(e_hz, int(cut_n)), mkey = __shfl(e_key, int(cut_n));
+                const int mlink = __shfl(e_link, int(cut_n));
+                if (lane == e) { e_lx = mlx; e_hx = mhx; e_ly = mly; e_hy = mhy; e_lz = mlz; e_hz = mhz; e_key = mkey; e_link = mlink; }
+            }
+        }
+    }
+    if (lane < cut_n) {
+        s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
+        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link), 0.0f);
+    }
     wave_lds_sync();
     return cut_n;
 }
@@ -804,7 +847,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t first_kind = (a.tp.shadow_enable && !PACKET) ? 0u : 1u;       // PACKET: the shadow rays never enter the queue
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
     // the queue holds AO rays only (shadow rays off, or walked as a packet): the cut is pruned to their reach ("cut_reach")
-    const bool ao_only = first_kind != 0u && cut_reach != 0u;
+    const bool ao_only = first_kind != 0u && (cut_reach & 1u) != 0u;      // cut_reach: bit 0 = prune by reach, bit 1 = expand the cut
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // CUT: bounds of the tile's ray origins
     f3 pk_origin = f3{ 0.0f, 0.0f, 0.0f }, pk_dir = f3{ 0.0f, 0.0f, 1.0f };              // PACKET: this pixel's shadow ray
@@ -855,7 +898,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (stats) t_packet = __builtin_readcyclecounter() - tp0;
     }
     uint32_t cut_n = 0;
-    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f);
+    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u);
     if (STATS) n_cut_entries = cut_n;
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
@@ -1113,7 +1156,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t tile_x0 = (bx * WAVES + wave) * TW, tile_y0 = a.row_begin + by * TH;
     const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;
-    const bool ao_only = first_kind != 0u && cut_reach != 0u;
+    const bool ao_only = first_kind != 0u && (cut_reach & 1u) != 0u;      // cut_reach: bit 0 = prune by reach, bit 1 = expand the cut
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
     float ao_reach = 0.0f;
@@ -1153,7 +1196,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kWideCutMax);
+    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kWideCutMax, cut_reach & 2u);
     uint32_t emask = 0;
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
@@ -1707,10 +1750,11 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile;
         const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0;
         const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
+        const uint32_t cut_flags = (ctx->options[kOptCutReach] != 0 ? 1u : 0u) | (ctx->options[kOptCutExpand] != 0 ? 2u : 0u);
 #define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
     launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
            stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
-           uint32_t(ctx->options[kOptCutReach] != 0))
+           cut_flags)
 #define VHR_LAUNCH_CUT(WV, SP, ST) do { if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
 #define VHR_LAUNCH_CUT_W(SP, ST) \
     do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
@@ -1731,7 +1775,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const bool wspill = wlevels < ctx->bvh_depth + 1u;
 #define VHR_LAUNCH_WIDE(SUBT, WV, SP, ST) \
     launch(ctx, (raygen_wide_kernel<SUBT, WV, SP, ST>), dim3(blocks_x * wtiles_y), dim3(kQueueBlock * WV), wstack_bytes * WV, a, wlevels, threshold, blocks_x, \
-           early_exit, uint32_t(ctx->options[kOptCutReach] != 0))
+           early_exit, cut_flags)
 #define VHR_LAUNCH_WIDE_S(SUBT, WV) \
     do { if (a.stats) { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, true); else VHR_LAUNCH_WIDE(SUBT, WV, false, true); } \
          else { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, false); else VHR_LAUNCH_WIDE(SUBT, WV, false, false); } } while (0)
