@@ -938,11 +938,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 // k = r / ncov without the integer division (~25 instructions): the queue is kind-major, k < kinds
                 uint32_t k = 0, rr = r;
                 while (rr >= ncov) { rr -= ncov; ++k; }
-                kind = k + first_kind;
+                kind = (cut_reach & 4u) ? last_kind - k : k + first_kind;     // "shadow_last": the shadow rays at the END of the queue
                 pix = s_list[rr];
                 ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
                 if (PREGEN) {
-                    const float *slot = s_dir + k * 3u * kQueueBlock + pix;
+                    const float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + pix;
                     rd = f3{ slot[0], slot[kQueueBlock], slot[2 * kQueueBlock] };
                 } else {
                     rd = ray_direction(a.tp, __float_as_uint(s_ray[6][pix]), kind, L, f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] });
@@ -1750,7 +1750,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile;
         const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0;
         const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
-        const uint32_t cut_flags = (ctx->options[kOptCutReach] != 0 ? 1u : 0u) | (ctx->options[kOptCutExpand] != 0 ? 2u : 0u);
+        const uint32_t cut_flags = (ctx->options[kOptCutReach] != 0 ? 1u : 0u) | (ctx->options[kOptCutExpand] != 0 ? 2u : 0u) | (ctx->options[kOptShadowLast] != 0 ? 4u : 0u);
 #define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
     launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
            stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
