@@ -81,19 +81,45 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel
 
     float prev_shadow = 0.0f, prev_ao = 0.0f, sum = 0.0f;
     float psm0 = 0.0f, psm1 = 0.0f, pam0 = 0.0f, pam1 = 0.0f;
-    {   // :65-77 -- the four bilinear taps.  All twelve gathers are issued before any is consumed (addresses
-        // clamped into the image, the in-bounds test applied afterwards), so their latencies overlap.
+    {   // :65-77 -- the four bilinear taps.  The two taps of a row are neighbouring texels: ONE load fetches both (16 bytes of an
+        // RGBA16F image at 8-byte alignment, 8 bytes of the RG16F one at 4 -- the CU's address unit charges per load instruction,
+        // not per byte: profiles/r2_pmc_memory.txt), six gathers instead of twelve, all issued before any is consumed.  The pair
+        // starts at column clamp(ax, 0, W - 2); a tap outside the image is rejected below whatever was loaded for it.
+        struct __attribute__((aligned(8))) Pair8 { uint2 t[2]; };
+        struct __attribute__((aligned(4))) Pair4 { uint32_t t[2]; };
         uint2 pn[4], hs[4];
         uint32_t mo[4];
         bool inb[4];
+        if (a.width >= 2u) {
+            const int x0 = min(max(ax, 0), int(a.width) - 2);
+            Pair8 pnp[2], hsp[2];
+            Pair4 mop[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sx = ax + (i & 1), sy = ay + (i >> 1);
-            inb[i] = sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h && uint32_t(sx) < a.width && uint32_t(sy) < a.height;
-            const size_t sidx = size_t(min(max(sy, 0), int(a.height) - 1)) * a.width + size_t(min(max(sx, 0), int(a.width) - 1));
-            pn[i] = a.prev_normals[sidx];
-            hs[i] = a.history[sidx];
-            mo[i] = a.moments_in[sidx];
+            for (int r = 0; r < 2; ++r) {
+                const size_t sidx = size_t(min(max(ay + r, 0), int(a.height) - 1)) * a.width + size_t(x0);
+                pnp[r] = *reinterpret_cast<const Pair8 *>(a.prev_normals + sidx);
+                hsp[r] = *reinterpret_cast<const Pair8 *>(a.history + sidx);
+                mop[r] = *reinterpret_cast<const Pair4 *>(a.moments_in + sidx);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sx = ax + (i & 1), sy = ay + (i >> 1);
+                inb[i] = sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h && uint32_t(sx) < a.width && uint32_t(sy) < a.height;
+                const bool second = sx > x0;            // (in bounds: sx is x0 or x0 + 1)
+                pn[i] = second ? pnp[i >> 1].t[1] : pnp[i >> 1].t[0];
+                hs[i] = second ? hsp[i >> 1].t[1] : hsp[i >> 1].t[0];
+                mo[i] = second ? mop[i >> 1].t[1] : mop[i >> 1].t[0];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sx = ax + (i & 1), sy = ay + (i >> 1);
+                inb[i] = sx >= 0 && sy >= 0 && float(sx) < a.display_w && float(sy) < a.display_h && uint32_t(sx) < a.width && uint32_t(sy) < a.height;
+                const size_t sidx = size_t(min(max(sy, 0), int(a.height) - 1)) * a.width + size_t(min(max(sx, 0), int(a.width) - 1));
+                pn[i] = a.prev_normals[sidx];
+                hs[i] = a.history[sidx];
+                mo[i] = a.moments_in[sidx];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
