@@ -606,7 +606,11 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
     constexpr int NP = (TH + PASS - 1) / PASS;       // passes = texels prefetched per thread
     constexpr int NK = (R + 3) / 4;                  // output pixels per thread
     static_assert(TW <= 256, "one thread per staged column");
-    __shared__ uint4 s_a[TH][TW];                    // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
+    // (a plain 16-byte vector type: the tap's texel is then ONE ds_read_b128; as HIP's uint4 struct the compiler fetched it as
+    // ds_read2_b64 = two 8-byte reads at a 16-byte lane stride, each a two-way bank conflict: 44.4 -> 43.5 us.  Packing nz and the id
+    // into one word as well -- two LDS reads per tap instead of three -- was measured slower, 44.8 us: the id compare then needs a mask)
+    typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
+    __shared__ lds_u4 s_a[TH][TW];                   // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
     __shared__ float s_nz[TH][TW];
     // ids are 16-bit patterns.  With STEP == 1 the taps' ids are neighbours in LDS and the compiler merges their loads into
     // ds_read_b64 / b96 at 2-byte alignment, which the LDS serialises (the step-1 launch ran 20 % behind the others: 56.7 vs
@@ -709,7 +713,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                         if ((idb & 0x7fffu) == 0u) idb = 0u;
                         if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;
                     }
-                    s_a[kk][c] = va;
+                    s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
                     s_nz[kk][c] = nz;
                     s_id[kk][c] = IdSlot(idb);
                 }
@@ -726,7 +730,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             const int k = ty + 4 * kq;
             const int cy = y0 + k * STEP;
             if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
-            const uint4 pa = s_a[k + 2][tx + 2 * STEP];
+            const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
             const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
             const float2 p_zw = unpack_rg16f(pa.z);
             const half2_t np_xy = as_half2(pa.w);
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             float s2 = p_zw.x, s3 = p_zw.y;
 #pragma unroll
             for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
-                uint4 qa[4];
+                lds_u4 qa[4];
                 f2v d[2];
                 bool same[4];
                 float kern[4];
