@@ -453,6 +453,11 @@ int vhr_get_build_times(vhr_context *ctx, double out[2]);
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */
 int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);
+/* Self-check of the last build (exact arithmetic, on the host): out[0] = child boxes checked, out[1] = centre / half-extent boxes that
+ * do not contain their (lo, hi) box, out[2] = 48-byte-node boxes that do not contain the centre / half-extent box (or whose links differ),
+ * out[3] = half-precision ("compact_nodes") boxes that do not contain theirs.  All three must be 0: the walkers' bit-identity with the
+ * oracle rests on box tests that only cull. */
+int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -230,3 +230,26 @@ def test_parallel_bvh_build_makes_the_same_tree():
         if ref is None:
             ref = got
         assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), threads
+
+
+def test_every_node_form_contains_its_box():
+    """The walkers read three derived node forms (centre / half extent, the same in 48 bytes with 16-bit half extents, half-precision
+    compact nodes); box tests only cull, so bit-identity with the oracle needs every derived box to CONTAIN the builder's (lo, hi) box in
+    exact arithmetic.  The library checks that on the host after every build (vhr_get_bvh_form_checks); here: the two benchmark scenes,
+    the tiny scene, and a scene far from the origin with very small and very large triangles (where fp32 centres lose bits and the
+    half extents span 12 orders of magnitude)."""
+    import dataclasses
+    rng = np.random.default_rng(7)
+    tiny = scenes.tiny_scene()
+    v = tiny.vertices.copy()
+    v["pos"] = v["pos"] * rng.choice(np.array([1e-4, 1.0, 3e3], np.float32), size=(len(v), 1)).astype(np.float32) + np.float32(12345.678)
+    far = dataclasses.replace(tiny, name="tiny_far", vertices=v)
+    for scene in (tiny, scenes.sponza_proc(0.5), scenes.bistro_proc(0.25, n_primitives=400, n_textures=4, texture_size=16), far):
+        c = lib.Context(64, 64)
+        try:
+            c.upload_scene(scene)
+            boxes, ch_bad, n48_bad, n16_bad = c.bvh_form_checks()
+            assert boxes == 2 * c.bvh_statistics()["nodes"] and boxes > 0
+            assert (ch_bad, n48_bad, n16_bad) == (0, 0, 0), (scene.name, ch_bad, n48_bad, n16_bad)
+        finally:
+            c.close()

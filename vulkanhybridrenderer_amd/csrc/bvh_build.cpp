@@ -448,4 +448,44 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     finalize16();
 }
 
+// Every derived node form must CONTAIN the (lo, hi) boxes of `nodes` in exact arithmetic -- that is all the walkers' bit-identity
+// rests on (boxes only cull).  out: boxes checked, centre / half-extent boxes that do not contain theirs, 48-byte boxes that do not
+// contain the centre / half-extent box, half-precision (compact) boxes that do not contain theirs.  (vhr_get_bvh_form_checks)
+void check_node_forms(const HostBvh &bvh, uint64_t out[4]) {
+    auto half_value = [](uint16_t h) -> double {
+        const int e = (h >> 10) & 31, m = h & 1023;
+        double v = e == 0 ? std::ldexp(double(m), -24) : (e == 31 ? (m ? std::nan("") : HUGE_VAL) : std::ldexp(double(1024 + m), e - 25));
+        return (h & 0x8000) ? -v : v;
+    };
+    auto upper = [](uint32_t w16) -> double { const uint32_t bits = w16 << 16; float f; std::memcpy(&f, &bits, 4); return double(f); };
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (size_t k = 0; k < bvh.nodes.size(); ++k) {
+        const BvhNode &nd = bvh.nodes[k];
+        const BvhNodeCH &ch = bvh.nodes_ch[k];
+        const BvhNode48 &n48 = bvh.nodes48[k];
+        const BvhNode16 &n16 = bvh.nodes16[k];
+        const double h48[6] = { upper(n48.hp[0] >> 16), upper(n48.hp[0] & 0xffffu), upper(n48.hp[1] >> 16), upper(n48.hp[1] & 0xffffu), upper(n48.hp[2] >> 16), upper(n48.hp[2] & 0xffffu) };
+        for (int which = 0; which < 2; ++which) {
+            const float *box = which == 0 ? nd.box0 : nd.box1;
+            const float *hh = which == 0 ? ch.h0 : ch.h1;
+            ++out[0];
+            for (int a = 0; a < 3; ++a) {
+                const double lo = box[2 * a], hi = box[2 * a + 1];
+                const double c = (a == 0 ? ch.cx : a == 1 ? ch.cy : ch.cz)[which], h = hh[a];
+                const double c48 = (a == 0 ? n48.cx : a == 1 ? n48.cy : n48.cz)[which], hw = h48[3 * which + a];
+                if (!(lo <= hi)) {                           // an absent child: never entered in any form
+                    if (!(h < 0.0)) ++out[1];
+                    if (!(hw < 0.0)) ++out[2];
+                    continue;
+                }
+                if (c - h > lo || c + h < hi) ++out[1];
+                if (c48 != c || hw < h) ++out[2];
+                const double l16 = double(bvh.centre[a]) + half_value(n16.h[6 * which + 2 * a]), h16 = double(bvh.centre[a]) + half_value(n16.h[6 * which + 2 * a + 1]);
+                if (l16 > lo || h16 < hi) ++out[3];
+            }
+        }
+        if (n48.child0 != nd.child0 || n48.child1 != nd.child1 || ch.child0 != nd.child0 || ch.child1 != nd.child1) ++out[2];
+    }
+}
+
 }  // namespace vhr

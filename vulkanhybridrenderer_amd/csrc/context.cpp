@@ -296,6 +296,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HostBvh bvh;
     const auto t_build0 = std::chrono::steady_clock::now();
     build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
+    check_node_forms(bvh, ctx->bvh_form_checks);
     const auto t_build1 = std::chrono::steady_clock::now();
     std::vector<float> nm(size_t(primitive_count) * 9);
     for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
@@ -517,6 +518,12 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     out[0] = ctx->node_count; out[1] = ctx->tri_count; out[2] = ctx->bvh_depth;
     out[3] = uint64_t(ctx->node_count) * sizeof(BvhNode); out[4] = uint64_t(ctx->tri_count) * sizeof(BvhTri);
+    return VHR_OK;
+}
+
+int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    for (int i = 0; i < 4; ++i) out[i] = ctx->bvh_form_checks[i];
     return VHR_OK;
 }
 
