@@ -4,7 +4,7 @@ import numpy as np, torch
 from vulkanhybridrenderer_amd import scenes, lib
 from vulkanhybridrenderer_amd.harness import HybridFrameLoop
 loop = HybridFrameLoop(scenes.sponza_proc(), 1920, 1080, 12)
-ctx = loop.ctx; ctx.set_option("raygen_chain", int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ctx = loop.ctx
 for label, tmax, aot in (("normal", 10000.0, 5.0), ("tmax tiny (no traversal)", 0.0100001, 0.0100001)):
     loop.tp["tmax"] = tmax; loop.tp["ao_tmax"] = aot
     ctx.set_trace_params(loop.tp)
