@@ -359,8 +359,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "atrous_blocks_per_cu" (1..64, default 64: more workgroups than tiles per CU at 1080p and 4K, i.e. one tile per workgroup --
  *                      measured faster than 8 persistent ones by 5 % at 1080p and 10 % at 4K), "atrous_xcd_aware" (default 1):
  *                      launch shape of variant 4
- *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 4 tiles per CU (default),
- *                      0 = never, 1 = always
+ *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 32 8-row tiles per CU (default: a 1080p
+ *                      frame and every strip use 4-row tiles, a 4K frame 8-row ones), 0 = never, 1 = always, 2 / 3 = for step 16 / steps 8 and 16 only
  *   "strip_shrink_overlap" strips only (vhr_set_strip): 1 = an a-trous launch with step s computes the owned rows extended by
  *                      overlap - (4s - 2) rows instead of the full overlap -- all that can be valid, and all that is needed,
  *                      after the reference's doubling schedule 1, 2, 4, ... s (hybrid_render_path.cpp:299-319); only for callers

@@ -1,0 +1,18 @@
+"""a-trous tile height per step size: option atrous_small_tiles -1 (auto) / 2 (4-row tiles for step 16) / 3 (for steps 8 and 16) / 1 (always)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vulkanhybridrenderer_amd import scenes
+from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+loop = HybridFrameLoop(scenes.sponza_proc(), 1920, 1080, 12)
+ctx = loop.ctx
+for v in (-1, -1, 1, 3, 2, -1, 1, 3, 2, -1, 1, 3, 2):
+    ctx.set_option("atrous_small_tiles", v)
+    for i in range(3): loop.frame(i)
+    ctx.set_kernel_timing(["svgf_atrous"]); ctx.kernel_time("svgf_atrous", reset=True)
+    for rep in range(4):
+        for i in range(3, 11): loop.frame(i)
+    torch.cuda.synchronize()
+    ms, k = ctx.kernel_time("svgf_atrous"); ctx.set_kernel_timing(False)
+    print(f"atrous_small_tiles {v}: {ms / 32 * 1e3:.1f} us per frame (5 launches)", flush=True)
+loop.close()

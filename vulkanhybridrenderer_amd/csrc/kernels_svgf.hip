@@ -806,15 +806,17 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
                            uint32_t(ctx->options[kOptAtrousXcdAware]));
 }
 
-// Thin launches (the row strip of one GPU out of 4 or 8) do not fill the chip with 8-row tiles: 195 rows x 1920 are 750
-// tiles for 256 CUs, and the launch then takes as long as one tile does at low occupancy.  Below ~4 tiles per CU the
-// 4-row tile (one pixel per thread, twice the blocks) is used instead.
+// 4-row tiles (one pixel per thread, twice the blocks, 2/3 of the LDS per block) or 8-row tiles (two pixels per thread, a quarter less
+// staging per pixel).  Thin launches -- the row strip of one GPU out of 4 or 8: 195 rows x 1920 are 750 8-row tiles for 256 CUs -- need
+// the smaller tile to fill the chip; measured in r2 (scratch/ab_atrous_tiles.py) the whole 1080p frame does too, 214.5 -> 209.2 us for
+// the five launches (the step-16 launch, whose 8-row tile takes 30 KB of LDS, 48.8 -> 44.6 us), while at 4K (63 8-row tiles per CU)
+// the 8-row tile stays ahead, 154.7 vs 159.2 us per launch.  "atrous_small_tiles" -1 (auto): 4-row tiles below 32 8-row tiles per CU.
 template <int STEP>
 static void launch_atrous_stream_auto(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t tiles8 = ((a.limit_x + kTileX - 1) / kTileX) * ((rows + 8 * STEP - 1) / (8 * STEP)) * STEP;
     const int small = ctx->options[kOptAtrousSmallTiles];        // -1 auto, 0 never, 1 always
-    if (small > 0 || (small < 0 && tiles8 < 4u * uint32_t(ctx->cu_count))) launch_atrous_stream<STEP, 4>(ctx, a);
+    if (small == 1 || (small == 2 && STEP >= 16) || (small == 3 && STEP >= 8) || (small < 0 && tiles8 < 32u * uint32_t(ctx->cu_count))) launch_atrous_stream<STEP, 4>(ctx, a);
     else launch_atrous_stream<STEP, 8>(ctx, a);
 }
 
