@@ -9,11 +9,14 @@ ctx = loop.ctx
 def run(label):
     for i in range(4): loop.frame(i)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(4, 36): loop.frame(i)
-    torch.cuda.synchronize()
-    print(f"{label}: {(time.perf_counter() - t0) / 32 * 1e3:.4f} ms/frame", flush=True)
-ctx.set_kernel_timing(["svgf_atrous"]); run("a-trous event pairs, pass timestamps on (bench)")
+    best = []
+    for rep in range(12):
+        t0 = time.perf_counter()
+        for i in range(4, 36): loop.frame(i)
+        torch.cuda.synchronize()
+        best.append((time.perf_counter() - t0) / 32 * 1e3)
+    print(f"{label}: median {sorted(best)[len(best) // 2]:.4f} ms/frame (min {min(best):.4f})", flush=True)
+ctx.set_kernel_timing(["svgf_atrous"]); run("warm-up"); run("a-trous event pairs, pass timestamps on (bench)")
 ctx.set_kernel_timing(False); run("no kernel event pairs, pass timestamps on")
 ctx.set_option("pass_timestamps", 0); run("no event pairs, no pass timestamps")
 ctx.set_kernel_timing(["svgf_atrous"]); run("a-trous event pairs, no pass timestamps")

@@ -73,7 +73,7 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
         if ((t.seen++ % stride) == 0 && t.used + 2 <= kTimerCapacity) {
             while (t.events.size() < t.used + 2) {
                 hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) break;
+                if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) break;
                 t.events.push_back(e);
             }
             if (t.events.size() >= t.used + 2) {

@@ -300,8 +300,8 @@ int vhr_graph_build(vhr_context *ctx) {
         for (auto &r : p.dependencies) { int rc = actualize(ctx, r); if (rc) return rc; }
         for (auto &r : p.outputs) { writers[r.name].push_back(p.name); int rc = actualize(ctx, r); if (rc) return rc; }
         if (!p.ev_begin && !ctx->host_only) {
-            HIP_TRY(ctx, hipEventCreate(&p.ev_begin));
-            HIP_TRY(ctx, hipEventCreate(&p.ev_end));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_begin, hipEventDisableSystemFence));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_end, hipEventDisableSystemFence));
         }
     }
     int rc = find_execution_order(ctx, writers);
