@@ -351,7 +351,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      the raw visibility needs no neighbour exchange before svgf.comp (default 0: owned rows only)
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
- *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 4)
+ *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 3)
  *   "bvh_build_threads" host threads of the next build: 0 = up to 16 of the machine's (default), 1 = the serial build; subtrees below
  *                      the top of the tree are built by a pool and spliced in -- the tree is the same whatever the count
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with

@@ -86,6 +86,7 @@ struct BvhTri {
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 
 constexpr int kMaxLeafTris = 4;      // encoding limit of a leaf link
+constexpr int kDefaultLeafTris = 3;  // r2, on the 48-byte-node kernel: 3 / 4 -> sponza_proc 351 / 372 us, bistro_proc 511 / 511 us (scratch/ab_leaf.py)
 constexpr int kMaxBvhDepth = 32;     // builder guarantee == traversal stack capacity
 constexpr int kTraceStack = 32;
 
@@ -269,7 +270,7 @@ struct vhr_context {
     float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
-    int bvh_leaf_tris = vhr::kMaxLeafTris;       // "bvh_leaf_triangles": leaf size of this context's next build
+    int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
     double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
 
