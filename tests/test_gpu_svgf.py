@@ -44,6 +44,36 @@ def test_atrous_single_dispatch(oracle, W, H, step):
         h.close()
 
 
+@pytest.mark.parametrize("W,H", [(1, 5), (2, 4), (3, 3), (67, 5)])
+@pytest.mark.parametrize("motion", [(0.4, 0.3), (-1.25, 0.5)])
+def test_temporal_narrow_images(oracle, W, H, motion):
+    """The kernel fetches the two bilinear taps of a row with ONE load starting at column clamp(ax, 0, W - 2) and picks the texel per
+    tap; a one-pixel-wide image takes the tap-by-tap path.  Images one, two and three pixels wide and an odd width, with motion
+    vectors that push taps over every border: bit-exact against the oracle like the wide case."""
+    normals, motion_img, rt = synthetic_svgf_inputs(W, H, seed=11, motion=motion)
+    prev_normals, _, _ = synthetic_svgf_inputs(W, H, seed=11)
+    rng = np.random.default_rng(3)
+    history = rng.random((H, W, 4)).astype(np.float16).view(np.uint16)
+    moments = rng.random((H, W, 2)).astype(np.float16).view(np.uint16)
+    pfd = simple_pfd(W, H)
+    h = None
+
+    def body(ec):
+        ec.dispatch(lib.SVGF_SHADER, (W + 7) // 8, (H + 7) // 8, 1, h.push_constants())
+
+    h = GpuSvgfHarness(W, H, body)
+    try:
+        h.ctx.upload(h.images["prev_normals"], prev_normals)
+        h.ctx.upload(h.images["history"], history)
+        h.ctx.upload(h.images["moments"], moments)
+        h.run(pfd, (normals, motion_img, rt))
+        ref_i, ref_m = oracle.svgf_temporal(pfd, normals, motion_img, rt, prev_normals, history, moments)
+        _close(h.ctx.download(h.images["a"]), ref_i, "temporal integrated", max_steps=0, min_exact=1.0)
+        _close(h.ctx.download(h.images["moments"]), ref_m, "temporal moments", max_steps=0, min_exact=1.0)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("motion", [(0.0, 0.0), (1.25, -0.5), (-3.5, 2.25)])
 def test_temporal_single_dispatch(oracle, motion):
     W, H = 160, 96
