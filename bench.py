@@ -153,6 +153,24 @@ def pmc_valu(args):
         return None
 
 
+def pmc_address_unit(args, raygen_ms):
+    """What bounds the ray-tracing kernel is the CU's address unit (TA): ~20 busy cycles per wave-level load instruction whatever its
+    width or the number of active lanes (profiles/r2_pmc_memory.txt).  The committed PMC run of this workload
+    (tools/pmc_ta.sh -> profiles/raygen_ta.json) gives the load instructions per launch and the TA's busy cycles; `floor_us` is the time
+    the launch needs with the address units of all 256 CUs busy every cycle, `frac` that floor over the launch time measured here."""
+    if (args.width, args.height, args.scene, args.gpus, args.ao_spp) != (1920, 1080, "sponza_proc", 1, 2):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "raygen_ta.json")) as f:
+            ta = json.load(f)
+        floor_us = ta["ta_busy_cycles_sum"] / 256.0 / CLOCK_HZ * 1e6
+        return {"load_instructions_per_launch": ta["wave_level_load_instructions"], "ta_busy_cycles_per_load": ta["ta_cycles_per_load_instruction"],
+                "ta_busy_frac_under_profiler": ta["ta_busy_frac"], "floor_us": round(floor_us, 1), "frac": round(floor_us / max(raygen_ms * 1e3, 1e-9), 4),
+                "source": "profiles/raygen_ta.json (rocprofv3 --pmc TA_TA_BUSY_sum, TA_FLAT_READ_WAVEFRONTS_sum; tools/pmc_ta.sh); floor = TA busy cycles / 256 CUs / 2.4 GHz"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
     """Blocks of exactly `steps` frames, each bracketed by barrier + synchronize, until `min_seconds` have been measured.
     Returns (block seconds, next frame index)."""
@@ -422,6 +440,7 @@ def main():
                 "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
                 "effective_traversal_gbs": round((trav_stats["node_visits"] * 64 + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6, 1),
                 "stack_overflows": int(ray_stats["stack_overflows"]),
+                "address_unit": pmc_address_unit(args, raygen_ms),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
             },
             # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); here a host
