@@ -296,6 +296,8 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HostBvh bvh;
     const auto t_build0 = std::chrono::steady_clock::now();
     build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
+    if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 32))     // the walkers address a 48-byte node with a 32-bit byte offset
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 89 million BVH nodes");
     check_node_forms(bvh, ctx->bvh_form_checks);
     const auto t_build1 = std::chrono::steady_clock::now();
     std::vector<float> nm(size_t(primitive_count) * 9);
