@@ -157,7 +157,7 @@ int32_t vhr_graph_get_image_format(vhr_context *ctx, const char *image_name);
 int vhr_graph_set_pass_epilogue(vhr_context *ctx, const char *render_pass_name,
                                 vhr_external_pass_callback callback, void *user);
 /* extension (interop): point a transient image at externally owned device memory of the same extent and
- * format (what VK_KHR_external_memory import would provide).  NULL restores the context-owned memory. */
+ * format (what VK_KHR_external_memory import would provide), 16-byte aligned.  NULL restores the context-owned memory. */
 int vhr_graph_bind_external_image(vhr_context *ctx, const char *image_name, void *device_ptr);
 
 /* ---------------------------------------------------------------------------------------------

@@ -134,3 +134,19 @@ def test_host_only_context_cannot_compute(ctx):
         ctx.download(lib.DENOISED)
     with pytest.raises(lib.VhrError):
         ctx.update_per_frame_ubo(3, np.zeros((), abi.per_frame_dtype))     # resource_idx < MAX_FRAMES_IN_FLIGHT
+
+
+def test_external_image_binding_rules(ctx):
+    """vhr_graph_bind_external_image: unknown image names and pointers that are not 16-byte aligned are refused (the kernels use
+    16-byte accesses); NULL restores the context-owned memory."""
+    p = lib.HybridRenderPath(ctx, shadow_mode=0, ambient_occlusion_mode=0, reflection_mode=2, denoise=True)
+    p.build()
+    with pytest.raises(lib.VhrError):
+        ctx.bind_external_image("no such image", 0x1000)
+    with pytest.raises(lib.VhrError, match="16-byte aligned"):
+        ctx.bind_external_image(lib.NORMALS, 0x1008)
+    ctx.bind_external_image(lib.NORMALS, 0x10000)                          # (never dereferenced on a host-only context)
+    assert int(ctx.transient_info(lib.NORMALS).device_ptr) == 0x10000
+    ctx.bind_external_image(lib.NORMALS, None)
+    assert int(ctx.transient_info(lib.NORMALS).device_ptr or 0) != 0x10000
+    p.destroy()

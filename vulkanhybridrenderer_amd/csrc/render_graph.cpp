@@ -438,6 +438,8 @@ int vhr_graph_bind_external_image(vhr_context *ctx, const char *image_name, void
     if (!ctx || !image_name) return VHR_ERROR_INVALID_ARGUMENT;
     auto it = ctx->images.find(image_name);
     if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + image_name + "'");
+    if (reinterpret_cast<uintptr_t>(device_ptr) & 15u)           // the kernels read and write these images with up to 16-byte accesses
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, std::string("external memory for '") + image_name + "' must be 16-byte aligned");
     it->second.slot_external[ctx->cur_slot] = device_ptr;       // belongs to the frame slot being recorded (slot 0 without frames in flight)
     it->second.ptr = device_ptr ? device_ptr : it->second.owned;
     return VHR_OK;
