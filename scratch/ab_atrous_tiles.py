@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vulkanhybridrenderer_amd import scenes
 from vulkanhybridrenderer_amd.harness import HybridFrameLoop
-loop = HybridFrameLoop(scenes.sponza_proc(), 1920, 1080, 12)
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+loop = HybridFrameLoop(scenes.sponza_proc(), W, H, 12)
 ctx = loop.ctx
-for v in (-1, -1, 1, 3, 2, -1, 1, 3, 2, -1, 1, 3, 2):
+for v in (0, 0, 1, 3, 2, 0, 1, 3, 2, 0, 1, 3, 2):
     ctx.set_option("atrous_small_tiles", v)
     for i in range(3): loop.frame(i)
     ctx.set_kernel_timing(["svgf_atrous"]); ctx.kernel_time("svgf_atrous", reset=True)
