@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <atomic>
 #include <limits>
 #include <queue>
@@ -169,7 +172,7 @@ struct Builder {
     }
 
     void build_parallel(uint32_t n, int threads) {
-        const unsigned hw = threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned hw = threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));   // (host_threads, defined below)
         if (hw == 1 || n < 32768u) {                     // small scenes: one thread
             build(nodes, max_depth, 0, n, 0);
             return;
@@ -264,10 +267,27 @@ inline uint16_t half_directed(float x, bool down) {
 
 inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((first << 2) | (count - 1)); }
 
+// [0, n) cut into one contiguous range per thread (the per-node / per-triangle loops around the tree build: independent items)
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F &&fn) {
+    if (threads <= 1 || n < 16384) { fn(size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    const size_t chunk = (n + threads - 1) / threads;
+    for (unsigned t = 1; t < threads; ++t) {
+        const size_t b = std::min(n, size_t(t) * chunk), e = std::min(n, b + chunk);
+        if (b < e) pool.emplace_back([&fn, b, e]() { fn(b, e); });
+    }
+    fn(size_t(0), std::min(n, chunk));
+    for (auto &th : pool) th.join();
+}
+unsigned host_threads(int threads) { return threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
+
 }  // namespace
 
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
                uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads) {
+    const bool k0trace = std::getenv("VHR_K0_TRACE") != nullptr; auto k0t = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (k0trace) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "K0 %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - k0t).count()); k0t = t; } };
     Builder b;
     b.leaf_tris = std::max(1, std::min(kMaxLeafTris, leaf_tris));
     size_t total = 0;
@@ -309,7 +329,9 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     b.tri_box.resize(n);
     b.centroid.resize(size_t(n) * 3);
     b.order.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
+    const unsigned hw = host_threads(threads);
+    parallel_for(n, hw, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
         const BvhTri &t = b.tris[i];
         Box bx;
         bx.reset();
@@ -320,14 +342,18 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         bx.grow(p2);
         b.tri_box[i] = bx;
         for (int a = 0; a < 3; ++a) b.centroid[size_t(i) * 3 + a] = 0.5f * (bx.lo[a] + bx.hi[a]);
-        b.order[i] = i;
+        b.order[i] = uint32_t(i);
     }
+    });
+    lap("triangles + boxes");
     b.nodes.reserve(size_t(n));
     b.build_parallel(n, threads);
+    lap("tree");
     out.max_depth = b.max_depth;
 
     out.tris.resize(n);
-    for (uint32_t i = 0; i < n; ++i) out.tris[i] = b.tris[b.order[i]];
+    parallel_for(n, hw, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) out.tris[i] = b.tris[b.order[i]]; });
+    lap("triangle order");
 
     const float inf = std::numeric_limits<float>::infinity();
     auto set_child = [&](BvhNode &node, int which, const TmpNode &child, int32_t link) {
@@ -341,7 +367,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     // centre / half-extent twin of every node (BvhNodeCH): c +- h must contain [lo, hi] in exact arithmetic
     auto finalize_ch = [&]() {
         out.nodes_ch.resize(out.nodes.size());
-        for (size_t k = 0; k < out.nodes.size(); ++k) {
+        parallel_for(out.nodes.size(), hw, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
             const BvhNode &nd = out.nodes[k];
             BvhNodeCH c{};
             for (int which = 0; which < 2; ++which) {
@@ -364,6 +391,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             c.child1 = nd.child1;
             out.nodes_ch[k] = c;
         }
+        });
         // the 48-byte form: half extents as the upper half of their fp32 pattern, rounded up (away from zero for the -1 of an
         // absent child, which is exact anyway)
         auto upper16 = [](float h) -> uint32_t {
@@ -373,7 +401,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             return bits >> 16;
         };
         out.nodes48.resize(out.nodes_ch.size());
-        for (size_t k = 0; k < out.nodes_ch.size(); ++k) {
+        parallel_for(out.nodes_ch.size(), hw, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
             const BvhNodeCH &c = out.nodes_ch[k];
             BvhNode48 n{};
             for (int w = 0; w < 2; ++w) { n.cx[w] = c.cx[w]; n.cy[w] = c.cy[w]; n.cz[w] = c.cz[w]; }
@@ -384,6 +413,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             n.child1 = c.child1;
             out.nodes48[k] = n;
         }
+        });
     };
 
     auto finalize16 = [&]() {
@@ -396,7 +426,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             }
         for (int a = 0; a < 3; ++a) out.centre[a] = (lo[a] <= hi[a]) ? 0.5f * (lo[a] + hi[a]) : 0.0f;
         out.nodes16.resize(out.nodes.size());
-        for (size_t k = 0; k < out.nodes.size(); ++k) {
+        parallel_for(out.nodes.size(), hw, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
             const BvhNode &nd = out.nodes[k];
             BvhNode16 c{};
             for (int a = 0; a < 3; ++a) {
@@ -410,6 +441,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             c.child1 = nd.child1;
             out.nodes16[k] = c;
         }
+        });
     };
 
     const TmpNode &root = b.nodes[0];
@@ -437,7 +469,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         if (b.nodes[t.right].left >= 0) q.push(t.right);
     }
     out.nodes.resize(bfs_order.size());
-    for (size_t k = 0; k < bfs_order.size(); ++k) {
+    parallel_for(bfs_order.size(), hw, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; ++k) {
         const TmpNode &t = b.nodes[bfs_order[k]];
         BvhNode node{};
         const TmpNode &l = b.nodes[t.left], &r = b.nodes[t.right];
@@ -445,7 +478,10 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         set_child(node, 1, r, r.left >= 0 ? bfs_index[t.right] : leaf_link(r.first, r.count));
         out.nodes[k] = node;
     }
+    });
+    lap("numbering + (lo, hi) nodes");
     finalize16();
+    lap("derived node forms");
 }
 
 // Every derived node form must CONTAIN the (lo, hi) boxes of `nodes` in exact arithmetic -- that is all the walkers' bit-identity
@@ -459,7 +495,11 @@ void check_node_forms(const HostBvh &bvh, uint64_t out[4]) {
     };
     auto upper = [](uint32_t w16) -> double { const uint32_t bits = w16 << 16; float f; std::memcpy(&f, &bits, 4); return double(f); };
     out[0] = out[1] = out[2] = out[3] = 0;
-    for (size_t k = 0; k < bvh.nodes.size(); ++k) {
+    std::atomic<uint64_t> total[4];
+    for (auto &t : total) t = 0;
+    parallel_for(bvh.nodes.size(), host_threads(0), [&](size_t k0, size_t k1) {
+    uint64_t out[4] = { 0, 0, 0, 0 };                  // this thread's counts
+    for (size_t k = k0; k < k1; ++k) {
         const BvhNode &nd = bvh.nodes[k];
         const BvhNodeCH &ch = bvh.nodes_ch[k];
         const BvhNode48 &n48 = bvh.nodes48[k];
@@ -486,6 +526,9 @@ void check_node_forms(const HostBvh &bvh, uint64_t out[4]) {
         }
         if (n48.child0 != nd.child0 || n48.child1 != nd.child1 || ch.child0 != nd.child0 || ch.child1 != nd.child1) ++out[2];
     }
+    for (int i = 0; i < 4; ++i) total[i] += out[i];
+    });
+    for (int i = 0; i < 4; ++i) out[i] = total[i];
 }
 
 }  // namespace vhr
