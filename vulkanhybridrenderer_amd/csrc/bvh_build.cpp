@@ -22,6 +22,7 @@
 #include <limits>
 #include <queue>
 #include <thread>
+#include <mutex>
 
 #include "vhr_internal.hpp"
 
@@ -53,6 +54,21 @@ struct TmpNode {
     uint32_t depth = 0;
 };
 
+// [0, n) cut into one contiguous range per thread (the per-node / per-triangle loops around the tree build: independent items)
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F &&fn) {
+    if (threads <= 1 || n < 16384) { fn(size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    const size_t chunk = (n + threads - 1) / threads;
+    for (unsigned t = 1; t < threads; ++t) {
+        const size_t b = std::min(n, size_t(t) * chunk), e = std::min(n, b + chunk);
+        if (b < e) pool.emplace_back([&fn, b, e]() { fn(b, e); });
+    }
+    fn(size_t(0), std::min(n, chunk));
+    for (auto &th : pool) th.join();
+}
+unsigned host_threads(int threads) { return threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
+
 struct Builder {
     std::vector<BvhTri> tris;          // flat order
     std::vector<Box> tri_box;
@@ -61,6 +77,7 @@ struct Builder {
     std::vector<TmpNode> nodes;
     uint32_t max_depth = 0;
     int leaf_tris = kMaxLeafTris;      // per build (vhr_set_option "bvh_leaf_triangles" of the context that builds)
+    unsigned top_threads = 1;          // > 1 while the one thread that builds the top of the tree may spread a big node's passes over triangles
 
     uint32_t levels_needed(uint32_t count) const {
         uint32_t leaves = (count + leaf_tris - 1) / leaf_tris;
@@ -88,9 +105,21 @@ struct Builder {
         n.box.reset();
         Box cb;
         cb.reset();
-        for (uint32_t i = first; i < first + count; ++i) {
-            n.box.grow(tri_box[order[i]]);
-            cb.grow(&centroid[size_t(order[i]) * 3]);
+        const bool wide = top_threads > 1 && count >= 131072u;      // min / max and counts: the same values in any order
+        if (wide) {
+            std::mutex m;
+            parallel_for(count, top_threads, [&](size_t i0, size_t i1) {
+                Box pb, pc;
+                pb.reset(); pc.reset();
+                for (size_t i = first + i0; i < first + i1; ++i) { pb.grow(tri_box[order[i]]); pc.grow(&centroid[size_t(order[i]) * 3]); }
+                std::lock_guard<std::mutex> g(m);
+                n.box.grow(pb); cb.grow(pc);
+            });
+        } else {
+            for (uint32_t i = first; i < first + count; ++i) {
+                n.box.grow(tri_box[order[i]]);
+                cb.grow(&centroid[size_t(order[i]) * 3]);
+            }
         }
         n.first = first;
         n.count = count;
@@ -113,11 +142,26 @@ struct Builder {
                 uint32_t bin_count[kBins] = {};
                 for (auto &b : bin_box) b.reset();
                 float scale = float(kBins) / ext;
-                for (uint32_t i = first; i < first + count; ++i) {
-                    uint32_t t = order[i];
-                    int b = std::min(kBins - 1, std::max(0, int((centroid[size_t(t) * 3 + axis] - cb.lo[axis]) * scale)));
-                    bin_box[b].grow(tri_box[t]);
-                    ++bin_count[b];
+                auto bin_range = [&](size_t i0, size_t i1, Box *bb, uint32_t *bc) {
+                    for (size_t i = first + i0; i < first + i1; ++i) {
+                        uint32_t t = order[i];
+                        int b = std::min(kBins - 1, std::max(0, int((centroid[size_t(t) * 3 + axis] - cb.lo[axis]) * scale)));
+                        bb[b].grow(tri_box[t]);
+                        ++bc[b];
+                    }
+                };
+                if (wide) {
+                    std::mutex m;
+                    parallel_for(count, top_threads, [&](size_t i0, size_t i1) {
+                        Box bb[kBins];
+                        uint32_t bc[kBins] = {};
+                        for (auto &b : bb) b.reset();
+                        bin_range(i0, i1, bb, bc);
+                        std::lock_guard<std::mutex> g(m);
+                        for (int b = 0; b < kBins; ++b) { bin_box[b].grow(bb[b]); bin_count[b] += bc[b]; }
+                    });
+                } else {
+                    bin_range(0, count, bin_box, bin_count);
                 }
                 float right_area[kBins];
                 uint32_t right_count[kBins];
@@ -178,7 +222,9 @@ struct Builder {
             return;
         }
         std::vector<Task> tasks;
+        top_threads = hw;
         build(nodes, max_depth, 0, n, 0, std::max<uint32_t>(4096u, n / (8u * hw)), &tasks);
+        top_threads = 1;
         std::vector<std::vector<TmpNode>> sub(tasks.size());
         std::vector<uint32_t> sub_depth(tasks.size(), 0);
         std::atomic<size_t> next{ 0 };
@@ -267,20 +313,6 @@ inline uint16_t half_directed(float x, bool down) {
 
 inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((first << 2) | (count - 1)); }
 
-// [0, n) cut into one contiguous range per thread (the per-node / per-triangle loops around the tree build: independent items)
-template <typename F>
-void parallel_for(size_t n, unsigned threads, F &&fn) {
-    if (threads <= 1 || n < 16384) { fn(size_t(0), n); return; }
-    std::vector<std::thread> pool;
-    const size_t chunk = (n + threads - 1) / threads;
-    for (unsigned t = 1; t < threads; ++t) {
-        const size_t b = std::min(n, size_t(t) * chunk), e = std::min(n, b + chunk);
-        if (b < e) pool.emplace_back([&fn, b, e]() { fn(b, e); });
-    }
-    fn(size_t(0), std::min(n, chunk));
-    for (auto &th : pool) th.join();
-}
-unsigned host_threads(int threads) { return threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
 
 }  // namespace
 
