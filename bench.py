@@ -203,6 +203,7 @@ def pmc_traffic(args):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL's peer-to-peer setup needs on this driver (already exported on the GPU boxes)
     import torch
     import torch.distributed as dist
     from vulkanhybridrenderer_amd import abi, scenes
