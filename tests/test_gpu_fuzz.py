@@ -1,0 +1,98 @@
+"""Randomised triangle soups: the GPU walk against the oracle's BVH AND its brute force, bit for bit -- arbitrary (unstructured,
+overlapping, degenerate) geometry instead of the tessellated surfaces of the named scenes."""
+import numpy as np
+import pytest
+
+from vulkanhybridrenderer_amd import abi, lib, scenes
+from vulkanhybridrenderer_amd.camera import directional_light
+from tests.helpers import GpuHybrid, f16, oracle_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def soup(seed, n_tris, n_prims):
+    """n_tris random triangles in a 6 x 4 x 6 m box above a floor, spread over n_prims primitives with random rigid transforms; every
+    20th triangle is degenerate (two equal vertices, three collinear ones, or all three equal), every 15th is a duplicate of its
+    predecessor, sizes from centimetres to metres."""
+    rng = np.random.default_rng(seed)
+    b = scenes._Builder()
+    b.add(scenes.plane([-5, 0, 5], [10, 0, 0], [0, 0, -10], 3, 3), base_color=(0.7, 0.7, 0.7, 1))
+    per = max(1, n_tris // n_prims)
+    for p in range(n_prims):
+        centre = rng.uniform([-3, 0.2, -3], [3, 4, 3], size=(per, 1, 3))
+        size = 10.0 ** rng.uniform(-2, 0.3, size=(per, 1, 1))
+        tri = (centre + rng.normal(size=(per, 3, 3)) * size).astype(np.float32)
+        for k in range(0, per, 20):
+            kind = (k // 20) % 3
+            if kind == 0: tri[k, 1] = tri[k, 0]
+            elif kind == 1: tri[k, 2] = 0.5 * (tri[k, 0] + tri[k, 1])
+            else: tri[k, 1] = tri[k, 2] = tri[k, 0]
+        for k in range(15, per, 15):
+            tri[k] = tri[k - 1]
+        pos = tri.reshape(-1, 3)
+        nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-20)
+        nrm = np.repeat(nrm, 3, axis=0).astype(np.float32)
+        uv = rng.random((len(pos), 2)).astype(np.float32)
+        idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+        t = scenes.trs(tuple(rng.uniform(-0.5, 0.5, 3)), rot_y=float(rng.uniform(-3, 3)), rot_x=float(rng.uniform(-0.5, 0.5)))
+        b.add((pos, nrm, uv, idx), t, base_color=scenes._palette(p))
+    camera = dict(position=(0.0, 2.2, 7.5), yaw=0.0, pitch=-0.15, yfov=0.9, znear=0.1, dolly=(0.02, 0.0, -0.04))
+    return b.finish(f"soup{seed}", camera, directional_light((0.25, -0.9, 0.3)))
+
+
+@pytest.mark.parametrize("seed,n_tris,n_prims", [(1, 60, 3), (2, 400, 5), (3, 2000, 8), (4, 9000, 12)])
+def test_random_triangle_soup_matches_oracle_bvh_and_brute_force(oracle, seed, n_tris, n_prims):
+    scene = soup(seed, n_tris, n_prims)
+    W, H = 96, 64
+    tp = abi.default_trace_params(reflections=False)
+    frames, osc, _ = oracle_frames(oracle, scene, W, H, 3, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
+    try:
+        assert g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+        for i, fr in enumerate(frames):
+            g.frame(fr["pfd"], fr["gbuf"])
+            got = g.ctx.download(lib.RAYTRACED)
+            assert np.array_equal(got, fr["shadow_ao"]), f"frame {i}: visibility differs from the oracle's BVH walk"
+            if n_tris <= 2000:                     # (the brute force is O(rays x triangles) on the CPU)
+                brute = osc.raygen(fr["pfd"], tp, fr["gbuf"][0], fr["gbuf"][2], use_bvh=False, want_reflections=False)[0]
+                assert np.array_equal(got, brute), f"frame {i}: visibility differs from the oracle's brute force"
+            if i == 1:                             # and every walker flavour, same bits
+                for key, val, back in (("raygen_variant", 0, 1), ("raygen_cut", 0, 1), ("compact_nodes", 1, 0), ("shadow_packet", 1, 0),
+                                       ("raygen_tile_pixels", 128, 64), ("cut_expand", 1, 0), ("shadow_last", 0, 1), ("lds_stack_levels", 2, 8)):
+                    g.ctx.set_option(key, val)
+                    g.ctx.execute(0, 0)
+                    g.ctx.synchronize()
+                    assert np.array_equal(g.ctx.download(lib.RAYTRACED), got), key
+                    g.ctx.set_option(key, back)
+        shadow = f16(frames[1]["shadow_ao"])[..., 0]
+        assert 0.0 < (shadow == 0).mean() < 1.0
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("seed,n_tris,n_prims", [(11, 300, 4), (12, 3000, 9)])
+def test_random_triangle_soup_mirror_ray(oracle, seed, n_tris, n_prims):
+    """The closest-hit walker (mirror ray, reflection_hit.rchit shading) on the same kind of geometry: equal hit masks, colours within 2
+    fp16 steps, for the per-pixel and the queue form, one and two bounces share the first hit."""
+    scene = soup(seed, n_tris, n_prims)
+    W, H = 96, 64
+    tp = abi.default_trace_params()
+    frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
+    try:
+        for i, fr in enumerate(frames):
+            g.frame(fr["pfd"], fr["gbuf"])
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"frame {i}: visibility"
+            for variant in (1, 0):
+                g.ctx.set_option("reflection_variant", variant)
+                g.ctx.execute(0, 0)
+                g.ctx.synchronize()
+                a, b = f16(g.ctx.download(lib.REFLECTIONS)), f16(fr["reflections"])
+                assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0), f"frame {i} variant {variant}: reflection hit mask"
+                tol = 2 * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)
+                assert (np.abs(a - b) <= tol).all(), f"frame {i} variant {variant}: reflection colour off by {np.abs(a - b).max()}"
+            g.ctx.set_option("reflection_variant", 1)
+        assert (f16(frames[1]["reflections"])[..., 3] > 0).mean() > 0.2
+    finally:
+        g.close()
