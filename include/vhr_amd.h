@@ -73,7 +73,8 @@ void vhr_default_trace_params(vhr_trace_params *out); /* raygen.rgen:29-65 const
  * (.cpp:703-801): uploads the flat vertex / index / primitive arrays and builds the acceleration
  * structure -- here a host-built binned-SAH BVH2 over the world-space (transform-baked), two-sided,
  * all-opaque triangle soup.  gl_GeometryIndexEXT == primitive index, gl_PrimitiveID == triangle index
- * within the primitive. */
+ * within the primitive.  On a VHR_CREATE_HOST_ONLY context the arrays are validated and the tree is built and checked
+ * (vhr_get_bvh_statistics, vhr_get_bvh_form_checks, vhr_get_build_times), nothing is uploaded. */
 int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t vertex_count,
                         const uint32_t *indices, uint32_t index_count,
                         const vhr_primitive *primitives, uint32_t primitive_count);

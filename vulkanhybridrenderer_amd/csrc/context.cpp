@@ -266,7 +266,8 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
                         uint32_t index_count, const vhr_primitive *primitives, uint32_t primitive_count) {
     if (!ctx || (!vertices && vertex_count) || (!indices && index_count) || (!primitives && primitive_count))
         return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: null array") : VHR_ERROR_INVALID_ARGUMENT;
-    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    // (a host-only context validates, builds the tree and checks its node forms, and stops before the upload: the builder is host code,
+    // and the CPU tests exercise it this way)
     // Validate every offset the kernels will dereference (an out-of-range index would fault the GPU).
     uint64_t total_triangles = 0;
     for (uint32_t p = 0; p < primitive_count; ++p) {
@@ -289,9 +290,11 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
             return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: vertex " + std::to_string(v) + " has a non-finite position");
     if (total_triangles >= (1ull << 29))            // a leaf link packs (first triangle << 2 | count - 1) into 31 bits
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: 2^29 triangles or more");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
-    free_scene(ctx);
+    if (!ctx->host_only) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
+        free_scene(ctx);
+    }
 
     HostBvh bvh;
     const auto t_build0 = std::chrono::steady_clock::now();
@@ -300,6 +303,14 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 89 million BVH nodes");
     check_node_forms(bvh, ctx->bvh_form_checks);
     const auto t_build1 = std::chrono::steady_clock::now();
+    if (ctx->host_only) {
+        ctx->node_count = uint32_t(bvh.nodes.size());
+        ctx->tri_count = uint32_t(bvh.tris.size());
+        ctx->bvh_depth = bvh.max_depth;
+        ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
+        ctx->geometry_upload_ms = 0.0;
+        return VHR_OK;
+    }
     std::vector<float> nm(size_t(primitive_count) * 9);
     for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
 
