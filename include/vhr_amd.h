@@ -459,6 +459,9 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);
  * out[3] = half-precision ("compact_nodes") boxes that do not contain theirs.  All three must be 0: the walkers' bit-identity with the
  * oracle rests on box tests that only cull. */
 int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]);
+/* A 64-bit hash of the last build's nodes and leaf triangles in their final order: two builds of the same input must agree whatever
+ * "bvh_build_threads" was. */
+int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out);
 
 #ifdef __cplusplus
 }

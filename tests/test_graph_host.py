@@ -171,9 +171,9 @@ def test_host_side_bvh_build_forms_and_thread_independence(vhr):
     are host code.  Every derived box contains its (lo, hi) box in exact arithmetic; the tree does not depend on the number of build
     threads; leaf sizes 1..4 give consistent counts."""
     from vulkanhybridrenderer_amd import scenes
-    for scene in (scenes.tiny_scene(), _soup_scene(5, 3000), _soup_scene(6, 40000), scenes.sponza_proc(0.35)):
+    for scene in (scenes.tiny_scene(), _soup_scene(5, 3000), _soup_scene(6, 40000), _soup_scene(7, 300000), scenes.sponza_proc(0.35)):
         stats = []
-        for threads in (1, 3, 0):
+        for threads in (1, 3, 7, 0):
             c = lib.Context(64, 64, host_only=True)
             try:
                 c.set_option("bvh_build_threads", threads)
@@ -182,10 +182,10 @@ def test_host_side_bvh_build_forms_and_thread_independence(vhr):
                 st = c.bvh_statistics()
                 assert boxes == 2 * st["nodes"] and (ch_bad, n48_bad, n16_bad) == (0, 0, 0), (scene.name, threads)
                 assert st["triangles"] == scene.triangle_count
-                stats.append((st["nodes"], st["triangles"], st["max_depth"]))
+                stats.append((st["nodes"], st["triangles"], st["max_depth"], c.bvh_fingerprint()))
             finally:
                 c.close()
-        assert stats[0] == stats[1] == stats[2], (scene.name, stats)
+        assert all(st == stats[0] for st in stats), (scene.name, stats)
     nodes = []
     for leaf in (1, 2, 3, 4):
         c = lib.Context(64, 64, host_only=True)

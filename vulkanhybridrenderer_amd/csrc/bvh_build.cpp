@@ -215,46 +215,77 @@ struct Builder {
         return id;
     }
 
+    // splice: a subtree's nodes keep their relative links, its root (its first node) replaces the deferred code in dst[0 .. top)
+    static void splice(std::vector<TmpNode> &dst, std::vector<std::vector<TmpNode>> &subs) {
+        const size_t top = dst.size();
+        std::vector<int32_t> root_of(subs.size());
+        size_t total = top;
+        for (const auto &v : subs) total += v.size();
+        dst.reserve(total);
+        for (size_t k = 0; k < subs.size(); ++k) {
+            const int32_t offset = int32_t(dst.size());
+            root_of[k] = offset;
+            for (TmpNode t : subs[k]) {
+                if (t.left >= 0) { t.left += offset; t.right += offset; }
+                dst.push_back(t);
+            }
+            std::vector<TmpNode>().swap(subs[k]);
+        }
+        for (size_t i = 0; i < top; ++i) {
+            TmpNode &t = dst[i];
+            if (t.left <= kDeferred) t.left = root_of[size_t(kDeferred - t.left)];
+            if (t.right <= kDeferred) t.right = root_of[size_t(kDeferred - t.right)];
+        }
+    }
+    template <typename F>
+    static void run_pool(unsigned threads, size_t n, F &&fn) {
+        std::atomic<size_t> next{ 0 };
+        auto worker = [&]() { for (size_t k = next.fetch_add(1); k < n; k = next.fetch_add(1)) fn(k); };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads && t < n; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+
+    // Three phases.  A: one thread splits the top of the tree down to regions of <= n / 8 triangles (the passes over a big node's
+    // triangles spread over the threads).  B: the regions' own tops, one region per thread, down to subtrees of a few thousand
+    // triangles.  C: those subtrees, from one queue.  Every piece is built into a node vector of its own and spliced in afterwards;
+    // `order` is partitioned in place on disjoint ranges, so nothing is shared, and the tree is the one thread's tree.
     void build_parallel(uint32_t n, int threads) {
-        const unsigned hw = threads > 0 ? unsigned(std::min(threads, 64)) : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));   // (host_threads, defined below)
+        const unsigned hw = host_threads(threads);
         if (hw == 1 || n < 32768u) {                     // small scenes: one thread
             build(nodes, max_depth, 0, n, 0);
             return;
         }
-        std::vector<Task> tasks;
+        const uint32_t region = std::max<uint32_t>(16384u, n / 8u), small = std::max<uint32_t>(4096u, n / (8u * hw));
+        std::vector<Task> regions;
         top_threads = hw;
-        build(nodes, max_depth, 0, n, 0, std::max<uint32_t>(4096u, n / (8u * hw)), &tasks);
+        build(nodes, max_depth, 0, n, 0, region, &regions);
         top_threads = 1;
-        std::vector<std::vector<TmpNode>> sub(tasks.size());
-        std::vector<uint32_t> sub_depth(tasks.size(), 0);
-        std::atomic<size_t> next{ 0 };
-        auto worker = [&]() {
-            for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
-                sub[k].reserve(size_t(tasks[k].count));
-                build(sub[k], sub_depth[k], tasks[k].first, tasks[k].count, tasks[k].depth);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < hw; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto &t : pool) t.join();
-        // splice: a subtree's nodes keep their relative links, its root replaces the deferred code in the top tree
-        std::vector<int32_t> root_of(tasks.size());
-        const size_t top = nodes.size();
-        for (size_t k = 0; k < tasks.size(); ++k) {
-            const int32_t offset = int32_t(nodes.size());
-            root_of[k] = offset;
-            for (TmpNode t : sub[k]) {
-                if (t.left >= 0) { t.left += offset; t.right += offset; }
-                nodes.push_back(t);
-            }
-            max_depth = std::max(max_depth, sub_depth[k]);
-        }
-        for (size_t i = 0; i < top; ++i) {
-            TmpNode &t = nodes[i];
-            if (t.left <= kDeferred) t.left = root_of[size_t(kDeferred - t.left)];
-            if (t.right <= kDeferred) t.right = root_of[size_t(kDeferred - t.right)];
-        }
+        std::vector<std::vector<TmpNode>> mid(regions.size());
+        std::vector<std::vector<Task>> tasks(regions.size());
+        std::vector<uint32_t> mid_depth(regions.size(), 0);
+        run_pool(hw, regions.size(), [&](size_t k) {
+            const Task &r = regions[k];
+            build(mid[k], mid_depth[k], r.first, r.count, r.depth, small, r.count > small ? &tasks[k] : nullptr);
+        });
+        struct Ref { uint32_t region, task; };
+        std::vector<Ref> flat;
+        for (size_t k = 0; k < regions.size(); ++k)
+            for (size_t j = 0; j < tasks[k].size(); ++j) flat.push_back(Ref{ uint32_t(k), uint32_t(j) });
+        std::vector<std::vector<std::vector<TmpNode>>> sub(regions.size());
+        for (size_t k = 0; k < regions.size(); ++k) sub[k].resize(tasks[k].size());
+        std::vector<uint32_t> sub_depth(flat.size(), 0);
+        run_pool(hw, flat.size(), [&](size_t f) {
+            const Task &t = tasks[flat[f].region][flat[f].task];
+            auto &v = sub[flat[f].region][flat[f].task];
+            v.reserve(size_t(t.count));
+            build(v, sub_depth[f], t.first, t.count, t.depth);
+        });
+        for (size_t k = 0; k < regions.size(); ++k) splice(mid[k], sub[k]);
+        splice(nodes, mid);
+        for (uint32_t d : mid_depth) max_depth = std::max(max_depth, d);
+        for (uint32_t d : sub_depth) max_depth = std::max(max_depth, d);
     }
 };
 
@@ -514,6 +545,20 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     lap("numbering + (lo, hi) nodes");
     finalize16();
     lap("derived node forms");
+}
+
+// A 64-bit multiplicative hash over the (lo, hi) nodes and the leaf triangles in their final order, eight bytes at a time: the
+// identity of a build (tests: the tree must not depend on the number of build threads)
+uint64_t bvh_fingerprint(const HostBvh &bvh) {
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const void *p, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    };
+    static_assert(sizeof(BvhNode) % 8 == 0 && sizeof(BvhTri) % 8 == 0, "whole words");
+    eat(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    eat(bvh.tris.data(), bvh.tris.size() * sizeof(BvhTri));
+    return h;
 }
 
 // Every derived node form must CONTAIN the (lo, hi) boxes of `nodes` in exact arithmetic -- that is all the walkers' bit-identity

@@ -302,6 +302,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 32))     // the walkers address a 48-byte node with a 32-bit byte offset
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 89 million BVH nodes");
     check_node_forms(bvh, ctx->bvh_form_checks);
+    ctx->bvh_fingerprint = bvh_fingerprint(bvh);
     const auto t_build1 = std::chrono::steady_clock::now();
     if (ctx->host_only) {
         ctx->node_count = uint32_t(bvh.nodes.size());
@@ -531,6 +532,12 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     out[0] = ctx->node_count; out[1] = ctx->tri_count; out[2] = ctx->bvh_depth;
     out[3] = uint64_t(ctx->node_count) * sizeof(BvhNode); out[4] = uint64_t(ctx->tri_count) * sizeof(BvhTri);
+    return VHR_OK;
+}
+
+int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    *out = ctx->bvh_fingerprint;
     return VHR_OK;
 }
 

@@ -145,6 +145,7 @@ struct HostBvh {
 
 // builds the BVH2 (csrc/bvh_build.cpp)
 void check_node_forms(const HostBvh &bvh, uint64_t out[4]);
+uint64_t bvh_fingerprint(const HostBvh &bvh);
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
                uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
 
@@ -266,6 +267,7 @@ struct vhr_context {
     vhr::BvhNode16 *d_nodes16 = nullptr;
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
     vhr::BvhNode48 *d_nodes48 = nullptr;
+    uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
     float bvh_centre[3] = { 0, 0, 0 };
     vhr::BvhTri *d_tris = nullptr;
