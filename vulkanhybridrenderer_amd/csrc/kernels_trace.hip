@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
         });
     wave_lds_sync();
-    if (BOUNCES > 1 && bounce == 0) {
+    if constexpr (BOUNCES > 1) if (bounce == 0) {
         // ---- second-bounce rays (trace_reflection's arithmetic), whole wave: a mirror ray from every first hit ----
         uint32_t n2 = 0;
 #pragma unroll
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (tri != kNoHit) {
             Hit h;
             h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
-            if (BOUNCES > 1) {
+            if constexpr (BOUNCES > 1) {
                 f4 second = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                    // reflection_miss.rmiss:7
                 const uint32_t tri2 = __float_as_uint(s_ray[6][p]);
                 if (tri2 != kNoHit) {
