@@ -66,6 +66,9 @@ def parse():
     p.add_argument("--min-seconds", type=float, default=1.0,
                    help="the timed block of --steps frames is repeated until this much time has been measured; value = the median block")
     p.add_argument("--no-extras", action="store_true", help="skip the extra blocks (mirror-ray frame, frames in flight) of the N = 1 line")
+    p.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                   help="vhr_set_option KEY VALUE on the context before the first frame (A-B runs and profiles; every option is result-neutral). "
+                        "Anything set this way is listed under config.options")
     p.add_argument("--allow-degraded", action="store_true",
                    help="N > 1: fall back (per-frame descriptors / no gather) instead of failing when the transport refuses the replayed exchanges")
     return p.parse_args()
@@ -239,6 +242,11 @@ def main():
                            allow_degraded=args.allow_degraded, **common)
     ctx = loop.ctx
     build_ms, upload_ms = ctx.build_times_ms()
+    option_overrides = {}
+    for kv in args.option:
+        key, _, val = kv.partition("=")
+        ctx.set_option(key, int(val))
+        option_overrides[key] = int(val)
 
     def barrier():
         loop.finish_pending_exchange()
@@ -399,6 +407,7 @@ def main():
                 "reference_issued_rays_per_covered_pixel": rrpp,
                 "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
                 "frames_in_flight": args.frames_in_flight,
+                "options": option_overrides or None,
                 "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo,
                 "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,

@@ -459,6 +459,11 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);
  * out[3] = half-precision ("compact_nodes") boxes that do not contain theirs.  All three must be 0: the walkers' bit-identity with the
  * oracle rests on box tests that only cull. */
 int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]);
+/* The same for the four-wide tree the "bvh_wide" walkers read (a collapse of the same BVH2, child boxes quantised to 8 bits per plane
+ * on a per-node power-of-two grid, rounded outward): out[0] = wide nodes, out[1] = child boxes checked, out[2] = quantised boxes that do
+ * NOT contain the binary tree's padded box of the same subtree in exact arithmetic, out[3] = structural errors (links that differ from
+ * the binary tree's, malformed grid words, triangles not covered exactly once).  out[2] and out[3] must be 0. */
+int vhr_get_bvh_wide_checks(vhr_context *ctx, uint64_t out[4]);
 /* A 64-bit hash of the last build's nodes and leaf triangles in their final order: two builds of the same input must agree whatever
  * "bvh_build_threads" was. */
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out);

@@ -46,12 +46,13 @@ def test_config2_1080p_whole_frames_against_the_oracle(oracle):
                                  ("raygen_cut", 0), ("lds_stack_levels", 2),        # 2 levels with the cut on: cut entries wait in the mask
                                  ("shadow_packet", 1),                              # shadow rays as one packet per tile instead of through the per-ray queue
                                  ("cut_expand", 1),                                 # the tile's cut expanded around the origins
-                                 ("shadow_last", 0)):                               # the queue with the shadow rays first
+                                 ("shadow_last", 0),                                # the queue with the shadow rays first
+                                 ("bvh_wide", 1)):                                  # the four-wide tree with 8-bit child boxes
                     g.ctx.set_option(key, val)
                     g.ctx.execute(0, 0)
                     g.ctx.synchronize()
                     assert np.array_equal(g.ctx.download(lib.RAYTRACED), sa), key
-                    g.ctx.set_option(key, {"raygen_variant": 1, "lds_stack_levels": 8, "refill_threshold": 16, "raygen_early_exit": 4, "raygen_cut": 1, "shadow_packet": 0, "cut_expand": 0, "shadow_last": 1}[key])
+                    g.ctx.set_option(key, {"raygen_variant": 1, "lds_stack_levels": 8, "refill_threshold": 16, "raygen_early_exit": 4, "raygen_cut": 1, "shadow_packet": 0, "cut_expand": 0, "shadow_last": 1, "bvh_wide": 0}[key])
     finally:
         g.close()
 

@@ -42,6 +42,9 @@ vhr::DeviceScene vhr_context::device_scene() const {
     s.nodes16 = d_nodes16;
     s.nodes_ch = d_nodes_ch;
     s.nodes48 = d_nodes48;
+    s.nodes4 = d_nodes4;
+    s.node4_count = node4_count;
+    s.pad1[0] = s.pad1[1] = s.pad1[2] = 0;
     s.centre[0] = bvh_centre[0]; s.centre[1] = bvh_centre[1]; s.centre[2] = bvh_centre[2];
     s.pad0 = 0.0f;
     s.tris = d_tris;
@@ -206,9 +209,10 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
 
 static void free_scene(vhr_context *ctx) {
     hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
-    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_nodes4); hipFree(ctx->d_tris);
     ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_tris = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_nodes4 = nullptr; ctx->d_tris = nullptr;
+    ctx->node4_count = 0;
     ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
 }
 
@@ -299,19 +303,24 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HostBvh bvh;
     const auto t_build0 = std::chrono::steady_clock::now();
     build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
-    if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 32))     // the walkers address a 48-byte node with a 32-bit byte offset
-        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 89 million BVH nodes");
-    check_node_forms(bvh, ctx->bvh_form_checks);
+    if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
+    const auto t_build1 = std::chrono::steady_clock::now();       // K0 proper ends here; the self-checks below are timed apart
+    check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
+    check_wide_nodes(bvh, ctx->bvh_wide_checks, ctx->bvh_build_threads);
     ctx->bvh_fingerprint = bvh_fingerprint(bvh);
-    const auto t_build1 = std::chrono::steady_clock::now();
+    ctx->bvh_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
+    ctx->bvh_wide_depth = bvh.wide_depth;
     if (ctx->host_only) {
         ctx->node_count = uint32_t(bvh.nodes.size());
+        ctx->node4_count = uint32_t(bvh.nodes4.size());
         ctx->tri_count = uint32_t(bvh.tris.size());
         ctx->bvh_depth = bvh.max_depth;
         ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
         ctx->geometry_upload_ms = 0.0;
         return VHR_OK;
     }
+    const auto t_upload0 = std::chrono::steady_clock::now();
     std::vector<float> nm(size_t(primitive_count) * 9);
     for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
 
@@ -330,16 +339,18 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes48), bvh.nodes48.data(), sizeof(BvhNode48) * bvh.nodes48.size()));
+    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes4), bvh.nodes4.data(), sizeof(BvhNode4) * bvh.nodes4.size()));
     HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
     for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
     ctx->vertex_count = vertex_count;
     ctx->index_count = index_count;
     ctx->primitive_count = primitive_count;
     ctx->node_count = uint32_t(bvh.nodes.size());
+    ctx->node4_count = uint32_t(bvh.nodes4.size());
     ctx->tri_count = uint32_t(bvh.tris.size());
     ctx->bvh_depth = bvh.max_depth;
     ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
-    ctx->geometry_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
+    ctx->geometry_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload0).count();
     return VHR_OK;
 }
 
@@ -464,7 +475,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -538,6 +549,12 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     *out = ctx->bvh_fingerprint;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_wide_checks(vhr_context *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    for (int i = 0; i < 4; ++i) out[i] = ctx->bvh_wide_checks[i];
     return VHR_OK;
 }
 

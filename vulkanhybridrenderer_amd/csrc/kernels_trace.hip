@@ -508,7 +508,9 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
 // pair = the word itself, second = one shift), links from the third load.  Feeds box_pair_ch unchanged.
 struct Node48Words { float4 q0, q1, q2; int2 links; };
 __device__ __forceinline__ Node48Words load_node48(const BvhNode48 *nodes, int cur) {
-    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + uint32_t(cur) * uint32_t(sizeof(BvhNode48)));
+    // `cur` is the node's BYTE offset (index * 48: what the 48-byte nodes' inner links hold, r3 -- one v_mul_lo_u32, a quarter-rate
+    // instruction, less per visit)
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + uint32_t(cur));
     const float4 r0 = np[0], r1 = np[1], r2 = np[2];
     Node48Words n;
     n.q0 = r0;
@@ -618,8 +620,9 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 // `reach` (this lane's contribution, 0 for lanes without rays; +inf = no pruning): an upper bound of how far any of the tile's
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
+// `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
 __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
-                                                   const int max_entries = kCutMax, const uint32_t expand = 0u) {
+                                                   const int max_entries = kCutMax, const uint32_t expand = 0u, const int link_bytes = int(sizeof(BvhNode48))) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -714,6 +717,78 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     }
     if (lane < cut_n) {
         s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
+        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
+    }
+    wave_lds_sync();
+    return cut_n;
+}
+
+// The shared descent on the FOUR-WIDE tree (BvhNode4, option "bvh_wide"): the same idea, one wide node per level -- the child whose
+// box contains the bounds of the tile's ray origins is followed, the node's other children (up to three) join the cut.  Child boxes
+// are decoded from the node's 8-bit grid (fp32, rounded to nearest: they are used by the same padded-box slab test as everything
+// else); links are the wide tree's (inner: wide node index, leaf: the shared leaf code).
+constexpr int kWideSpill = 64;       // scratch part of a wide walk's stack: 3 pending subtrees per level of the wide tree (launch_raygen checks)
+
+__device__ __forceinline__ uint32_t build_tile_cut_wide(const BvhNode4 *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach,
+                                                        const int max_entries) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
+        omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
+        reach = fmaxf(reach, __shfl_xor(reach, off));
+    }
+    auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
+    omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    reach = uni(reach);
+    const float reach2 = reach * reach;
+    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f;      // entry e lives in lane e until the end
+    int e_link = 0;
+    uint32_t cut_n = 0;
+    auto add_entry = [&](const float b[6], int link) {
+        const float gx = fmaxf(fmaxf(b[0] - omax.x, omin.x - b[1]), 0.0f), gy = fmaxf(fmaxf(b[2] - omax.y, omin.y - b[3]), 0.0f),
+                    gz = fmaxf(fmaxf(b[4] - omax.z, omin.z - b[5]), 0.0f);
+        if ((gx * gx + gy * gy) + gz * gz > reach2) return;                               // out of every ray's reach
+        if (lane == cut_n) { e_lx = b[0]; e_hx = b[1]; e_ly = b[2]; e_hy = b[3]; e_lz = b[4]; e_hz = b[5]; e_link = link; }
+        ++cut_n;
+    };
+    int node = 0;
+    float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };
+    bool open = true;
+    while (int(cut_n) + 4 <= max_entries) {            // a node adds at most three entries on the way down, four where the descent ends
+        const uniform_i4_ptr np = (uniform_i4_ptr)(uintptr_t)(nodes + node);
+        const v4i w0 = np[0], w1 = np[1], w2 = np[2];
+        const float O[3] = { __int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z) };
+        const float S[3] = { __uint_as_float(uint32_t(w0.x) << 23), __uint_as_float(uint32_t(w0.y) << 23), __uint_as_float(uint32_t(w0.z) << 23) };
+        const uint32_t qlo[3] = { uint32_t(w0.w), uint32_t(w1.x), uint32_t(w1.y) }, qhi[3] = { uint32_t(w1.z), uint32_t(w1.w), uint32_t(w2.x) };
+        float box[4][6];
+        int link[4];
+        bool valid[4], inside[4];
+        int follow = -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            valid[c] = ((qlo[0] >> (8 * c)) & 0xffu) <= ((qhi[0] >> (8 * c)) & 0xffu);      // an absent child has 255 > 0
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                box[c][2 * ax] = __builtin_fmaf(float((qlo[ax] >> (8 * c)) & 0xffu), S[ax], O[ax]);
+                box[c][2 * ax + 1] = __builtin_fmaf(float((qhi[ax] >> (8 * c)) & 0xffu), S[ax], O[ax]);
+            }
+            const int byte = int(uint32_t(w2.w) << (24 - 8 * c)) >> 24;
+            link[c] = (byte < 0 ? w2.z : w2.y) + byte;
+            inside[c] = valid[c] && byte >= 0 && box[c][0] <= omin.x && omax.x <= box[c][1] && box[c][2] <= omin.y && omax.y <= box[c][3] &&
+                        box[c][4] <= omin.z && omax.z <= box[c][5];
+            if (follow < 0 && inside[c]) follow = c;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (valid[c] && c != follow) add_entry(box[c], link[c]);
+        if (follow < 0) { open = false; break; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c == follow) { for (int k = 0; k < 6; ++k) fb[k] = box[c][k]; node = link[c]; }
+    }
+    if (open) add_entry(fb, node);
+    if (lane < cut_n) {
+        s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
         s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link), 0.0f);
     }
     wave_lds_sync();
@@ -802,7 +877,7 @@ __device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &s
     return occluded;
 }
 
-template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false>
+template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false, bool WIDE = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
                                                                           const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t cut_reach) {
@@ -826,9 +901,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
     // LDS stack rows: [0] = sentinel (what a pop of the empty stack returns), [1 .. stack_levels] = entries
     // 0 .. stack_levels-1, [stack_levels+1, +2] = dummies that absorb the accesses of entries living in scratch
-    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
+    constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
+    constexpr int kSpillEntries = WIDE ? kWideSpill : kTraceStack;
+    int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
-    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + 3u) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
+    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + kExtraRows) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -898,7 +976,10 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (stats) t_packet = __builtin_readcyclecounter() - tp0;
     }
     uint32_t cut_n = 0;
-    if (CUT && total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u);
+    if (CUT && total) {
+        if constexpr (WIDE) cut_n = build_tile_cut_wide(a.scene.nodes4, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax);
+        else cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u, COMPACT ? 1 : int(sizeof(BvhNode48)));
+    }
     if (STATS) n_cut_entries = cut_n;
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
@@ -915,7 +996,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
-    int spill[SPILL ? kTraceStack : 1];
+    int spill[SPILL ? kSpillEntries : 1];
     const float tmin = a.tp.tmin;
     float tmin_v = tmin;                              // one VGPR copy for the asm-operand min/max of the slab test
     asm volatile("" : "+v"(tmin_v));
@@ -987,6 +1068,75 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;   // ballot(true) = the walkers left; early_exit in 0..15 sixteenths, so the first trip always runs
             ++n_nodes;
+            if constexpr (WIDE) {
+                // ---- one FOUR-WIDE node (BvhNode4): three loads, the ray moved into the node's 8-bit grid, four boxes ----
+                const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.scene.nodes4) + uint32_t(cur) * uint32_t(sizeof(BvhNode4)));
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
+                // plane = O + q * S  =>  t = q * (S / d) + (O - o) / d; S is the word's low byte moved into the exponent field
+                const float idx = rinv.x * __uint_as_float(n0.x << 23), idy = rinv.y * __uint_as_float(n0.y << 23), idz = rinv.z * __uint_as_float(n0.z << 23);
+                const float oqx = __builtin_fmaf(__uint_as_float(n0.x), rinv.x, noi.x), oqy = __builtin_fmaf(__uint_as_float(n0.y), rinv.y, noi.y),
+                            oqz = __builtin_fmaf(__uint_as_float(n0.z), rinv.z, noi.z);
+                // the planes a ray meets first are the lower ones where it travels upward, the upper ones where it travels downward
+                const bool ngx = rinv.x < 0.0f, ngy = rinv.y < 0.0f, ngz = rinv.z < 0.0f;
+                const uint32_t nxw = ngx ? n1.z : n0.w, fxw = ngx ? n0.w : n1.z;
+                const uint32_t nyw = ngy ? n1.w : n1.x, fyw = ngy ? n1.x : n1.w;
+                const uint32_t nzw = ngz ? n2.x : n1.y, fzw = ngz ? n1.y : n2.x;
+                auto ub = [](uint32_t w, int c) { return float((w >> (8 * c)) & 0xffu); };                 // v_cvt_f32_ubyteN
+                auto pair = [&](uint32_t w, int c, float id, float oq) {
+                    return __builtin_elementwise_fma(f2v{ ub(w, c), ub(w, c + 1) }, f2v{ id, id }, f2v{ oq, oq });
+                };
+                const f2v nx01 = pair(nxw, 0, idx, oqx), nx23 = pair(nxw, 2, idx, oqx), fx01 = pair(fxw, 0, idx, oqx), fx23 = pair(fxw, 2, idx, oqx);
+                const f2v ny01 = pair(nyw, 0, idy, oqy), ny23 = pair(nyw, 2, idy, oqy), fy01 = pair(fyw, 0, idy, oqy), fy23 = pair(fyw, 2, idy, oqy);
+                const f2v nz01 = pair(nzw, 0, idz, oqz), nz23 = pair(nzw, 2, idz, oqz), fz01 = pair(fzw, 0, idz, oqz), fz23 = pair(fzw, 2, idz, oqz);
+                const float tnc[4] = { hw_max3(nx01.x, ny01.x, hw_max(nz01.x, tmin_v)), hw_max3(nx01.y, ny01.y, hw_max(nz01.y, tmin_v)),
+                                       hw_max3(nx23.x, ny23.x, hw_max(nz23.x, tmin_v)), hw_max3(nx23.y, ny23.y, hw_max(nz23.y, tmin_v)) };
+                const float tfc[4] = { hw_min3(fx01.x, fy01.x, hw_min(fz01.x, tmax)), hw_min3(fx01.y, fy01.y, hw_min(fz01.y, tmax)),
+                                       hw_min3(fx23.x, fy23.x, hw_min(fz23.x, tmax)), hw_min3(fx23.y, fy23.y, hw_min(fz23.y, tmax)) };
+                // the nearest hit child is entered, the others wait on the stack.  Key = entry distance with the slot in its two low
+                // bits (positive floats order like integers; the keys of a node are distinct), all ones for a child that is missed.
+                uint32_t key[4];
+                int link[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    key[c] = tnc[c] <= tfc[c] ? ((__float_as_uint(tnc[c]) & ~3u) | uint32_t(c)) : 0xffffffffu;
+                    const int byte = int(n2.w << (24 - 8 * c)) >> 24;
+                    link[c] = (byte < 0 ? int(n2.z) : int(n2.y)) + byte;
+                }
+                const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                const bool any_hit_child = kmin != 0xffffffffu;
+                // Row min(sp, L + 1) holds the top entry (the sentinel when the stack is empty).  The four links are written one after
+                // the other from the row above it; the write position only advances past a link that has to wait, so the entered
+                // child and the missed ones are overwritten or stay above the new top (rows L + 2 .. L + 5 absorb the rest).
+                int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
+                int top = row[0];
+                uint32_t wo = kQueueBlock;
+                bool wait[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    wait[c] = key[c] != 0xffffffffu && key[c] != kmin;
+                    row[wo] = link[c];
+                    wo += wait[c] ? uint32_t(kQueueBlock) : 0u;
+                }
+                const int pushed = int(wo / kQueueBlock) - 1;
+                if (__any(uint32_t(sp) + 3u > stack_levels)) {          // (wave-uniform, rare) entries beyond the LDS levels live in scratch
+                    if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
+                    uint32_t e = uint32_t(sp);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (wait[c]) {
+                            if (e >= stack_levels) {
+                                if (SPILL && e - stack_levels < uint32_t(kSpillEntries)) spill[e - stack_levels] = link[c];
+                                else overflow |= 1u;                                  // cannot happen (launch_raygen checks the wide depth); counted
+                            }
+                            ++e;
+                        }
+                    }
+                }
+                const int entered = key[0] == kmin ? link[0] : (key[1] == kmin ? link[1] : (key[2] == kmin ? link[2] : link[3]));
+                cur = any_hit_child ? entered : top;
+                sp += any_hit_child ? pushed : -1;
+                continue;
+            }
             float tn0, tn1;
             bool h0, h1;
             int2 links;
@@ -1013,9 +1163,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             // deep entries: behind a wave-uniform test, so that the hot path keeps plain ds_read / ds_write (an
             // if-converted "LDS or scratch" access becomes a flat load plus ten instructions of pointer selection)
             if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
                 if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillEntries)) spill[uint32_t(sp) - stack_levels] = farc;
                     else overflow |= both ? 1u : 0u;                              // cannot happen (builder depth bound); counted
                 }
             }
@@ -1043,7 +1193,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             if (!found) {                                                          // pop (the sentinel if nothing is pending)
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
                 }
                 --sp;
             }
@@ -1755,7 +1905,19 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
            stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
            cut_flags)
-#define VHR_LAUNCH_CUT(WV, SP, ST) do { if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
+        // "bvh_wide": the same kernel on the four-wide tree (BvhNode4).  Its LDS stack is three levels shallower by default (a wide
+        // visit needs four more dummy rows; 5 + 6 rows keep the LDS per wave -- and with it 7 waves per SIMD -- where the binary
+        // walker's 8 + 3 are); a wide walk holds at most three pending subtrees per level of the wide tree, which the scratch part of
+        // the stack must cover, else the binary walker runs.
+        const uint32_t wide_levels = std::max<uint32_t>(1u, uint32_t(std::max(4, ctx->options[kOptLdsStackLevels])) - 3u);
+        const size_t wide_stack_bytes = size_t(wide_levels + 6) * kQueueBlock * sizeof(int);
+        const bool wide = ctx->options[kOptBvhWide] != 0 && ctx->d_nodes4 && ctx->node4_count != 0 && !packet &&
+                          3u * ctx->bvh_wide_depth <= uint32_t(kWideSpill);
+#define VHR_LAUNCH_CUT_WIDE(WV, ST)                                                                                               \
+    launch(ctx, (raygen_queue_kernel<false, WV, false, false, true, ST, true, false, true>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+           wide_stack_bytes * WV, a, wide_levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
+           cut_flags)
+#define VHR_LAUNCH_CUT(WV, SP, ST) do { if (wide) VHR_LAUNCH_CUT_WIDE(WV, ST); else if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
 #define VHR_LAUNCH_CUT_W(SP, ST) \
     do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
         const bool compact = ctx->options[kOptCompactNodes] != 0;
@@ -1799,6 +1961,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         else { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, false); else VHR_LAUNCH_QUEUE_W(false, false, false, false); }
 #undef VHR_LAUNCH_CUT_W
 #undef VHR_LAUNCH_CUT
+#undef VHR_LAUNCH_CUT_WIDE
 #undef VHR_LAUNCH_CUT_P
 #undef VHR_LAUNCH_QUEUE_W
 #undef VHR_LAUNCH_QUEUE

@@ -73,6 +73,32 @@ struct BvhNode48 {
 };
 static_assert(sizeof(BvhNode48) == 48, "BvhNode48");
 
+// The WIDE tree (r3, option "bvh_wide"): a four-wide collapse of the same BVH2 -- a node holds up to four child boxes, so a ray makes
+// about half as many dependent node round trips -- in 48 bytes = THREE 16-byte loads per visit (the same three the binary node costs:
+// the walk is bound by wave-level load instructions, ~20 cycles of the CU's address unit each).  The child boxes are quantised to
+// 8 bits per plane on a per-node grid:
+//   plane = O[axis] + q * 2^(e[axis] - 127),   O[axis] = the fp32 number whose bit pattern is origin[axis] AS IT STANDS,
+//   e[axis] = origin[axis] & 0xff, bit 8 of origin[axis] is zero  (so that origin[axis] << 23 IS the fp32 scale: one shift).
+// Lower planes are rounded DOWN, upper planes UP, against the padded (lo, hi) box the binary tree stores for the same subtree:
+// the quantised box contains it in exact arithmetic (checked on the host after every build, check_wide_nodes), boxes only cull,
+// results are unchanged.  A walker never builds the planes: it moves the RAY into the node's grid (three multiplies, three
+// FMAs) and evaluates t = q * (scale / d) + (O - o) / d per plane.
+//   q0 = (origin.x, origin.y, origin.z, qlo.x)   q1 = (qlo.y, qlo.z, qhi.x, qhi.y)   q2 = (qhi.z, child_base, leaf_base, meta)
+//   qlo.a / qhi.a: byte c = child c's lower / upper plane on axis a.  An absent child has qlo = 255, qhi = 0 on every axis.
+//   meta: byte c, signed.  >= 0: inner child, link = child_base + byte (a node's inner children are consecutive nodes, in slot
+//   order).  < 0: leaf, byte = -1 - ((off << 2) | (count - 1)), link = leaf_base + byte with leaf_base = -(first << 2) where
+//   `first` is the first triangle of the node's leaf children (consecutive in `tris`, in slot order) -- which is the binary
+//   tree's leaf code ~(((first + off) << 2) | (count - 1)), so the leaf stage of the walkers is shared.
+struct BvhNode4 {
+    uint32_t origin[3];
+    uint32_t qlo[3];
+    uint32_t qhi[3];
+    int32_t child_base;
+    int32_t leaf_base;
+    uint32_t meta;
+};
+static_assert(sizeof(BvhNode4) == 48, "BvhNode4");
+
 // Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
 // (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
 struct BvhTri {
@@ -103,6 +129,7 @@ struct DeviceScene {
     const BvhNode16 *nodes16;
     const BvhNodeCH *nodes_ch;       // centre / half-extent form of `nodes` (same indices, same links)
     const BvhNode48 *nodes48;        // the same in 48 bytes (same indices, same links)
+    const BvhNode4 *nodes4;          // the four-wide collapse of the same tree (its own indices; leaf codes shared)
     float centre[3];                 // origin of the half-precision boxes
     float pad0;
     const BvhTri *tris;
@@ -112,6 +139,7 @@ struct DeviceScene {
     const float *normal_matrices;    // 9 floats per primitive, column-major inverseTranspose(mat3(transform))
     const DeviceTexture *textures;
     uint32_t node_count, tri_count, primitive_count, texture_count;
+    uint32_t node4_count, pad1[3];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -138,13 +166,20 @@ struct HostBvh {
     std::vector<BvhNode16> nodes16;
     std::vector<BvhNodeCH> nodes_ch;
     std::vector<BvhNode48> nodes48;
+    std::vector<BvhNode4> nodes4;
+    // host-side cross references of the wide tree, for check_wide_nodes only (never uploaded): wide node -> the binary node it was
+    // collapsed from; wide child slot -> (binary node << 1 | which) whose box0 / box1 is that child's box
+    std::vector<uint32_t> wide_root;
+    std::vector<uint32_t> wide_child_ref;      // 4 per wide node, 0xffffffff for an absent child
     float centre[3] = { 0, 0, 0 };
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
+    uint32_t wide_depth = 0;          // levels of the four-wide tree (a walk holds at most 3 pending subtrees per level)
 };
 
 // builds the BVH2 (csrc/bvh_build.cpp)
-void check_node_forms(const HostBvh &bvh, uint64_t out[4]);
+void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads = 0);
+void check_wide_nodes(const HostBvh &bvh, uint64_t out[4], int threads = 0);
 uint64_t bvh_fingerprint(const HostBvh &bvh);
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
                uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
@@ -215,7 +250,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptCount = 30 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptCount = 31 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelKinds = 8 };
@@ -267,6 +302,9 @@ struct vhr_context {
     vhr::BvhNode16 *d_nodes16 = nullptr;
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
     vhr::BvhNode48 *d_nodes48 = nullptr;
+    vhr::BvhNode4 *d_nodes4 = nullptr;
+    uint32_t node4_count = 0, bvh_wide_depth = 0;
+    uint64_t bvh_wide_checks[4] = { 0, 0, 0, 0 };   // check_wide_nodes of the last build (vhr_get_bvh_wide_checks)
     uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
     float bvh_centre[3] = { 0, 0, 0 };
@@ -275,6 +313,7 @@ struct vhr_context {
     int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
     double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
+    double bvh_check_ms = 0.0;                                 // the self-checks of the node forms + the fingerprint (not part of K0)
 
     // RenderGraph state
     std::map<std::string, vhr::PassDescription> pass_descriptions;
@@ -308,7 +347,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 4, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
