@@ -356,7 +356,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "bvh_build_threads" host threads of the next build: 0 = up to 16 of the machine's (default), 1 = the serial build; subtrees below
  *                      the top of the tree are built by a pool and spliced in -- the tree is the same whatever the count
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
- *                      persistent workgroups that prefetch the next tile into registers (default)
+ *                      persistent workgroups that prefetch the next tile into registers, 5 = 4 with a tap's normal / id / kernel
+ *                      weight carried in the exponent of its luminance weight (one v_log_f32 for the squaring chain; default)
  *   "atrous_blocks_per_cu" (1..64, default 64: more workgroups than tiles per CU at 1080p and 4K, i.e. one tile per workgroup --
  *                      measured faster than 8 persistent ones by 5 % at 1080p and 10 % at 4K), "atrous_xcd_aware" (default 1):
  *                      launch shape of variant 4

@@ -221,6 +221,13 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
 // ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(fast)
 
+// Knock-out builds of the streaming a-trous kernel (timing experiments only, results are wrong by construction): -DVHR_ATROUS_KO=n
+// removes one ingredient of the tap loop -- 1 the two v_exp_f32, 2 the pow(., 128) chain, 3 the id compare, 4 the variance sums,
+// 5 the LDS tap reads, 6 the taps altogether, 7 the whole luminance term, 8 the whole normal / id weight.  profiles/r3_atrous_knockouts.txt
+#ifndef VHR_ATROUS_KO
+#define VHR_ATROUS_KO 0
+#endif
+
 __device__ __forceinline__ float pow128(float x) {      // max(0, pow(x, 128)); pow of x <= 0 defined as 0
     x = fmaxf(x, 0.0f);
     x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
@@ -597,7 +604,15 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
 // ---------------------------------------------------------------------------------------------
 // ONE_TILE: the grid has a workgroup per tile (the default launch): no tile loop, and the prefetch registers die before the
 // taps start instead of carrying the next tile through them.
-template <int STEP, int R, bool ONE_TILE>
+// LOGW (r3, "atrous_variant" 5, the default): the weight of a tap leaves the exponent only once.  The shader's
+//   w_ch = k * max(0, n.n')^128 * [id == id'] * exp(-|l - l'| / (4 sqrt(var) + 1e-6))                 (svgf_atrous_filter.comp:40-51, 86-89)
+// is evaluated as exp2(L - |l - l'| * inv_ch) with L = 128 * log2(max(0, n.n')) + log2(k), or -inf where the ids differ (exp2(-inf) = 0,
+// log2(0) = -inf: the same zeros the product form gives).  Per tap that is one v_log_f32 and one v_fma_f32 for the 3.5 + 0.5 + 1 packed
+// multiplies of the squaring chain, the kernel constant and e * w, and two v_fma_f32 (|.| and sign as operand modifiers) for the packed
+// multiply by inv.  On this chip a packed fp32 instruction occupies the SIMD for 4 cycles, a plain one for 2, a transcendental for 8
+// (profiles/r3_atrous_knockouts.txt: the kernel's time follows lane operations, not instructions): 34 instead of 39 units per tap.
+// v_log_f32 / v_exp_f32 are 1-ulp instructions; 128 * log2(x) moves a weight by <= ~1e-5 relative, far below the fp16 step of the output.
+template <int STEP, int R, bool ONE_TILE, bool LOGW = false>
 __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total,
                                                                  const uint32_t xcd_aware) {
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
@@ -637,10 +652,45 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
         x0 = int(bx) * kTileX;
         y0 = int(a.row_begin) + group * (R * STEP) + phase;
     };
+    // Addresses are 32-bit byte offsets from the (uniform) image bases -- an image is far below 4 GiB, rows below 2^24 bytes: one
+    // v_mad_u32_u24 per texel instead of the two v_mad_u64_u32 + 64-bit shifts and adds a size_t index costs (r3: the per-tile fixed
+    // part was a third of the kernel's vector instructions).
+    const char *const in_base = reinterpret_cast<const char *>(a.in), *const nm_base = reinterpret_cast<const char *>(a.normals);
+    const uint32_t row_bytes = uint32_t(W) * 8u;
+    auto texel_offset = [&](int sy, int sx) { return __umul24(uint32_t(sy), row_bytes) + uint32_t(sx) * 8u; };
     auto prefetch = [&](uint32_t v) {
         int x0, y0;
         tile_origin(v, x0, y0);
         const int sx = x0 - 2 * STEP + c;
+        // A tile whose halo lies inside the image (nine in ten at 1080p; a workgroup-uniform test) loads without per-texel bounds tests,
+        // zero fills and exec-mask regions: the general path below spends more scalar and vector instructions on those than on the loads.
+        const bool interior = x0 - 2 * STEP >= 0 && x0 + kTileX + 2 * STEP <= max_x && y0 - 2 * STEP >= 0 && y0 + (TH - 3) * STEP < max_y;
+        if (interior) {
+            pf_ok = (1u << NP) - 1u;
+            if (stager) {
+                const uint32_t off0 = texel_offset(y0 + (r0 - 2) * STEP, sx);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (p * PASS + r0 < TH) {
+                        const uint32_t off = off0 + uint32_t(p * PASS * STEP) * row_bytes;
+                        pf_in[p] = *reinterpret_cast<const uint2 *>(in_base + off);
+                        pf_nm[p] = *reinterpret_cast<const uint2 *>(nm_base + off);
+                    }
+                }
+            }
+            const bool edge_lane = tx == 0 || tx == 63;
+#pragma unroll
+            for (int kq = 0; kq < NK; ++kq) {
+                const uint32_t off = texel_offset(y0 + (ty + 4 * kq) * STEP - 1, x0 + tx) + 4u;       // .zw = the two variances
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    pv_own[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + off + uint32_t(j) * row_bytes);
+                    pv_edge[kq][j] = 0u;
+                    if (edge_lane) pv_edge[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u) + uint32_t(j) * row_bytes);
+                }
+            }
+            return;
+        }
         const bool col_ok = stager && sx >= 0 && sx < max_x;
         pf_ok = 0;
 #pragma unroll
@@ -650,9 +700,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             pf_in[p] = make_uint2(0u, 0u);
             pf_nm[p] = make_uint2(0u, 0u);
             if (col_ok && kk < TH && sy >= 0 && sy < max_y) {
-                const size_t sidx = size_t(sy) * W + sx;
-                pf_in[p] = a.in[sidx];
-                pf_nm[p] = a.normals[sidx];
+                const uint32_t off = texel_offset(sy, sx);
+                pf_in[p] = *reinterpret_cast<const uint2 *>(in_base + off);
+                pf_nm[p] = *reinterpret_cast<const uint2 *>(nm_base + off);
                 pf_ok |= 1u << p;
             }
         }
@@ -665,9 +715,10 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int sy = cy + j - 1;
-                const bool row_ok = sy >= 0 && sy < max_y;
-                pv_own[kq][j] = (row_ok && cx < max_x) ? a.in[size_t(sy) * W + cx].y : 0u;      // .zw = the two variances
-                pv_edge[kq][j] = (row_ok && edge_lane) ? a.in[size_t(sy) * W + ex].y : 0u;
+                const bool row_ok = sy >= 0 && sy < max_y;                                      // (the same for every lane of the wave)
+                const uint32_t off = texel_offset(sy, cx) + 4u;                                  // .zw = the two variances
+                pv_own[kq][j] = (row_ok && cx < max_x) ? *reinterpret_cast<const uint32_t *>(in_base + off) : 0u;
+                pv_edge[kq][j] = (row_ok && edge_lane) ? *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u)) : 0u;
             }
         }
     };
@@ -696,28 +747,31 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
         }
         // ---- registers -> LDS (converted once per texel) ----
         if (stager) {
+            auto stage = [&](const bool all_loaded) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int kk = p * PASS + r0;
-                if (kk < TH) {
-                    uint4 va = make_uint4(0u, 0u, 0u, 0u);
-                    float nz = 0.0f;
-                    uint32_t idb = kInvalidId;
-                    if (pf_ok & (1u << p)) {
-                        const uint2 vin = pf_in[p], n = pf_nm[p];
-                        const float2 xy = unpack_rg16f(vin.x);
-                        va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
-                        nz = float(as_half2(n.y).x);
-                        _Float16 idh = __builtin_truncf16(as_half2(n.y).y);   // int(w) as a half; -0 folded into +0
-                        idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
-                        if ((idb & 0x7fffu) == 0u) idb = 0u;
-                        if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;
+                for (int p = 0; p < NP; ++p) {
+                    const int kk = p * PASS + r0;
+                    if (kk < TH) {
+                        uint4 va = make_uint4(0u, 0u, 0u, 0u);
+                        float nz = 0.0f;
+                        uint32_t idb = kInvalidId;
+                        if (all_loaded || (pf_ok & (1u << p))) {
+                            const uint2 vin = pf_in[p], n = pf_nm[p];
+                            const float2 xy = unpack_rg16f(vin.x);
+                            va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
+                            nz = float(as_half2(n.y).x);
+                            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);   // int(w) as a half; -0 folded into +0
+                            idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
+                            if ((idb & 0x7fffu) == 0u) idb = 0u;
+                            if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;
+                        }
+                        s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
+                        s_nz[kk][c] = nz;
+                        s_id[kk][c] = IdSlot(idb);
                     }
-                    s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
-                    s_nz[kk][c] = nz;
-                    s_id[kk][c] = IdSlot(idb);
                 }
-            }
+            };
+            if (pf_ok == (1u << NP) - 1u) stage(true); else stage(false);       // (an interior tile: workgroup-uniform)
         }
         __syncthreads();
         const uint32_t vn = v + gridDim.x;
@@ -742,27 +796,78 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             f2v s01 = p_xy;
             float s2 = p_zw.x, s3 = p_zw.y;
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
+            for (int g = 0; g < (VHR_ATROUS_KO == 6 ? 0 : 6); ++g) {                        // :72-94, four taps per trip
                 lds_u4 qa[4];
                 f2v d[2];
                 bool same[4];
                 float kern[4];
+                if constexpr (LOGW) {
+                    float L[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                  // skip the centre (:77)
+                        const int y = idx / 5 - 2, x = idx % 5 - 2;
+                        const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+                        qa[h] = s_a[row][col];
+                        // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
+                        const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
+                        const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
+                        float dd = np_z * s_nz[row][col];
+                        dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);  // :44-46
+                        const float lg = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));           // log2; -inf at 0
+                        L[h] = uint32_t(s_id[row][col]) == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();      // :40-42, :87
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
+                        const f2v dl = p_xy - q_xy;
+                        const f2v w2 = f2v{ __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.x), inv.x, L[h])),
+                                            __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.y), inv.y, L[h])) };          // :88-89 with :87 in the exponent
+                        sw += w2;                                                           // :91
+                        s01 = __builtin_elementwise_fma(w2, q_xy, s01);                     // :92
+                        const f2v wq = w2 * w2;
+                        const half2_t q_zw = as_half2(qa[h].z);
+                        s2 = fmaf(wq.x, float(q_zw.x), s2);
+                        s3 = fmaf(wq.y, float(q_zw.y), s3);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                      // skip the centre (:77)
                     const int y = idx / 5 - 2, x = idx % 5 - 2;
                     const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+#if VHR_ATROUS_KO == 5
+                    qa[h] = pa; (void)row; (void)col;
+#else
                     qa[h] = s_a[row][col];
+#endif
                     const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
                     const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
                     kern[h] = kx * ky;                                                      // :62-68
+#if VHR_ATROUS_KO == 5
+                    float dd = np_z * np_z;
+#elif VHR_ATROUS_KO == 8
+                    float dd = 1.0f;
+#else
                     float dd = np_z * s_nz[row][col];
+#endif
+#if VHR_ATROUS_KO != 8
                     dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // :44-46
                     d[h >> 1][h & 1] = fmaxf(dd, 0.0f);
+#else
+                    d[h >> 1][h & 1] = dd;
+#endif
+#if VHR_ATROUS_KO == 5 || VHR_ATROUS_KO == 3 || VHR_ATROUS_KO == 8
+                    same[h] = true;
+#else
                     same[h] = uint32_t(s_id[row][col]) == idp;                              // :40-42
+#endif
                 }
+#if VHR_ATROUS_KO != 2 && VHR_ATROUS_KO != 8
 #pragma unroll
                 for (int sq = 0; sq < 7; ++sq) { d[0] *= d[0]; d[1] *= d[1]; }              // pow(., 128), interleaved chains
+#endif
                 d[0] *= f2v{ kern[0], kern[1] };
                 d[1] *= f2v{ kern[2], kern[3] };
 #pragma unroll
@@ -770,20 +875,29 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                     const float w = same[h] ? d[h >> 1][h & 1] : 0.0f;                      // :87
                     const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
                     const f2v tt = (p_xy - q_xy) * inv;
+#if VHR_ATROUS_KO == 1
+                    const f2v e = tt;
+#elif VHR_ATROUS_KO == 7
+                    const f2v e = f2v{ 1.0f, 1.0f }; (void)tt;
+#else
                     const f2v e = f2v{ __builtin_amdgcn_exp2f(-fabsf(tt.x)), __builtin_amdgcn_exp2f(-fabsf(tt.y)) };   // :88-89
+#endif
                     const f2v w2 = e * f2v{ w, w };
                     sw += w2;                                                               // :91
                     s01 = __builtin_elementwise_fma(w2, q_xy, s01);                         // :92
+#if VHR_ATROUS_KO != 4
                     const f2v wq = w2 * w2;
                     const half2_t q_zw = as_half2(qa[h].z);
                     s2 = fmaf(wq.x, float(q_zw.x), s2);
                     s3 = fmaf(wq.y, float(q_zw.y), s3);
+#endif
                 }
             }
             const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
             const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
-        a.out[size_t(cy) * W + cx] = texel;
-        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
+            const uint32_t out_off = texel_offset(cy, cx);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
+            if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
         }
         if (!more) break;
         __syncthreads();                             // every wave is done with this tile's LDS image
@@ -798,12 +912,15 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t tiles_x = (a.limit_x + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
     const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
     const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
-    if (grid == tiles_total)
-        launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total,
-                           uint32_t(ctx->options[kOptAtrousXcdAware]));
-    else
-        launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total,
-                           uint32_t(ctx->options[kOptAtrousXcdAware]));
+    const bool logw = ctx->options[kOptAtrousVariant] == 5;      // 4: the product form of the weights (A-B)
+    const uint32_t xcd = uint32_t(ctx->options[kOptAtrousXcdAware]);
+    if (grid == tiles_total) {
+        if (logw) launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
+        else launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
+    } else {
+        if (logw) launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
+        else launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
+    }
 }
 
 // 4-row tiles (one pixel per thread, twice the blocks, 2/3 of the LDS per block) or 8-row tiles (two pixels per thread, a quarter less
@@ -1000,7 +1117,7 @@ static int issue_atrous(vhr_context *ctx, const AtrousArgs &a) {
     ctx->time_begin(kKernelAtrous);
     const int variant = ctx->options[kOptAtrousVariant];
     bool tiled = variant != 0;
-    if (variant == 4) {
+    if (variant == 4 || variant == 5) {
         switch (step) {
             case 1: launch_atrous_stream_auto<1>(ctx, a); break;
             case 2: launch_atrous_stream_auto<2>(ctx, a); break;
