@@ -626,13 +626,10 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
     // into one word as well -- two LDS reads per tap instead of three -- was measured slower, 44.8 us: the id compare then needs a mask)
     typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
     __shared__ lds_u4 s_a[TH][TW];                   // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
-    __shared__ float s_nz[TH][TW];
-    // ids are 16-bit patterns.  With STEP == 1 the taps' ids are neighbours in LDS and the compiler merges their loads into
-    // ds_read_b64 / b96 at 2-byte alignment, which the LDS serialises (the step-1 launch ran 20 % behind the others: 56.7 vs
-    // 47 us); a 32-bit slot per id keeps the merged loads dword aligned.  Wider steps keep 16-bit slots (no merging
-    // possible, and their larger tiles would lose a resident block per CU to the extra LDS).
-    using IdSlot = typename std::conditional<STEP == 1, uint32_t, uint16_t>::type;
-    __shared__ IdSlot s_id[TH][TW];
+    // the truncated id's half pattern (low 16 bits: a 16-bit compare reads just those) and nz as the half it is (high 16 bits; its
+    // product with the centre's fp32 nz joins the dot product through one v_fma_mix_f32) in ONE word: two LDS reads per tap instead of three, 20 bytes per staged texel -- the step-16 tile
+    // (8 x 128 texels) then takes 20 KB and eight workgroups stay resident per CU like for the smaller steps (r3)
+    __shared__ uint32_t s_ni[TH][TW];
     const int W = int(a.width), H = int(a.height);
     const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
     const int tid = int(threadIdx.x);
@@ -753,21 +750,19 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                     const int kk = p * PASS + r0;
                     if (kk < TH) {
                         uint4 va = make_uint4(0u, 0u, 0u, 0u);
-                        float nz = 0.0f;
-                        uint32_t idb = kInvalidId;
+                        uint32_t ni = kInvalidId;
                         if (all_loaded || (pf_ok & (1u << p))) {
                             const uint2 vin = pf_in[p], n = pf_nm[p];
                             const float2 xy = unpack_rg16f(vin.x);
                             va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
-                            nz = float(as_half2(n.y).x);
-                            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);   // int(w) as a half; -0 folded into +0
-                            idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
-                            if ((idb & 0x7fffu) == 0u) idb = 0u;
-                            if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;
+                            // int(w) as a half (:57, :83).  The taps compare ids as HALVES (v_cmp_eq_f16): -0 == +0 like int(-0.x) == 0, and a
+                            // NaN id becomes 0 here, which is what int(NaN) is in the oracle (decision viii)
+                            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
+                            idh = idh == idh ? idh : _Float16(0.0f);
+                            ni = (n.y << 16) | uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
                         }
                         s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
-                        s_nz[kk][c] = nz;
-                        s_id[kk][c] = IdSlot(idb);
+                        s_ni[kk][c] = ni;
                     }
                 }
             };
@@ -788,8 +783,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
             const float2 p_zw = unpack_rg16f(pa.z);
             const half2_t np_xy = as_half2(pa.w);
-            const float np_z = s_nz[k + 2][tx + 2 * STEP];
-            const uint32_t idp = s_id[k + 2][tx + 2 * STEP];
+            const uint32_t nip = s_ni[k + 2][tx + 2 * STEP];
+            const float np_z = float(as_half2(nip).y);
+            const _Float16 idp = as_half2(nip).x;
             const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
                                  __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
             f2v sw = f2v{ 1.0f, 1.0f };                                                     // :70-71
@@ -812,10 +808,12 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                         // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
                         const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
                         const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
-                        float dd = np_z * s_nz[row][col];
-                        dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);  // :44-46
+                        const uint32_t niq = s_ni[row][col];
+                        float dd;                                                           // :44-46: nz nz' (the half widened by the instruction) ...
+                        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(niq), "v"(np_z));
+                        dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);  // ... + nx nx' + ny ny'
                         const float lg = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));           // log2; -inf at 0
-                        L[h] = uint32_t(s_id[row][col]) == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();      // :40-42, :87
+                        L[h] = as_half2(niq).x == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();    // :40-42, :87 (out of the image: a NaN id)
                     }
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
@@ -845,12 +843,13 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                     const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
                     const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
                     kern[h] = kx * ky;                                                      // :62-68
+                    const uint32_t niq = s_ni[row][col];
 #if VHR_ATROUS_KO == 5
                     float dd = np_z * np_z;
 #elif VHR_ATROUS_KO == 8
                     float dd = 1.0f;
 #else
-                    float dd = np_z * s_nz[row][col];
+                    float dd = np_z * float(as_half2(niq).y);
 #endif
 #if VHR_ATROUS_KO != 8
                     dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // :44-46
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
 #if VHR_ATROUS_KO == 5 || VHR_ATROUS_KO == 3 || VHR_ATROUS_KO == 8
                     same[h] = true;
 #else
-                    same[h] = uint32_t(s_id[row][col]) == idp;                              // :40-42
+                    same[h] = as_half2(niq).x == idp;                                       // :40-42
 #endif
                 }
 #if VHR_ATROUS_KO != 2 && VHR_ATROUS_KO != 8
