@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
 ATROUS_BYTES_PER_PIXEL = 24      # read integrated 8 + normals/id 8, write 8
+TEMPORAL_BYTES_PER_PIXEL = 52    # normals 8 + motion 8 + current 4 + previous normals 8 + history 8 + moments 4, integrated 8 + moments 4 out
 
 
 def parse():
@@ -351,14 +352,17 @@ def main():
     degraded = list(loop.degraded)
     gather_on, gather_error, plan, tp, rpp, rrpp = loop.gather, loop.gather_error, loop.plan, loop.tp, loop.rays_per_pixel, loop.reference_rays_per_pixel
     trace_overlap = getattr(loop, "trace_overlap", False)
+    loop_atrous_steps = loop.atrous_steps
     loop.close()
 
     # ---- extra blocks of the N = 1 line (each its own context, after the timed region): what raygen.rgen's pass costs with its
     # always-on mirror ray, and the same workload with two frames in flight ----
     extras = {}
     if world == 1 and not args.no_extras:
-        def one(**kw):
+        def one(options=None, **kw):
             lp = HybridFrameLoop(scene, W, H, n_frames, **common, **kw)
+            for key, val in {**option_overrides, **(options or {})}.items():
+                lp.ctx.set_option(key, val)
 
             def sync():
                 torch.cuda.synchronize()
@@ -375,6 +379,11 @@ def main():
             ms, mr = one(reflections=1, frames_in_flight=args.frames_in_flight)
             extras["ms_per_step_with_mirror_ray"] = ms                   # raygen.rgen:59-65 always traces it
             extras["value_with_mirror_ray"] = mr
+        # the reference's fifth a-trous iteration is dead work (its output is overwritten before anything reads it); the
+        # timed region above executes it like the reference does, this is the same frame with it elided (opt-in "svgf_elide_unread")
+        ms, mr = one(options={"svgf_elide_unread": 1}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
+        extras["ms_per_step_without_dead_iteration"] = ms
+        extras["value_without_dead_iteration"] = mr
         other = 2 if args.frames_in_flight == 1 else 1
         ms, mr = one(reflections=_bounces(args), frames_in_flight=other)
         extras[f"ms_per_step_frames_in_flight_{other}"] = ms
@@ -382,7 +391,13 @@ def main():
 
     if rank == 0:
         valu = pmc_valu(args)
-        valu_floor_us = valu * 4.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
+        # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles of its SIMD-32
+        valu_floor_us = valu * 2.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
+        temporal_us = kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3
+        rows_temporal = (min(H, y1 + plan.overlap) - max(0, y0 - plan.overlap)) if world > 1 else H
+        temporal_bytes = int(TEMPORAL_BYTES_PER_PIXEL * W * rows_temporal)
+        svgf_pass_us = passes_median.get("SVGF Denoise Pass", 0.0) * 1e3
+        svgf_pass_bytes = int(temporal_bytes + loop_atrous_steps * atrous_bytes + 3 * 16 * W * (y1 - y0))
         out = {
             "metric": "Mrays/s (unique rays) + ms/frame, Sponza 1080p RT shadows+AO+SVGF",
             "value": round(total_rays / dt_max / 1e6, 2),
@@ -420,7 +435,7 @@ def main():
                         "ms_per_step_with_mirror_ray is the frame with it",
             },
             "roofline": {
-                "kernel": "svgf_atrous_stream_kernel<step, 8> (svgf_atrous_filter.comp)",
+                "kernel": "svgf_atrous_stream_kernel<step, 4 rows per tile at 1080p (8 at 4K), one tile per workgroup, weights in the exponent> (svgf_atrous_filter.comp)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits; "
@@ -433,13 +448,18 @@ def main():
                 # what actually bounds the kernel: issue of its vector instructions (PMC: lanes 96-97 % active, traffic 1.2-1.3 x algorithmic)
                 "valu": None if not valu else {
                     "insts_per_launch": valu, "floor_us": round(valu_floor_us, 2), "frac": round(valu_floor_us / atrous_us, 4) if atrous_us > 0 else None,
-                    # measured on this chip (scratch/issue_rates.hip, profiles/r2_issue_rates.txt): with 8 waves resident a SIMD issues a vector
-                    # instruction every ~2 cycles, not every 4 (4-5 is what ONE wave alone gets)
-                    "floor_us_at_measured_issue_rate": round(valu_floor_us / 2.0, 2),
-                    "frac_at_measured_issue_rate": round(valu_floor_us / 2.0 / atrous_us, 4) if atrous_us > 0 else None,
-                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 4 cycles / (1024 SIMDs x 2.4 GHz) "
-                              "as VERDICT r1 defines it; profiles/r2_pmc_stalls.txt: 59 % of the waves' cycles are issue stalls, 20 % memory / LDS waits"},
+                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 2 cycles / (1024 SIMDs x 2.4 GHz), "
+                              "a wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md).  The knock-out builds (profiles/r3_atrous_knockouts.txt) price the kernel's mix higher: a packed "
+                              "fp32 instruction 4 cycles, a transcendental 8"},
             },
+            # the rest of the denoiser against the same HBM peak (VERDICT r2 #2d): svgf.comp alone, and the whole SVGF pass with the
+            # reference's schedule (1 temporal + 5 a-trous + 3 blits = 220 B/px) over the pass's median GPU time
+            "roofline_temporal": {"kernel": "svgf_temporal_kernel (svgf.comp)", "bound": "hbm", "algorithmic_bytes_per_launch": temporal_bytes,
+                                  "avg_launch_us": round(temporal_us, 2), "achieved": round(temporal_bytes / max(temporal_us, 1e-9) / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(temporal_bytes / max(temporal_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4)},
+            "roofline_svgf_pass": {"pass": "SVGF Denoise Pass (hybrid_render_path.cpp:245-331)", "bound": "hbm", "algorithmic_bytes_per_frame": svgf_pass_bytes,
+                                   "median_us": round(svgf_pass_us, 1), "achieved": round(svgf_pass_bytes / max(svgf_pass_us, 1e-9) / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(svgf_pass_bytes / max(svgf_pass_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 4)},
             "traversal": {
                 "kernel": "raygen_queue_kernel (raygen.rgen's shadow + AO rays + miss.rmiss); the mirror ray runs in reflection_kernel (kernels_us.reflection)",
                 "avg_launch_ms": round(raygen_ms, 4),

@@ -62,6 +62,12 @@ int  vhr_create(const vhr_create_info *info, vhr_context **out);
 void vhr_destroy(vhr_context *ctx);
 const char *vhr_last_error(const vhr_context *ctx);   /* ctx may be NULL: error of the last failed vhr_create */
 int  vhr_synchronize(vhr_context *ctx);               /* hipStreamSynchronize on the context stream */
+/* The HIP stream (hipStream_t) the library is enqueueing on right now.  Outside vhr_graph_execute that is the stream given to
+ * vhr_create.  Inside a pass or epilogue callback it is the stream that pass is ordered on: with "frames_in_flight" > 1 the passes up to
+ * the last ray-tracing pass run on a second, library-owned stream, and an external graphics pass (the G-buffer producer) MUST enqueue its
+ * work there -- or make that stream wait for its own -- for the Raytrace Pass to see a complete G-buffer (render_graph.cpp:722-796 orders
+ * the same hand-over with image barriers). */
+int  vhr_get_current_stream(vhr_context *ctx, void **stream);
 const char *vhr_version(void);
 int  vhr_abi_struct_sizes(uint32_t out[8]);            /* vertex, material, primitive, light, per-frame, push constants, trace params, 0 */
 void vhr_default_trace_params(vhr_trace_params *out); /* raygen.rgen:29-65 constants */
@@ -411,7 +417,14 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      graph-owned transient image exists once per index, an external binding (vhr_graph_bind_external_image)
  *                      belongs to the index being executed, and the two streams are ordered by events derived from the pass
  *                      declarations.  External graphics passes before the ray-tracing pass must enqueue on the stream current
- *                      during their callback.  Images bit-identical to n = 1.
+ *                      during their callback: vhr_get_current_stream.  Images bit-identical to n = 1.
+ *   "bvh_wide"         1 = the any-hit queue kernel walks the four-wide tree (48-byte nodes, child boxes quantised to 8 bits per plane,
+ *                      rounded outward; vhr_get_bvh_wide_checks): half the node visits and 38 % fewer load instructions for 35 % more
+ *                      vector instructions -- measured slower (sponza_proc 1080p 404 vs 318 us): default 0.  Bit-identical.
+ *   "svgf_elide_unread" 1 = an a-trous dispatch of a compute pass whose output image nothing later in that pass reads or publishes is
+ *                      not launched -- the reference's fifth a-trous iteration (hybrid_render_path.cpp:299-328 publishes the fourth;
+ *                      SURVEY 8 a5).  Everything the pass publishes is bit-identical; the skipped dispatch's storage image keeps older
+ *                      contents, which is why this is opt-in (default 0).
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -245,6 +245,12 @@ void vhr_destroy(vhr_context *ctx) {
 
 const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+int vhr_get_current_stream(vhr_context *ctx, void **stream) {
+    if (!ctx || !stream) return VHR_ERROR_INVALID_ARGUMENT;
+    *stream = static_cast<void *>(ctx->stream);       // inside a pass callback of vhr_graph_execute: the stream that pass is ordered on
+    return VHR_OK;
+}
+
 int vhr_synchronize(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return VHR_OK;
@@ -475,7 +481,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }

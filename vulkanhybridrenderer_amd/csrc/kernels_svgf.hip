@@ -1158,10 +1158,39 @@ static int issue_cmd(vhr_context *ctx, const SvgfCmd &cmd) {
     }
 }
 
+// "svgf_elide_unread" (opt-in): an a-trous dispatch whose output image no later command of the same pass reads, and which is not
+// published through a fused blit, is not launched.  That is exactly the reference's fifth a-trous iteration: its host loop
+// (hybrid_render_path.cpp:299-328) publishes iteration 3's image and lets iteration 4's be overwritten by the next frame's first
+// iteration before anything reads it -- 7 % of the frame for nothing.  Off by default because the library cannot
+// know that the caller never looks at that storage image between frames; with the option on it is left holding older contents.
+// Everything the pass publishes -- Denoised, history, moments, previous normals -- is bit-identical (tests/test_gpu_svgf.py).
+static bool dead_atrous(const std::vector<SvgfCmd> &rec, size_t k) {
+    const SvgfCmd &w = rec[k];
+    if (w.kind != SvgfCmd::Atrous || w.a.out2) return false;
+    const void *img = w.a.out;
+    for (size_t j = k + 1; j < rec.size(); ++j) {
+        const SvgfCmd &c = rec[j];
+        switch (c.kind) {
+            case SvgfCmd::Temporal:
+                if (c.t.normals == img || c.t.motion == img || c.t.prev_normals == img || c.t.history == img || c.t.raytraced == img || c.t.moments_in == img) return false;
+                break;
+            case SvgfCmd::Atrous:
+                if (c.a.normals == img || c.a.in == img) return false;
+                break;
+            default:
+                if (c.src_base == img) return false;
+                break;
+        }
+    }
+    return true;
+}
+
 int flush_recorded(vhr_context *ctx) {
     int rc = VHR_OK;
-    for (const SvgfCmd &cmd : ctx->recorded) {
-        rc = issue_cmd(ctx, cmd);
+    const bool elide = ctx->options[kOptSvgfElideUnread] != 0;
+    for (size_t k = 0; k < ctx->recorded.size(); ++k) {
+        if (elide && dead_atrous(ctx->recorded, k)) continue;
+        rc = issue_cmd(ctx, ctx->recorded[k]);
         if (rc != VHR_OK) break;
     }
     ctx->recorded.clear();

@@ -373,8 +373,13 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
             HIP_TRY(ctx, hipEventRecord(ctx->front_done[slot], ctx->front_stream));
             HIP_TRY(ctx, hipStreamWaitEvent(back, ctx->front_done[slot], 0));
         }
-        ctx->stream = back;                                                    // epilogues (the caller's exchanges) belong to the caller's stream
+        // Epilogues run on the stream their consumers are on: the caller's, where the pass ran there or has just been handed over to
+        // it (the last front pass); a front pass with more front passes behind it keeps the front stream, so that its epilogue is
+        // ordered between the two (it used to land on the caller's stream, unordered against either).  Whichever it is,
+        // vhr_get_current_stream tells the callback.
+        ctx->stream = (split && pi + 1 < ctx->front_passes) ? ctx->front_stream : back;
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
+        ctx->stream = back;
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
     }
     if (split) {

@@ -250,7 +250,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptCount = 31 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptCount = 32 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelKinds = 8 };
@@ -347,7 +347,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never

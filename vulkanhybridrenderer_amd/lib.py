@@ -32,7 +32,7 @@ EXPORTS = [
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
-    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
+    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
@@ -197,6 +197,7 @@ def load():
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_form_checks.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_wide_checks.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_current_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.vhr_get_bvh_fingerprint.argtypes = [vp, C.POINTER(u64)]
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
@@ -551,6 +552,12 @@ class Context:
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
 
     KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4, "ssao": 5, "ssao_blur": 6, "ssr": 7}
+
+    def current_stream(self):
+        """hipStream_t (as an int) the library is enqueueing on right now: inside a pass callback, the stream that pass is ordered on."""
+        out = C.c_void_p()
+        self.check(self.L.vhr_get_current_stream(self.handle, C.byref(out)), "get_current_stream")
+        return int(out.value or 0)
 
     def set_option(self, key, value):
         self.check(self.L.vhr_set_option(self.handle, key.encode(), int(value)), "set_option")
