@@ -67,6 +67,11 @@ def parse():
     p.add_argument("--min-seconds", type=float, default=1.0,
                    help="the timed block of --steps frames is repeated until this much time has been measured; value = the median block")
     p.add_argument("--no-extras", action="store_true", help="skip the extra blocks (mirror-ray frame, frames in flight) of the N = 1 line")
+    p.add_argument("--grid", default="auto", help="N > 1: the screen decomposition -- auto = the planner's grid of screen tiles (2x4 at N = 8: the busiest "
+                   "rank computes +19 % instead of a row strip's +44 %), strips = row strips, or ROWSxCOLS")
+    p.add_argument("--comm", default="auto", choices=["auto", "torch", "c_abi"],
+                   help="N > 1: who moves the halos and the gather -- torch = torch.distributed P2P (tiling.py), c_abi = the library's own RCCL calls "
+                        "(vhr_comm_*, csrc/comm.cpp), auto = c_abi on the nccl backend if it comes up and reproduces the single-context frame, else torch")
     p.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                    help="vhr_set_option KEY VALUE on the context before the first frame (A-B runs and profiles; every option is result-neutral). "
                         "Anything set this way is listed under config.options")
@@ -113,25 +118,25 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
         loop.frame(i)
         loop.finish_pending_exchange()
         torch.cuda.synchronize()
-        y0, y1 = loop.owned_rows()
-        mine = alias_tensor(loop.ctx.transient_info(lib.DENOISED))[y0:y1].contiguous().view(torch.int16)
+        x0, x1, y0, y1 = loop.owned_rect()
+        mine = alias_tensor(loop.ctx.transient_info(lib.DENOISED))[y0:y1, x0:x1].contiguous().view(torch.int16)
         mine = mine.cpu() if cpu else mine
         sizes = [None] * world
-        dist.all_gather_object(sizes, (y0, y1))
+        dist.all_gather_object(sizes, (x0, x1, y0, y1))
         if rank == 0:
             ref.frame(i)
             torch.cuda.synchronize()
             full = alias_tensor(ref.ctx.transient_info(lib.DENOISED)).view(torch.int16)
             full = full.cpu() if cpu else full
-            ok &= bool(torch.equal(mine, full[y0:y1]))
-            gathered = loop.gathered_frame()                              # C2: the frame assembled on rank 0 by tiling.StripGather
+            ok &= bool(torch.equal(mine, full[y0:y1, x0:x1]))
+            gathered = loop.gathered_frame()                              # C2: the frame assembled on rank 0 (tiling.StripGather / vhr_comm_*)
             if gathered is not None:
                 ok &= bool(torch.equal(gathered.view(torch.int16).cpu(), full.cpu()))
             for r in range(1, world):
-                a, b = sizes[r]
-                buf = torch.empty((b - a, W, 4), dtype=torch.int16, device=mine.device)
+                a0, a1, b0, b1 = sizes[r]
+                buf = torch.empty((b1 - b0, a1 - a0, 4), dtype=torch.int16, device=mine.device)
                 dist.recv(buf, src=r)
-                ok &= bool(torch.equal(buf, full[a:b]))
+                ok &= bool(torch.equal(buf, full[b0:b1, a0:a1]))
         else:
             dist.send(mine, dst=0)
     if ref is not None:
@@ -238,9 +243,31 @@ def main():
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup + (args.verify_frames if world > 1 else 0), args.max_gbuffers)
     common = dict(shadow=True, ao_spp=args.ao_spp, denoise=True, device=local_rank)
-    loop = HybridFrameLoop(scene, W, H, n_frames, reflections=_bounces(args), rank=rank, world=world, dist=dist if world > 1 else None,
-                           trace_overlap=not args.exchange_raytraced, gather=not args.no_gather, frames_in_flight=args.frames_in_flight,
-                           allow_degraded=args.allow_degraded, **common)
+    grid = None if args.grid == "auto" else ("strips" if args.grid == "strips" else tuple(int(v) for v in args.grid.lower().split("x")))
+    # who moves the halos: the library's own RCCL calls need one GPU per rank (RCCL refuses two ranks on one device)
+    comm_mode = args.comm if args.comm != "auto" else ("c_abi" if (world > 1 and args.backend == "nccl" and not args.share_device) else "torch")
+    comm_note = None
+
+    def make_loop(mode):
+        return HybridFrameLoop(scene, W, H, n_frames, reflections=_bounces(args), rank=rank, world=world, dist=dist if world > 1 else None,
+                               trace_overlap=not args.exchange_raytraced, gather=not args.no_gather, frames_in_flight=args.frames_in_flight,
+                               allow_degraded=args.allow_degraded, grid=grid, comm=mode if world > 1 else "torch", **common)
+    try:
+        loop = make_loop(comm_mode)
+        up = 1
+    except Exception as e:   # noqa: BLE001
+        if not (args.comm == "auto" and comm_mode == "c_abi"):
+            raise
+        loop, up, comm_note = None, 0, f"c_abi did not come up on rank {rank}: {e!r}"
+    if world > 1 and args.comm == "auto" and comm_mode == "c_abi":      # every rank must be on the same route
+        flags = [None] * world
+        dist.all_gather_object(flags, (up, comm_note))
+        if not all(f[0] for f in flags):
+            comm_note = next(f[1] for f in flags if not f[0])
+            if loop is not None:
+                loop.close()
+            comm_mode = "torch"
+            loop = make_loop("torch")
     ctx = loop.ctx
     build_ms, upload_ms = ctx.build_times_ms()
     option_overrides = {}
@@ -262,12 +289,24 @@ def main():
     strip_check = None
     if world > 1 and args.verify_frames > 0:
         strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
+        if strip_check != "bit-identical" and args.comm == "auto" and comm_mode == "c_abi":
+            # the library's RCCL route has never met a second device before (rounds 1-3 had one GPU per box): if its first frames do not
+            # reproduce the single-context frame, say so and measure the torch.distributed route instead
+            comm_note = "c_abi ran but its tiles differed from the single-context frame; fell back to torch.distributed"
+            barrier()
+            loop.close()
+            comm_mode = "torch"
+            loop = make_loop("torch")
+            ctx = loop.ctx
+            for key, val in option_overrides.items():
+                ctx.set_option(key, val)
+            strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
         f = args.verify_frames
         barrier()
         if strip_check != "bit-identical":
             # a decomposition that does not reproduce the single-context frame measures something else: no value is printed
             if rank == 0:
-                print(json.dumps({"error": "row strips differ from the single-context frame", "strips_vs_single_context": strip_check,
+                print(json.dumps({"error": "the ranks' tiles differ from the single-context frame", "strips_vs_single_context": strip_check,
                                   "n_gpus": world}), flush=True)
             loop.close()
             dist.barrier()
@@ -322,13 +361,18 @@ def main():
     ray_stats, trav_stats = ctx.ray_statistics(), ctx.traversal_statistics()
     ctx.set_ray_statistics(False)
     y0, y1 = loop.owned_rows()
-    # rows an a-trous launch computes, averaged over the 5 launches of a frame: strips shrink the overlap per iteration
-    # (tiling.atrous_output_extent: 28, 24, 16, 0, 0 of E = 30); at N = 1 this is H
+    # pixels an a-trous launch computes, averaged over the 5 launches of a frame: strips / tiles shrink the overlap per iteration
+    # (tiling.atrous_output_extent: 28, 24, 16, 0, 0 of E = 30); at N = 1 this is W x H
     from vulkanhybridrenderer_amd import tiling
+
+    def computed_pixels(extend):
+        cx0, cx1, cy0, cy1 = loop.plan.computed_rect(extend)
+        return (cx1 - cx0) * (cy1 - cy0)
     exts = [tiling.atrous_output_extent(loop.plan.overlap, 1 << i) if world > 1 else 0 for i in range(loop.atrous_steps)]
-    rows_svgf = sum(min(H, y1 + e) - max(0, y0 - e) for e in exts) / len(exts)
+    pixels_svgf = sum(computed_pixels(e) for e in exts) / len(exts)
     atrous_us = kt["svgf_atrous"][0] / max(1, kt["svgf_atrous"][1]) * 1e3
-    atrous_bytes = int(ATROUS_BYTES_PER_PIXEL * W * rows_svgf)
+    atrous_bytes = int(ATROUS_BYTES_PER_PIXEL * pixels_svgf)
+    pixels_temporal, pixels_owned = computed_pixels(None), computed_pixels(0)
     achieved = atrous_bytes / (atrous_us * 1e-6) / 1e9 if atrous_us > 0 else 0.0
     raygen_ms = kt["raygen"][0] / max(1, kt["raygen"][1])
     passes = {}
@@ -394,10 +438,9 @@ def main():
         # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles of its SIMD-32
         valu_floor_us = valu * 2.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
         temporal_us = kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3
-        rows_temporal = (min(H, y1 + plan.overlap) - max(0, y0 - plan.overlap)) if world > 1 else H
-        temporal_bytes = int(TEMPORAL_BYTES_PER_PIXEL * W * rows_temporal)
+        temporal_bytes = int(TEMPORAL_BYTES_PER_PIXEL * pixels_temporal)
         svgf_pass_us = passes_median.get("SVGF Denoise Pass", 0.0) * 1e3
-        svgf_pass_bytes = int(temporal_bytes + loop_atrous_steps * atrous_bytes + 3 * 16 * W * (y1 - y0))
+        svgf_pass_bytes = int(temporal_bytes + loop_atrous_steps * atrous_bytes + 3 * 16 * pixels_owned)
         out = {
             "metric": "Mrays/s (unique rays) + ms/frame, Sponza 1080p RT shadows+AO+SVGF",
             "value": round(total_rays / dt_max / 1e6, 2),
@@ -420,10 +463,12 @@ def main():
                 "triangles": scene.triangle_count, "primitives": int(len(scene.primitives)),
                 "rays_per_covered_pixel": rpp,
                 "reference_issued_rays_per_covered_pixel": rrpp,
-                "parallelism": f"row strips x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"row strips x{world}" if plan.grid_cols == 1 else f"screen tiles {plan.grid_rows} x {plan.grid_cols} (rows x columns)") if world > 1 else "single GPU",
+                "exchanges_through": None if world == 1 else ("vhr_comm_* (the library's own RCCL calls, csrc/comm.cpp)" if comm_mode == "c_abi" else "torch.distributed P2P (tiling.py)"),
+                "exchanges_note": comm_note,
                 "frames_in_flight": args.frames_in_flight,
                 "options": option_overrides or None,
-                "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo,
+                "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo_rows, "history_halo_cols": plan.halo_cols if plan.grid_cols > 1 else None,
                 "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
                 "multi_gpu_on_hardware": None if world == 1 else "this line IS the measurement; the repository holds no earlier multi-GPU run (rounds 1-2 had one GPU)",

@@ -298,13 +298,22 @@ int vhr_standin_raytraced_composition(vhr_context *ctx, const char *raytraced_ou
  * ones.  All ranges are clamped to the image.  Default: whole image, overlap 0, halo 0.  The halo rows of the
  * history images are filled by the caller's neighbour exchange (vulkanhybridrenderer_amd/tiling.py over RCCL). */
 int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo);
+/* The same for a SCREEN TILE (BASELINE.json north_star: "the framebuffer shards by screen tile"): this context owns the rectangle
+ * [col_begin, col_end) x [row_begin, row_end).  The ray queue kernels trace it (plus `overlap` pixels all round with "trace_overlap"),
+ * svgf.comp and the a-trous launches compute it extended by `overlap` on both axes, the blits copy it extended by halo_rows /
+ * halo_cols (>= overlap: what next frame's svgf.comp may read).  The kernels' A-B variants and the other paths' kernels compute whole
+ * rows of the tile's row range instead: a superset, same results inside the rectangle.  vhr_set_strip is the all-columns case. */
+int vhr_set_tile(vhr_context *ctx, uint32_t col_begin, uint32_t col_end, uint32_t row_begin, uint32_t row_end, uint32_t overlap,
+                 uint32_t halo_rows, uint32_t halo_cols);
 
 /* ---- C1 / C2: the row-strip decomposition's exchanges inside the library (RCCL point-to-point, one process per GPU) ----------
  * The reference is single-GPU (one queue, renderer.cpp:135); these calls exist for an integrator that shards the framebuffer by
  * row strips.  The row arithmetic follows the reference's SVGF schedule (hybrid_render_path.cpp:288-329:
  * the published image is the output of a-trous iteration n-2, iteration i reads +-2*2^i rows) and is the one
  * vulkanhybridrenderer_amd/tiling.py uses (tests/test_comm_plan.py compares the two).  RCCL is loaded on first use.
- * N > 1 has not run on hardware yet (rounds 1-2 had one GPU): world size 1 is smoke-tested, the planner is tested on the CPU. */
+ * N > 1 has not run on hardware yet (rounds 1-3 had one GPU): world size 1 is smoke-tested, the planner is tested on the CPU.
+ * Error handling: a failure inside a grouped batch closes the group, marks the communicator unusable and is reported; what was
+ * enqueued before it is drained by vhr_comm_finish_frame_exchanges. */
 typedef struct vhr_strip_plan {
     uint32_t rank, world, height;
     uint32_t row_begin, row_end;     /* owned rows [g*H/N, (g+1)*H/N) */
@@ -312,6 +321,18 @@ typedef struct vhr_strip_plan {
     uint32_t halo;                   /* Hh = E + ceil(max |motion.y| * H) + 2: rows of history / moments fetched from each neighbour */
 } vhr_strip_plan;
 typedef struct vhr_row_exchange { int32_t peer; uint32_t send_begin, send_end, recv_begin, recv_end; } vhr_row_exchange;
+/* Screen tiles: a grid of grid_rows x grid_cols rectangles, rank = tile_row * grid_cols + tile_col; tile (r, c) owns columns
+ * [c*W/C, (c+1)*W/C) and rows [r*H/R, (r+1)*H/R).  Row strips are the one-column grid. */
+typedef struct vhr_tile_plan {
+    uint32_t rank, world, width, height;
+    uint32_t grid_rows, grid_cols;
+    uint32_t col_begin, col_end, row_begin, row_end;     /* the owned rectangle */
+    uint32_t overlap;                /* E: pixels the SVGF kernels recompute beyond the rectangle, on every cut side */
+    uint32_t halo_rows, halo_cols;   /* E + ceil(max |motion| * extent) + 2 on a cut axis (E on an axis that is not cut): the margin of
+                                      * history / moments fetched from the neighbours */
+} vhr_tile_plan;
+typedef struct vhr_rect { uint32_t x0, x1, y0, y1; } vhr_rect;                 /* [x0, x1) x [y0, y1) */
+typedef struct vhr_rect_exchange { int32_t peer; vhr_rect send, recv; } vhr_rect_exchange;     /* an empty rectangle is all zeros */
 #define VHR_COMM_UNIQUE_ID_BYTES 128
 typedef struct vhr_comm vhr_comm;
 
@@ -322,9 +343,20 @@ int vhr_strip_plan_make(uint32_t height, uint32_t world, uint32_t rank, uint32_t
 /* the neighbours' row ranges of an n_rows-deep halo; returns their number (0..2) */
 int vhr_strip_plan_exchanges(const vhr_strip_plan *plan, uint32_t n_rows, vhr_row_exchange out[2]);
 
+/* (grid_rows, grid_cols) with grid_rows * grid_cols == world that makes a rank compute the fewest pixels, (W / cols + 2E) x (H / rows + 2E) */
+int vhr_tile_grid_choose(uint32_t width, uint32_t height, uint32_t world, uint32_t overlap, uint32_t *grid_rows, uint32_t *grid_cols);
+/* grid_rows == 0 or grid_cols == 0: vhr_tile_grid_choose picks the grid.  VHR_ERROR_OUT_OF_SLOTS when a tile is thinner than its halo. */
+int vhr_tile_plan_make(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
+                       uint32_t max_motion_cols, uint32_t atrous_steps, vhr_tile_plan *out);
+/* the rectangles a margin of (halo_rows, halo_cols) pixels takes from / gives to each peer (up to 8); returns their number or < 0 */
+int vhr_tile_plan_exchanges(const vhr_tile_plan *plan, uint32_t halo_rows, uint32_t halo_cols, vhr_rect_exchange *out, uint32_t capacity);
+
 int vhr_comm_get_unique_id(uint8_t out[VHR_COMM_UNIQUE_ID_BYTES]);      /* ncclGetUniqueId on one rank; the caller hands it to the others */
-/* ncclCommInitRank + vhr_set_strip(plan): collective over the `world` processes of the plan */
+/* ncclCommInitRank + vhr_set_strip(plan) / vhr_set_tile(plan): collective over the `world` processes of the plan.  The plan must be one
+ * the planner returns (it is recomputed and compared: two ranks that disagree on a rectangle would hang RCCL).  vhr_comm_destroy gives the
+ * context the whole image back. */
 int vhr_comm_create(vhr_context *ctx, const vhr_strip_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out);
+int vhr_comm_create_tiled(vhr_context *ctx, const vhr_tile_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out);
 void vhr_comm_destroy(vhr_comm *comm);
 const char *vhr_comm_last_error(const vhr_comm *comm);
 /* Raytrace Pass epilogue, only with "trace_overlap" off: the overlap rows of the raw shadow / AO image from the neighbours, in the

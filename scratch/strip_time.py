@@ -1,5 +1,6 @@
-"""Compute-only frame time of ONE rank's strip (middle rank of N), no exchanges: the lower bound a rank of an
-N-GPU run needs per frame, with the overlap rows' rays traced locally."""
+"""Compute-only frame time of ONE rank's share of the 1080p frame (the busiest rank of N), no exchanges: the lower bound a rank of an
+N-GPU run needs per frame, with the overlap margin's rays traced locally.  Row strips and the planner's screen tiles side by side.
+usage: python scratch/strip_time.py [frames_in_flight]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -10,16 +11,15 @@ W, H = 1920, 1080
 scene = scenes.sponza_proc()
 FIF = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 loop = HybridFrameLoop(scene, W, H, 24, shadow=True, ao_spp=2, reflections=False, denoise=True, frames_in_flight=FIF)
+base = None
 for n in (1, 2, 4, 8):
-    for shared, small, shrink in ((0, -1, 1),):
-        if n == 1: shrink = 0
-        r = n // 2
-        plan = tiling.make_plan(H, n, r, loop.max_motion_rows)
-        loop.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
+    for grid in (("strips", None) if n > 1 else ("strips",)):
+        plans = [tiling.make_tile_plan(W, H, n, r, loop.max_motion_rows, loop.max_motion_cols, grid=grid) for r in range(n)]
+        area = lambda p: (p.computed_rect()[1] - p.computed_rect()[0]) * (p.computed_rect()[3] - p.computed_rect()[2])
+        plan = max(plans, key=area)                       # the busiest rank
+        loop.ctx.set_tile(plan.col_begin, plan.col_end, plan.row_begin, plan.row_end, plan.overlap, plan.halo_rows, plan.halo_cols)
         loop.ctx.set_option("trace_overlap", 1 if n > 1 else 0)
-        loop.ctx.set_option("raygen_shared_tile", shared)
-        loop.ctx.set_option("atrous_small_tiles", small)
-        loop.ctx.set_option("strip_shrink_overlap", shrink)
+        loop.ctx.set_option("strip_shrink_overlap", 1 if n > 1 else 0)
         for i in range(4): loop.frame(i)
         torch.cuda.synchronize()
         ts = []
@@ -34,6 +34,10 @@ for n in (1, 2, 4, 8):
         torch.cuda.synchronize()
         kt = {k: loop.ctx.kernel_time(k) for k in ("raygen", "svgf_temporal", "svgf_atrous", "blit")}
         loop.ctx.set_kernel_timing(False)
-        print(f"frames_in_flight {FIF} N={n} rows {plan.rows}+{2*plan.overlap if n>1 else 0} shrink_overlap={shrink}: {np.median(ts):.4f} ms/frame  " +
+        ms = float(np.median(ts))
+        base = ms if n == 1 else base
+        c = plan.computed_rect()
+        print(f"frames_in_flight {FIF} N={n} grid {plan.grid_rows}x{plan.grid_cols} owned {plan.col_end - plan.col_begin}x{plan.row_end - plan.row_begin} computed {c[1] - c[0]}x{c[3] - c[2]} "
+              f"(+{100.0 * area(plan) * n / (W * H) - 100.0:.0f} %): {ms:.4f} ms/frame = {100.0 * base / (n * ms):.0f} % of linear  " +
               " ".join(f"{k} {v[0]/max(1,v[1])*1e3:.1f}us" for k, v in kt.items()), flush=True)
 loop.close()

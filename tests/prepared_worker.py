@@ -43,6 +43,39 @@ def main():
             for r in range(world):
                 a, b = tiling.strip_bounds(H, world, r)
                 bad += int((gather.full[a:b] != float(10 * frame + r + 1)).any())
+    # The same with SCREEN TILES (VHR_TEST_GRID=RxC): rectangles from up to 8 neighbours, column ranges packed into / unpacked from
+    # persistent staging tensors by PreparedExchange, rectangles assembled by the gather
+    grid = os.environ.get("VHR_TEST_GRID")
+    if grid:
+        gr, gc = (int(v) for v in grid.split("x"))
+        TH, TW = 60, 80
+        tp = tiling.make_tile_plan(TW, TH, world, rank, 1, 2, 3, grid=(gr, gc))          # 3 iterations: overlap 6, halos 9 / 10
+        ta, tb = torch.full((TH, TW, 4), -1.0), torch.full((TH, TW, 2), -1.0)
+        tprep = tiling.PreparedExchange(dist, [ta, tb], tp, (tp.halo_rows, tp.halo_cols))
+        x0, x1, y0, y1 = tp.rect
+        for frame in range(3):
+            for t in (ta, tb):
+                t[y0:y1, x0:x1] = float(100 * frame + rank)
+            pending = tprep.start()
+            if pending is not None:
+                pending.finish()
+            for peer, _, recv in tp.rect_exchanges(tp.halo_rows, tp.halo_cols):
+                if recv:
+                    for t in (ta, tb):
+                        bad += int((t[recv[2]:recv[3], recv[0]:recv[1]] != float(100 * frame + peer)).any())
+            for t in (ta, tb):
+                bad += int((t[y0:y1, x0:x1] != float(100 * frame + rank)).any())
+        timg = torch.full((TH, TW, 4), -7.0)
+        tgather = tiling.StripGather(dist, timg, tp)
+        for frame in range(2):
+            timg[y0:y1, x0:x1] = float(10 * frame + rank + 1)
+            pending = tgather.start()
+            if pending is not None:
+                pending.finish()
+            if rank == 0:
+                for r in range(world):
+                    a0, a1, b0, b1 = tiling.tile_bounds(TW, TH, gr, gc, r // gc, r % gc)
+                    bad += int((tgather.full[b0:b1, a0:a1] != float(10 * frame + r + 1)).any())
     res = torch.tensor([bad], dtype=torch.int64)
     dist.all_reduce(res)
     if rank == 0:

@@ -32,6 +32,61 @@ def test_c_planner_equals_tiling(vhr, height, world):
             assert L.vhr_atrous_output_extent(overlap, 1 << i) == tiling.atrous_output_extent(overlap, 1 << i)
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160), (131, 97)])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_c_tile_planner_equals_tiling(vhr, size, world):
+    """Screen tiles (VERDICT r2 #4a): the grid chosen, every rank's rectangle, overlap, halos and the rectangles exchanged with each
+    of up to 8 neighbours are the same in tiling.py and in the C planner -- for the planner's own grid and for every factorisation."""
+    W, H = size
+    grids = [None] + [(r, world // r) for r in range(1, world + 1) if world % r == 0]
+    for motion_rows, motion_cols, steps in ((0, 0, 5), (3, 5, 5), (1, 2, 3)):
+        overlap = tiling.atrous_overlap(steps) if world > 1 else 0
+        assert lib.tile_grid(W, H, world, overlap) == tiling.choose_grid(W, H, world, overlap)
+        for grid in grids:
+            gr, gc = grid if grid else (0, 0)
+            for rank in range(world):
+                try:
+                    want = tiling.make_tile_plan(W, H, world, rank, motion_rows, motion_cols, steps, grid=grid)
+                except ValueError:
+                    assert lib.tile_plan(W, H, world, rank, gr, gc, motion_rows, motion_cols, steps) is None      # a tile thinner than its halo: both refuse
+                    continue
+                got = lib.tile_plan(W, H, world, rank, gr, gc, motion_rows, motion_cols, steps)
+                assert got is not None
+                assert tuple(getattr(got, n) for n, _ in got._fields_) == \
+                       (want.rank, want.world, want.width, want.height, want.grid_rows, want.grid_cols, want.col_begin, want.col_end, want.row_begin, want.row_end,
+                        want.overlap, want.halo_rows, want.halo_cols)
+                for hr, hc in ((want.halo_rows, want.halo_cols), (want.overlap, want.overlap), (1, 1)):
+                    c_side = lib.tile_plan_exchanges(got, hr, hc)
+                    py_side = [(peer, send or (0, 0, 0, 0), recv or (0, 0, 0, 0)) for peer, send, recv in want.rect_exchanges(hr, hc)]
+                    assert c_side == py_side
+    # row strips are the one-column grid: same rows, same halo
+    for rank in range(world):
+        try:
+            strip = tiling.make_plan(H, world, rank, 3, 5)
+        except ValueError:
+            continue
+        tile = tiling.make_tile_plan(W, H, world, rank, 3, 0, 5, grid="strips")
+        assert (tile.row_begin, tile.row_end, tile.overlap, tile.halo_rows, tile.col_begin, tile.col_end) == (strip.row_begin, strip.row_end, strip.overlap, strip.halo, 0, W)
+        assert [(p, s[2:], r[2:]) for p, s, r in tile.rect_exchanges(strip.halo, 0) if s and r] == strip.exchanges(strip.halo)
+
+
+def test_every_pixel_has_one_owner_and_halos_are_symmetric():
+    """Tiles partition the image, and what A sends to B is what B receives from A."""
+    W, H, world = 640, 360, 6
+    for grid in ((2, 3), (3, 2), (1, 6), (6, 1)):
+        plans = [tiling.make_tile_plan(W, H, world, r, 2, 3, 5, grid=grid) for r in range(world)]
+        cover = [[0] * W for _ in range(H)]
+        for p in plans:
+            for y in range(p.row_begin, p.row_end):
+                for x in range(p.col_begin, p.col_end):
+                    cover[y][x] += 1
+        assert all(v == 1 for row in cover for v in row)
+        ex = {p.rank: {peer: (s, r) for peer, s, r in p.rect_exchanges(p.halo_rows, p.halo_cols)} for p in plans}
+        for a in range(world):
+            for b, (send, recv) in ex[a].items():
+                assert ex[b][a] == (recv, send)
+
+
 @pytest.mark.gpu
 def test_comm_world_size_one_smoke():
     """World size 1 on the GPU box: RCCL loads, the communicator initialises, a frame's exchanges are no-ops that leave the

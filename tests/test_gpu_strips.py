@@ -14,23 +14,31 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0):
+    """`world` contexts on one GPU, one thread each, each computing its strip (grid "strips") or screen tile (grid (rows, cols) or None =
+    the planner's choice) with host-side copies standing in for the RCCL exchanges.  Returns (plans, per-rank per-frame (raytraced,
+    denoised) cut to the owned rectangle)."""
     tp = abi.default_trace_params(reflections=False)
-    plans = [tiling.make_plan(H, world, r, max_motion_rows) for r in range(world)]
+    plans = [tiling.make_tile_plan(W, H, world, r, max_motion_rows, max_motion_cols, grid=grid) for r in range(world)]
     ranks = [GpuHybrid(scene, W, H, reflections=False, trace_params=tp, gbuffer="standin") for _ in range(world)]
     barrier = threading.Barrier(world)
     results = [[] for _ in range(world)]
     errors = []
 
-    def exchange(rank, key_of, n_rows):
-        """Synchronous host-side stand-in for tiling.exchange_rows: copy the peer-owned halo rows into my image."""
+    def cut(img, rect):
+        x0, x1, y0, y1 = rect
+        return img[y0:y1, x0:x1]
+
+    def exchange(rank, key_of, margin):
+        """Synchronous host-side stand-in for tiling.exchange_rows: copy the peer-owned margin into my image."""
         g = ranks[rank]
         g.ctx.synchronize()
         barrier.wait()
         for key in key_of(g):
             mine = g.ctx.download(key)
-            for peer, _, (ra, rb) in plans[rank].exchanges(n_rows):
-                mine[ra:rb] = ranks[peer].ctx.download(key_of(ranks[peer])[key_of(g).index(key)])[ra:rb]
+            for peer, _, recv in plans[rank].rect_exchanges(*margin):
+                if recv:
+                    cut(mine, recv)[...] = cut(ranks[peer].ctx.download(key_of(ranks[peer])[key_of(g).index(key)]), recv)
             barrier.wait()              # everyone has read before anyone writes
             g.ctx.upload(key, mine)
             barrier.wait()
@@ -38,18 +46,20 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
     def worker(rank):
         try:
             g, plan = ranks[rank], plans[rank]
-            g.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo)
+            if plan.grid_cols == 1:
+                g.ctx.set_strip(plan.row_begin, plan.row_end, plan.overlap, plan.halo_rows)
+            else:
+                g.ctx.set_tile(plan.col_begin, plan.col_end, plan.row_begin, plan.row_end, plan.overlap, plan.halo_rows, plan.halo_cols)
             pc = g.path.push_constants()
             g.ctx.set_option("trace_overlap", 1 if trace_overlap else 0)
             g.ctx.set_option("strip_shrink_overlap", 1 if shrink else 0)
             if not trace_overlap:
-                g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], plan.overlap))
+                g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], (plan.overlap, plan.overlap)))
             g.ctx.set_pass_epilogue("SVGF Denoise Pass", lambda c: exchange(
-                rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], plan.halo))
+                rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], (plan.halo_rows, plan.halo_cols)))
             for pfd in pfds:
                 g.frame(pfd)
-                results[rank].append((g.ctx.download(lib.RAYTRACED)[plan.row_begin:plan.row_end],
-                                      g.ctx.download(lib.DENOISED)[plan.row_begin:plan.row_end]))
+                results[rank].append((cut(g.ctx.download(lib.RAYTRACED), plan.rect).copy(), cut(g.ctx.download(lib.DENOISED), plan.rect).copy()))
                 barrier.wait()
         except Exception as e:   # noqa: BLE001
             errors.append(e)
@@ -67,30 +77,58 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
     return plans, results
 
 
+def _single_context_reference(scene, W, H, pfds):
+    """Every frame's (raytraced, denoised) of one whole-image context, and the largest motion in rows and columns."""
+    single = GpuHybrid(scene, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
+    ref, mv_rows, mv_cols = [], 0.0, 0.0
+    try:
+        for pfd in pfds:
+            single.frame(pfd)
+            ref.append((single.ctx.download(lib.RAYTRACED), single.ctx.download(lib.DENOISED)))
+            mv = f16(single.ctx.download(lib.MOTION))
+            d = single.ctx.download(lib.DEPTH)
+            if (d != 0).any():
+                mv_rows = max(mv_rows, float(np.nanmax(np.abs(np.nan_to_num(mv[..., 1][d != 0])))) * H)
+                mv_cols = max(mv_cols, float(np.nanmax(np.abs(np.nan_to_num(mv[..., 0][d != 0])))) * W)
+    finally:
+        single.close()
+    return ref, int(np.ceil(mv_rows)), int(np.ceil(mv_cols))
+
+
+def _check_against_reference(plans, results, ref):
+    for r, plan in enumerate(plans):
+        x0, x1, y0, y1 = plan.rect
+        for f, (rt, den) in enumerate(results[r]):
+            assert np.array_equal(rt, ref[f][0][y0:y1, x0:x1]), f"rank {r} frame {f}: raytraced rectangle differs"
+            assert np.array_equal(den, ref[f][1][y0:y1, x0:x1]), f"rank {r} frame {f}: denoised rectangle differs"
+
+
+@pytest.mark.parametrize("world,grid,trace_overlap,shrink", [(4, (2, 2), True, True), (4, (2, 2), False, False), (6, (2, 3), True, True), (6, (3, 2), True, False),
+                                                             (3, (1, 3), True, True), (2, None, False, True)])
+def test_virtual_screen_tiles_bit_identical(world, grid, trace_overlap, shrink):
+    """BASELINE.json north_star: "the framebuffer shards by screen tile".  A grid of rows x cols contexts, each computing its rectangle
+    (+ the overlap recomputed, + history halos copied in from the neighbours, corners included), reproduces the single-context
+    frames bit for bit -- column strips (1 x 3), the planner's own choice (None), with and without the raw-visibility exchange."""
+    scene = scenes.tiny_scene()
+    W, H = 144, 132
+    pfds = camera.dolly_frames(scene, W, H, 5)
+    ref, mv_rows, mv_cols = _single_context_reference(scene, W, H, pfds)
+    plans, results = _run_strips(scene, W, H, world, pfds, mv_rows, trace_overlap, shrink, grid=grid, max_motion_cols=mv_cols)
+    if grid:
+        assert (plans[0].grid_rows, plans[0].grid_cols) == grid
+    _check_against_reference(plans, results, ref)
+
+
 @pytest.mark.parametrize("world,trace_overlap,shrink", [(2, False, False), (3, False, False), (2, True, False), (3, True, False),
                                                         (2, True, True), (3, True, True), (3, False, True)])
 def test_virtual_strips_bit_identical(world, trace_overlap, shrink):
     scene = scenes.tiny_scene()
     W, H = 96, 132
     pfds = camera.dolly_frames(scene, W, H, 5)
-    single = GpuHybrid(scene, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
-    ref = []
-    max_mv = 0.0
-    try:
-        for pfd in pfds:
-            single.frame(pfd)
-            ref.append((single.ctx.download(lib.RAYTRACED), single.ctx.download(lib.DENOISED)))
-            mv = f16(single.ctx.download(lib.MOTION))[..., 1]
-            d = single.ctx.download(lib.DEPTH)
-            if (d != 0).any():
-                max_mv = max(max_mv, float(np.nanmax(np.abs(np.nan_to_num(mv[d != 0])))) * H)
-    finally:
-        single.close()
-    plans, results = _run_strips(scene, W, H, world, pfds, int(np.ceil(max_mv)), trace_overlap, shrink)
-    for r, plan in enumerate(plans):
-        for f, (rt, den) in enumerate(results[r]):
-            assert np.array_equal(rt, ref[f][0][plan.row_begin:plan.row_end]), f"rank {r} frame {f}: raytraced rows differ"
-            assert np.array_equal(den, ref[f][1][plan.row_begin:plan.row_end]), f"rank {r} frame {f}: denoised rows differ"
+    ref, mv_rows, _ = _single_context_reference(scene, W, H, pfds)
+    plans, results = _run_strips(scene, W, H, world, pfds, mv_rows, trace_overlap, shrink)
+    assert all(p.grid_cols == 1 for p in plans)
+    _check_against_reference(plans, results, ref)
 
 
 def test_golden_fixtures_on_gpu():

@@ -62,20 +62,41 @@ def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink, strip
     assert int(overlap) == 30
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_prepared_exchange_replays(tmp_path, world):
+@pytest.mark.parametrize("world,grid,strip_shrink,shrink", [(4, "2x2", 1, 0), (4, "2x2", 0, 0), (2, "1x2", 1, 0), (4, "2x2", 0, 1)])
+def test_screen_tiles_equal_single_process_gloo(oracle, tmp_path, world, grid, strip_shrink, shrink):
+    """The same check for SCREEN TILES (a grid of rows x cols rectangles, corner neighbours included): every pixel a rank did not
+    compute or receive is NaN, each rank's owned rectangle and the frame gathered on rank 0 equal the single-process result; one
+    pixel less of overlap (the negative control) is caught."""
+    out = tmp_path / "result.txt"
+    port = 29811 + world + 10 * strip_shrink + 40 * shrink + (5 if grid == "1x2" else 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", VHR_TEST_GRID=grid,
+               VHR_TEST_SHRINK_OVERLAP=str(shrink), VHR_TEST_STRIP_SHRINK=str(strip_shrink), VHR_TEST_STRIP_SHRINK_BIAS="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "96", "112", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad, overlap, halo = out.read_text().split()
+    if shrink:
+        assert int(bad) > 0
+        return
+    assert int(bad) == 0, f"{bad} (rank, frame) pairs differ from the single-process result"
+    assert int(overlap) == 30
+
+
+@pytest.mark.parametrize("world,grid", [(2, ""), (3, ""), (4, "2x2"), (6, "2x3")])
+def test_prepared_exchange_replays(tmp_path, world, grid):
     """The P2P descriptor lists the RCCL path builds once and replays every frame (tiling.PreparedExchange, tiling.StripGather),
-    on CPU over gloo, with strips of unequal height (97 rows)."""
+    on CPU over gloo, with strips of unequal height (97 rows) -- and, for a grid, with screen tiles as well."""
     out = tmp_path / "prepared.txt"
     port = 29700 + world
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", VHR_TEST_GRID=grid)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "prepared_worker.py"), str(out), "97", "16", "9"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     bad, nops = out.read_text().split()
     assert int(bad) == 0
-    assert int(nops) == 4                      # rank 0: one neighbour x two tensors x (send + recv)
+    assert int(nops) == 4                      # rank 0 (strips): one neighbour x two tensors x (send + recv)
 
 
 @pytest.mark.parametrize("world", [2, 3])

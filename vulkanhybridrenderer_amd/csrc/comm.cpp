@@ -1,28 +1,40 @@
-// C1 / C2 of SURVEY.md section 2 inside the library: the neighbour halo exchanges and the strip gather of the row-strip
-// decomposition (section 8e) as RCCL point-to-point calls -- ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd, one
-// process per GPU -- so that a C++ integrator has the multi-GPU path without Python (vulkanhybridrenderer_amd/tiling.py issues the
-// same exchanges through torch.distributed for bench.py).  The reference has no counterpart (single GPU, one queue,
-// renderer.cpp:135); what is followed is the schedule of its SVGF pass (hybrid_render_path.cpp:288-329), from which the overlap
-// and halo sizes derive.
+// C1 / C2 of SURVEY.md section 2 inside the library: the halo exchanges and the gather of the screen-space decomposition
+// (section 8e) as RCCL point-to-point calls -- ncclSend / ncclRecv inside ONE ncclGroupStart / ncclGroupEnd per frame, one process
+// per GPU -- so that a C++ integrator has the multi-GPU path without Python (vulkanhybridrenderer_amd/tiling.py issues the same
+// exchanges through torch.distributed).  The reference has no counterpart (single GPU, one queue, renderer.cpp:135); what is
+// followed is the schedule of its SVGF pass (hybrid_render_path.cpp:288-329), from which the overlap and halo sizes derive.
 //
-// The row arithmetic lives HERE once (vhr_strip_plan_make / _exchanges / vhr_atrous_output_extent) and tiling.py is checked
-// against it (tests/test_comm_plan.py), so the two hosts cannot diverge.
+// The decomposition is a grid of grid_rows x grid_cols screen tiles (BASELINE.json: "the framebuffer shards by screen tile"); row
+// strips are the grid_cols == 1 case and keep their own entry points.  The rectangle arithmetic lives HERE once
+// (vhr_tile_plan_make / _exchanges, vhr_strip_plan_*, vhr_atrous_output_extent) and tiling.py is checked against it
+// (tests/test_comm_plan.py), so the two hosts cannot diverge.
 //
-// RCCL is loaded on first use (dlopen): a single-GPU user of libvhr_amd.so has no dependency on it, and a process that already
-// holds an RCCL (torch) shares that copy.
+// RCCL is loaded on first use (dlopen): a single-GPU user of libvhr_amd.so has no dependency on it -- neither at run time nor at
+// build time (the few types used are declared below, rccl.h is not included) -- and a process that already holds an RCCL (torch)
+// shares that copy.
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
-
-#include <rccl/rccl.h>
+#include <vector>
 
 #include "vhr_internal.hpp"
 
 using namespace vhr;
 
 namespace {
+
+// What this file needs of <rccl/rccl.h> (NCCL 2.x ABI, unchanged since 2.0): opaque communicator, 128-byte unique id, result and
+// data-type enumerators.
+typedef struct ncclComm *ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+typedef int ncclDataType_t;
+constexpr ncclDataType_t ncclUint8 = 1;
+static_assert(VHR_COMM_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
 
 struct Rccl {
     void *handle = nullptr;
@@ -39,48 +51,65 @@ struct Rccl {
 
 Rccl &rccl() {
     static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
-    // A copy the process already holds first (the loader knows libraries by soname, librccl.so.1: a PyTorch process has its
-    // own build loaded), else the ROCm installation's -- with local scope, so that this library's choice never rebinds
-    // anybody else's ncclXxx references.
-    for (int flags : { RTLD_NOW | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL }) {
-        for (const char *name : { "librccl.so.1", "librccl.so" }) {
-            r.handle = dlopen(name, flags);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // A copy the process already holds first (the loader knows libraries by soname, librccl.so.1: a PyTorch process has its
+        // own build loaded), else the ROCm installation's -- with local scope, so that this library's choice never rebinds
+        // anybody else's ncclXxx references.
+        for (int flags : { RTLD_NOW | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL }) {
+            for (const char *name : { "librccl.so.1", "librccl.so" }) {
+                r.handle = dlopen(name, flags);
+                if (r.handle) break;
+            }
             if (r.handle) break;
         }
-        if (r.handle) break;
-    }
-    if (!r.handle) { r.error = std::string("RCCL not found: ") + dlerror(); return r; }
-    auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + n; return p; };
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.handle) { const char *e = dlerror(); r.error = std::string("RCCL not found: ") + (e ? e : "librccl.so"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
     return r;
+}
+
+// owned rectangle of tile (tr, tc) of a grid
+void tile_bounds(uint32_t width, uint32_t height, uint32_t grid_rows, uint32_t grid_cols, uint32_t tr, uint32_t tc, vhr_rect &out) {
+    out.x0 = uint32_t(uint64_t(tc) * width / grid_cols);
+    out.x1 = uint32_t(uint64_t(tc + 1) * width / grid_cols);
+    out.y0 = uint32_t(uint64_t(tr) * height / grid_rows);
+    out.y1 = uint32_t(uint64_t(tr + 1) * height / grid_rows);
+}
+vhr_rect grown(const vhr_rect &r, uint32_t dx, uint32_t dy, uint32_t width, uint32_t height) {
+    return vhr_rect{ r.x0 > dx ? r.x0 - dx : 0u, uint32_t(std::min<uint64_t>(width, uint64_t(r.x1) + dx)), r.y0 > dy ? r.y0 - dy : 0u,
+                     uint32_t(std::min<uint64_t>(height, uint64_t(r.y1) + dy)) };
+}
+bool intersect(const vhr_rect &a, const vhr_rect &b, vhr_rect &out) {
+    out = vhr_rect{ std::max(a.x0, b.x0), std::min(a.x1, b.x1), std::max(a.y0, b.y0), std::min(a.y1, b.y1) };
+    return out.x0 < out.x1 && out.y0 < out.y1;
 }
 
 }  // namespace
 
 struct vhr_comm {
     vhr_context *ctx = nullptr;
-    vhr_strip_plan plan = {};
+    vhr_tile_plan plan = {};
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;          // the exchanges' own stream: they run beside the next frame's ray tracing
     hipEvent_t ready = nullptr, done = nullptr;
-    bool pending = false;
+    bool pending = false;                  // exchanges are (or may be) in flight on `stream`: finish has to wait for `done`
+    bool broken = false;                   // an enqueue failed half way: the peers may be out of step, nothing more is started
+    // staging for rectangles that are not whole rows (RCCL moves contiguous bytes): one buffer per direction, grown on demand
+    char *send_stage = nullptr, *recv_stage = nullptr;
+    size_t send_capacity = 0, recv_capacity = 0;
     std::string error;
     int fail(int code, const std::string &msg) { error = msg; if (ctx) ctx->error = msg; return code; }
 };
 
-#define NCCL_TRY(c, expr)                                                                                  \
-    do {                                                                                                   \
-        ncclResult_t r_ = (expr);                                                                          \
-        if (r_ != ncclSuccess) return (c)->fail(VHR_ERROR_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
-    } while (0)
 #define HIPC_TRY(c, expr)                                                                                  \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -89,7 +118,7 @@ struct vhr_comm {
 
 extern "C" {
 
-// ---- the planner (tiling.atrous_overlap / atrous_output_extent / strip_bounds / make_plan / StripPlan.exchanges) ----
+// ---- the planner (tiling.atrous_overlap / atrous_output_extent / tile_bounds / make_tile_plan / TilePlan.exchanges) ----
 uint32_t vhr_atrous_overlap(uint32_t atrous_steps) {
     // the published image is iteration n-2's output (hybrid_render_path.cpp:322-325); iteration i reads +-2*2^i rows
     // (svgf_atrous_filter.comp:72-75): sum_{i=0}^{n-2} 2*2^i = 2*(2^(n-1) - 1)
@@ -101,19 +130,96 @@ uint32_t vhr_atrous_output_extent(uint32_t overlap, uint32_t step) {
     return overlap > used ? overlap - used : 0u;
 }
 
+// The grid for `world` tiles that recomputes the least: (rows, cols) with rows * cols == world minimising the pixels the SVGF
+// kernels compute on the busiest rank (its rectangle grown by E on every cut side, clipped to the image).  1080p, E = 30:
+// 8 -> 2 x 4, 540 x 570 = +19 % over the 480 x 540 owned, where 8 row strips compute 1920 x 195 = +44 %.
+int vhr_tile_grid_choose(uint32_t width, uint32_t height, uint32_t world, uint32_t overlap, uint32_t *grid_rows, uint32_t *grid_cols) {
+    if (!grid_rows || !grid_cols || world == 0 || width == 0 || height == 0) return VHR_ERROR_INVALID_ARGUMENT;
+    uint64_t best = ~0ull;
+    uint32_t best_skew = ~0u;
+    for (uint32_t r = 1; r <= world; ++r) {
+        if (world % r) continue;
+        const uint32_t c = world / r;
+        if (r > height || c > width) continue;
+        uint64_t worst = 0;                                  // the slowest rank: its rectangle grown by the overlap, clipped to the image
+        for (uint32_t tr = 0; tr < r; ++tr)
+            for (uint32_t tc = 0; tc < c; ++tc) {
+                vhr_rect t;
+                tile_bounds(width, height, r, c, tr, tc, t);
+                const vhr_rect g = grown(t, c > 1 ? overlap : 0u, r > 1 ? overlap : 0u, width, height);
+                worst = std::max(worst, uint64_t(g.x1 - g.x0) * (g.y1 - g.y0));
+            }
+        const uint32_t skew = r > c ? r - c : c - r;         // ties: the squarer grid (shorter seams)
+        if (worst < best || (worst == best && skew < best_skew)) { best = worst; best_skew = skew; *grid_rows = r; *grid_cols = c; }
+    }
+    return best == ~0ull ? VHR_ERROR_INVALID_ARGUMENT : VHR_OK;
+}
+
+int vhr_tile_plan_make(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
+                       uint32_t max_motion_cols, uint32_t atrous_steps, vhr_tile_plan *out) {
+    if (!out || world == 0 || rank >= world || height == 0 || width == 0) return VHR_ERROR_INVALID_ARGUMENT;
+    const uint32_t overlap = world > 1 ? vhr_atrous_overlap(atrous_steps) : 0u;
+    if (grid_rows == 0 || grid_cols == 0) {
+        const int rc = vhr_tile_grid_choose(width, height, world, overlap, &grid_rows, &grid_cols);
+        if (rc != VHR_OK) return rc;
+    }
+    if (uint64_t(grid_rows) * grid_cols != world || grid_rows > height || grid_cols > width) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_tile_plan p = {};
+    p.rank = rank; p.world = world; p.width = width; p.height = height;
+    p.grid_rows = grid_rows; p.grid_cols = grid_cols;
+    vhr_rect own;
+    tile_bounds(width, height, grid_rows, grid_cols, rank / grid_cols, rank % grid_cols, own);
+    p.col_begin = own.x0; p.col_end = own.x1; p.row_begin = own.y0; p.row_end = own.y1;
+    if (world > 1) {
+        p.overlap = overlap;
+        // svgf.comp reads the reprojected position +-1 (svgf.comp:52-60,81-84); an axis that is not cut needs no halo
+        p.halo_rows = grid_rows > 1 ? overlap + max_motion_rows + 2u : overlap;
+        p.halo_cols = grid_cols > 1 ? overlap + max_motion_cols + 2u : overlap;
+        // a halo must come from the adjacent tile alone
+        for (uint32_t r = 0; r < grid_rows; ++r) { vhr_rect t; tile_bounds(width, height, grid_rows, grid_cols, r, 0, t); if (grid_rows > 1 && p.halo_rows > t.y1 - t.y0) return VHR_ERROR_OUT_OF_SLOTS; }
+        for (uint32_t c = 0; c < grid_cols; ++c) { vhr_rect t; tile_bounds(width, height, grid_rows, grid_cols, 0, c, t); if (grid_cols > 1 && p.halo_cols > t.x1 - t.x0) return VHR_ERROR_OUT_OF_SLOTS; }
+    }
+    *out = p;
+    return VHR_OK;
+}
+
+// For a margin of (halo_rows, halo_cols) pixels: what this rank receives from each peer = the peer's owned pixels inside my
+// grown rectangle, and what it sends = my owned pixels inside the peer's grown rectangle (symmetric by construction; up to 8
+// peers).  Returns the number of exchanges written (<= capacity), or a negative error.
+int vhr_tile_plan_exchanges(const vhr_tile_plan *p, uint32_t halo_rows, uint32_t halo_cols, vhr_rect_exchange *out, uint32_t capacity) {
+    if (!p || (!out && capacity)) return VHR_ERROR_INVALID_ARGUMENT;
+    if (p->world <= 1 || (halo_rows == 0 && halo_cols == 0)) return 0;
+    const vhr_rect mine{ p->col_begin, p->col_end, p->row_begin, p->row_end };
+    const vhr_rect my_need = grown(mine, p->grid_cols > 1 ? halo_cols : 0u, p->grid_rows > 1 ? halo_rows : 0u, p->width, p->height);
+    uint32_t n = 0;
+    for (uint32_t peer = 0; peer < p->world; ++peer) {
+        if (peer == p->rank) continue;
+        vhr_rect theirs;
+        tile_bounds(p->width, p->height, p->grid_rows, p->grid_cols, peer / p->grid_cols, peer % p->grid_cols, theirs);
+        const vhr_rect their_need = grown(theirs, p->grid_cols > 1 ? halo_cols : 0u, p->grid_rows > 1 ? halo_rows : 0u, p->width, p->height);
+        vhr_rect_exchange e{};
+        e.peer = int32_t(peer);
+        const bool r = intersect(my_need, theirs, e.recv), s = intersect(their_need, mine, e.send);
+        if (!r && !s) continue;
+        if (!r) e.recv = vhr_rect{ 0, 0, 0, 0 };
+        if (!s) e.send = vhr_rect{ 0, 0, 0, 0 };
+        if (n >= capacity) return VHR_ERROR_OUT_OF_SLOTS;
+        out[n++] = e;
+    }
+    return int(n);
+}
+
+// ---- row strips: the one-column grid, in its own vocabulary ----
 int vhr_strip_plan_make(uint32_t height, uint32_t world, uint32_t rank, uint32_t max_motion_rows, uint32_t atrous_steps, vhr_strip_plan *out) {
     if (!out || world == 0 || rank >= world || height == 0) return VHR_ERROR_INVALID_ARGUMENT;
-    auto bounds = [&](uint32_t r, uint32_t &a, uint32_t &b) { a = uint32_t(uint64_t(r) * height / world); b = uint32_t(uint64_t(r + 1) * height / world); };
+    vhr_tile_plan t;
+    const int rc = vhr_tile_plan_make(1u << 20, height, world, rank, world, 1, max_motion_rows, 0, atrous_steps, &t);      // (the width plays no part)
+    if (rc != VHR_OK) return rc;
     vhr_strip_plan p = {};
     p.rank = rank; p.world = world; p.height = height;
-    bounds(rank, p.row_begin, p.row_end);
-    if (world > 1) {
-        p.overlap = vhr_atrous_overlap(atrous_steps);
-        p.halo = p.overlap + max_motion_rows + 2u;       // svgf.comp reads the reprojected position +-1 (svgf.comp:52-60,81-84)
-        uint32_t smallest = height;
-        for (uint32_t r = 0; r < world; ++r) { uint32_t a, b; bounds(r, a, b); smallest = std::min(smallest, b - a); }
-        if (p.halo > smallest) return VHR_ERROR_OUT_OF_SLOTS;      // strips thinner than the history halo: use fewer GPUs
-    }
+    p.row_begin = t.row_begin; p.row_end = t.row_end;
+    p.overlap = t.overlap;
+    p.halo = world > 1 ? t.halo_rows : 0u;
     *out = p;
     return VHR_OK;
 }
@@ -133,39 +239,62 @@ int vhr_strip_plan_exchanges(const vhr_strip_plan *p, uint32_t n_rows, vhr_row_e
 
 // ---- the communicator ----
 int vhr_comm_get_unique_id(uint8_t out[VHR_COMM_UNIQUE_ID_BYTES]) {
-    static_assert(VHR_COMM_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
     if (!out) return VHR_ERROR_INVALID_ARGUMENT;
     Rccl &r = rccl();
     if (!r.error.empty()) return VHR_ERROR_NO_DEVICE;
     ncclUniqueId id;
     if (r.GetUniqueId(&id) != ncclSuccess) return VHR_ERROR_DEVICE;
-    std::memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    std::memcpy(out, id.internal, sizeof(id.internal));
     return VHR_OK;
 }
 
-int vhr_comm_create(vhr_context *ctx, const vhr_strip_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out) {
-    if (!ctx || !plan || !unique_id || !out || plan->rank >= plan->world) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
+int vhr_comm_create_tiled(vhr_context *ctx, const vhr_tile_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out) {
+    if (!ctx || !plan || !unique_id || !out || plan->rank >= plan->world)
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
-    if (plan->height != ctx->height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan's height is not the context's");
+    if (plan->height != ctx->height || plan->width != ctx->width) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan's extent is not the context's");
+    // A plan the planner would not have made -- bounds off the grid, a halo that reaches past the adjacent tile -- makes the two ends
+    // of an exchange disagree on its size, which hangs RCCL: recompute it from its own parameters and compare.
+    {
+        vhr_tile_plan check;
+        const uint32_t mr = plan->grid_rows > 1 && plan->halo_rows >= plan->overlap + 2u ? plan->halo_rows - plan->overlap - 2u : 0u;
+        const uint32_t mc = plan->grid_cols > 1 && plan->halo_cols >= plan->overlap + 2u ? plan->halo_cols - plan->overlap - 2u : 0u;
+        uint32_t steps = 0;
+        while (steps < 16 && vhr_atrous_overlap(steps) < plan->overlap) ++steps;
+        if (plan->world == 1) steps = 5;
+        const int rc = vhr_tile_plan_make(plan->width, plan->height, plan->world, plan->rank, plan->grid_rows, plan->grid_cols, mr, mc, steps, &check);
+        if (rc != VHR_OK || std::memcmp(&check, plan, sizeof(check)) != 0)
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan is not one vhr_tile_plan_make / vhr_strip_plan_make returns");
+    }
     Rccl &r = rccl();
     if (!r.error.empty()) return ctx->fail(VHR_ERROR_NO_DEVICE, r.error);
     vhr_comm *c = new vhr_comm;
     c->ctx = ctx;
     c->plan = *plan;
-    auto bail = [&](int code, const std::string &msg) { ctx->error = msg; vhr_comm_destroy(c); return code; };
+    auto bail = [&](int code, const std::string &msg) { vhr_comm_destroy(c); ctx->error = msg; return code; };
     if (hipSetDevice(ctx->device) != hipSuccess) return bail(VHR_ERROR_DEVICE, "vhr_comm_create: hipSetDevice failed");
     ncclUniqueId id;
-    std::memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    std::memcpy(id.internal, unique_id, sizeof(id.internal));
     const ncclResult_t rc = r.CommInitRank(&c->nccl, int(plan->world), id, int(plan->rank));
     if (rc != ncclSuccess) { c->nccl = nullptr; return bail(VHR_ERROR_DEVICE, std::string("ncclCommInitRank: ") + r.GetErrorString(rc)); }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
         return bail(VHR_ERROR_DEVICE, "vhr_comm_create: stream / event creation failed");
-    // the context computes its strip from now on: owned rows + overlap recomputed, blits extended by the halo
-    const int src = vhr_set_strip(ctx, plan->row_begin, plan->row_end, plan->overlap, plan->halo);
+    // the context computes its tile from now on: owned rectangle + overlap recomputed, blits extended by the halos
+    const int src = vhr_set_tile(ctx, plan->col_begin, plan->col_end, plan->row_begin, plan->row_end, plan->overlap, plan->halo_rows, plan->halo_cols);
     if (src != VHR_OK) { const std::string msg = ctx->error; return bail(src, msg); }
     *out = c;
     return VHR_OK;
+}
+
+int vhr_comm_create(vhr_context *ctx, const vhr_strip_plan *plan, const uint8_t unique_id[VHR_COMM_UNIQUE_ID_BYTES], vhr_comm **out) {
+    if (!ctx || !plan) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
+    vhr_tile_plan t = {};
+    t.rank = plan->rank; t.world = plan->world; t.width = ctx->width; t.height = plan->height;
+    t.grid_rows = plan->world; t.grid_cols = 1;
+    t.col_begin = 0; t.col_end = ctx->width; t.row_begin = plan->row_begin; t.row_end = plan->row_end;
+    t.overlap = plan->overlap; t.halo_rows = plan->world > 1 ? plan->halo : 0u; t.halo_cols = plan->overlap;
+    return vhr_comm_create_tiled(ctx, &t, unique_id, out);
 }
 
 void vhr_comm_destroy(vhr_comm *c) {
@@ -176,92 +305,184 @@ void vhr_comm_destroy(vhr_comm *c) {
     if (c->ready) hipEventDestroy(c->ready);
     if (c->done) hipEventDestroy(c->done);
     if (c->stream) hipStreamDestroy(c->stream);
+    hipFree(c->send_stage);
+    hipFree(c->recv_stage);
+    if (c->ctx) vhr_set_tile(c->ctx, 0, c->ctx->width, 0, c->ctx->height, 0, 0, 0);       // the context owns the whole image again
     delete c;
 }
 
 const char *vhr_comm_last_error(const vhr_comm *c) { return c ? c->error.c_str() : "null communicator"; }
 
-// One grouped batch: for each neighbour, `n_rows` rows of every image, in place (I send rows I own next to the shared boundary and
-// receive the rows the peer owns next to it).  Enqueued on `stream`.
-static int enqueue_row_exchange(vhr_comm *c, Image *const *images, int n_images, uint32_t n_rows, hipStream_t stream) {
-    vhr_row_exchange ex[2];
-    const int n = vhr_strip_plan_exchanges(&c->plan, n_rows, ex);
-    if (n <= 0) return VHR_OK;
-    Rccl &r = rccl();
-    NCCL_TRY(c, r.GroupStart());
-    for (int k = 0; k < n; ++k)
-        for (int i = 0; i < n_images; ++i) {
-            const Image &im = *images[i];
-            const size_t row = size_t(im.width) * im.bpp;
-            char *base = static_cast<char *>(im.ptr);
-            NCCL_TRY(c, r.Send(base + row * ex[k].send_begin, row * (ex[k].send_end - ex[k].send_begin), ncclUint8, ex[k].peer, c->nccl, stream));
-            NCCL_TRY(c, r.Recv(base + row * ex[k].recv_begin, row * (ex[k].recv_end - ex[k].recv_begin), ncclUint8, ex[k].peer, c->nccl, stream));
-        }
-    NCCL_TRY(c, r.GroupEnd());
+}  // extern "C"
+
+namespace {
+
+// One rectangle of one image on the wire.  Whole rows are contiguous in the image and go as they are; a column range is packed
+// into / unpacked from a staging buffer with a strided device copy on the same stream (RCCL moves contiguous bytes).
+struct Piece {
+    Image *image;
+    vhr_rect rect;
+    int peer;
+    bool send;
+    size_t stage_offset;       // into the send / receive staging buffer; SIZE_MAX: in place
+};
+
+size_t rect_bytes(const Image &im, const vhr_rect &r) { return size_t(r.x1 - r.x0) * (r.y1 - r.y0) * im.bpp; }
+bool whole_rows(const Image &im, const vhr_rect &r) { return r.x0 == 0 && r.x1 == im.width; }
+char *rect_ptr(const Image &im, const vhr_rect &r) { return static_cast<char *>(im.ptr) + (size_t(r.y0) * im.width + r.x0) * im.bpp; }
+
+int grow_stage(vhr_comm *c, char *&buf, size_t &capacity, size_t need) {
+    if (need <= capacity) return VHR_OK;
+    // (the old buffer may still be read by exchanges in flight: they are behind `done`, which the caller has waited for)
+    if (buf) HIPC_TRY(c, hipFree(buf));
+    buf = nullptr; capacity = 0;
+    HIPC_TRY(c, hipMalloc(reinterpret_cast<void **>(&buf), need));
+    capacity = need;
     return VHR_OK;
 }
 
-// Exchange #1 (only with "trace_overlap" off): the overlap rows of the raw shadow / AO image from the neighbours, in the
-// context's stream order -- svgf.comp, enqueued next, reads them.  Call it from the Raytrace Pass's epilogue.
+// Everything of one frame in ONE group: packs, sends and receives, unpacks.  The first failure inside the group is remembered, the
+// group is closed all the same (a return between ncclGroupStart and ncclGroupEnd would leave every later RCCL call of this thread,
+// ncclCommDestroy included, queued into it -- ADVICE r2), and the communicator refuses further work: its peers may be out of step.
+int run_pieces(vhr_comm *c, std::vector<Piece> &pieces, hipStream_t stream) {
+    if (pieces.empty()) return VHR_OK;
+    Rccl &r = rccl();
+    size_t send_need = 0, recv_need = 0;
+    for (Piece &p : pieces) {
+        if (whole_rows(*p.image, p.rect)) { p.stage_offset = SIZE_MAX; continue; }
+        size_t &need = p.send ? send_need : recv_need;
+        p.stage_offset = need;
+        need += (rect_bytes(*p.image, p.rect) + 255) & ~size_t(255);
+    }
+    int rc = grow_stage(c, c->send_stage, c->send_capacity, send_need);
+    if (rc != VHR_OK) return rc;
+    rc = grow_stage(c, c->recv_stage, c->recv_capacity, recv_need);
+    if (rc != VHR_OK) return rc;
+    auto copy2d = [&](char *dst, size_t dpitch, const char *src, size_t spitch, const Image &im, const vhr_rect &q) {
+        return hipMemcpy2DAsync(dst, dpitch, src, spitch, size_t(q.x1 - q.x0) * im.bpp, q.y1 - q.y0, hipMemcpyDeviceToDevice, stream);
+    };
+    for (const Piece &p : pieces)                                   // pack what leaves
+        if (p.send && p.stage_offset != SIZE_MAX) {
+            const size_t line = size_t(p.rect.x1 - p.rect.x0) * p.image->bpp;
+            HIPC_TRY(c, copy2d(c->send_stage + p.stage_offset, line, rect_ptr(*p.image, p.rect), size_t(p.image->width) * p.image->bpp, *p.image, p.rect));
+        }
+    std::string first_error;
+    ncclResult_t g = r.GroupStart();
+    if (g != ncclSuccess) return c->fail(VHR_ERROR_DEVICE, std::string("ncclGroupStart: ") + r.GetErrorString(g));
+    for (const Piece &p : pieces) {
+        char *buf = p.stage_offset == SIZE_MAX ? rect_ptr(*p.image, p.rect) : (p.send ? c->send_stage : c->recv_stage) + p.stage_offset;
+        const size_t bytes = rect_bytes(*p.image, p.rect);
+        const ncclResult_t e = p.send ? r.Send(buf, bytes, ncclUint8, p.peer, c->nccl, stream) : r.Recv(buf, bytes, ncclUint8, p.peer, c->nccl, stream);
+        if (e != ncclSuccess && first_error.empty()) first_error = std::string(p.send ? "ncclSend: " : "ncclRecv: ") + r.GetErrorString(e);
+        if (e != ncclSuccess) break;
+    }
+    g = r.GroupEnd();                                               // always
+    if (g != ncclSuccess && first_error.empty()) first_error = std::string("ncclGroupEnd: ") + r.GetErrorString(g);
+    if (!first_error.empty()) { c->broken = true; return c->fail(VHR_ERROR_DEVICE, first_error); }
+    for (const Piece &p : pieces)                                   // unpack what arrived
+        if (!p.send && p.stage_offset != SIZE_MAX) {
+            const size_t line = size_t(p.rect.x1 - p.rect.x0) * p.image->bpp;
+            HIPC_TRY(c, copy2d(rect_ptr(*p.image, p.rect), size_t(p.image->width) * p.image->bpp, c->recv_stage + p.stage_offset, line, *p.image, p.rect));
+        }
+    return VHR_OK;
+}
+
+// the halo exchange of `images` for a margin of (halo_rows, halo_cols), appended to `pieces`
+int add_halo_pieces(vhr_comm *c, Image *const *images, int n_images, uint32_t halo_rows, uint32_t halo_cols, std::vector<Piece> &pieces) {
+    vhr_rect_exchange ex[64];
+    const int n = vhr_tile_plan_exchanges(&c->plan, halo_rows, halo_cols, ex, 64);
+    if (n < 0) return c->fail(n, "vhr_comm: more than 64 peers in a halo exchange");
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < n_images; ++i) {
+            if (ex[k].send.x1 > ex[k].send.x0) pieces.push_back(Piece{ images[i], ex[k].send, ex[k].peer, true, 0 });
+            if (ex[k].recv.x1 > ex[k].recv.x0) pieces.push_back(Piece{ images[i], ex[k].recv, ex[k].peer, false, 0 });
+        }
+    return VHR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Exchange #1 (only with "trace_overlap" off): the overlap margin of the raw shadow / AO image from the neighbours, in the
+// context's stream order -- svgf.comp, enqueued next, reads it.  Call it from the Raytrace Pass's epilogue.
 int vhr_comm_exchange_raytraced(vhr_comm *c, const char *raytraced_image) {
     if (!c || !raytraced_image) return VHR_ERROR_INVALID_ARGUMENT;
+    if (c->broken) return c->fail(VHR_ERROR_GRAPH, "vhr_comm: an earlier exchange failed half way; the communicator is unusable");
     auto it = c->ctx->images.find(raytraced_image);
     if (it == c->ctx->images.end()) return c->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + raytraced_image + "'");
     Image *im = &it->second;
-    return enqueue_row_exchange(c, &im, 1, c->plan.overlap, c->ctx->stream);
+    std::vector<Piece> pieces;
+    const int rc = add_halo_pieces(c, &im, 1, c->plan.overlap, c->plan.overlap, pieces);
+    if (rc != VHR_OK) return rc;
+    if (c->pending) {          // the staging buffers are shared with the frame exchanges on the other stream: they have to be through
+        HIPC_TRY(c, hipStreamWaitEvent(c->ctx->stream, c->done, 0));
+        c->pending = false;
+    }
+    return run_pieces(c, pieces, c->ctx->stream);
 }
 
-// After the SVGF pass (its epilogue): exchange #2 -- `halo` rows of the temporal history and of the moments history just written,
-// for the NEXT frame's svgf.comp -- and, if `denoised_image` is given, the gather (C2) of every rank's owned rows of it into
-// `gathered_frame` on `root` (a device buffer of the whole image there, ignored elsewhere).  Both run on the communicator's own
-// stream behind what the context has enqueued so far, i.e. beside the next frame's ray tracing; nothing waits for them here.
+// After the SVGF pass (its epilogue): exchange #2 -- the halo of the temporal history and of the moments history just written, for
+// the NEXT frame's svgf.comp -- and, if `denoised_image` is given, the gather (C2) of every rank's owned rectangle of it into
+// `gathered_frame` on `root` (a device buffer of the whole image there, ignored elsewhere).  One grouped batch on the communicator's
+// own stream behind what the context has enqueued so far, i.e. beside the next frame's ray tracing; nothing waits for it here.
 int vhr_comm_start_frame_exchanges(vhr_comm *c, int32_t history_storage_image, int32_t moments_storage_image, const char *denoised_image,
                                    int32_t root, void *gathered_frame) {
     if (!c) return VHR_ERROR_INVALID_ARGUMENT;
     vhr_context *ctx = c->ctx;
+    if (c->broken) return c->fail(VHR_ERROR_GRAPH, "vhr_comm: an earlier exchange failed half way; the communicator is unusable");
     auto storage = [&](int32_t id) -> Image * {
         return (id >= 0 && uint32_t(id) < vhr_context::kMaxGlobalResources && ctx->storage_images[id].used) ? &ctx->storage_images[id] : nullptr;
     };
     Image *imgs[2] = { storage(history_storage_image), storage(moments_storage_image) };
     if (!imgs[0] || !imgs[1]) return c->fail(VHR_ERROR_NOT_FOUND, "vhr_comm_start_frame_exchanges: no such storage image");
     if (c->pending) return c->fail(VHR_ERROR_GRAPH, "vhr_comm_start_frame_exchanges: the previous frame's exchanges were not finished");
-    HIPC_TRY(c, hipSetDevice(ctx->device));
-    HIPC_TRY(c, hipEventRecord(c->ready, ctx->stream));
-    HIPC_TRY(c, hipStreamWaitEvent(c->stream, c->ready, 0));
+    // everything that can be refused is refused before anything is enqueued
+    Image gathered{};                         // the root's full-frame destination, addressed like an image
+    std::vector<Piece> pieces;
+    Image *den = nullptr;
     if (denoised_image && c->plan.world > 1) {
         auto it = ctx->images.find(denoised_image);
         if (it == ctx->images.end()) return c->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + denoised_image + "'");
         if (root < 0 || uint32_t(root) >= c->plan.world) return c->fail(VHR_ERROR_INVALID_ARGUMENT, "gather root out of range");
-        const Image &im = it->second;
-        const size_t row = size_t(im.width) * im.bpp;
-        Rccl &r = rccl();
+        den = &it->second;
+        const vhr_rect mine{ c->plan.col_begin, c->plan.col_end, c->plan.row_begin, c->plan.row_end };
         if (int32_t(c->plan.rank) == root) {
             if (!gathered_frame) return c->fail(VHR_ERROR_INVALID_ARGUMENT, "the gather's root needs a destination buffer");
-            char *full = static_cast<char *>(gathered_frame);
-            NCCL_TRY(c, r.GroupStart());
+            gathered = *den;
+            gathered.ptr = gathered_frame;
             for (uint32_t peer = 0; peer < c->plan.world; ++peer) {
                 if (int32_t(peer) == root) continue;
-                const uint32_t a = uint32_t(uint64_t(peer) * c->plan.height / c->plan.world), b = uint32_t(uint64_t(peer + 1) * c->plan.height / c->plan.world);
-                NCCL_TRY(c, r.Recv(full + row * a, row * (b - a), ncclUint8, int(peer), c->nccl, c->stream));
+                vhr_rect theirs;
+                tile_bounds(c->plan.width, c->plan.height, c->plan.grid_rows, c->plan.grid_cols, peer / c->plan.grid_cols, peer % c->plan.grid_cols, theirs);
+                pieces.push_back(Piece{ &gathered, theirs, int(peer), false, 0 });
             }
-            NCCL_TRY(c, r.GroupEnd());
-            HIPC_TRY(c, hipMemcpyAsync(full + row * c->plan.row_begin, static_cast<const char *>(im.ptr) + row * c->plan.row_begin,
-                                       row * (c->plan.row_end - c->plan.row_begin), hipMemcpyDeviceToDevice, c->stream));
         } else {
-            NCCL_TRY(c, r.GroupStart());
-            NCCL_TRY(c, r.Send(static_cast<const char *>(im.ptr) + row * c->plan.row_begin, row * (c->plan.row_end - c->plan.row_begin), ncclUint8, root, c->nccl, c->stream));
-            NCCL_TRY(c, r.GroupEnd());
+            pieces.push_back(Piece{ den, mine, root, true, 0 });
         }
     }
-    const int rc = enqueue_row_exchange(c, imgs, 2, c->plan.halo, c->stream);
-    if (rc != VHR_OK) return rc;
-    HIPC_TRY(c, hipEventRecord(c->done, c->stream));
+    const int arc = add_halo_pieces(c, imgs, 2, c->plan.halo_rows, c->plan.halo_cols, pieces);
+    if (arc != VHR_OK) return arc;
+    HIPC_TRY(c, hipSetDevice(ctx->device));
+    HIPC_TRY(c, hipEventRecord(c->ready, ctx->stream));
+    HIPC_TRY(c, hipStreamWaitEvent(c->stream, c->ready, 0));
+    // From here on work may be in flight on the communicator's stream whatever happens next: `pending` is set first and `done` is
+    // recorded on every path, so that vhr_comm_finish_frame_exchanges always has something true to wait for.
     c->pending = true;
-    return VHR_OK;
+    int rc = run_pieces(c, pieces, c->stream);
+    if (rc == VHR_OK && den && int32_t(c->plan.rank) == root) {       // the root's own rectangle: a local copy, same stream
+        const vhr_rect mine{ c->plan.col_begin, c->plan.col_end, c->plan.row_begin, c->plan.row_end };
+        const size_t pitch = size_t(den->width) * den->bpp;
+        if (hipMemcpy2DAsync(rect_ptr(gathered, mine), pitch, rect_ptr(*den, mine), pitch, size_t(mine.x1 - mine.x0) * den->bpp, mine.y1 - mine.y0,
+                             hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            rc = c->fail(VHR_ERROR_DEVICE, "vhr_comm_start_frame_exchanges: the root's local copy failed");
+    }
+    if (hipEventRecord(c->done, c->stream) != hipSuccess && rc == VHR_OK) rc = c->fail(VHR_ERROR_DEVICE, "hipEventRecord(done) failed");
+    return rc;
 }
 
 // Before the next frame's svgf.comp (the Raytrace Pass's epilogue): the context's stream waits for the exchanges started after the
-// previous frame's SVGF pass.  No host synchronisation.
+// previous frame's SVGF pass -- also after a start that failed half way (what it did enqueue is drained).  No host synchronisation.
 int vhr_comm_finish_frame_exchanges(vhr_comm *c) {
     if (!c) return VHR_ERROR_INVALID_ARGUMENT;
     if (!c->pending) return VHR_OK;

@@ -157,6 +157,7 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
         ctx->width = info->width;
         ctx->height = info->height;
         ctx->row_end = info->height;
+        ctx->col_end = info->width;
         ctx->storage_images.resize(vhr_context::kMaxGlobalResources);
         vhr_default_trace_params(&ctx->trace_params);
         *out = ctx;
@@ -176,6 +177,8 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
     ctx->height = info->height;
     ctx->row_begin = 0;
     ctx->row_end = info->height;
+    ctx->col_begin = 0;
+    ctx->col_end = info->width;
     if (info->flags & VHR_CREATE_INTERNAL_STREAM) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
             g_create_error = "vhr_create: hipStreamCreate failed";
@@ -458,14 +461,24 @@ int vhr_set_trace_params(vhr_context *ctx, const vhr_trace_params *p) {
     return VHR_OK;
 }
 
+int vhr_set_tile(vhr_context *ctx, uint32_t col_begin, uint32_t col_end, uint32_t row_begin, uint32_t row_end, uint32_t overlap,
+                 uint32_t halo_rows, uint32_t halo_cols) {
+    if (!ctx || row_begin > row_end || row_end > ctx->height || col_begin > col_end || col_end > ctx->width || halo_rows < overlap || halo_cols < overlap)
+        return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "set_tile: need begin <= end <= extent on both axes and halos >= overlap") : VHR_ERROR_INVALID_ARGUMENT;
+    ctx->row_begin = row_begin;
+    ctx->row_end = row_end;
+    ctx->col_begin = col_begin;
+    ctx->col_end = col_end;
+    ctx->overlap = overlap;
+    ctx->halo = halo_rows;
+    ctx->halo_cols = halo_cols;
+    return VHR_OK;
+}
+
 int vhr_set_strip(vhr_context *ctx, uint32_t row_begin, uint32_t row_end, uint32_t overlap, uint32_t halo) {
     if (!ctx || row_begin > row_end || row_end > ctx->height || halo < overlap)
         return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "set_strip: need row_begin <= row_end <= height and halo >= overlap") : VHR_ERROR_INVALID_ARGUMENT;
-    ctx->row_begin = row_begin;
-    ctx->row_end = row_end;
-    ctx->overlap = overlap;
-    ctx->halo = halo;
-    return VHR_OK;
+    return vhr_set_tile(ctx, 0, ctx->width, row_begin, row_end, overlap, halo, std::max(halo, ctx->width));      // every column: a strip
 }
 
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {

@@ -62,7 +62,7 @@ __device__ __forceinline__ bool is_valid_reprojection(const TemporalArgs &a, int
 }
 
 __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel(const TemporalArgs a) {
-    const uint32_t cx = blockIdx.x * kSvgfBlockX + threadIdx.x;
+    const uint32_t cx = a.col_begin + blockIdx.x * kSvgfBlockX + threadIdx.x;
     const uint32_t cy = a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y;
     if (cx >= a.limit_x || cy >= a.row_end || cy >= a.limit_y) return;
     const size_t idx = size_t(cy) * a.width + cx;
@@ -177,6 +177,13 @@ static void strip_rows(const vhr_context *ctx, uint32_t height, uint32_t extend,
     r1 = uint32_t(std::min<uint64_t>(height, uint64_t(e) + extend));
     if (e <= b) { r0 = r1 = 0; }
 }
+// the same for the columns of a screen tile (vhr_set_tile; a strip owns every column)
+static void strip_cols(const vhr_context *ctx, uint32_t width, uint32_t extend, uint32_t &c0, uint32_t &c1) {
+    const uint32_t b = std::min(ctx->col_begin, width), e = std::min(ctx->col_end, width);
+    c0 = b > extend ? b - extend : 0;
+    c1 = uint32_t(std::min<uint64_t>(width, uint64_t(e) + extend));
+    if (e <= b) { c0 = c1 = 0; }
+}
 
 int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &motion,
                          const Image &raytraced, const Image &prev_normals, const Image &history, Image &moments,
@@ -204,6 +211,11 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
     a.limit_x = uint32_t(std::min<uint64_t>(W, uint64_t(x_groups) * 8));
     a.limit_y = uint32_t(std::min<uint64_t>(H, uint64_t(y_groups) * 8));
     strip_rows(ctx, H, ctx->overlap, a.row_begin, a.row_end);
+    {
+        uint32_t c1;
+        strip_cols(ctx, W, ctx->overlap, a.col_begin, c1);
+        a.limit_x = std::min(a.limit_x, c1);
+    }
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
     // the dispatch reads a snapshot (ptr) and writes the new moments (alt): flip (oracle decision ii) -- host-side state, so
@@ -646,7 +658,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
         const uint32_t t = xcd_aware ? xcd_remap(v, tiles_total) : v;
         const uint32_t by = t / tiles_x, bx = t - by * tiles_x;
         const int group = int(by) / STEP, phase = int(by) - group * STEP;
-        x0 = int(bx) * kTileX;
+        x0 = int(a.col_begin) + int(bx) * kTileX;
         y0 = int(a.row_begin) + group * (R * STEP) + phase;
     };
     // Addresses are 32-bit byte offsets from the (uniform) image bases -- an image is far below 4 GiB, rows below 2^24 bytes: one
@@ -908,7 +920,7 @@ template <int STEP, int R>
 static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
-    const uint32_t tiles_x = (a.limit_x + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
+    const uint32_t tiles_x = (a.limit_x - a.col_begin + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
     const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
     const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
     const bool logw = ctx->options[kOptAtrousVariant] == 5;      // 4: the product form of the weights (A-B)
@@ -930,7 +942,7 @@ static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
 template <int STEP>
 static void launch_atrous_stream_auto(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
-    const uint32_t tiles8 = ((a.limit_x + kTileX - 1) / kTileX) * ((rows + 8 * STEP - 1) / (8 * STEP)) * STEP;
+    const uint32_t tiles8 = ((a.limit_x - a.col_begin + kTileX - 1) / kTileX) * ((rows + 8 * STEP - 1) / (8 * STEP)) * STEP;
     const int small = ctx->options[kOptAtrousSmallTiles];        // -1 auto, 0 never, 1 always
     if (small == 1 || (small == 2 && STEP >= 16) || (small == 3 && STEP >= 8) || (small < 0 && tiles8 < 32u * uint32_t(ctx->cu_count))) launch_atrous_stream<STEP, 4>(ctx, a);
     else launch_atrous_stream<STEP, 8>(ctx, a);
@@ -970,6 +982,11 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
         extend = consumed >= extend ? 0u : uint32_t(extend - consumed);
     }
     strip_rows(ctx, H, extend, a.row_begin, a.row_end);
+    {
+        uint32_t c1;
+        strip_cols(ctx, W, extend, a.col_begin, c1);          // screen tiles: the same margin on the columns
+        a.limit_x = std::min(a.limit_x, c1);
+    }
     a.step = step;
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
@@ -1030,21 +1047,26 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     if (src.width != dst.width || src.height != dst.height)          // asserts at compute_execution_context.cpp:179-180
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: extents differ");
     if (src.bpp != dst.bpp) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "BlitImage: formats of different texel size are not supported");
-    uint32_t r0, r1;
+    uint32_t r0, r1, c0, c1;
     strip_rows(ctx, src.height, ctx->halo, r0, r1);
-    if (r1 <= r0 || src.ptr == dst.ptr) return VHR_OK;
-    const size_t row = size_t(src.width) * src.bpp, offset = r0 * row, bytes = (r1 - r0) * row;
+    strip_cols(ctx, src.width, ctx->halo_cols, c0, c1);
+    if (r1 <= r0 || c1 <= c0 || src.ptr == dst.ptr) return VHR_OK;
+    const bool all_cols = c0 == 0 && c1 == src.width;
+    const size_t row = size_t(src.width) * src.bpp, offset = r0 * row + size_t(c0) * src.bpp, bytes = (r1 - r0) * row;
     SvgfCmd cmd{};
     cmd.kind = SvgfCmd::Copy;
     cmd.copy_src = static_cast<const char *>(src.ptr) + offset;
     cmd.copy_dst = static_cast<char *>(dst.ptr) + offset;
     cmd.copy_bytes = bytes;
+    cmd.copy_rows = all_cols ? 0u : r1 - r0;                        // a column range (screen tiles): row pieces
+    cmd.copy_pitch = row;
+    cmd.copy_row_bytes = size_t(c1 - c0) * src.bpp;
     cmd.src_base = src.ptr;
     cmd.dst_base = dst.ptr;
     if (!ctx->recording) return issue_cmd(ctx, cmd);
     // ---- fusion: the blit becomes a second store of the recorded a-trous dispatch that produced its source ----
     if (ctx->options[kOptFuseBlits] && src.bpp == 8) {
-        const bool whole = ctx->row_begin == 0 && ctx->row_end >= src.height;
+        const bool whole = ctx->row_begin == 0 && ctx->row_end >= src.height && all_cols;
         auto touches = [](const SvgfCmd &c, const void *p, bool writes_only) {
             switch (c.kind) {
                 case SvgfCmd::Temporal:
@@ -1061,8 +1083,9 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
             if (touches(w, src.ptr, true)) {
                 // w wrote the source last.  Fusable iff it is an a-trous launch over whole rows that the blit covers (on a
                 // strip the blit's extra rows hold nothing valid and are refilled by the neighbour exchange, see vhr_set_strip)
-                if (w.kind == SvgfCmd::Atrous && w.a.out == src.ptr && !w.a.out2 && w.a.limit_x == w.a.width && !touches(w, dst.ptr, false) &&
-                    w.a.row_begin >= r0 && w.a.row_end <= r1 && (!whole || (w.a.row_begin == r0 && w.a.row_end == r1 && w.a.limit_y >= r1))) {
+                if (w.kind == SvgfCmd::Atrous && w.a.out == src.ptr && !w.a.out2 && w.a.col_begin >= c0 && w.a.limit_x <= c1 && !touches(w, dst.ptr, false) &&
+                    w.a.row_begin >= r0 && w.a.row_end <= r1 &&
+                    (!whole || (w.a.row_begin == r0 && w.a.row_end == r1 && w.a.limit_y >= r1 && w.a.col_begin == 0 && w.a.limit_x == w.a.width))) {
                     w.a.out2 = static_cast<uint2 *>(dst.ptr);
                     return VHR_OK;
                 }
@@ -1075,12 +1098,28 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
     return VHR_OK;
 }
 
+// a column range of rows (screen tiles): `rows` pieces of `words` 4-byte words, `pitch_words` apart in both images
+__global__ __launch_bounds__(256) void copy_rect_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t words, uint32_t rows, size_t pitch_words) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= words) return;
+    for (uint32_t y = blockIdx.y; y < rows; y += gridDim.y) dst[size_t(y) * pitch_words + x] = src[size_t(y) * pitch_words + x];
+}
+
 static int issue_copy(vhr_context *ctx, const SvgfCmd &cmd) {
     const char *s8 = cmd.copy_src;
     char *d8 = cmd.copy_dst;
     const size_t bytes = cmd.copy_bytes;
     hipError_t copy_rc = hipSuccess;
     ctx->time_begin(kKernelCopy);
+    if (cmd.copy_rows) {                                             // texels are 4 or 8 bytes: whole 4-byte words at 4-byte alignment
+        const uint32_t words = uint32_t(cmd.copy_row_bytes / 4);
+        launch(ctx, copy_rect_kernel, dim3((words + 255) / 256, std::min<uint32_t>(cmd.copy_rows, 1024u)), dim3(256), 0,
+               reinterpret_cast<const uint32_t *>(s8), reinterpret_cast<uint32_t *>(d8), words, cmd.copy_rows, cmd.copy_pitch / 4);
+        copy_rc = hipGetLastError();
+        ctx->time_end(kKernelCopy);
+        if (copy_rc != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "BlitImage: device copy failed");
+        return VHR_OK;
+    }
     if (((reinterpret_cast<uintptr_t>(s8) | reinterpret_cast<uintptr_t>(d8) | bytes) & 15u) == 0) {
         const size_t count = bytes / 16;
         const uint32_t blocks = uint32_t(std::min<size_t>((count + 1023) / 1024, size_t(ctx->cu_count) * 8));
@@ -1096,8 +1135,8 @@ static int issue_copy(vhr_context *ctx, const SvgfCmd &cmd) {
 }
 
 static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
-    if (a.row_end > a.row_begin && a.limit_x && a.limit_y) {
-        const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+    if (a.row_end > a.row_begin && a.limit_x > a.col_begin && a.limit_y) {
+        const dim3 grid((a.limit_x - a.col_begin + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
         ctx->time_begin(kKernelTemporal);
         launch(ctx, svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
         ctx->time_end(kKernelTemporal);
@@ -1111,7 +1150,8 @@ static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
 // ---------------------------------------------------------------------------------------------
 static int issue_atrous(vhr_context *ctx, const AtrousArgs &a) {
     const int32_t step = a.step;
-    if (a.row_end <= a.row_begin || !a.limit_x || !a.limit_y) return VHR_OK;
+    if (a.row_end <= a.row_begin || a.limit_x <= a.col_begin || !a.limit_y) return VHR_OK;
+    // (only the default streaming kernel starts at col_begin; the A-B variants compute the rows from column 0: a superset)
     const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
     ctx->time_begin(kKernelAtrous);
     const int variant = ctx->options[kOptAtrousVariant];

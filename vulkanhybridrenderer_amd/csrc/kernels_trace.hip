@@ -359,6 +359,8 @@ struct RaygenArgs {
     void *reflections;       // RGBA16F or nullptr
     uint32_t width, height;  // launch size == image size
     uint32_t row_begin, row_end;
+    uint32_t col_begin, col_end;     // screen tiles (vhr_set_tile): the columns the queue kernels trace -- col_begin a multiple of the tile
+                                     // width, [0, width) otherwise; the per-pixel kernels trace whole rows (a superset)
     RayStats *stats;         // nullptr = off
 };
 
@@ -557,9 +559,9 @@ __device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t
 // block share nothing and never synchronise with each other.
 template <int WAVES>
 __device__ __forceinline__ void tile_pixel(uint32_t block_tile, uint32_t tiles_x, uint32_t wave, uint32_t local, uint32_t row_begin, uint32_t tile_rows,
-                                           uint32_t &x, uint32_t &y) {
+                                           uint32_t &x, uint32_t &y, uint32_t col_begin = 0u) {
     const uint32_t by = block_tile / tiles_x, bx = block_tile - by * tiles_x;
-    x = (bx * WAVES + wave) * 8u + (local & 7u);
+    x = col_begin + (bx * WAVES + wave) * 8u + (local & 7u);
     y = row_begin + by * tile_rows + (local >> 3);          // tile_rows < 8: the lanes of the tile's missing rows stay out of range
 }
 
@@ -910,9 +912,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y);
-    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y);
-    const bool in_range = x < W && y < a.row_end && (lane >> 3) < tile_rows;
+    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y, a.col_begin);
+    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y, a.col_begin);
+    const bool in_range = x < a.col_end && y < a.row_end && (lane >> 3) < tile_rows;
     const bool setup_wave = !SHARED || wave == 0;         // SHARED: wave 0 prepares the tile, the others join at the barrier
     bool covered = false;
     float depth = 0.0f;
@@ -1723,8 +1725,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     };
 #pragma unroll
     for (uint32_t sub = 0; sub < 2; ++sub) {
-        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
-        const bool in_range = x < W && y < a.row_end;
+        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const bool in_range = x < a.col_end && y < a.row_end;
         const float depth = in_range ? a.depth[size_t(y) * W + x] : 0.0f;                    // rgen:19
         const bool covered = depth != 0.0f;
         if (in_range && !covered) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);   // rgen:22
@@ -1806,7 +1808,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (uint32_t sub = 0; sub < 2; ++sub) {
         if (!((covered_mask[sub] >> lane) & 1ull)) continue;
-        const uint32_t x = tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
         const uint32_t p = sub * 64u + lane;
         f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                           // reflection_miss.rmiss:7
         const uint32_t tri = traced ? __float_as_uint(s_ray[0][p]) : kNoHit;
@@ -1852,12 +1854,18 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     const uint32_t owned_begin = std::min(ctx->row_begin, height), owned_end = std::min(ctx->row_end, height);
     a.row_begin = owned_begin;
     a.row_end = owned_end;
+    // screen tiles: the owned columns, on 16-pixel tile boundaries (a few columns more than owned are harmless: rays are per pixel)
+    const uint32_t owned_col_begin = std::min(ctx->col_begin, width), owned_col_end = std::min(ctx->col_end, width);
+    a.col_begin = owned_col_begin & ~15u;
+    a.col_end = owned_col_end;
     a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
     ctx->raytraced_pixels = 0;                 // ray statistics are the hybrid path's again
-    if (a.row_end <= a.row_begin) return VHR_OK;
-    if (ctx->options[kOptTraceOverlap]) {      // strips: trace the rows the denoiser recomputes too (no exchange of raw visibility)
+    if (a.row_end <= a.row_begin || a.col_end <= a.col_begin) return VHR_OK;
+    if (ctx->options[kOptTraceOverlap]) {      // strips / tiles: trace the margin the denoiser recomputes too (no exchange of raw visibility)
         a.row_begin = owned_begin > ctx->overlap ? owned_begin - ctx->overlap : 0u;
         a.row_end = uint32_t(std::min<uint64_t>(height, uint64_t(owned_end) + ctx->overlap));
+        a.col_begin = (owned_col_begin > ctx->overlap ? owned_col_begin - ctx->overlap : 0u) & ~15u;
+        a.col_end = uint32_t(std::min<uint64_t>(width, uint64_t(owned_col_end) + ctx->overlap));
     }
     if (a.stats) {
         if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
@@ -1881,7 +1889,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         // strips included (1080p / 8: 123 -> 131 us; full frame 452 -> 523 us): a shorter queue keeps fewer lanes busy.
         const uint32_t rows_traced = a.row_end - a.row_begin;
         const uint32_t tile_rows = uint32_t(std::max(1, std::min(8, ctx->options[kOptRaygenTileRows])));
-        const uint32_t tiles_x = (width + 7) / 8, tiles_y = (rows_traced + tile_rows - 1) / tile_rows;
+        const uint32_t tiles_x = (a.col_end - a.col_begin + 7) / 8, tiles_y = (rows_traced + tile_rows - 1) / tile_rows;
         const int waves = ctx->options[kOptWavesPerBlock];
         const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
 #define VHR_LAUNCH_QUEUE(P, WV, C, SP, ST)                                                                                        \
@@ -1968,15 +1976,17 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
     }
     ctx->time_end(kKernelRaygen);
-    if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {       // not denoised: owned rows only
+    if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {       // not denoised: owned rows (and columns) only
         a.row_begin = owned_begin;
         a.row_end = owned_end;
+        a.col_begin = owned_col_begin & ~15u;
+        a.col_end = owned_col_end;
         ctx->time_begin(kKernelReflection);
         if (a.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
-            const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
+            const uint32_t tiles_x = (a.col_end - a.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
 #define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
             const bool spill = levels < ctx->bvh_depth + 1u;

@@ -216,8 +216,9 @@ struct TemporalArgs {
     uint2 *integrated_out;                                     // RGBA16F
     uint32_t *moments_out;                                     // RG16F
     uint32_t width, height;       // image extent
-    uint32_t limit_x, limit_y;    // pixels covered by the dispatch (groups * 8, clamped)
+    uint32_t limit_x, limit_y;    // pixels covered by the dispatch (groups * 8, clamped; limit_x also clamped to the tile's last column)
     uint32_t row_begin, row_end;  // rows this context computes
+    uint32_t col_begin;           // first column this context computes (screen tiles, vhr_set_tile; 0 for row strips)
     float display_w, display_h;   // pfd.display_size
 };
 struct AtrousArgs {
@@ -225,6 +226,7 @@ struct AtrousArgs {
     uint2 *out;
     uint2 *out2;                  // second destination of the same texels (a blit fused into the launch), or nullptr
     uint32_t width, height, limit_x, limit_y, row_begin, row_end;
+    uint32_t col_begin;           // first column computed (screen tiles); limit_x is the end of the column range
     int32_t step;
     float display_w, display_h;
 };
@@ -236,7 +238,8 @@ struct SvgfCmd {
     enum Kind { Temporal, Atrous, Copy } kind;
     TemporalArgs t;
     AtrousArgs a;
-    const char *copy_src; char *copy_dst; size_t copy_bytes;       // Copy: row range applied
+    const char *copy_src; char *copy_dst; size_t copy_bytes;       // Copy: row range applied (whole rows: one contiguous range)
+    size_t copy_pitch, copy_row_bytes; uint32_t copy_rows;         // Copy of a column range (screen tiles): copy_rows pieces of copy_row_bytes, copy_pitch apart; copy_rows == 0: contiguous
     const void *src_base; void *dst_base;                          // Copy: the images' base pointers (hazard checks)
 };
 
@@ -323,8 +326,10 @@ struct vhr_context {
     std::unordered_map<std::string, std::string> compute_kernel_owner;    // shader -> pass (global key)
     bool built = false;
 
-    // strips
+    // strips / screen tiles (vhr_set_strip, vhr_set_tile): the owned rectangle, the margin the SVGF kernels recompute around it
+    // (`overlap`, both axes) and the margin the blits copy (`halo` rows, `halo_cols` columns: what next frame's svgf.comp may read)
     uint32_t row_begin = 0, row_end = 0, overlap = 0, halo = 0;
+    uint32_t col_begin = 0, col_end = 0, halo_cols = 0;
 
     // Frames in flight (vulkan_common.h:9 MAX_FRAMES_IN_FLIGHT, renderer.cpp:103-146: the reference's CPU runs up to three
     // frames ahead and its queue overlaps whatever the barriers allow).  With "frames_in_flight" n > 1 (read at vhr_graph_build)

@@ -31,7 +31,10 @@ def alias_tensor(info):
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
                  atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True,
-                 frames_in_flight=1, allow_degraded=False):
+                 frames_in_flight=1, allow_degraded=False, grid=None, comm="torch"):
+        """grid: the screen decomposition for world > 1 -- None = the planner's choice (tiling.choose_grid), "strips" = row strips,
+        or (grid_rows, grid_cols).  comm: "torch" = the exchanges through torch.distributed (tiling.StripExchanges), "c_abi" = through
+        the library's own RCCL calls (vhr_comm_*, csrc/comm.cpp; the unique id travels over torch.distributed's store)."""
         import torch
         self.torch = torch
         self.scene, self.W, self.H = scene, width, height
@@ -62,20 +65,37 @@ class HybridFrameLoop:
         self.denoise = denoise
         self.atrous_steps = atrous_steps
         self._precompute_gbuffers()
-        self.plan = tiling.make_plan(height, world, rank, self.max_motion_rows, atrous_steps)
+        self.plan = tiling.make_tile_plan(width, height, world, rank, self.max_motion_rows, self.max_motion_cols, atrous_steps, grid=grid)
+        self.comm_mode, self.comm, self._gather_buffer = comm, None, None
         if world > 1:
-            self.ctx.set_strip(self.plan.row_begin, self.plan.row_end, self.plan.overlap, self.plan.halo)
+            p = self.plan
+            if comm == "c_abi":          # vhr_comm_create_tiled sets the tile itself
+                ids = [lib.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                cplan = lib.tile_plan(width, height, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps)
+                self.comm = lib.Comm(self.ctx, cplan, ids[0])
+            elif p.grid_cols == 1:
+                self.ctx.set_strip(p.row_begin, p.row_end, p.overlap, p.halo_rows)
+            else:
+                self.ctx.set_tile(p.col_begin, p.col_end, p.row_begin, p.row_end, p.overlap, p.halo_rows, p.halo_cols)
             # trace_overlap: the overlap rows' shadow/AO rays are traced here too (rays are per-pixel independent), which
             # removes exchange #1 from the critical path; only the deferred history exchange remains (tiling.py)
             self.trace_overlap = bool(trace_overlap) and denoise
             self.ctx.set_option("trace_overlap", 1 if self.trace_overlap else 0)
             # the path's own host driver runs the doubling a-trous schedule, so later iterations may compute fewer overlap rows
             self.ctx.set_option("strip_shrink_overlap", 1)
-            self.exchanges = tiling.StripExchanges(dist, self.plan, trace_overlap=self.trace_overlap, denoise=denoise, gather=self._gather_requested,
-                                                   allow_degraded=self._allow_degraded)
-            self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
-            if denoise:
-                self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)
+            if self.comm is None:
+                self.exchanges = tiling.StripExchanges(dist, self.plan, trace_overlap=self.trace_overlap, denoise=denoise, gather=self._gather_requested,
+                                                       allow_degraded=self._allow_degraded)
+                self.ctx.set_pass_epilogue("Raytrace Pass", self._exchange_raytraced)
+                if denoise:
+                    self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._exchange_history)
+            else:
+                if self._gather_requested and denoise and rank == 0:
+                    self._gather_buffer = torch.empty((height, width, 4), dtype=torch.float16, device="cuda")
+                self.ctx.set_pass_epilogue("Raytrace Pass", self._comm_after_raytrace)
+                if denoise:
+                    self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._comm_after_svgf)
         self.pc = self.path.push_constants() if denoise else None
 
     # ---- stand-in for the raster G-buffer stage ----
@@ -83,7 +103,7 @@ class HybridFrameLoop:
         torch = self.torch
         self.gbuffers = []
         covered = []
-        max_mv = 0.0
+        max_mv = max_mvx = 0.0
         self._binding = False
         for i, pfd in enumerate(self.pfds):
             self.ctx.update_per_frame_ubo(0, pfd)
@@ -97,8 +117,12 @@ class HybridFrameLoop:
             mv = torch.nan_to_num(mv, nan=0.0)[d != 0]
             if mv.numel():
                 max_mv = max(max_mv, float(mv.abs().max().item()) * self.H)
+            mvx = torch.nan_to_num(m[..., 0].float(), nan=0.0)[d != 0]
+            if mvx.numel():
+                max_mvx = max(max_mvx, float(mvx.abs().max().item()) * self.W)
         self.covered_pixels = covered
         self.max_motion_rows = int(np.ceil(max_mv))
+        self.max_motion_cols = int(np.ceil(max_mvx))
         self._binding = True
 
     def frame_slot(self, i):
@@ -128,6 +152,8 @@ class HybridFrameLoop:
     # the per-frame communication itself lives in tiling.StripExchanges (shared with the CPU gloo test); these are the hooks
     @property
     def gather(self):
+        if self.comm:
+            return bool(self._gather_requested and self.denoise)
         return self.exchanges.gather if self.exchanges else False
 
     @property
@@ -141,10 +167,25 @@ class HybridFrameLoop:
     def finish_pending_exchange(self):
         if self.exchanges:
             self.exchanges.finish_pending()
+        if self.comm:
+            self.comm.finish_frame_exchanges()
 
     def gathered_frame(self):
         """Rank 0: the full denoised frame assembled by the last finished gather (a torch tensor), else None."""
+        if self.comm:
+            return self._gather_buffer
         return self.exchanges.gathered_frame() if self.exchanges else None
+
+    # the same two hooks through the library's own RCCL calls (comm == "c_abi")
+    def _comm_after_raytrace(self, ctx):
+        self.comm.finish_frame_exchanges()            # the previous frame's exchange #2 and gather land before svgf.comp reads the halo
+        if not self.trace_overlap and self.denoise:
+            self.comm.exchange_raytraced(lib.RAYTRACED)
+
+    def _comm_after_svgf(self, ctx):
+        buf = self._gather_buffer
+        self.comm.start_frame_exchanges(int(self.pc["shadow_and_ao_history"]), int(self.pc["shadow_and_ao_moments_history"]),
+                                        lib.DENOISED if (self._gather_requested and self.denoise) else None, 0, buf.data_ptr() if buf is not None else None)
 
     def _exchange_raytraced(self, ctx):           # epilogue of the Raytrace Pass
         self.exchanges.after_raytrace(lambda: self._alias(ctx.transient_info(lib.RAYTRACED)))
@@ -165,14 +206,23 @@ class HybridFrameLoop:
     def owned_rows(self):
         return self.plan.row_begin, self.plan.row_end
 
+    def owned_rect(self):
+        """(x0, x1, y0, y1) of this rank's screen tile."""
+        return self.plan.rect
+
     def rays_in_frame(self, i, owned_only=True):
         """Unique rays traced by this rank in frame i."""
         if self.world == 1 or not owned_only:
             return self.covered_pixels[self.frame_slot(i)] * self.rays_per_pixel
-        d = self.gbuffers[self.frame_slot(i)][2][self.plan.row_begin:self.plan.row_end]
+        x0, x1, y0, y1 = self.plan.rect
+        d = self.gbuffers[self.frame_slot(i)][2][y0:y1, x0:x1]
         return int(self.torch.count_nonzero(d).item()) * self.rays_per_pixel
 
     def close(self):
         self.finish_pending_exchange()
+        if self.comm:
+            self.ctx.synchronize()
+            self.comm.destroy()
+            self.comm = None
         self.path.destroy()
         self.ctx.close()

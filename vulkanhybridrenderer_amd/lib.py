@@ -29,12 +29,12 @@ EXPORTS = [
     "vhr_compute_blit_image_storage_to_storage", "vhr_hybrid_create", "vhr_hybrid_destroy", "vhr_hybrid_build",
     "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
-    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip",
+    "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip", "vhr_set_tile",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
-    "vhr_strip_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
@@ -91,6 +91,20 @@ class StripPlanC(C.Structure):
 
 class RowExchangeC(C.Structure):
     _fields_ = [("peer", C.c_int32), ("send_begin", C.c_uint32), ("send_end", C.c_uint32), ("recv_begin", C.c_uint32), ("recv_end", C.c_uint32)]
+
+
+class TilePlanC(C.Structure):
+    """vhr_tile_plan (include/vhr_amd.h): the C planner's screen tile, field for field tiling.TilePlan."""
+    _fields_ = [(n, C.c_uint32) for n in ("rank", "world", "width", "height", "grid_rows", "grid_cols", "col_begin", "col_end", "row_begin", "row_end",
+                                          "overlap", "halo_rows", "halo_cols")]
+
+
+class RectC(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("x1", C.c_uint32), ("y0", C.c_uint32), ("y1", C.c_uint32)]
+
+
+class RectExchangeC(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("send", RectC), ("recv", RectC)]
 
 
 class HybridSettings(C.Structure):
@@ -192,6 +206,7 @@ def load():
     L.vhr_raytraced_last_error.argtypes = [vp]
     L.vhr_raytraced_last_error.restype = C.c_char_p
     L.vhr_set_strip.argtypes = [vp, u32, u32, u32, u32]
+    L.vhr_set_tile.argtypes = [vp, u32, u32, u32, u32, u32, u32, u32]
     L.vhr_set_ray_statistics.argtypes = [vp, i32]
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
@@ -210,6 +225,10 @@ def load():
     L.vhr_atrous_output_extent.argtypes = [u32, u32]
     L.vhr_strip_plan_make.argtypes = [u32, u32, u32, u32, u32, C.POINTER(StripPlanC)]
     L.vhr_strip_plan_exchanges.argtypes = [C.POINTER(StripPlanC), u32, C.POINTER(RowExchangeC)]
+    L.vhr_tile_grid_choose.argtypes = [u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.vhr_tile_plan_make.argtypes = [u32, u32, u32, u32, u32, u32, u32, u32, u32, C.POINTER(TilePlanC)]
+    L.vhr_tile_plan_exchanges.argtypes = [C.POINTER(TilePlanC), u32, u32, C.POINTER(RectExchangeC), u32]
+    L.vhr_comm_create_tiled.argtypes = [vp, C.POINTER(TilePlanC), C.c_char_p, C.POINTER(vp)]
     L.vhr_comm_get_unique_id.argtypes = [C.c_char_p]
     L.vhr_comm_create.argtypes = [vp, C.POINTER(StripPlanC), C.c_char_p, C.POINTER(vp)]
     L.vhr_comm_destroy.argtypes = [vp]
@@ -351,6 +370,11 @@ class Context:
     def set_strip(self, row_begin, row_end, overlap=0, halo=None):
         halo = overlap if halo is None else halo
         self.check(self.L.vhr_set_strip(self.handle, row_begin, row_end, overlap, halo), "set_strip")
+
+    def set_tile(self, col_begin, col_end, row_begin, row_end, overlap=0, halo_rows=None, halo_cols=None):
+        halo_rows = overlap if halo_rows is None else halo_rows
+        halo_cols = overlap if halo_cols is None else halo_cols
+        self.check(self.L.vhr_set_tile(self.handle, col_begin, col_end, row_begin, row_end, overlap, halo_rows, halo_cols), "set_tile")
 
     # ---- RenderGraph ----
     def destroy_resources(self):
@@ -702,13 +726,45 @@ def strip_plan_exchanges(plan, n_rows):
     return [(out[i].peer, (out[i].send_begin, out[i].send_end), (out[i].recv_begin, out[i].recv_end)) for i in range(n)]
 
 
+def tile_grid(width, height, world, overlap):
+    """vhr_tile_grid_choose: (grid_rows, grid_cols) of the C planner."""
+    r, c = C.c_uint32(), C.c_uint32()
+    rc = load().vhr_tile_grid_choose(width, height, world, overlap, C.byref(r), C.byref(c))
+    if rc != 0:
+        raise VhrError(f"vhr_tile_grid_choose: {rc}")
+    return int(r.value), int(c.value)
+
+
+def tile_plan(width, height, world, rank, grid_rows=0, grid_cols=0, max_motion_rows=0, max_motion_cols=0, atrous_steps=5):
+    """vhr_tile_plan_make: the C planner (csrc/comm.cpp).  None when a tile is thinner than its history halo."""
+    p = TilePlanC()
+    rc = load().vhr_tile_plan_make(width, height, world, rank, grid_rows, grid_cols, max_motion_rows, max_motion_cols, atrous_steps, C.byref(p))
+    if rc == -4:                      # VHR_ERROR_OUT_OF_SLOTS
+        return None
+    if rc != 0:
+        raise VhrError(f"vhr_tile_plan_make: {rc}")
+    return p
+
+
+def tile_plan_exchanges(plan, halo_rows, halo_cols):
+    out = (RectExchangeC * 64)()
+    n = load().vhr_tile_plan_exchanges(C.byref(plan), halo_rows, halo_cols, out, 64)
+    if n < 0:
+        raise VhrError(f"vhr_tile_plan_exchanges: {n}")
+    rect = lambda r: (r.x0, r.x1, r.y0, r.y1)
+    return [(out[i].peer, rect(out[i].send), rect(out[i].recv)) for i in range(n)]
+
+
 class Comm:
-    """vhr_comm_*: the strip exchanges inside the library (RCCL).  One per context and process."""
+    """vhr_comm_*: the strip / tile exchanges inside the library (RCCL).  One per context and process."""
 
     def __init__(self, ctx, plan, unique_id):
         self.ctx = ctx
         self.handle = C.c_void_p()
-        ctx.check(ctx.L.vhr_comm_create(ctx.handle, C.byref(plan), unique_id, C.byref(self.handle)), "vhr_comm_create")
+        if isinstance(plan, TilePlanC):
+            ctx.check(ctx.L.vhr_comm_create_tiled(ctx.handle, C.byref(plan), unique_id, C.byref(self.handle)), "vhr_comm_create_tiled")
+        else:
+            ctx.check(ctx.L.vhr_comm_create(ctx.handle, C.byref(plan), unique_id, C.byref(self.handle)), "vhr_comm_create")
 
     @staticmethod
     def unique_id():

@@ -1,5 +1,8 @@
-"""Multi-GPU decomposition of the hot path: the framebuffer is sharded by ROW STRIPS, one process per GPU,
-the scene / BVH / textures / G-buffer replicated (the reference itself is single-GPU).
+"""Multi-GPU decomposition of the hot path: the framebuffer is sharded by SCREEN TILES -- a grid of grid_rows x grid_cols
+rectangles, row strips being the one-column grid (TilePlan / StripPlan) -- one process per GPU, the scene / BVH / textures /
+G-buffer replicated (BASELINE.json north_star; the reference itself is single-GPU).  Below, "rows" of a strip
+read "rows and columns" for a tile: the overlap E and the history halo apply on every cut side, and an exchange moves rectangles
+(a column range is not contiguous in a row-major image: it travels through a contiguous staging tensor).
 
 Per frame and per rank (strip = rows [y0, y1), E = overlap, Hh = history halo):
 
@@ -93,6 +96,132 @@ def make_plan(height, world, rank, max_motion_rows, atrous_steps=5):
     return StripPlan(rank, world, height, y0, y1, overlap, halo)
 
 
+def tile_bounds(width, height, grid_rows, grid_cols, tile_row, tile_col):
+    """(x0, x1, y0, y1) owned by tile (tile_row, tile_col): columns [c*W/C, (c+1)*W/C), rows [r*H/R, (r+1)*H/R)."""
+    return ((tile_col * width) // grid_cols, ((tile_col + 1) * width) // grid_cols, (tile_row * height) // grid_rows, ((tile_row + 1) * height) // grid_rows)
+
+
+def _grown(rect, dx, dy, width, height):
+    x0, x1, y0, y1 = rect
+    return (max(0, x0 - dx), min(width, x1 + dx), max(0, y0 - dy), min(height, y1 + dy))
+
+
+def _intersect(a, b):
+    r = (max(a[0], b[0]), min(a[1], b[1]), max(a[2], b[2]), min(a[3], b[3]))
+    return r if r[0] < r[1] and r[2] < r[3] else None
+
+
+def choose_grid(width, height, world, overlap):
+    """(grid_rows, grid_cols) with rows * cols == world whose busiest rank computes the fewest pixels: its rectangle grown by the
+    overlap on every cut side, clipped to the image; ties go to the squarer grid.  1080p, E = 30: 8 -> 2 x 4 (540 x 570 = +19 % over
+    the 480 x 540 owned; 8 row strips compute 1920 x 195 = +44 %)."""
+    best = None
+    for r in range(1, world + 1):
+        if world % r:
+            continue
+        c = world // r
+        if r > height or c > width:
+            continue
+        worst = 0
+        for tr in range(r):
+            for tc in range(c):
+                g = _grown(tile_bounds(width, height, r, c, tr, tc), overlap if c > 1 else 0, overlap if r > 1 else 0, width, height)
+                worst = max(worst, (g[1] - g[0]) * (g[3] - g[2]))
+        key = (worst, abs(r - c))
+        if best is None or key < best[0]:
+            best = (key, (r, c))
+    if best is None:
+        raise ValueError("no grid fits")
+    return best[1]
+
+
+@dataclass(frozen=True)
+class TilePlan:
+    rank: int
+    world: int
+    width: int
+    height: int
+    grid_rows: int
+    grid_cols: int
+    col_begin: int
+    col_end: int
+    row_begin: int
+    row_end: int
+    overlap: int          # E: pixels recomputed beyond the rectangle by the SVGF kernels, on every cut side
+    halo_rows: int        # margin of history / moments fetched from the neighbours (E on an axis that is not cut)
+    halo_cols: int
+
+    @property
+    def halo(self):
+        return self.halo_rows
+
+    @property
+    def rect(self):
+        return (self.col_begin, self.col_end, self.row_begin, self.row_end)
+
+    def computed_rect(self, extend=None):
+        """The rectangle the SVGF kernels compute: the owned one grown by `extend` (default: the overlap) on every cut side."""
+        e = self.overlap if extend is None else extend
+        return _grown(self.rect, e if self.grid_cols > 1 else 0, e if self.grid_rows > 1 else 0, self.width, self.height)
+
+    def rect_exchanges(self, halo_rows, halo_cols):
+        """[(peer, send rect or None, recv rect or None)]: what a margin of (halo_rows, halo_cols) pixels takes from each peer = the
+        peer's owned pixels inside my grown rectangle, and gives = my owned pixels inside the peer's grown rectangle."""
+        if self.world <= 1 or (halo_rows == 0 and halo_cols == 0):
+            return []
+        dx, dy = (halo_cols if self.grid_cols > 1 else 0), (halo_rows if self.grid_rows > 1 else 0)
+        mine = self.rect
+        my_need = _grown(mine, dx, dy, self.width, self.height)
+        out = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            theirs = tile_bounds(self.width, self.height, self.grid_rows, self.grid_cols, peer // self.grid_cols, peer % self.grid_cols)
+            recv, send = _intersect(my_need, theirs), _intersect(_grown(theirs, dx, dy, self.width, self.height), mine)
+            if recv or send:
+                out.append((peer, send, recv))
+        return out
+
+
+def make_tile_plan(width, height, world, rank, max_motion_rows=0, max_motion_cols=0, atrous_steps=5, grid=None):
+    """grid: None = choose_grid, "strips" = row strips, or (grid_rows, grid_cols)."""
+    overlap = atrous_overlap(atrous_steps) if world > 1 else 0
+    if grid is None:
+        grid = choose_grid(width, height, world, overlap)
+    elif grid == "strips":
+        grid = (world, 1)
+    gr, gc = grid
+    if gr * gc != world or gr > height or gc > width:
+        raise ValueError(f"a {gr} x {gc} grid does not hold {world} ranks")
+    x0, x1, y0, y1 = tile_bounds(width, height, gr, gc, rank // gc, rank % gc)
+    if world == 1:
+        return TilePlan(rank, world, width, height, 1, 1, 0, width, 0, height, 0, 0, 0)
+    halo_rows = overlap + int(max_motion_rows) + 2 if gr > 1 else overlap
+    halo_cols = overlap + int(max_motion_cols) + 2 if gc > 1 else overlap
+    for r in range(gr):
+        b = tile_bounds(width, height, gr, gc, r, 0)
+        if gr > 1 and halo_rows > b[3] - b[2]:
+            raise ValueError(f"tiles of {b[3] - b[2]} rows are thinner than the {halo_rows}-row history halo: use fewer GPUs or another grid")
+    for c in range(gc):
+        b = tile_bounds(width, height, gr, gc, 0, c)
+        if gc > 1 and halo_cols > b[1] - b[0]:
+            raise ValueError(f"tiles of {b[1] - b[0]} columns are thinner than the {halo_cols}-column history halo: use fewer GPUs or another grid")
+    return TilePlan(rank, world, width, height, gr, gc, x0, x1, y0, y1, overlap, halo_rows, halo_cols)
+
+
+def _rects_of(plan, margin, width):
+    """The rectangle exchanges of a plan for a margin: `margin` is n_rows for a StripPlan, (halo_rows, halo_cols) or n for a TilePlan."""
+    if isinstance(plan, TilePlan):
+        hr, hc = margin if isinstance(margin, tuple) else (margin, margin)
+        return plan.rect_exchanges(hr, hc)
+    return [(peer, (0, width, sa, sb), (0, width, ra, rb)) for peer, (sa, sb), (ra, rb) in plan.exchanges(margin)]
+
+
+def _view(t, rect):
+    x0, x1, y0, y1 = rect
+    return t[y0:y1] if (x0 == 0 and x1 == t.shape[1]) else t[y0:y1, x0:x1]
+
+
 class PendingExchange:
     """A started neighbour exchange; finish() makes the current stream (or the host, for staged gloo) wait for it."""
 
@@ -108,12 +237,12 @@ class PendingExchange:
 
 
 def start_exchange(dist, tensors, plan, n_rows, group=None):
-    """Neighbour halo exchange of `n_rows` rows of each [H, ...] tensor (device or host), in place; returns a
-    PendingExchange (or None if there is nothing to exchange).
+    """Neighbour halo exchange of a margin of each [H, W, ...] tensor (device or host), in place; `n_rows` is the number of rows for a
+    StripPlan, (halo_rows, halo_cols) or one number for a TilePlan.  Returns a PendingExchange (or None if there is nothing to exchange).
 
     One grouped batch of point-to-point ops (ncclGroupStart/End under the "nccl" = RCCL backend): each
     neighbour pair talks over its direct xGMI link; no collective involves more than two ranks."""
-    if plan.world == 1 or n_rows <= 0:
+    if plan.world == 1 or not n_rows:
         return None
     # Device tensors travel device-to-device under "nccl" (RCCL).  Under "gloo" (CPU transport: the CI route
     # for exercising this code with several ranks on one GPU) they are staged through host memory.
@@ -121,58 +250,76 @@ def start_exchange(dist, tensors, plan, n_rows, group=None):
     ops = []
     keep = []
     staged = []
-    for peer, (sa, sb), (ra, rb) in plan.exchanges(n_rows):
+    for peer, send_rect, recv_rect in _rects_of(plan, n_rows, tensors[0].shape[1]):
         for t in tensors:
-            recv = t[ra:rb]
-            if not recv.is_contiguous():
-                raise ValueError("row slices of a [H, ...] tensor must be contiguous")
-            send = t[sa:sb].cpu() if stage else t[sa:sb]
-            if stage:
-                host = recv.cpu()
-                staged.append((recv, host))
-                recv = host
-            ops.append(dist.P2POp(dist.isend, send, peer, group=group))
-            ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
-            keep.append(send)      # keep the send buffers alive until completion
+            if send_rect:
+                send = _view(t, send_rect)
+                send = send.cpu() if stage else (send if send.is_contiguous() else send.contiguous())     # a column range: packed
+                ops.append(dist.P2POp(dist.isend, send, peer, group=group))
+                keep.append(send)      # keep the send buffers alive until completion
+            if recv_rect:
+                recv = _view(t, recv_rect)
+                if stage:
+                    host = recv.cpu()
+                    staged.append((recv, host))
+                    recv = host
+                elif not recv.is_contiguous():
+                    tmp = recv.new_empty(recv.shape)
+                    staged.append((recv, tmp))      # unpacked when the exchange is finished
+                    recv = tmp
+                ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
     if not ops:
         return None
     return PendingExchange(dist.batch_isend_irecv(ops), staged, keep)
 
 
 class PreparedExchange:
-    """The P2P descriptors of one recurring device-to-device exchange (same tensors, same rows every frame), built once:
+    """The P2P descriptors of one recurring device-to-device exchange (same tensors, same rectangles every frame), built once:
     start() is then a single batch_isend_irecv call -- per frame the host only pays for the grouped launch, not for slicing
-    tensors and constructing eight P2POps (a 1080p frame on 8 GPUs leaves the host ~0.2 ms per frame in total)."""
+    tensors and constructing the P2POps (a 1080p frame on 8 GPUs leaves the host ~0.2 ms per frame in total).  Column ranges go
+    through persistent contiguous staging tensors: packed at start(), unpacked when the exchange is finished."""
 
     def __init__(self, dist, tensors, plan, n_rows, group=None):
         self.dist = dist
-        self.ops, self.keep = [], []
-        if plan.world == 1 or n_rows <= 0:
+        self.ops, self.keep, self.pack, self.unpack = [], [], [], []
+        if plan.world == 1 or not n_rows:
             return
         if dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors):
             raise ValueError("prepared exchanges are device-to-device (RCCL); the staged gloo route goes through start_exchange")
-        for peer, (sa, sb), (ra, rb) in plan.exchanges(n_rows):
+        for peer, send_rect, recv_rect in _rects_of(plan, n_rows, tensors[0].shape[1]):
             for t in tensors:
-                send, recv = t[sa:sb], t[ra:rb]
-                if not (send.is_contiguous() and recv.is_contiguous()):
-                    raise ValueError("row slices of a [H, ...] tensor must be contiguous")
-                self.ops.append(dist.P2POp(dist.isend, send, peer, group=group))
-                self.ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
-                self.keep += [send, recv]
+                if send_rect:
+                    send = _view(t, send_rect)
+                    if not send.is_contiguous():
+                        tmp = send.new_empty(send.shape)
+                        self.pack.append((tmp, send))
+                        send = tmp
+                    self.ops.append(dist.P2POp(dist.isend, send, peer, group=group))
+                    self.keep.append(send)
+                if recv_rect:
+                    recv = _view(t, recv_rect)
+                    if not recv.is_contiguous():
+                        tmp = recv.new_empty(recv.shape)
+                        self.unpack.append((recv, tmp))
+                        recv = tmp
+                    self.ops.append(dist.P2POp(dist.irecv, recv, peer, group=group))
+                    self.keep.append(recv)
 
     def start(self):
         if not self.ops:
             return None
-        return PendingExchange(self.dist.batch_isend_irecv(self.ops), [], self.keep)
+        for tmp, src in self.pack:
+            tmp.copy_(src, non_blocking=True)
+        return PendingExchange(self.dist.batch_isend_irecv(self.ops), list(self.unpack), self.keep)
 
 
 class StripGather:
-    """C2 of SURVEY.md section 8e: the owners' rows of a per-strip image (the denoised shadow/AO image) assembled into one
+    """C2 of SURVEY.md section 8e: the owners' rectangles of a per-rank image (the denoised shadow/AO image) assembled into one
     full frame on `root` -- what the display GPU's composition stage consumes.  Point-to-point like the halo exchanges (each
-    rank sends its strip straight to the root over its direct xGMI link; strips need not be equally tall), descriptors built
+    rank sends its rectangle straight to the root over its direct xGMI link; tiles need not be equal), descriptors built
     once and replayed every frame, started after the SVGF pass and finished before the next frame's SVGF pass rewrites the
-    image, i.e. it overlaps the next frame's ray tracing.  Under gloo with device tensors (CI route) the rows are staged
-    through host memory."""
+    image, i.e. it overlaps the next frame's ray tracing.  Under gloo with device tensors (CI route) the data is staged
+    through host memory; column ranges (tiles) go through contiguous staging tensors either way."""
 
     def __init__(self, dist, image, plan, root=0, group=None):
         import torch
@@ -180,40 +327,41 @@ class StripGather:
         self.staged = dist.get_backend(group) == "gloo" and image.is_cuda
         self.group = group
         self.full = None
-        self.ops, self.keep = [], []
         if plan.world == 1:
             return
-        bounds = [strip_bounds(plan.height, plan.world, r) for r in range(plan.world)]
+        H, W = image.shape[0], image.shape[1]
+        if isinstance(plan, TilePlan):
+            self.rects = [tile_bounds(plan.width, plan.height, plan.grid_rows, plan.grid_cols, r // plan.grid_cols, r % plan.grid_cols) for r in range(plan.world)]
+        else:
+            self.rects = [(0, W) + strip_bounds(plan.height, plan.world, r) for r in range(plan.world)]
+        self.mine = self.rects[plan.rank]
         if plan.rank == root:
             self.full = torch.empty_like(image, device="cpu" if self.staged else image.device)
-            self.recv_rows = [(r, a, b) for r, (a, b) in enumerate(bounds) if r != root]
-        if not self.staged:
-            if plan.rank == root:
-                for r, a, b in self.recv_rows:
-                    self.ops.append(dist.P2POp(dist.irecv, self.full[a:b], r, group=group))
-            else:
-                send = image[plan.row_begin:plan.row_end]
-                self.ops.append(dist.P2POp(dist.isend, send, root, group=group))
-                self.keep.append(send)
 
     def start(self):
-        """Begin gathering the current contents of the image's owned rows; returns a PendingExchange (None for one strip)."""
+        """Begin gathering the current contents of the image's owned rectangle; returns a PendingExchange (None for one rank)."""
         p = self.plan
         if p.world == 1:
             return None
-        ops, keep = self.ops, self.keep
-        if self.staged:
-            ops, keep = [], []
-            if p.rank == self.root:
-                for r, a, b in self.recv_rows:
-                    ops.append(self.dist.P2POp(self.dist.irecv, self.full[a:b], r, group=self.group))
-            else:
-                send = self.image[p.row_begin:p.row_end].cpu()
-                ops.append(self.dist.P2POp(self.dist.isend, send, self.root, group=self.group))
-                keep.append(send)
-        if p.rank == self.root:                         # the root's own rows: a local copy, in stream order
-            self.full[p.row_begin:p.row_end].copy_(self.image[p.row_begin:p.row_end], non_blocking=True)
-        return PendingExchange(self.dist.batch_isend_irecv(ops), [], keep)
+        ops, keep, unpack = [], [], []
+        if p.rank == self.root:
+            for r, rect in enumerate(self.rects):
+                if r == self.root:
+                    continue
+                dst = _view(self.full, rect)
+                if not dst.is_contiguous():
+                    tmp = dst.new_empty(dst.shape)
+                    unpack.append((dst, tmp))
+                    dst = tmp
+                ops.append(self.dist.P2POp(self.dist.irecv, dst, r, group=self.group))
+                keep.append(dst)
+            _view(self.full, self.mine).copy_(_view(self.image, self.mine), non_blocking=True)      # the root's own rectangle: a local copy, in stream order
+        else:
+            send = _view(self.image, self.mine)
+            send = send.cpu() if self.staged else (send if send.is_contiguous() else send.contiguous())
+            ops.append(self.dist.P2POp(self.dist.isend, send, self.root, group=self.group))
+            keep.append(send)
+        return PendingExchange(self.dist.batch_isend_irecv(ops), unpack, keep)
 
 
 def exchange_rows(dist, tensors, plan, n_rows, group=None):
@@ -249,6 +397,9 @@ class StripExchanges:
         self._pending = self._pending_gather = None
         self._last_gather = None
 
+    def _halo(self):
+        return (self.plan.halo_rows, self.plan.halo_cols) if isinstance(self.plan, TilePlan) else self.plan.halo
+
     def finish_pending(self):
         if self._pending is not None:
             self._pending.finish()
@@ -265,7 +416,7 @@ class StripExchanges:
         self.finish_pending()
         if self.trace_overlap or not self.denoise or self.plan.world == 1:
             return
-        exchange_rows(self.dist, [raytraced() if callable(raytraced) else raytraced], self.plan, self.plan.overlap, self.group)   # exchange #1
+        exchange_rows(self.dist, [raytraced() if callable(raytraced) else raytraced], self.plan, self.plan.overlap, self.group)   # exchange #1 (overlap on every cut side)
 
     def _fallback(self, what, e):
         if not self.allow_degraded:
@@ -293,10 +444,10 @@ class StripExchanges:
                 key = (history.data_ptr(), moments.data_ptr())
                 prepared = self._prepared.get(key)
                 if prepared is None:
-                    prepared = self._prepared[key] = PreparedExchange(self.dist, [history, moments], self.plan, self.plan.halo, self.group)
+                    prepared = self._prepared[key] = PreparedExchange(self.dist, [history, moments], self.plan, self._halo(), self.group)
                 self._pending = prepared.start()          # consumed by the NEXT frame
                 return
             except Exception as e:   # noqa: BLE001
                 self._use_prepared = False
                 self._fallback("prepared exchange disabled (descriptors rebuilt every frame)", e)
-        self._pending = start_exchange(self.dist, [history, moments], self.plan, self.plan.halo, self.group)
+        self._pending = start_exchange(self.dist, [history, moments], self.plan, self._halo(), self.group)
