@@ -403,10 +403,16 @@ def main():
     # always-on mirror ray, and the same workload with two frames in flight ----
     extras = {}
     if world == 1 and not args.no_extras:
-        def one(options=None, **kw):
+        def one(options=None, device_k0=None, **kw):
             lp = HybridFrameLoop(scene, W, H, n_frames, **common, **kw)
             for key, val in {**option_overrides, **(options or {})}.items():
                 lp.ctx.set_option(key, val)
+            if device_k0 is not None:          # the same scene on the tree the DEVICE builds ("bvh_builder" 1, csrc/kernels_bvh.hip)
+                lp.ctx.set_option("bvh_builder", 1)
+                lp.ctx.upload_scene(scene)
+                device_k0["k0_build_ms"], device_k0["k0_upload_ms"] = (round(v, 1) for v in lp.ctx.build_times_ms())
+                device_k0["builder_used"] = "device (PLOC along the Morton order)" if lp.ctx.bvh_builder_used() == 1 else "host (the device tree was refused: too deep)"
+                device_k0["bvh_max_depth"] = int(lp.ctx.bvh_statistics()["max_depth"])
 
             def sync():
                 torch.cuda.synchronize()
@@ -428,6 +434,12 @@ def main():
         ms, mr = one(options={"svgf_elide_unread": 1}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
         extras["ms_per_step_without_dead_iteration"] = ms
         extras["value_without_dead_iteration"] = mr
+        # K0 where the reference runs it (resource_manager.cpp:650,692,792 build BLAS / TLAS on the GPU): the device-built tree costs a
+        # fraction of the host's SAH build and a few node visits more per ray; the timed region above uses the host tree (the default)
+        dk = {}
+        ms, mr = one(device_k0=dk, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
+        dk["ms_per_step"], dk["value"] = ms, mr
+        extras["device_k0"] = dk
         other = 2 if args.frames_in_flight == 1 else 1
         ms, mr = one(reflections=_bounces(args), frames_in_flight=other)
         extras[f"ms_per_step_frames_in_flight_{other}"] = ms

@@ -391,6 +391,10 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 3)
+ *   "bvh_builder"      builder of the next vhr_update_geometry: 0 = binned SAH on the host (default: the better tree), 1 = an LBVH built on
+ *                      the device like the reference's BLAS / TLAS (resource_manager.cpp:650,692,792): Morton sort, Karras hierarchy,
+ *                      bottom-up boxes, the same node forms -- one-time cost 20-40x lower, a tree the walkers need more visits in.
+ *                      Images are bit-identical with either (any-hit results do not depend on the tree, closest hits commit by (t, index)).
  *   "bvh_build_threads" host threads of the next build: 0 = up to 16 of the machine's (default), 1 = the serial build; subtrees below
  *                      the top of the tree are built by a pool and spliced in -- the tree is the same whatever the count
  *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
@@ -496,6 +500,9 @@ int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_
 /* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792;
  * here the binned-SAH build runs on the host): out[0] = build, out[1] = upload of scene + tree, in milliseconds of host time. */
 int vhr_get_build_times(vhr_context *ctx, double out[2]);
+/* Which builder made the current tree: 0 = the host's binned SAH, 1 = the device's LBVH ("bvh_builder" 1; it falls back to the host
+ * builder for a scene of a single leaf and for a tree deeper than the walkers' stacks) */
+int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

@@ -309,9 +309,64 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         free_scene(ctx);
     }
 
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        *dst = nullptr;
+        if (bytes == 0) return hipSuccess;
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    double upload_ms = 0.0;
+    if (!ctx->host_only) {                 // the scene arrays first: the device builder reads them where the walkers will
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<float> nm(size_t(primitive_count) * 9);
+        for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_vertices), vertices, sizeof(vhr_vertex) * vertex_count));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_indices), indices, sizeof(uint32_t) * index_count));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_primitives), primitives, sizeof(vhr_primitive) * primitive_count));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_normal_matrices), nm.data(), sizeof(float) * nm.size()));
+        upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+
     HostBvh bvh;
+    bool device_built = false;
+    ctx->bvh_builder_used = 0;
+    // ---- "bvh_builder" 1: the tree built on the device (csrc/kernels_bvh.hip), where the reference builds its BLAS / TLAS ----
+    if (ctx->bvh_builder == 1 && !ctx->host_only && total_triangles >= 2ull * uint64_t(ctx->bvh_leaf_tris)) {
+        std::vector<uint32_t> prefix(primitive_count);
+        uint32_t acc = 0;
+        for (uint32_t p = 0; p < primitive_count; ++p) { prefix[p] = acc; acc += primitives[p].index_count / 3; }
+        // (a primitive without triangles shares its prefix with the next one: the search below picks the LAST primitive whose prefix is
+        // <= t, which is the one that owns triangle t, because an empty primitive's successor starts at the same value)
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (rc == VHR_OK) {
+            device_built = true;
+            ctx->bvh_builder_used = 1;
+            ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            // the host-side self-checks want the result: fetched outside the build's time like the checks themselves
+            bvh.nodes.resize(ctx->node_count); bvh.nodes_ch.resize(ctx->node_count); bvh.nodes48.resize(ctx->node_count); bvh.nodes16.resize(ctx->node_count);
+            bvh.tris.resize(ctx->tri_count);
+            HIP_TRY(ctx, hipMemcpy(bvh.nodes.data(), ctx->d_nodes, sizeof(BvhNode) * ctx->node_count, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bvh.nodes_ch.data(), ctx->d_nodes_ch, sizeof(BvhNodeCH) * ctx->node_count, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bvh.nodes48.data(), ctx->d_nodes48, sizeof(BvhNode48) * ctx->node_count, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bvh.nodes16.data(), ctx->d_nodes16, sizeof(BvhNode16) * ctx->node_count, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bvh.tris.data(), ctx->d_tris, sizeof(BvhTri) * ctx->tri_count, hipMemcpyDeviceToHost));
+            for (int a = 0; a < 3; ++a) bvh.centre[a] = ctx->bvh_centre[a];
+            bvh.max_depth = ctx->bvh_depth;
+        } else {
+            hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
+            ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_tris = nullptr;
+            ctx->node_count = ctx->tri_count = 0;
+            if (rc != VHR_ERROR_OUT_OF_SLOTS) return rc;          // (out of slots: deeper than the walkers' stacks, or a one-leaf scene -> the host builder)
+        }
+    }
     const auto t_build0 = std::chrono::steady_clock::now();
-    build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
+    if (!device_built) {
+        build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
+        ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+    }
     if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
     const auto t_build1 = std::chrono::steady_clock::now();       // K0 proper ends here; the self-checks below are timed apart
@@ -325,41 +380,36 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         ctx->node4_count = uint32_t(bvh.nodes4.size());
         ctx->tri_count = uint32_t(bvh.tris.size());
         ctx->bvh_depth = bvh.max_depth;
-        ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
         ctx->geometry_upload_ms = 0.0;
         return VHR_OK;
     }
-    const auto t_upload0 = std::chrono::steady_clock::now();
-    std::vector<float> nm(size_t(primitive_count) * 9);
-    for (uint32_t p = 0; p < primitive_count; ++p) normal_matrix3(primitives[p].transform, &nm[size_t(p) * 9]);
-
-    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        *dst = nullptr;
-        if (bytes == 0) return hipSuccess;
-        hipError_t e = hipMalloc(dst, bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_vertices), vertices, sizeof(vhr_vertex) * vertex_count));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_indices), indices, sizeof(uint32_t) * index_count));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_primitives), primitives, sizeof(vhr_primitive) * primitive_count));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_normal_matrices), nm.data(), sizeof(float) * nm.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes48), bvh.nodes48.data(), sizeof(BvhNode48) * bvh.nodes48.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes4), bvh.nodes4.data(), sizeof(BvhNode4) * bvh.nodes4.size()));
-    HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
-    for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
+    if (!device_built) {
+        const auto t_upload0 = std::chrono::steady_clock::now();
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes), bvh.nodes.data(), sizeof(BvhNode) * bvh.nodes.size()));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes48), bvh.nodes48.data(), sizeof(BvhNode48) * bvh.nodes48.size()));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes4), bvh.nodes4.data(), sizeof(BvhNode4) * bvh.nodes4.size()));
+        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
+        for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
+        ctx->node_count = uint32_t(bvh.nodes.size());
+        ctx->node4_count = uint32_t(bvh.nodes4.size());
+        ctx->tri_count = uint32_t(bvh.tris.size());
+        ctx->bvh_depth = bvh.max_depth;
+        upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload0).count();
+    } else {
+        ctx->node4_count = 0;                  // (the four-wide collapse is the host builder's: "bvh_wide" falls back to the binary walker)
+    }
     ctx->vertex_count = vertex_count;
     ctx->index_count = index_count;
     ctx->primitive_count = primitive_count;
-    ctx->node_count = uint32_t(bvh.nodes.size());
-    ctx->node4_count = uint32_t(bvh.nodes4.size());
-    ctx->tri_count = uint32_t(bvh.tris.size());
-    ctx->bvh_depth = bvh.max_depth;
-    ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t_build1 - t_build0).count();
-    ctx->geometry_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload0).count();
+    ctx->geometry_upload_ms = upload_ms;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used) {
+    if (!ctx || !used) return VHR_ERROR_INVALID_ARGUMENT;
+    *used = ctx->bvh_builder_used;
     return VHR_OK;
 }
 
@@ -486,6 +536,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!std::strcmp(key, "bvh_leaf_triangles")) {          // applies to the next vhr_update_geometry
         if (value < 1 || value > kMaxLeafTris) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_leaf_triangles must be 1..4");
         ctx->bvh_leaf_tris = value;
+        return VHR_OK;
+    }
+    if (!std::strcmp(key, "bvh_builder")) {                  // applies to the next vhr_update_geometry
+        if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (host binned SAH) or 1 (device LBVH)");
+        ctx->bvh_builder = value;
         return VHR_OK;
     }
     if (!std::strcmp(key, "bvh_build_threads")) {            // applies to the next vhr_update_geometry; the tree does not depend on it

@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // 0 .. stack_levels-1, [stack_levels+1, +2] = dummies that absorb the accesses of entries living in scratch
     // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
     constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
-    constexpr int kSpillEntries = WIDE ? kWideSpill : kTraceStack;
+    constexpr int kSpillEntries = WIDE ? kWideSpill : kSpillStack;
     int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
     float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + kExtraRows) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t next = 0;
     uint32_t overflow = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;
-    volatile int spill[SPILL ? kTraceStack : 1];     // volatile: stays in scratch (see wave_queue_walk)
+    volatile int spill[SPILL ? kSpillStack : 1];     // volatile: stays in scratch (see wave_queue_walk)
     const float tmin = a.tp.tmin;
     float tmin_v = tmin;
     asm volatile("" : "+v"(tmin_v));
@@ -1423,9 +1423,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             int top = row[0];
             row[kQueueBlock] = farc;
             if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillStack)) spill[uint32_t(sp) - stack_levels] = farc;
                     else overflow |= both ? 1u : 0u;
                 }
             }
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             if (!found) {
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 }
                 --sp;
             }
@@ -1576,7 +1576,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
     bool has = false;
     // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
     // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
-    volatile int spill[SPILL ? kTraceStack : 1];
+    volatile int spill[SPILL ? kSpillStack : 1];
     float tmin_v = tmin;
     asm volatile("" : "+v"(tmin_v));
     for (;;) {
@@ -1628,9 +1628,9 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             int top = row[0];
             row[kQueueBlock] = farc;
             if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kTraceStack)) spill[uint32_t(sp) - stack_levels] = farc;
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillStack)) spill[uint32_t(sp) - stack_levels] = farc;
                     else overflow |= both ? 1u : 0u;
                 }
             }
@@ -1661,7 +1661,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             } else {
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];             // pop (the sentinel if nothing is pending)
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kTraceStack - 1)];
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 }
                 --sp;
             }
