@@ -1155,8 +1155,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
             }
             const bool both = h0 && h1, none = !(h0 || h1);
-            const bool first0 = tn0 <= tn1;
-            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
+            // Child 0 is entered if it is hit and child 1 is not, or is not nearer; the child NOT entered goes to the stack slot (a
+            // meaningful entry only when both are hit).  Three selects and two carries per visit (r3; the (near, far) form took ten
+            // vector instructions: masks are scalar work, selects are not).
+            const bool enter0 = bool(int(h0) & (int(!h1) | int(tn0 <= tn1)));         // (bitwise: && and || would become exec-mask regions)
+            const int nearc = enter0 ? links.x : links.y, farc = enter0 ? links.y : links.x;
             // One address serves both accesses: row min(sp, L+1) holds the top entry (sp - 1; the sentinel when the stack
             // is empty), the row after it is where entry sp goes.  The write is harmless when !both (above the top).
             int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
@@ -1171,8 +1174,13 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     else overflow |= both ? 1u : 0u;                              // cannot happen (builder depth bound); counted
                 }
             }
-            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));         // popping the empty stack yields the sentinel
-            sp += (both ? 1 : 0) - (none ? 1 : 0);                                // (-1 then, together with the sentinel)
+            cur = none ? top : nearc;                                             // popping the empty stack yields the sentinel
+            {   // sp += h0 + h1 - 1: +1 both, 0 one, -1 none (with the sentinel) -- two add-with-carry, the hit masks as the carries
+                int t;
+                unsigned long long carry_out;
+                asm("v_addc_co_u32_e64 %0, %1, %2, -1, %3" : "=v"(t), "=s"(carry_out) : "v"(sp), "s"(__ballot(h0)));
+                asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(t), "s"(__ballot(h1)));
+            }
         }
         const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
         // ---- leaf ----
