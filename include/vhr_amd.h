@@ -388,7 +388,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "raygen_shared_tile" 1 = the waves of a workgroup split ONE 8x8-pixel tile's ray queue, 0 = one tile per wave
  *   "trace_overlap"    strips only: 1 = the shadow/AO rays of the overlap rows are traced by this context as well, so
  *                      the raw visibility needs no neighbour exchange before svgf.comp (default 0: owned rows only)
- *   "compact_nodes"    1 = 32-byte nodes with outward-rounded half-precision boxes, 0 = 64-byte fp32 nodes (default)
+ *   "compact_nodes"    1 (default) = the any-hit queue kernel walks 32-byte nodes: both child boxes as centre and half extent in IEEE halves
+ *                      relative to the scene centre, widened until they contain the fp32 boxes in exact arithmetic (vhr_get_bvh_form_checks),
+ *                      read straight into v_fma_mix_f32 -- two 16-byte loads per visit instead of three, no unpacking; 0 = the 48-byte
+ *                      nodes (fp32 centres, truncated fp32 half extents).  Boxes only cull: bit-identical.  A scene whose extent
+ *                      does not fit the half range around its centre has no such nodes and is walked on the 48-byte ones.
  *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
  *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 3)
  *   "bvh_builder"      builder of the next vhr_update_geometry: 0 = binned SAH on the host (default: the better tree), 1 = an LBVH built on
@@ -425,7 +429,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      contain the box of its ray origins and keeps the siblings it passes (at most 16) in LDS; a ray tests
  *                      those boxes when it is fetched and starts below them instead of at the root (default; same
  *                      triangles tested in a different order, visibility bit-identical), 0 = every ray starts at the root.
- *                      Ignored with "compact_nodes", the shared-tile variant and pre-generated rays.
+ *                      Ignored with the shared-tile variant and pre-generated rays.
  *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair
  *                      (default 1 = every launch).  A timed dispatch costs ~6 us that the next kernel waits for; bench.py samples
  *                      the a-trous launches with stride 6 (coprime with the 5 launches of a frame, so every step size is sampled).
@@ -461,6 +465,14 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      not launched -- the reference's fifth a-trous iteration (hybrid_render_path.cpp:299-328 publishes the fourth;
  *                      SURVEY 8 a5).  Everything the pass publishes is bit-identical; the skipped dispatch's storage image keeps older
  *                      contents, which is why this is opt-in (default 0).
+ *   "svgf_async_unread" 1 (default) = that same dispatch, when it is launched, is issued last and on a side stream of the context, ordered
+ *                      behind the pass's other commands by an event: nothing on the frame's critical path waits for it, and it runs beside
+ *                      whatever the context's stream does next (the next frame's ray tracing).  The context's stream waits for it before
+ *                      the next compute pass, before storage-image uploads / downloads / vhr_get_storage_image, and in vhr_synchronize.
+ *                      Only with "frames_in_flight" 1, whole-image dispatches (no strips / tiles) and when the pass itself copies the
+ *                      G-buffer normals the dispatch reads (hybrid_render_path.cpp:319; the copy is read instead, the G-buffer belongs
+ *                      to the next frame by then); else the dispatch stays in place.  Every image bit-identical, the dispatch's own
+ *                      output included.  0 = every dispatch in recorded order on the context's stream.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
@@ -468,7 +480,8 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
  * the dispatch packet -- hipExtLaunchKernelGGL's start / stop events, the dispatch's own begin / end timestamps -- instead of
  * hipEventRecord, whose barrier packet costs ~4 us of stream time per record)
  * kind: 0 = raygen (K1: shadow + AO rays; with raygen_variant 0 also the mirror ray), 1 = svgf.comp (K3),
- * 2 = svgf_atrous_filter.comp (K4), 3 = blits (K5), 4 = the mirror-ray kernel (K1's reflection ray + K2).
+ * 2 = svgf_atrous_filter.comp (K4) on the context's stream, 3 = blits (K5), 4 = the mirror-ray kernel (K1's reflection ray + K2),
+ * 5 / 6 / 7 = ssao.comp / ssao_blur.comp / ssr.comp, 8 = K4 dispatches issued on the side stream ("svgf_async_unread").
  * kind_mask has bit (1 << kind) set for every kind to time (0 = off).  vhr_get_kernel_time synchronises, folds
  * the recorded pairs into (total milliseconds, launch count) and optionally resets the totals. */
 int vhr_set_kernel_timing(vhr_context *ctx, int32_t kind_mask);

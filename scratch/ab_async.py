@@ -1,0 +1,43 @@
+"""svgf_async_unread (the dead fifth a-trous dispatch on the side stream, beside the next frame's ray tracing) and compact_nodes (32-byte nodes):
+frame time by wall clock and bit-identity of every SVGF storage image + Denoised after 10 frames.
+usage: python scratch/ab_async.py [scene] [option=value ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vulkanhybridrenderer_amd import scenes, lib
+from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+names = [a for a in sys.argv[1:] if "=" not in a] or ["sponza_proc"]
+extra = [a.split("=") for a in sys.argv[1:] if "=" in a]
+arms = [dict(svgf_async_unread=1, compact_nodes=1), dict(svgf_async_unread=1, compact_nodes=0, raygen_tile_pixels=128), dict(svgf_async_unread=0, compact_nodes=0, raygen_tile_pixels=128), dict(svgf_async_unread=1, compact_nodes=1, raygen_early_exit=6),
+        dict(svgf_async_unread=1, compact_nodes=1, refill_threshold=8), dict(svgf_async_unread=1, compact_nodes=1, lds_stack_levels=6)]
+for name in names:
+    scene = getattr(scenes, name)()
+    ref = None
+    for arm in arms:
+        loop = HybridFrameLoop(scene, 1920, 1080, 12)
+        ctx = loop.ctx
+        for k, v in extra: ctx.set_option(k, int(v))
+        for k, v in arm.items(): ctx.set_option(k, v)
+        for i in range(10): loop.frame(i)
+        ctx.synchronize()
+        pc = loop.path.push_constants()
+        ids = {"integrated_x": int(pc["integrated_shadow_and_ao"][0]), "integrated_y": int(pc["integrated_shadow_and_ao"][1]),
+               "prev_normals": int(pc["prev_frame_normals_and_object_ids"]), "history": int(pc["shadow_and_ao_history"]), "moments": int(pc["shadow_and_ao_moments_history"])}
+        imgs = {k: ctx.download(v) for k, v in ids.items()}
+        imgs["denoised"] = ctx.download(lib.DENOISED)
+        if ref is None: ref = imgs
+        same = {k: bool(np.array_equal(v, ref[k])) for k, v in imgs.items()}
+        times = []
+        for rep in range(7):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(10, 74): loop.frame(i)
+            torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 64 * 1e3)
+        ctx.set_kernel_timing(["raygen", "svgf_atrous", "svgf_atrous_async", "svgf_temporal"])
+        for k in ("raygen", "svgf_atrous", "svgf_atrous_async", "svgf_temporal"): ctx.kernel_time(k, reset=True)
+        for i in range(10, 42): loop.frame(i)
+        torch.cuda.synchronize()
+        kt = {k: ctx.kernel_time(k) for k in ("raygen", "svgf_atrous", "svgf_atrous_async", "svgf_temporal")}
+        ctx.set_kernel_timing(False)
+        print(f"{name} {arm}: ms/frame median {np.median(times):.4f} min {min(times):.4f}; " +
+              ", ".join(f"{k} {ms / max(1, n) * 1e3:.1f} us x{n}" for k, (ms, n) in kt.items()) + f"; identical {same}", flush=True)
+        loop.close()

@@ -8,7 +8,7 @@ for the multi-frame denoised image: RMSE <= 1e-4 (BASELINE.json) and max abs err
 import numpy as np
 import pytest
 
-from vulkanhybridrenderer_amd import abi, lib, scenes
+from vulkanhybridrenderer_amd import abi, camera, lib, scenes
 from tests.helpers import (GpuHybrid, GpuSvgfHarness, f16, oracle_frames, simple_pfd, synthetic_svgf_inputs, ulp16_diff)
 
 pytestmark = pytest.mark.gpu
@@ -237,6 +237,7 @@ def test_kernel_timing_stride_samples_every_nth_launch():
     pfds = camera.dolly_frames(sc, W, H, 6)
     g = GpuHybrid(sc, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
     try:
+        g.ctx.set_option("svgf_async_unread", 0)          # all five a-trous launches of a frame on the context's stream, one kernel kind
         g.ctx.set_kernel_timing(["svgf_atrous", "svgf_temporal"])
         for pfd in pfds:
             g.frame(pfd)
@@ -264,6 +265,7 @@ def test_dead_fifth_iteration_elided_publishes_the_same_images():
         c = loop.ctx
         try:
             c.set_option("svgf_elide_unread", elide)
+            c.set_option("svgf_async_unread", 0)          # (its own test below)
             c.set_kernel_timing(["svgf_atrous"])
             c.kernel_time("svgf_atrous", reset=True)
             frames = []
@@ -281,3 +283,41 @@ def test_dead_fifth_iteration_elided_publishes_the_same_images():
     for f, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), f"frame {f}: published image {k} differs with the dead iteration elided"
+
+
+def test_dead_fifth_iteration_on_the_side_stream_changes_no_image():
+    """Option "svgf_async_unread" (default 1): the a-trous dispatch nothing reads is issued last and on the context's side stream, beside the
+    next frame's G-buffer and ray-tracing work.  Here the G-buffer of every frame is written in place by the stand-in kernel on the
+    context's stream with no synchronisation between frames -- the dispatch must read the pass's own copy of the normals, not the image
+    the next frame is already overwriting -- and after 3 and after 10 frames every image of the pass, both ping-pong images included,
+    equals the in-order schedule's bit for bit.  40 launches stay on the context's stream, 10 go to the side stream."""
+    W, H = 480, 270
+    scene = scenes.sponza_proc()
+    pfds = camera.dolly_frames(scene, W, H, 10)
+    outs = {}
+    for mode in (0, 1):
+        c = lib.Context(W, H, device=0)
+        try:
+            c.upload_scene(scene)
+            c.set_option("svgf_async_unread", mode)
+            path = lib.HybridRenderPath(c, 0, 0, 2, True, 5, lambda cc: cc.standin_gbuffer(0))
+            path.build()
+            c.set_kernel_timing(["svgf_atrous", "svgf_atrous_async"])
+            c.kernel_time("svgf_atrous", reset=True); c.kernel_time("svgf_atrous_async", reset=True)
+            snaps = []
+            for i, pfd in enumerate(pfds):
+                c.update_per_frame_ubo(0, pfd)
+                c.execute(0, 0)
+                if i in (2, 9):
+                    pc = path.push_constants()
+                    ids = [int(pc["integrated_shadow_and_ao"][0]), int(pc["integrated_shadow_and_ao"][1]), int(pc["prev_frame_normals_and_object_ids"]),
+                           int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])]
+                    snaps.append([c.download(lib.DENOISED)] + [c.download(k) for k in ids])
+            outs[mode] = (snaps, c.kernel_time("svgf_atrous")[1], c.kernel_time("svgf_atrous_async")[1])
+            path.destroy()
+        finally:
+            c.close()
+    assert outs[0][1:] == (50, 0) and outs[1][1:] == (40, 10)
+    for s, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with the dead iteration on the side stream"

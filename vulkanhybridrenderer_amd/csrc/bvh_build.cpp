@@ -303,6 +303,37 @@ inline void padded(const Box &b, float lo[3], float hi[3]) {
     }
 }
 
+// value of a half bit pattern (exact)
+inline double half_value(uint16_t h) {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const double v = e == 0 ? std::ldexp(double(m), -24) : (e == 31 ? (m ? std::nan("") : HUGE_VAL) : std::ldexp(double(1024 + m), e - 25));
+    return (h & 0x8000) ? -v : v;
+}
+
+uint16_t half_directed(float x, bool down);
+
+// One axis of one child box of the 32-byte node form (BvhNode16): centre (relative to `origin`) and half extent as halves such that
+// origin + c +- h contains [lo, hi] in exact arithmetic with a few fp32 ulp to spare (the walker rounds o - origin and the FMAs).
+// Neither half is subnormal.  An absent child (lo > hi) gets c = 0, h = -1.  false: the half range does not reach (the form is unusable).
+inline bool half_centre_extent(float lo, float hi, float origin, uint16_t &c16, uint16_t &h16) {
+    if (!(lo <= hi)) { c16 = 0; h16 = 0xbc00; return true; }
+    const double mid = 0.5 * double(lo) + 0.5 * double(hi) - double(origin);
+    // nearest half of the centre: directed conversion both ways, the closer one (ties: either is fine)
+    const uint16_t dn = half_directed(float(mid), true), up = half_directed(float(mid), false);
+    c16 = std::fabs(half_value(dn) - mid) <= std::fabs(half_value(up) - mid) ? dn : up;
+    if (((c16 >> 10) & 31) == 0) c16 = 0;                                 // subnormal centre: 0 (h below absorbs the difference)
+    if (((c16 >> 10) & 31) == 31) return false;
+    const double c = double(origin) + half_value(c16);
+    double need = std::max(double(hi) - c, c - double(lo));
+    need += (std::fabs(double(origin)) + std::fabs(half_value(c16)) + need) * 4.8e-7 + 1e-30;
+    float nf = float(need);
+    if (double(nf) < need) nf = std::nextafter(nf, std::numeric_limits<float>::infinity());
+    h16 = half_directed(nf, false);
+    if (((h16 >> 10) & 31) == 0) h16 = 0x0400;                            // smallest normal half
+    if (((h16 >> 10) & 31) == 31) return false;
+    return true;
+}
+
 // float -> half bits, rounded toward -inf (down = true) or +inf; |x| beyond the half range saturates outward to +-inf
 inline uint16_t half_directed(float x, bool down) {
     if (std::isnan(x)) return 0x7e00;
@@ -556,22 +587,27 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             }
         for (int a = 0; a < 3; ++a) out.centre[a] = (lo[a] <= hi[a]) ? 0.5f * (lo[a] + hi[a]) : 0.0f;
         out.nodes16.resize(out.nodes.size());
+        std::atomic<uint32_t> overflow{ 0 };
         parallel_for(out.nodes.size(), hw, [&](size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) {
             const BvhNode &nd = out.nodes[k];
             BvhNode16 c{};
-            for (int a = 0; a < 3; ++a) {
-                // (x - centre) is rounded to fp32 first: go one more ulp outward by rounding the fp32 difference outward too
-                c.h[2 * a] = half_directed(std::nextafter(nd.box0[2 * a] - out.centre[a], -inf), true);
-                c.h[2 * a + 1] = half_directed(std::nextafter(nd.box0[2 * a + 1] - out.centre[a], inf), false);
-                c.h[6 + 2 * a] = half_directed(std::nextafter(nd.box1[2 * a] - out.centre[a], -inf), true);
-                c.h[6 + 2 * a + 1] = half_directed(std::nextafter(nd.box1[2 * a + 1] - out.centre[a], inf), false);
+            for (int which = 0; which < 2; ++which) {
+                const float *box = which == 0 ? nd.box0 : nd.box1;
+                for (int a = 0; a < 3; ++a) {
+                    uint16_t c16, h16;
+                    if (!half_centre_extent(box[2 * a], box[2 * a + 1], out.centre[a], c16, h16)) overflow = 1;
+                    c.c[2 * a + which] = c16;
+                    c.h[2 * a + which] = h16;
+                }
             }
-            c.child0 = nd.child0;
-            c.child1 = nd.child1;
+            // inner links as BYTE offsets (index * 32), like the 48-byte nodes'
+            c.child0 = nd.child0 >= 0 ? nd.child0 * int32_t(sizeof(BvhNode16)) : nd.child0;
+            c.child1 = nd.child1 >= 0 ? nd.child1 * int32_t(sizeof(BvhNode16)) : nd.child1;
             out.nodes16[k] = c;
         }
         });
+        out.nodes16_valid = overflow == 0 && out.nodes.size() * sizeof(BvhNode16) < (size_t(1) << 31);
     };
 
     // ---- the wide nodes themselves: per axis a grid (origin, power-of-two scale) that reaches from the lowest lower plane to the
@@ -723,13 +759,8 @@ uint64_t bvh_fingerprint(const HostBvh &bvh) {
 
 // Every derived node form must CONTAIN the (lo, hi) boxes of `nodes` in exact arithmetic -- that is all the walkers' bit-identity
 // rests on (boxes only cull).  out: boxes checked, centre / half-extent boxes that do not contain theirs, 48-byte boxes that do not
-// contain the centre / half-extent box, half-precision (compact) boxes that do not contain theirs.  (vhr_get_bvh_form_checks)
+// contain the centre / half-extent box, half-precision 32-byte (compact) boxes that do not contain theirs.  (vhr_get_bvh_form_checks)
 void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads) {
-    auto half_value = [](uint16_t h) -> double {
-        const int e = (h >> 10) & 31, m = h & 1023;
-        double v = e == 0 ? std::ldexp(double(m), -24) : (e == 31 ? (m ? std::nan("") : HUGE_VAL) : std::ldexp(double(1024 + m), e - 25));
-        return (h & 0x8000) ? -v : v;
-    };
     auto upper = [](uint32_t w16) -> double { const uint32_t bits = w16 << 16; float f; std::memcpy(&f, &bits, 4); return double(f); };
     out[0] = out[1] = out[2] = out[3] = 0;
     std::atomic<uint64_t> total[4];
@@ -750,23 +781,39 @@ void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads) {
                 const double lo = box[2 * a], hi = box[2 * a + 1];
                 const double c = (a == 0 ? ch.cx : a == 1 ? ch.cy : ch.cz)[which], h = hh[a];
                 const double c48 = (a == 0 ? n48.cx : a == 1 ? n48.cy : n48.cz)[which], hw = h48[3 * which + a];
+                // the 32-byte form: centre + c16 +- h16 in exact arithmetic, no subnormal / inf / NaN half (checked only when the form is in use)
+                const uint16_t cb = n16.c[2 * a + which], hb = n16.h[2 * a + which];
+                const double c16 = double(bvh.centre[a]) + half_value(cb), h16 = half_value(hb);
+                const bool normal16 = (cb == 0 || (((cb >> 10) & 31) != 0 && ((cb >> 10) & 31) != 31)) && ((hb >> 10) & 31) != 0 && ((hb >> 10) & 31) != 31;
                 if (!(lo <= hi)) {                           // an absent child: never entered in any form
                     if (!(h < 0.0)) ++out[1];
                     if (!(hw < 0.0)) ++out[2];
+                    if (bvh.nodes16_valid && !(h16 < 0.0)) ++out[3];
                     continue;
                 }
                 if (c - h > lo || c + h < hi) ++out[1];
                 if (c48 != c || hw < h) ++out[2];
-                const double l16 = double(bvh.centre[a]) + half_value(n16.h[6 * which + 2 * a]), h16 = double(bvh.centre[a]) + half_value(n16.h[6 * which + 2 * a + 1]);
-                if (l16 > lo || h16 < hi) ++out[3];
+                if (bvh.nodes16_valid && (!normal16 || !(c16 - h16 <= lo) || !(c16 + h16 >= hi))) ++out[3];
             }
         }
         auto as48 = [](int32_t link) { return link >= 0 ? link * int32_t(sizeof(BvhNode48)) : link; };
         if (n48.child0 != as48(nd.child0) || n48.child1 != as48(nd.child1) || ch.child0 != nd.child0 || ch.child1 != nd.child1) ++out[2];
+        auto as16 = [](int32_t link) { return link >= 0 ? link * int32_t(sizeof(BvhNode16)) : link; };
+        if (bvh.nodes16_valid && (n16.child0 != as16(nd.child0) || n16.child1 != as16(nd.child1))) ++out[3];
     }
     for (int i = 0; i < 4; ++i) total[i] += out[i];
     });
     for (int i = 0; i < 4; ++i) out[i] = total[i];
+}
+
+bool nodes16_in_range(const HostBvh &bvh) {
+    if (bvh.nodes16.size() != bvh.nodes.size() || bvh.nodes16.size() * sizeof(BvhNode16) >= (size_t(1) << 31)) return false;
+    for (const BvhNode16 &n : bvh.nodes16)
+        for (int i = 0; i < 6; ++i) {
+            const int ec = (n.c[i] >> 10) & 31, eh = (n.h[i] >> 10) & 31;
+            if (ec == 31 || (ec == 0 && n.c[i] != 0) || eh == 31 || eh == 0) return false;
+        }
+    return true;
 }
 
 // The wide tree against the binary one (what the wide walkers' bit-identity rests on).  out: wide nodes; child boxes checked; child

@@ -100,7 +100,16 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
 int vhr_context::sync_streams() {
     if (host_only) return VHR_OK;
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
+    if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
+    side_pending = false;
     if (hipStreamSynchronize(stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize failed");     // (a null handle is the default stream)
+    return VHR_OK;
+}
+
+int vhr_context::join_side() {
+    if (!side_pending) return VHR_OK;
+    side_pending = false;
+    if (hipStreamWaitEvent(stream, side_done, 0) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamWaitEvent(side stream) failed");
     return VHR_OK;
 }
 
@@ -230,6 +239,9 @@ void vhr_destroy(vhr_context *ctx) {
     ctx->sync_streams();
     vhr_graph_destroy_resources(ctx);
     if (ctx->front_stream) hipStreamDestroy(ctx->front_stream);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
+    if (ctx->side_done) hipEventDestroy(ctx->side_done);
     for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
         if (!im.used) continue;
         hipFree(im.ptr);
@@ -354,6 +366,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
             HIP_TRY(ctx, hipMemcpy(bvh.nodes16.data(), ctx->d_nodes16, sizeof(BvhNode16) * ctx->node_count, hipMemcpyDeviceToHost));
             HIP_TRY(ctx, hipMemcpy(bvh.tris.data(), ctx->d_tris, sizeof(BvhTri) * ctx->tri_count, hipMemcpyDeviceToHost));
             for (int a = 0; a < 3; ++a) bvh.centre[a] = ctx->bvh_centre[a];
+            bvh.nodes16_valid = nodes16_in_range(bvh);
             bvh.max_depth = ctx->bvh_depth;
         } else {
             hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
@@ -372,6 +385,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     const auto t_build1 = std::chrono::steady_clock::now();       // K0 proper ends here; the self-checks below are timed apart
     check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
     check_wide_nodes(bvh, ctx->bvh_wide_checks, ctx->bvh_build_threads);
+    ctx->nodes16_valid = bvh.nodes16_valid && ctx->bvh_form_checks[3] == 0;      // else the walkers stay on the 48-byte nodes
     ctx->bvh_fingerprint = bvh_fingerprint(bvh);
     ctx->bvh_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
     ctx->bvh_wide_depth = bvh.wide_depth;
@@ -549,7 +563,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -661,14 +675,16 @@ int vhr_get_transient_image(vhr_context *ctx, const char *name, vhr_image_info *
 int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out) {
     if (!ctx || !out || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // the caller is about to use the pointer on the context's stream
     return image_info(ctx, ctx->storage_images[id], out);
 }
 
-static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t bytes, bool to_device) {
+static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t bytes, bool to_device, bool storage = false) {
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
+    if (storage) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // a side-stream dispatch works on storage images only
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
@@ -690,12 +706,12 @@ int vhr_download_transient_image(vhr_context *ctx, const char *name, void *host_
 int vhr_upload_storage_image(vhr_context *ctx, int32_t id, const void *host_data, uint64_t bytes) {
     if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
-    return copy_image(ctx, ctx->storage_images[id], const_cast<void *>(host_data), bytes, true);
+    return copy_image(ctx, ctx->storage_images[id], const_cast<void *>(host_data), bytes, true, true);
 }
 int vhr_download_storage_image(vhr_context *ctx, int32_t id, void *host_data, uint64_t bytes) {
     if (!ctx || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
-    return copy_image(ctx, ctx->storage_images[id], host_data, bytes, false);
+    return copy_image(ctx, ctx->storage_images[id], host_data, bytes, false, true);
 }
 
 int vhr_standin_gbuffer(vhr_context *ctx, uint32_t resource_idx, const char *normals_image, const char *motion_image, const char *depth_image) {

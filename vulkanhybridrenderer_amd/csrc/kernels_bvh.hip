@@ -281,14 +281,29 @@ __global__ __launch_bounds__(256) void k0_forms_kernel(const BvhNode *__restrict
             }
             (a == 0 ? c.cx : a == 1 ? c.cy : c.cz)[which] = cc;
             hdst[a] = hh;
-            // half-precision boxes relative to the scene centre, rounded outward; the fp32 difference goes one ulp outward first
-            const __half l16 = __float2half_rd(nextafterf(lo - centre[a], -inf)), u16 = __float2half_ru(nextafterf(hi - centre[a], inf));
-            h16.h[6 * which + 2 * a] = __half_as_ushort(l16);
-            h16.h[6 * which + 2 * a + 1] = __half_as_ushort(u16);
+            // the 32-byte form (BvhNode16): centre relative to the scene centre and half extent as halves, no subnormals; centre + c +- h
+            // contains [lo, hi] in exact arithmetic with a few fp32 ulp to spare (the host's half_centre_extent; an overflow leaves inf,
+            // which the host sees in the downloaded nodes and then keeps the walkers on the 48-byte form)
+            uint16_t cb = 0, hb = 0xbc00;
+            if (lo <= hi) {
+                const double mid = 0.5 * double(lo) + 0.5 * double(hi) - double(centre[a]);
+                cb = __half_as_ushort(__float2half_rn(float(mid)));
+                if (((cb >> 10) & 31) == 0) cb = 0;
+                const double cv = double(centre[a]) + double(__half2float(__ushort_as_half(cb)));
+                double need = fmax(double(hi) - cv, cv - double(lo));
+                need += (fabs(double(centre[a])) + fabs(cv - double(centre[a])) + need) * 4.8e-7 + 1e-30;
+                float nf = float(need);
+                if (double(nf) < need) nf = nextafterf(nf, inf);
+                hb = __half_as_ushort(__float2half_ru(nf));
+                if (((hb >> 10) & 31) == 0) hb = 0x0400;
+            }
+            h16.c[2 * a + which] = cb;
+            h16.h[2 * a + which] = hb;
         }
     }
     c.child0 = nd.child0; c.child1 = nd.child1;
-    h16.child0 = nd.child0; h16.child1 = nd.child1;
+    h16.child0 = nd.child0 >= 0 ? nd.child0 * int32_t(sizeof(BvhNode16)) : nd.child0;
+    h16.child1 = nd.child1 >= 0 ? nd.child1 * int32_t(sizeof(BvhNode16)) : nd.child1;
     nodes_ch[k] = c;
     nodes16[k] = h16;
     BvhNode48 n48{};

@@ -1153,7 +1153,7 @@ static int issue_atrous(vhr_context *ctx, const AtrousArgs &a) {
     if (a.row_end <= a.row_begin || a.limit_x <= a.col_begin || !a.limit_y) return VHR_OK;
     // (only the default streaming kernel starts at col_begin; the A-B variants compute the rows from column 0: a superset)
     const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
-    ctx->time_begin(kKernelAtrous);
+    ctx->time_begin(ctx->async_atrous ? kKernelAtrousAsync : kKernelAtrous);
     const int variant = ctx->options[kOptAtrousVariant];
     bool tiled = variant != 0;
     if (variant == 4 || variant == 5) {
@@ -1225,13 +1225,87 @@ static bool dead_atrous(const std::vector<SvgfCmd> &rec, size_t k) {
     return true;
 }
 
+// "svgf_async_unread" (default 1): the same dead dispatch, when the option above leaves it in, does not have to sit on the frame's
+// critical path either.  Nothing in its pass reads what it writes, so it is issued LAST, on the context's side stream, ordered
+// behind the pass's other commands by an event; the caller's stream goes on with the next frame (the ray-tracing kernel, which is
+// bound by memory latency and leaves vector issue slots free, while this kernel is bound by vector issue) and waits for the side
+// stream's event before the next command of the library that could touch the images involved (join_side: the next compute pass,
+// image uploads / downloads / queries, vhr_synchronize).  Conditions, all checked here, else the dispatch stays where it was
+// recorded: one stream per frame ("frames_in_flight" 1), whole-image work (no strips / tiles), no later command of the pass writes
+// the dispatch's input or output, and the G-buffer normals it reads are available as a copy made by a later full-image blit of the
+// same pass (hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals) -- the G-buffer itself is
+// rewritten by the next frame's first pass, the copy only by the next SVGF pass, which joins first.  Same kernels on the same
+// inputs: every image, the dead dispatch's own output included, is bit-identical (tests/test_gpu_svgf.py).
+static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, size_t k, const void *&normals_copy) {
+    const SvgfCmd &w = rec[k];
+    const size_t image_bytes = size_t(w.a.width) * w.a.height * sizeof(uint2);
+    if (w.a.row_begin != 0 || w.a.row_end < w.a.height || w.a.col_begin != 0 || w.a.limit_x < w.a.width) return false;      // strips / tiles
+    normals_copy = nullptr;
+    for (size_t j = k + 1; j < rec.size(); ++j) {
+        const SvgfCmd &c = rec[j];
+        switch (c.kind) {
+            case SvgfCmd::Temporal:
+                if (c.t.integrated_out == w.a.in || c.t.integrated_out == w.a.out || c.t.moments_out == static_cast<const void *>(w.a.in)) return false;
+                break;
+            case SvgfCmd::Atrous:
+                if (c.a.out == w.a.in || c.a.out == w.a.out || c.a.out2 == w.a.in || c.a.out2 == w.a.out) return false;
+                break;
+            default:
+                if (c.dst_base == w.a.in || c.dst_base == w.a.out) return false;
+                if (c.dst_base == normals_copy) normals_copy = nullptr;                    // overwritten again: not a copy any more
+                if (c.src_base == w.a.normals && c.copy_rows == 0 && c.copy_src == static_cast<const char *>(c.src_base) && c.copy_bytes == image_bytes)
+                    normals_copy = c.dst_base;
+                break;
+        }
+    }
+    (void)ctx;
+    return normals_copy != nullptr;
+}
+
 int flush_recorded(vhr_context *ctx) {
     int rc = VHR_OK;
     const bool elide = ctx->options[kOptSvgfElideUnread] != 0;
+    const bool async = ctx->options[kOptSvgfAsyncUnread] != 0 && ctx->frames_in_flight == 1;
+    if (!ctx->recorded.empty()) { rc = ctx->join_side(); if (rc != VHR_OK) { ctx->recorded.clear(); return rc; } }
+    size_t deferred = size_t(-1);
+    const void *normals_copy = nullptr;
     for (size_t k = 0; k < ctx->recorded.size(); ++k) {
-        if (elide && dead_atrous(ctx->recorded, k)) continue;
+        if (dead_atrous(ctx->recorded, k)) {
+            if (elide) continue;
+            if (async && deferred == size_t(-1) && async_candidate(ctx, ctx->recorded, k, normals_copy)) { deferred = k; continue; }
+        }
         rc = issue_cmd(ctx, ctx->recorded[k]);
         if (rc != VHR_OK) break;
+    }
+    if (rc == VHR_OK && deferred != size_t(-1)) {
+        SvgfCmd cmd = ctx->recorded[deferred];
+        cmd.a.normals = static_cast<const uint2 *>(normals_copy);
+        bool ok = true;
+        if (!ctx->side_stream) {
+            int prio_lo = 0, prio_hi = 0;            // (numerically lower = higher priority)
+            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            const int mode = ctx->options[kOptSvgfAsyncUnread];
+            const int prio = mode == 2 ? prio_hi : (mode == 3 ? prio_lo : 0);
+            ok = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
+        }
+        ok = ok && hipEventRecord(ctx->side_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->side_stream, ctx->side_ready, 0) == hipSuccess;
+        if (!ok) {                                   // no side stream: the dispatch runs in order after all
+            rc = issue_cmd(ctx, ctx->recorded[deferred]);
+        } else {
+            hipStream_t const main_stream = ctx->stream;
+            PassDescription *const pass = ctx->cur_pass;
+            ctx->stream = ctx->side_stream;
+            ctx->cur_pass = nullptr;                 // the pass's time stamps stay on the caller's stream
+            ctx->async_atrous = true;                // timed as its own kernel kind
+            rc = issue_atrous(ctx, cmd.a);
+            ctx->async_atrous = false;
+            ctx->cur_pass = pass;
+            if (hipEventRecord(ctx->side_done, ctx->side_stream) != hipSuccess && rc == VHR_OK) rc = ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(side stream) failed");
+            ctx->stream = main_stream;
+            ctx->side_pending = true;
+        }
     }
     ctx->recorded.clear();
     return rc;

@@ -506,6 +506,35 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
     h1 = tn1 <= tf1;
 }
 
+// Both child boxes of a 32-byte node (BvhNode16, r3b): centres and half extents are HALVES, child 0 in the low and child 1 in the high half of
+// each word, and v_fma_mix_f32 widens the half operand inside the instruction -- 18 plain FMAs, no unpacking (a packed fp32 FMA
+// occupies the SIMD twice as long as a plain one: the 9 packed FMAs of the fp32 form are the same lane operations).  `noi` is
+// -(o - scene centre) / d: the centres are relative to the scene centre.  Culling only (see BvhNode16).
+#define VHR_MIX(name, mods, sel)                                                                                                       \
+    __device__ __forceinline__ float name(uint32_t h, float b, float c) {                                                             \
+        float r;                                                                                                                       \
+        asm("v_fma_mix_f32 %0, " mods "%1, %2, %3 op_sel:[" sel ",0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c));      \
+        return r;                                                                                                                      \
+    }
+VHR_MIX(mix_lo, "", "0")
+VHR_MIX(mix_hi, "", "1")
+VHR_MIX(mix_lo_neg, "-", "0")
+VHR_MIX(mix_hi_neg, "-", "1")
+#undef VHR_MIX
+
+__device__ __forceinline__ void box_pair_ch16(const uint32_t cx, const uint32_t cy, const uint32_t cz, const uint32_t hx, const uint32_t hy, const uint32_t hz,
+                                              f3 inv, f3 ainv, f3 noi, float tmin, float tlimit, bool &h0, bool &h1, float &tn0, float &tn1) {
+    const float cx0 = mix_lo(cx, inv.x, noi.x), cx1 = mix_hi(cx, inv.x, noi.x);
+    const float cy0 = mix_lo(cy, inv.y, noi.y), cy1 = mix_hi(cy, inv.y, noi.y);
+    const float cz0 = mix_lo(cz, inv.z, noi.z), cz1 = mix_hi(cz, inv.z, noi.z);
+    tn0 = hw_max3(mix_lo_neg(hx, ainv.x, cx0), mix_lo_neg(hy, ainv.y, cy0), hw_max(mix_lo_neg(hz, ainv.z, cz0), tmin));
+    tn1 = hw_max3(mix_hi_neg(hx, ainv.x, cx1), mix_hi_neg(hy, ainv.y, cy1), hw_max(mix_hi_neg(hz, ainv.z, cz1), tmin));
+    const float tf0 = hw_min3(mix_lo(hx, ainv.x, cx0), mix_lo(hy, ainv.y, cy0), hw_min(mix_lo(hz, ainv.z, cz0), tlimit));
+    const float tf1 = hw_min3(mix_hi(hx, ainv.x, cx1), mix_hi(hy, ainv.y, cy1), hw_min(mix_hi(hz, ainv.z, cz1), tlimit));
+    h0 = tn0 <= tf0;
+    h1 = tn1 <= tf1;
+}
+
 // One visit's worth of a 48-byte node (BvhNode48): three 16-byte loads, the half extents widened back to fp32 words (first of a
 // pair = the word itself, second = one shift), links from the third load.  Feeds box_pair_ch unchanged.
 struct Node48Words { float4 q0, q1, q2; int2 links; };
@@ -980,7 +1009,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t cut_n = 0;
     if (CUT && total) {
         if constexpr (WIDE) cut_n = build_tile_cut_wide(a.scene.nodes4, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax);
-        else cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u, COMPACT ? 1 : int(sizeof(BvhNode48)));
+        else cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)));
     }
     if (STATS) n_cut_entries = cut_n;
     uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
@@ -1143,11 +1172,10 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             bool h0, h1;
             int2 links;
             if (COMPACT) {
-                const uint4 *np = reinterpret_cast<const uint4 *>(a.scene.nodes16 + cur);
+                // `cur` is the node's BYTE offset (index * 32); two 16-byte loads per visit
+                const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.scene.nodes16) + uint32_t(cur));
                 const uint4 c0 = np[0], c1 = np[1];
-                auto unpack = [](uint32_t w) { const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&w)); return f2v{ f.x, f.y }; };
-                h0 = box_test_pk(unpack(c0.x), unpack(c0.y), unpack(c0.z), rinv, noi, tmin_v, tmax, tn0);
-                h1 = box_test_pk(unpack(c0.w), unpack(c1.x), unpack(c1.y), rinv, noi, tmin_v, tmax, tn1);
+                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
                 const Node48Words nw = load_node48(a.scene.nodes48, cur);
@@ -1914,7 +1942,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
         // the shared descent ("raygen_cut", default): own-tile waves on the plain fp32 nodes
         const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile;
-        const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0;
+        const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
         const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
         const uint32_t cut_flags = (ctx->options[kOptCutReach] != 0 ? 1u : 0u) | (ctx->options[kOptCutExpand] != 0 ? 2u : 0u) | (ctx->options[kOptShadowLast] != 0 ? 4u : 0u);
 #define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
@@ -1936,7 +1964,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #define VHR_LAUNCH_CUT(WV, SP, ST) do { if (wide) VHR_LAUNCH_CUT_WIDE(WV, ST); else if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
 #define VHR_LAUNCH_CUT_W(SP, ST) \
     do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
-        const bool compact = ctx->options[kOptCompactNodes] != 0;
+        const bool compact = ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
         // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
         const bool spill = levels < ctx->bvh_depth + 1u;
         // A/B variants (pre-generated directions, compact nodes) exist in the diagnostic flavour only
@@ -1962,10 +1990,14 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #undef VHR_LAUNCH_WIDE_S
 #undef VHR_LAUNCH_WIDE
         }
-        else if (compact_cut && tile_rows == 8u && !a.stats) {     // A-B: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of four)
-            const uint32_t bx = (tiles_x + 1) / 2;
-            if (spill) launch(ctx, (raygen_queue_kernel<false, 2, true, false, true, false, true, false>), dim3(bx * tiles_y), dim3(kQueueBlock * 2), stack_bytes * 2, a, levels, threshold, 0u, bx, 0u, early_exit, tile_rows, 0u);
-            else launch(ctx, (raygen_queue_kernel<false, 2, true, false, false, false, true, false>), dim3(bx * tiles_y), dim3(kQueueBlock * 2), stack_bytes * 2, a, levels, threshold, 0u, bx, 0u, early_exit, tile_rows, 0u);
+        else if (compact_cut && !packet && !wide) {     // the default: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of three)
+#define VHR_LAUNCH_CUT16(WV, SP, ST) launch(ctx, (raygen_queue_kernel<false, WV, true, false, SP, ST, true, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
+                                            stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, cut_flags)
+#define VHR_LAUNCH_CUT16_W(SP, ST) do { if (waves >= 4) VHR_LAUNCH_CUT16(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT16(2, SP, ST); else VHR_LAUNCH_CUT16(1, SP, ST); } while (0)
+            if (a.stats) { if (spill) VHR_LAUNCH_CUT16_W(true, true); else VHR_LAUNCH_CUT16_W(false, true); }
+            else { if (spill) VHR_LAUNCH_CUT16_W(true, false); else VHR_LAUNCH_CUT16_W(false, false); }
+#undef VHR_LAUNCH_CUT16_W
+#undef VHR_LAUNCH_CUT16
         }
         else if (cut) {
             if (a.stats) { if (spill) VHR_LAUNCH_CUT_W(true, true); else VHR_LAUNCH_CUT_W(false, true); }

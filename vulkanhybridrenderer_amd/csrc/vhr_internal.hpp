@@ -32,13 +32,18 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 
-// The same node with its boxes as IEEE halves RELATIVE TO THE SCENE CENTRE, rounded outward (lo toward -inf, hi
-// toward +inf) -- 32 B = 2 x dwordx4 loads per visit instead of 4.  Boxes only cull, and an outward-rounded box
-// contains the fp32 one, so the set of triangles tested can only grow and results are unchanged; what shrinks is
-// the number of L1 line accesses per visit, the throughput limit of the traversal kernel (PMC: ~0.5 TCP accesses
-// per clock per CU).  h[0..5] = box0 (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z), h[6..11] = box1.
+// The same node in 32 bytes = TWO 16-byte loads per visit (r3b): both boxes as centre and half extent in IEEE HALVES, centres
+// relative to the scene centre (the walker shifts the ray origin once per ray).  The slab distances come straight out of
+// v_fma_mix_f32, which widens a half operand inside the instruction: no unpacking, 18 plain FMAs for the 9 packed ones of the fp32
+// form (the same lane operations).  c is the half nearest to the fp32 box centre, h the smallest normal half for which
+// centre + c +- h contains the padded (lo, hi) box in exact arithmetic, plus a few fp32 ulp for the walker's own rounding; boxes only
+// cull, so results are unchanged.  No half here is subnormal (c flushes to 0, h starts at 2^-14).
+//   q0 = (c.x, c.y, c.z, h.x) words, child 0 in the low half and child 1 in the high half of each; q1 = (h.y, h.z, child0, child1)
+// Inner links are BYTE offsets (index * 32).  An absent child has h = -1; a scene whose extent overflows the half range has no
+// such form (HostBvh::nodes16_valid = false: the walkers stay on the 48-byte nodes).
 struct BvhNode16 {
-    uint16_t h[12];
+    uint16_t c[6];                   // (c0.x, c1.x, c0.y, c1.y, c0.z, c1.z)
+    uint16_t h[6];                   // (h0.x, h1.x, h0.y, h1.y, h0.z, h1.z)
     int32_t child0, child1;
 };
 static_assert(sizeof(BvhNode16) == 32, "BvhNode16");
@@ -175,6 +180,7 @@ struct HostBvh {
     std::vector<uint32_t> wide_root;
     std::vector<uint32_t> wide_child_ref;      // 4 per wide node, 0xffffffff for an absent child
     float centre[3] = { 0, 0, 0 };
+    bool nodes16_valid = false;        // false: some box does not fit the half range around `centre` (the walkers then stay on nodes48)
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
     uint32_t wide_depth = 0;          // levels of the four-wide tree (a walk holds at most 3 pending subtrees per level)
@@ -183,6 +189,7 @@ struct HostBvh {
 // builds the BVH2 (csrc/bvh_build.cpp)
 void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads = 0);
 void check_wide_nodes(const HostBvh &bvh, uint64_t out[4], int threads = 0);
+bool nodes16_in_range(const HostBvh &bvh);      // no inf / NaN / subnormal half in the 32-byte form (a device-built tree: the host decides)
 uint64_t bvh_fingerprint(const HostBvh &bvh);
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
                uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
@@ -259,10 +266,10 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptCount = 32 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptCount = 33 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
-enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelKinds = 8 };
+enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelAtrousAsync = 8, kKernelKinds = 9 };
 struct KernelTimer {
     std::vector<hipEvent_t> events;     // begin/end pairs
     size_t used = 0;                    // events recorded since the last drain
@@ -317,6 +324,7 @@ struct vhr_context {
     uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
     float bvh_centre[3] = { 0, 0, 0 };
+    bool nodes16_valid = false;      // the 32-byte half-precision nodes exist for this tree (extent within the half range) and passed the containment check
     vhr::BvhTri *d_tris = nullptr;
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
     int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
@@ -352,7 +360,16 @@ struct vhr_context {
     bool back_pending[3] = { false, false, false };
     size_t front_passes = 0;           // passes [0, front_passes) of execution_order run on front_stream
     uint32_t cur_slot = 0;
-    int sync_streams();                // waits for both streams
+    int sync_streams();                // waits for every stream of the context
+    // "svgf_async_unread": a compute pass's a-trous dispatch whose output nothing reads (the reference's fifth iteration) is issued on
+    // `side_stream` after the pass's other commands, beside whatever the caller's stream does next (the next frame's ray tracing);
+    // side_done is recorded behind it and join_side() makes the caller's stream wait for it before anything of the library touches
+    // the images it reads or writes again.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_ready = nullptr, side_done = nullptr;
+    bool side_pending = false;
+    bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
+    int join_side();                   // the current stream waits for the side stream's pending dispatch (no-op without one)
 
     // statistics
     bool ray_stats_enabled = false;
@@ -360,7 +377,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 0, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never

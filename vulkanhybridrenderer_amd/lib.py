@@ -582,7 +582,7 @@ class Context:
         self.check(self.L.vhr_get_bvh_statistics(self.handle, out), "bvh_statistics")
         return dict(nodes=out[0], triangles=out[1], max_depth=out[2], node_bytes=out[3], triangle_bytes=out[4])
 
-    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4, "ssao": 5, "ssao_blur": 6, "ssr": 7}
+    KERNEL_KINDS = {"raygen": 0, "svgf_temporal": 1, "svgf_atrous": 2, "blit": 3, "reflection": 4, "ssao": 5, "ssao_blur": 6, "ssr": 7, "svgf_atrous_async": 8}
 
     def current_stream(self):
         """hipStream_t (as an int) the library is enqueueing on right now: inside a pass callback, the stream that pass is ordered on."""
