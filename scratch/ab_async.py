@@ -8,8 +8,7 @@ from vulkanhybridrenderer_amd import scenes, lib
 from vulkanhybridrenderer_amd.harness import HybridFrameLoop
 names = [a for a in sys.argv[1:] if "=" not in a] or ["sponza_proc"]
 extra = [a.split("=") for a in sys.argv[1:] if "=" in a]
-arms = [dict(svgf_async_unread=1, compact_nodes=1), dict(svgf_async_unread=1, compact_nodes=0, raygen_tile_pixels=128), dict(svgf_async_unread=0, compact_nodes=0, raygen_tile_pixels=128), dict(svgf_async_unread=1, compact_nodes=1, raygen_early_exit=6),
-        dict(svgf_async_unread=1, compact_nodes=1, refill_threshold=8), dict(svgf_async_unread=1, compact_nodes=1, lds_stack_levels=6)]
+arms = [dict(svgf_async_unread=0), dict(svgf_async_unread=1), dict(svgf_elide_unread=1), dict(svgf_async_unread=1, fuse_blits=0), dict(svgf_async_unread=0)]
 for name in names:
     scene = getattr(scenes, name)()
     ref = None

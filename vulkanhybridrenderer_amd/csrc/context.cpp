@@ -684,7 +684,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
-    if (storage) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // a side-stream dispatch works on storage images only
+    if (storage || to_device) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // (a side-stream dispatch reads storage images and the pass's published copies)
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }

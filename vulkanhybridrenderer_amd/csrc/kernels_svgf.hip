@@ -1236,8 +1236,20 @@ static bool dead_atrous(const std::vector<SvgfCmd> &rec, size_t k) {
 // same pass (hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals) -- the G-buffer itself is
 // rewritten by the next frame's first pass, the copy only by the next SVGF pass, which joins first.  Same kernels on the same
 // inputs: every image, the dead dispatch's own output included, is bit-identical (tests/test_gpu_svgf.py).
-static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, size_t k, const void *&normals_copy) {
+static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, size_t k, const void *&normals_copy, const void *&input_copy) {
     const SvgfCmd &w = rec[k];
+    // The dispatch's input, too, may exist twice: the a-trous dispatch that wrote it may have stored the same texels into a second image
+    // (a fused blit: hybrid_render_path.cpp:320-323 publishes iteration 3's image as "Denoised ...").  Reading that copy instead moves
+    // the point where the caller's stream has to wait from the next frame's svgf.comp (which overwrites the ping-pong image) to its
+    // first a-trous dispatch (which overwrites this dispatch's output).
+    input_copy = nullptr;
+    for (size_t j = 0; j < k; ++j) {
+        const SvgfCmd &c = rec[j];
+        if (c.kind == SvgfCmd::Atrous && c.a.out == w.a.in && c.a.out2 && c.a.row_begin == 0 && c.a.row_end >= c.a.height && c.a.col_begin == 0 && c.a.limit_x >= c.a.width) input_copy = c.a.out2;
+        else if (c.kind == SvgfCmd::Atrous && (c.a.out == input_copy || c.a.out2 == input_copy)) input_copy = nullptr;
+        else if (c.kind == SvgfCmd::Copy && c.dst_base == input_copy) input_copy = nullptr;
+        else if (c.kind == SvgfCmd::Temporal && c.t.integrated_out == input_copy) input_copy = nullptr;
+    }
     const size_t image_bytes = size_t(w.a.width) * w.a.height * sizeof(uint2);
     if (w.a.row_begin != 0 || w.a.row_end < w.a.height || w.a.col_begin != 0 || w.a.limit_x < w.a.width) return false;      // strips / tiles
     normals_copy = nullptr;
@@ -1249,12 +1261,16 @@ static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, s
                 break;
             case SvgfCmd::Atrous:
                 if (c.a.out == w.a.in || c.a.out == w.a.out || c.a.out2 == w.a.in || c.a.out2 == w.a.out) return false;
+                if (c.a.out == input_copy || c.a.out2 == input_copy) input_copy = nullptr;
                 break;
             default:
                 if (c.dst_base == w.a.in || c.dst_base == w.a.out) return false;
                 if (c.dst_base == normals_copy) normals_copy = nullptr;                    // overwritten again: not a copy any more
+                if (c.dst_base == input_copy) input_copy = nullptr;
                 if (c.src_base == w.a.normals && c.copy_rows == 0 && c.copy_src == static_cast<const char *>(c.src_base) && c.copy_bytes == image_bytes)
                     normals_copy = c.dst_base;
+                if (c.src_base == w.a.in && c.copy_rows == 0 && c.copy_src == static_cast<const char *>(c.src_base) && c.copy_bytes == image_bytes)
+                    input_copy = c.dst_base;                                               // (the same blit, not fused: "fuse_blits" 0)
                 break;
         }
     }
@@ -1266,20 +1282,36 @@ int flush_recorded(vhr_context *ctx) {
     int rc = VHR_OK;
     const bool elide = ctx->options[kOptSvgfElideUnread] != 0;
     const bool async = ctx->options[kOptSvgfAsyncUnread] != 0 && ctx->frames_in_flight == 1;
-    if (!ctx->recorded.empty()) { rc = ctx->join_side(); if (rc != VHR_OK) { ctx->recorded.clear(); return rc; } }
     size_t deferred = size_t(-1);
-    const void *normals_copy = nullptr;
+    const void *normals_copy = nullptr, *input_copy = nullptr;
+    // does command c touch what the side stream's pending dispatch reads (`side_reads`) or writes (`side_writes`)?
+    auto conflicts = [&](const SvgfCmd &c) {
+        auto reads = [&](const void *p) { return p && p == ctx->side_writes; };
+        auto writes = [&](const void *p) { return p && (p == ctx->side_writes || p == ctx->side_reads[0] || p == ctx->side_reads[1]); };
+        switch (c.kind) {
+            case SvgfCmd::Temporal:
+                return reads(c.t.normals) || reads(c.t.motion) || reads(c.t.prev_normals) || reads(c.t.history) || reads(c.t.raytraced) || reads(c.t.moments_in) ||
+                       writes(c.t.integrated_out) || writes(c.t.moments_out);
+            case SvgfCmd::Atrous:
+                return reads(c.a.normals) || reads(c.a.in) || writes(c.a.out) || writes(c.a.out2);
+            default:
+                return reads(c.src_base) || writes(c.dst_base);
+        }
+    };
     for (size_t k = 0; k < ctx->recorded.size(); ++k) {
         if (dead_atrous(ctx->recorded, k)) {
             if (elide) continue;
-            if (async && deferred == size_t(-1) && async_candidate(ctx, ctx->recorded, k, normals_copy)) { deferred = k; continue; }
+            if (async && deferred == size_t(-1) && async_candidate(ctx, ctx->recorded, k, normals_copy, input_copy)) { deferred = k; continue; }
         }
+        if (ctx->side_pending && conflicts(ctx->recorded[k])) { rc = ctx->join_side(); if (rc != VHR_OK) break; }
         rc = issue_cmd(ctx, ctx->recorded[k]);
         if (rc != VHR_OK) break;
     }
+    if (rc == VHR_OK && deferred != size_t(-1) && ctx->side_pending) rc = ctx->join_side();      // one dispatch at a time on the side stream
     if (rc == VHR_OK && deferred != size_t(-1)) {
         SvgfCmd cmd = ctx->recorded[deferred];
         cmd.a.normals = static_cast<const uint2 *>(normals_copy);
+        if (input_copy) cmd.a.in = static_cast<const uint2 *>(input_copy);
         bool ok = true;
         if (!ctx->side_stream) {
             int prio_lo = 0, prio_hi = 0;            // (numerically lower = higher priority)
@@ -1305,6 +1337,7 @@ int flush_recorded(vhr_context *ctx) {
             if (hipEventRecord(ctx->side_done, ctx->side_stream) != hipSuccess && rc == VHR_OK) rc = ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(side stream) failed");
             ctx->stream = main_stream;
             ctx->side_pending = true;
+            ctx->side_reads[0] = cmd.a.in; ctx->side_reads[1] = cmd.a.normals; ctx->side_writes = cmd.a.out;
         }
     }
     ctx->recorded.clear();

@@ -510,27 +510,30 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
 // each word, and v_fma_mix_f32 widens the half operand inside the instruction -- 18 plain FMAs, no unpacking (a packed fp32 FMA
 // occupies the SIMD twice as long as a plain one: the 9 packed FMAs of the fp32 form are the same lane operations).  `noi` is
 // -(o - scene centre) / d: the centres are relative to the scene centre.  Culling only (see BvhNode16).
-#define VHR_MIX(name, mods, sel)                                                                                                       \
+#define VHR_MIX(name, mods, b_open, b_close, sel)                                                                                      \
     __device__ __forceinline__ float name(uint32_t h, float b, float c) {                                                             \
         float r;                                                                                                                       \
-        asm("v_fma_mix_f32 %0, " mods "%1, %2, %3 op_sel:[" sel ",0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c));      \
+        asm("v_fma_mix_f32 %0, " mods "%1, " b_open "%2" b_close ", %3 op_sel:[" sel ",0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(b), "v"(c));      \
         return r;                                                                                                                      \
     }
-VHR_MIX(mix_lo, "", "0")
-VHR_MIX(mix_hi, "", "1")
-VHR_MIX(mix_lo_neg, "-", "0")
-VHR_MIX(mix_hi_neg, "-", "1")
+VHR_MIX(mix_lo, "", "", "", "0")
+VHR_MIX(mix_hi, "", "", "", "1")
+// h * |b| + c and -h * |b| + c: the ray's |1 / d| as an operand modifier of the instruction (no register copy of it)
+VHR_MIX(mix_lo_abs, "", "|", "|", "0")
+VHR_MIX(mix_hi_abs, "", "|", "|", "1")
+VHR_MIX(mix_lo_neg_abs, "-", "|", "|", "0")
+VHR_MIX(mix_hi_neg_abs, "-", "|", "|", "1")
 #undef VHR_MIX
 
 __device__ __forceinline__ void box_pair_ch16(const uint32_t cx, const uint32_t cy, const uint32_t cz, const uint32_t hx, const uint32_t hy, const uint32_t hz,
-                                              f3 inv, f3 ainv, f3 noi, float tmin, float tlimit, bool &h0, bool &h1, float &tn0, float &tn1) {
+                                              f3 inv, f3 noi, float tmin, float tlimit, bool &h0, bool &h1, float &tn0, float &tn1) {
     const float cx0 = mix_lo(cx, inv.x, noi.x), cx1 = mix_hi(cx, inv.x, noi.x);
     const float cy0 = mix_lo(cy, inv.y, noi.y), cy1 = mix_hi(cy, inv.y, noi.y);
     const float cz0 = mix_lo(cz, inv.z, noi.z), cz1 = mix_hi(cz, inv.z, noi.z);
-    tn0 = hw_max3(mix_lo_neg(hx, ainv.x, cx0), mix_lo_neg(hy, ainv.y, cy0), hw_max(mix_lo_neg(hz, ainv.z, cz0), tmin));
-    tn1 = hw_max3(mix_hi_neg(hx, ainv.x, cx1), mix_hi_neg(hy, ainv.y, cy1), hw_max(mix_hi_neg(hz, ainv.z, cz1), tmin));
-    const float tf0 = hw_min3(mix_lo(hx, ainv.x, cx0), mix_lo(hy, ainv.y, cy0), hw_min(mix_lo(hz, ainv.z, cz0), tlimit));
-    const float tf1 = hw_min3(mix_hi(hx, ainv.x, cx1), mix_hi(hy, ainv.y, cy1), hw_min(mix_hi(hz, ainv.z, cz1), tlimit));
+    tn0 = hw_max3(mix_lo_neg_abs(hx, inv.x, cx0), mix_lo_neg_abs(hy, inv.y, cy0), hw_max(mix_lo_neg_abs(hz, inv.z, cz0), tmin));
+    tn1 = hw_max3(mix_hi_neg_abs(hx, inv.x, cx1), mix_hi_neg_abs(hy, inv.y, cy1), hw_max(mix_hi_neg_abs(hz, inv.z, cz1), tmin));
+    const float tf0 = hw_min3(mix_lo_abs(hx, inv.x, cx0), mix_lo_abs(hy, inv.y, cy0), hw_min(mix_lo_abs(hz, inv.z, cz0), tlimit));
+    const float tf1 = hw_min3(mix_hi_abs(hx, inv.x, cx1), mix_hi_abs(hy, inv.y, cy1), hw_min(mix_hi_abs(hz, inv.z, cz1), tlimit));
     h0 = tn0 <= tf0;
     h1 = tn1 <= tf1;
 }
@@ -918,7 +921,15 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
     constexpr int COPIES = SHARED ? 1 : WAVES;
     __shared__ uint32_t s_vis_all[COPIES][kQueueBlock];   // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
-    __shared__ float s_ray_all[COPIES][7][kQueueBlock];   // per covered pixel: ray origin (3), normal (3), RNG seed (1)
+    // per covered pixel: ray origin (3), normal (3), RNG seed (1).  The cut kernels (the default) keep 5 words instead -- the normal as the
+    // G-buffer's own half bits (2 words), the seed recomputed from the pixel at refill: with 512 bytes less per wave 16 workgroups
+    // (8 waves per SIMD) fit a CU's LDS at 8 stack levels instead of 15
+#ifdef VHR_RAY_WORDS7          // (A-B builds only)
+    constexpr int RAYW = 7;
+#else
+    constexpr int RAYW = (CUT && !PREGEN && !SHARED) ? 5 : 7;
+#endif
+    __shared__ float s_ray_all[COPIES][RAYW][kQueueBlock];
     __shared__ uint8_t s_list_all[COPIES][kQueueBlock];   // compacted covered pixels
     __shared__ uint32_t s_next, s_ncov;                   // SHARED: queue head and covered-pixel count of the tile
     __shared__ float4 s_cut_all[CUT ? COPIES : 1][CUT ? kCutMax : 1][2];   // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // from it -- the LDS bases, the wave's tile -- stays in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     uint32_t (&s_vis)[kQueueBlock] = s_vis_all[SHARED ? 0 : wave];
-    float (&s_ray)[7][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
+    float (&s_ray)[RAYW][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
     uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
     float4 (&s_cut)[CUT ? kCutMax : 1][2] = s_cut_all[CUT ? (SHARED ? 0 : wave) : 0];
     // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
@@ -966,8 +977,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const float u = (float(x) + 0.5f) / float(W);
         const float v = (float(y) + 0.5f) / float(H);
         const f3 P = get_world_space_position(a.pfd, depth, u, v);                           // rgen:26
-        const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
-        const f3 N = f3{ nid.x, nid.y, nid.z };
+        const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];    // rgen:28 (R16G16B16A16: nx ny | nz id)
+        const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
         const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
@@ -980,6 +991,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + lane;
                 slot[0] = d.x; slot[kQueueBlock] = d.y; slot[2 * kQueueBlock] = d.z;
             }
+        } else if constexpr (RAYW == 5) {
+            s_ray[3][lane] = __uint_as_float(nraw.x); s_ray[4][lane] = __uint_as_float(nraw.y);
         } else {
             s_ray[3][lane] = N.x; s_ray[4][lane] = N.y; s_ray[5][lane] = N.z;
             s_ray[6][lane] = __uint_as_float(seed);
@@ -1056,6 +1069,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 if (PREGEN) {
                     const float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + pix;
                     rd = f3{ slot[0], slot[kQueueBlock], slot[2 * kQueueBlock] };
+                } else if constexpr (RAYW == 5) {
+                    const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nzw = __float_as_uint(s_ray[4][pix]);
+                    const uint32_t px = x - (lane & 7u) + (pix & 7u), py = y - (lane >> 3) + (pix >> 3);     // the tile's origin + the pixel's place in it
+                    rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                            // rgen:17
+                                       f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) });
                 } else {
                     rd = ray_direction(a.tp, __float_as_uint(s_ray[6][pix]), kind, L, f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] });
                 }
@@ -1175,7 +1193,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 // `cur` is the node's BYTE offset (index * 32); two 16-byte loads per visit
                 const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.scene.nodes16) + uint32_t(cur));
                 const uint4 c0 = np[0], c1 = np[1];
-                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
+                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
                 const Node48Words nw = load_node48(a.scene.nodes48, cur);
@@ -1218,14 +1236,23 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             ++n_leaves;
             // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
             // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
-            for (uint32_t i = 0; i < count; ++i) {
-                ++n_tris;
-                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
-                const float4 ta = tp[0], tb = tp[1];
-                const float tcx = reinterpret_cast<const float *>(tp)[8];
-                if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
-                    found = true;
-                    break;
+            // ... and the NEXT triangle's loads are in flight while this one is tested (r3b: the leaf's up to three tests were three
+            // dependent round trips; the last trip reloads its own triangle, which keeps the loop free of branches; measured -1.3 %
+            // on sponza_proc, +0.7 % on bistro_proc: the leaf stage does not wait for memory much)
+            {
+                const BvhTri *const leaf = a.scene.tris + first;
+                float4 ta = reinterpret_cast<const float4 *>(leaf)[0], tb = reinterpret_cast<const float4 *>(leaf)[1];
+                float tcx = reinterpret_cast<const float *>(leaf)[8];
+                for (uint32_t i = 0; i < count; ++i) {
+                    ++n_tris;
+                    const BvhTri *const nt = leaf + min(i + 1u, count - 1u);
+                    const float4 na = reinterpret_cast<const float4 *>(nt)[0], nb = reinterpret_cast<const float4 *>(nt)[1];
+                    const float ncx = reinterpret_cast<const float *>(nt)[8];
+                    if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
+                        found = true;
+                        break;
+                    }
+                    ta = na; tb = nb; tcx = ncx;
                 }
             }
             if (!found) {                                                          // pop (the sentinel if nothing is pending)

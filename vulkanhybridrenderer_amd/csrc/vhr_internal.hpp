@@ -368,6 +368,7 @@ struct vhr_context {
     hipStream_t side_stream = nullptr;
     hipEvent_t side_ready = nullptr, side_done = nullptr;
     bool side_pending = false;
+    const void *side_reads[2] = { nullptr, nullptr }, *side_writes = nullptr;      // the images the pending dispatch reads / writes (hazard checks)
     bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
     int join_side();                   // the current stream waits for the side stream's pending dispatch (no-op without one)
 
