@@ -317,16 +317,17 @@ def main():
         loop.frame(i)
     f += args.warmup
     barrier()
-    # Only the roofline kernel (a-trous) carries event pairs inside the timed region, and only every 6th of its launches
+    # Only the roofline kernel (a-trous) carries event pairs inside the timed region, and only every 11th / 13th of its launches
     # (a dispatch with an event pair costs ~6 us that the next kernel waits for: all five launches of a frame timed = +30 us on
-    # a 0.67 ms frame; 6 is coprime with 5, so the sample walks through the five step sizes evenly).  The other kernels are
-    # timed in a short extra loop afterwards so that their event records do not sit in the measured frames.
+    # a 0.5 ms frame, every 6th still +5 us; the stride is coprime with the launches per frame, so the sample walks through the
+    # step sizes evenly: ~600 samples per second of timed region).  The other kernels are timed in a short extra loop afterwards
+    # so that their event records do not sit in the measured frames.
     # "svgf_async_unread" (default at N = 1, one frame in flight): the reference's dead fifth a-trous dispatch leaves the context's stream
     # and runs on the side stream beside the next frame's ray tracing.  The roofline then covers the FOUR launches on the frame's critical
-    # path (stride 5, coprime with 4); the side stream's launch is timed as its own kind in the extra loop below and reported beside it.
+    # path; the side stream's launch is timed as its own kind in the extra loop below and reported beside it.
     async_dead = (world == 1 and args.frames_in_flight == 1 and option_overrides.get("svgf_async_unread", 1) != 0
                   and not option_overrides.get("svgf_elide_unread", 0) and loop.denoise and loop.atrous_steps == 5)
-    ATROUS_TIMING_STRIDE = 5 if async_dead else 6
+    ATROUS_TIMING_STRIDE = 13 if async_dead else 11       # coprime with the 4 (5) launches per frame on the context's stream: every step size sampled evenly
     ctx.set_option("kernel_timing_stride", ATROUS_TIMING_STRIDE)
     ctx.set_kernel_timing(["svgf_atrous"])
     for k in ("raygen", "svgf_temporal", "svgf_atrous", "svgf_atrous_async", "blit", "reflection"):

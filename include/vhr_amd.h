@@ -417,9 +417,15 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      whole wave (default), 0 = one pixel per thread (also what two bounces use)
  *   "raytraced_variant" the raytraced render path's "Raytracing Pass": 1 = work-queue kernel (primary closest-hit walk, shadow
  *                      any-hit walk, shading with the whole wave; default), 0 = one pixel per thread
- *   "pass_timestamps"  1 = every ray-tracing / compute pass carries begin / end timestamps for
- *                      vhr_graph_gather_performance_statistics (default; the reference's vkCmdWriteTimestamp pair,
- *                      render_graph.cpp:167-182; ~1.5 us per dispatch), 0 = off.  External graphics passes are not stamped.
+ *   "pass_timestamps"  1 (default) = every ray-tracing / compute pass carries begin / end timestamps for
+ *                      vhr_graph_gather_performance_statistics (the reference's vkCmdWriteTimestamp pair, render_graph.cpp:167-182),
+ *                      written by the kernels themselves: the first thread of a pass's first kernel stores the device's wall clock as the
+ *                      begin, the first thread of the NEXT kernel on the (in-order) stream stores it as the end -- for the frame's last
+ *                      pass that is the next frame's first kernel, or a one-thread kernel issued by whatever call waits for the stream
+ *                      first (vhr_synchronize, vhr_graph_gather_performance_statistics, downloads); ~3 us per frame.  2 = the same with
+ *                      that one-thread kernel issued at the end of every vhr_graph_execute (hosts that neither run ahead of the GPU nor
+ *                      wait for it; +6 us per frame).  3 = HIP event pairs on the dispatch packets (rounds 1-3a; 16 us per frame, and the
+ *                      only form with "frames_in_flight" > 1).  0 = off.  External graphics passes are not stamped.
  *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 8 (default), 4 or 2 (measured slower)
  *   "fuse_blits"       1 = a compute pass records its dispatches and blits and issues them when its callback returns; a
  *                      same-extent blit whose source is the output of a recorded a-trous dispatch (and whose destination nothing

@@ -86,7 +86,7 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
             }
         }
     }
-    if (cur_pass && options[vhr::kOptPassTimestamps] && cur_pass->ev_begin) {
+    if (cur_pass && options[vhr::kOptPassTimestamps] && cur_pass->ev_begin && !(in_kernel_stamps() && cur_pass->stamp_index >= 0)) {
         if (!cur_pass->begin_stamped) {
             if (!start) start = cur_pass->ev_begin;
             else hipEventRecord(cur_pass->ev_begin, stream);
@@ -97,8 +97,22 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
     }
 }
 
+// The stamps of the next kernel launch (vhr::launch): the end of the pass that finished last, the begin of the running pass's first kernel.
+vhr::Stamps vhr_context::take_stamps() {
+    vhr::Stamps st{ nullptr, nullptr };
+    if (no_stamps || !in_kernel_stamps()) return st;
+    if (pending_end) { st.prev_end = pending_end; pending_end = nullptr; }
+    if (cur_pass && options[vhr::kOptPassTimestamps] && cur_pass->stamp_index >= 0 && !cur_pass->begin_stamped) {
+        st.begin = &d_stamps[cur_pass->stamp_index].begin;
+        cur_pass->begin_stamped = true;
+        cur_pass->stamped_in_kernel = true;
+    }
+    return st;
+}
+
 int vhr_context::sync_streams() {
     if (host_only) return VHR_OK;
+    if (pending_end) vhr::launch_stamp(this);          // the end of the last pass, before the host waits for it
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
     if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
     side_pending = false;
@@ -210,11 +224,15 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, info->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
     if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), sizeof(RayStats)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ctx->d_tile_counter), sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_tile_counter), sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), sizeof(vhr::PassStampPair) * vhr::kMaxStampedPasses) != hipSuccess ||
+        hipMemset(ctx->d_stamps, 0, sizeof(vhr::PassStampPair) * vhr::kMaxStampedPasses) != hipSuccess) {
         g_create_error = "vhr_create: device initialisation failed";
         vhr_destroy(ctx);
         return VHR_ERROR_DEVICE;
     }
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, info->device) == hipSuccess && khz > 0) ctx->wall_clock_khz = double(khz);
     *out = ctx;
     return VHR_OK;
 }
@@ -242,6 +260,7 @@ void vhr_destroy(vhr_context *ctx) {
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
     if (ctx->side_done) hipEventDestroy(ctx->side_done);
+    hipFree(ctx->d_stamps);
     for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
         if (!im.used) continue;
         hipFree(im.ptr);

@@ -66,7 +66,8 @@ struct SsaoArgs {
     float radius;
 };
 
-__global__ __launch_bounds__(kScreenBlockX *kScreenBlockY) void ssao_kernel(const SsaoArgs a) {
+__global__ __launch_bounds__(kScreenBlockX *kScreenBlockY) void ssao_kernel(const SsaoArgs a, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t x = blockIdx.x * kScreenBlockX + threadIdx.x;
     const uint32_t y = a.row_begin + blockIdx.y * kScreenBlockY + threadIdx.y;
     if (x >= a.limit_x || y >= a.row_end || y >= a.limit_y) return;
@@ -111,7 +112,8 @@ constexpr int kBlurTileX = 64, kBlurTileY = 16;
 constexpr int kBlurLdsW = kBlurTileX + 2 * kBlurR, kBlurLdsH = kBlurTileY + 2 * kBlurR;
 constexpr int kBlurLdsStride = 80;                  // floats per LDS row: a multiple of 4, so every thread's 16-float window is 16-byte aligned
 
-__global__ __launch_bounds__(256) void ssao_blur_kernel(const BlurArgs a) {
+__global__ __launch_bounds__(256) void ssao_blur_kernel(const BlurArgs a, const Stamps st) {
+    vhr_stamp(st);
     // .x of the raw image as fp32; texels the shader skips (outside the display or the image) are stored as -0.0f, whose
     // addition leaves every partial sum unchanged (x + -0 == x, and the sum starts at +0)
     __shared__ __attribute__((aligned(16))) float tile[kBlurLdsH][kBlurLdsStride];
@@ -193,7 +195,8 @@ struct SsrArgs {
 
 __device__ __forceinline__ float distance3(f3 p, f3 q) { const f3 d = p - q; return sqrtf(dot3(d, d)); }
 
-__global__ __launch_bounds__(kScreenBlockX *kScreenBlockY) void ssr_kernel(const SsrArgs a) {
+__global__ __launch_bounds__(kScreenBlockX *kScreenBlockY) void ssr_kernel(const SsrArgs a, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t x = blockIdx.x * kScreenBlockX + threadIdx.x;
     const uint32_t y = a.row_begin + blockIdx.y * kScreenBlockY + threadIdx.y;
     if (x >= a.limit_x || y >= a.row_end || y >= a.limit_y) return;

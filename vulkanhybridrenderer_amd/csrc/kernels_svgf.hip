@@ -61,7 +61,8 @@ __device__ __forceinline__ bool is_valid_reprojection(const TemporalArgs &a, int
     return true;
 }
 
-__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel(const TemporalArgs a) {
+__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel(const TemporalArgs a, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t cx = a.col_begin + blockIdx.x * kSvgfBlockX + threadIdx.x;
     const uint32_t cy = a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y;
     if (cx >= a.limit_x || cy >= a.row_end || cy >= a.limit_y) return;
@@ -246,7 +247,8 @@ __device__ __forceinline__ float pow128(float x) {      // max(0, pow(x, 128)); 
     return x;
 }
 
-__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(const AtrousArgs a) {
+__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(const AtrousArgs a, const Stamps st) {
+    vhr_stamp(st);
     const int cx = int(blockIdx.x * kSvgfBlockX + threadIdx.x);
     const int cy = int(a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y);
     if (uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) return;
@@ -329,7 +331,8 @@ constexpr int kTileX = 64;
 constexpr uint32_t kInvalidId = 0xffffu;     // NaN half: never equal to a truncated object id
 
 template <int STEP, int R>
-__global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs a) {
+__global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs a, const Stamps st) {
+    vhr_stamp(st);
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
     constexpr int TH = R + 4;                        // staged comb rows
     constexpr int VW = kTileX + 2;                   // variance columns
@@ -475,7 +478,8 @@ __device__ __forceinline__ float wave_shl1(float edge, float v) {
 }
 
 template <int STEP, int R>
-__global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArgs a) {
+__global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArgs a, const Stamps st) {
+    vhr_stamp(st);
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
     constexpr int TH = R + 4;                        // staged comb rows
     constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block (TW <= 128 columns each)
@@ -626,7 +630,8 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
 // v_log_f32 / v_exp_f32 are 1-ulp instructions; 128 * log2(x) moves a weight by <= ~1e-5 relative, far below the fp16 step of the output.
 template <int STEP, int R, bool ONE_TILE, bool LOGW = false>
 __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total,
-                                                                 const uint32_t xcd_aware) {
+                                                                 const uint32_t xcd_aware, const Stamps st) {
+    vhr_stamp(st);
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
     constexpr int TH = R + 4;                        // staged comb rows
     constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block
@@ -1005,7 +1010,8 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
 // under --pmc FETCH_SIZE to obtain the correction factor for OUR access pattern before pricing the a-trous traffic.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void calibration_read_kernel(const T *src, size_t count, uint32_t *sink) {
+__global__ __launch_bounds__(256) void calibration_read_kernel(const T *src, size_t count, uint32_t *sink, const Stamps st) {
+    vhr_stamp(st);
     uint32_t acc = 0;
     for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256) {
         const T v = src[i];
@@ -1033,7 +1039,8 @@ int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_p
 // 16 bytes per lane, 4 independent loads in flight per lane.  A plain kernel instead of hipMemcpyAsync: same bandwidth
 // on a full 1080p image, but the runtime's copy path costs ~7 us however small the copy is, which is what the row
 // strips of a multi-GPU run would pay three times per frame.
-__global__ __launch_bounds__(256) void copy_rows_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t count) {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t count, const Stamps st) {
+    vhr_stamp(st);
     const size_t stride = size_t(gridDim.x) * 256;
     size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
     for (; i + 3 * stride < count; i += 4 * stride) {
@@ -1099,7 +1106,8 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
 }
 
 // a column range of rows (screen tiles): `rows` pieces of `words` 4-byte words, `pitch_words` apart in both images
-__global__ __launch_bounds__(256) void copy_rect_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t words, uint32_t rows, size_t pitch_words) {
+__global__ __launch_bounds__(256) void copy_rect_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t words, uint32_t rows, size_t pitch_words, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= words) return;
     for (uint32_t y = blockIdx.y; y < rows; y += gridDim.y) dst[size_t(y) * pitch_words + x] = src[size_t(y) * pitch_words + x];
@@ -1196,6 +1204,18 @@ static int issue_cmd(vhr_context *ctx, const SvgfCmd &cmd) {
         case SvgfCmd::Atrous: return issue_atrous(ctx, cmd.a);
         default: return issue_copy(ctx, cmd);
     }
+}
+
+// the end stamp of a pass that has no kernel of the library behind it in the frame (see vhr::Stamps)
+__global__ void stamp_kernel(const Stamps st) {
+    vhr_stamp(st);
+}
+void launch_stamp(vhr_context *ctx) {
+    if (!ctx->pending_end) return;
+    vhr::PassDescription *const pass = ctx->cur_pass;
+    ctx->cur_pass = nullptr;
+    launch(ctx, stamp_kernel, dim3(1), dim3(1), 0);
+    ctx->cur_pass = pass;
 }
 
 // "svgf_elide_unread" (opt-in): an a-trous dispatch whose output image no later command of the same pass reads, and which is not
@@ -1331,7 +1351,9 @@ int flush_recorded(vhr_context *ctx) {
             ctx->stream = ctx->side_stream;
             ctx->cur_pass = nullptr;                 // the pass's time stamps stay on the caller's stream
             ctx->async_atrous = true;                // timed as its own kernel kind
+            ctx->no_stamps = true;                   // (pass time stamps belong to the caller's stream)
             rc = issue_atrous(ctx, cmd.a);
+            ctx->no_stamps = false;
             ctx->async_atrous = false;
             ctx->cur_pass = pass;
             if (hipEventRecord(ctx->side_done, ctx->side_stream) != hipSuccess && rc == VHR_OK) rc = ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(side stream) failed");

@@ -371,7 +371,8 @@ __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32
     y = row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
-__global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a) {
+__global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a, const Stamps st) {
+    vhr_stamp(st);
     __shared__ int s_stack[kTraceStack * kTraceBlock];
     int *stack = s_stack + threadIdx.x;
     uint32_t x, y;
@@ -914,7 +915,8 @@ __device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &s
 template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false, bool WIDE = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
-                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t cut_reach) {
+                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t cut_reach, const Stamps st) {
+    vhr_stamp(st);
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
     extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
     const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
@@ -1345,7 +1347,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
 // ---------------------------------------------------------------------------------------------
 template <int SUB, int WAVES, bool SPILL, bool STATS>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_wide_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
-                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t cut_reach) {
+                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t cut_reach, const Stamps st) {
+    vhr_stamp(st);
     static_assert(SUB == 2 || SUB == 4, "16x8 or 16x16 pixels per wave");
     constexpr int PIX = kQueueBlock * SUB;
     constexpr uint32_t TW = 16u, TH = SUB == 4 ? 16u : 8u;
@@ -1583,7 +1586,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
 }
 
 // Mirror ray of raygen.rgen:59-65 (closest hit, reflection_hit.rchit / reflection_miss.rmiss), one pixel per thread.
-__global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArgs a) {
+__global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArgs a, const Stamps st) {
+    vhr_stamp(st);
     __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
     int *stack = s_refl_stack + threadIdx.x;
     uint32_t x, y;
@@ -1759,7 +1763,8 @@ constexpr int kReflRays = 128;
 template <bool SPILL, int BOUNCES>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const uint32_t use_cut) {
+    const uint32_t early_exit, const uint32_t use_cut, const Stamps st) {
+    vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
     // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
     // and rows 3-5 are rewritten with the second direction between the two walks
@@ -2147,7 +2152,8 @@ struct RaytracedArgs {
 __device__ __forceinline__ uint32_t unorm8(float f);
 
 template <bool ALPHA>
-__global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedArgs a) {
+__global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedArgs a, const Stamps st) {
+    vhr_stamp(st);
     __shared__ int s_rt_stack[kTraceStack * kTraceBlock];
     int *stack = s_rt_stack + threadIdx.x;
     uint32_t x, y;
@@ -2194,7 +2200,8 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
 template <bool SPILL, bool ALPHA>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void raytraced_queue_kernel(
     const RaytracedArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const uint32_t use_cut) {
+    const uint32_t early_exit, const uint32_t use_cut, const Stamps st) {
+    vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints
     // rows 0-2: primary direction -> primary hit record (triangle, u, v); rows 3-5: shadow-ray origin -> row 3 = its answer
     __shared__ float s_ray_all[2][6][kReflRays];
@@ -2365,7 +2372,8 @@ constexpr int kGbufferMaxLayers = 32;      // discarded surfaces a primary ray m
 
 __device__ __forceinline__ uint32_t unorm8(float f) { return uint32_t(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f + 0.5f); }
 
-__global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs a) {
+__global__ __launch_bounds__(kTraceBlock) void gbuffer_kernel(const GbufferArgs a, const Stamps st) {
+    vhr_stamp(st);
     __shared__ int s_stack[kTraceStack * kTraceBlock];
     int *stack = s_stack + threadIdx.x;
     uint32_t x, y;
@@ -2479,7 +2487,8 @@ struct ShadowMapArgs {
     uint32_t size, row_begin, row_end;
 };
 
-__global__ __launch_bounds__(kTraceBlock) void shadow_map_kernel(const ShadowMapArgs a) {
+__global__ __launch_bounds__(kTraceBlock) void shadow_map_kernel(const ShadowMapArgs a, const Stamps st) {
+    vhr_stamp(st);
     __shared__ int s_stack[kTraceStack * kTraceBlock];
     int *stack = s_stack + threadIdx.x;
     uint32_t x, y;
@@ -2563,7 +2572,8 @@ __device__ __forceinline__ uint8_t srgb8(float c) {       // sRGB attachment sto
     return uint8_t(e * 255.0f + 0.5f);
 }
 
-__global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs a) {
+__global__ __launch_bounds__(256) void composition_kernel(const CompositionArgs a, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), j = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.width || j >= a.height) return;
     const uint32_t W = a.width, H = a.height, gy = H - 1 - j;         // flipped presentation viewport (pipeline.cpp:175-178)
@@ -2670,7 +2680,8 @@ int upload_srgb_lut(const float *lut) {
 
 // raytraced_render_path/composition.vert:5-8 + composition.frag:11-13: "RaytracedOutput" sampled at the texel centre,
 // written to the B8G8R8A8_SRGB swapchain through the flipped presentation viewport (pipeline.cpp:175-178).
-__global__ __launch_bounds__(256) void raytraced_composition_kernel(const uchar4 *in, uchar4 *out, uint32_t W, uint32_t H) {
+__global__ __launch_bounds__(256) void raytraced_composition_kernel(const uchar4 *in, uchar4 *out, uint32_t W, uint32_t H, const Stamps st) {
+    vhr_stamp(st);
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63u), j = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || j >= H) return;
     const uchar4 p = in[size_t(H - 1 - j) * W + x];

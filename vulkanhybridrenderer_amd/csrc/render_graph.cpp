@@ -294,6 +294,7 @@ int vhr_graph_build(vhr_context *ctx) {
     if (ctx->images.empty())                                  // the slot count of existing images stands (Build after DestroyResources changes it)
         ctx->frames_in_flight = ctx->host_only ? 1 : std::max(1, std::min(3, ctx->options[vhr::kOptFramesInFlight]));
     std::map<std::string, std::vector<std::string>> writers;
+    int stamp_slots = 0;
     // the reference iterates an unordered_map; registration order is the deterministic choice here
     for (auto &name : ctx->registration_order) {
         PassDescription &p = ctx->pass_descriptions[name];
@@ -303,6 +304,7 @@ int vhr_graph_build(vhr_context *ctx) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_begin, hipEventDisableSystemFence));
             HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_end, hipEventDisableSystemFence));
         }
+        p.stamp_index = stamp_slots < vhr::kMaxStampedPasses ? stamp_slots++ : -1;       // in-kernel time stamps (vhr::Stamps); beyond the table: events
     }
     int rc = find_execution_order(ctx, writers);
     if (rc) return rc;
@@ -351,7 +353,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         // vkCmdWriteTimestamp x2 (render_graph.cpp:167-182): the stamps ride on the pass's first and last kernel dispatch
         // (vhr_context::dispatch_events).  External (graphics) passes enqueue nothing here and are timed by their owner's API.
         const bool stamps = ctx->options[vhr::kOptPassTimestamps] != 0 && p.kind != PassKind::Graphics;
-        p.begin_stamped = p.end_on_last_dispatch = false;
+        p.begin_stamped = p.end_on_last_dispatch = p.stamped_in_kernel = false;
         ctx->cur_pass = stamps ? &p : nullptr;
         if (p.kind == PassKind::Graphics) {
             if (p.external_cb) p.external_cb(p.user, ctx);
@@ -367,7 +369,8 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
             if (frc != VHR_OK) { ctx->cur_pass = nullptr; return frc; }
         }
         ctx->cur_pass = nullptr;
-        if (stamps && p.begin_stamped && !p.end_on_last_dispatch) HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
+        if (stamps && p.stamped_in_kernel) ctx->pending_end = &ctx->d_stamps[p.stamp_index].end;      // the next kernel on the stream stores it
+        else if (stamps && p.begin_stamped && !p.end_on_last_dispatch) HIP_TRY(ctx, hipEventRecord(p.ev_end, ctx->stream));
         p.timed = stamps && p.begin_stamped;
         if (split && pi + 1 == ctx->front_passes) {                            // the back of the frame consumes what its front produced
             HIP_TRY(ctx, hipEventRecord(ctx->front_done[slot], ctx->front_stream));
@@ -386,6 +389,11 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         HIP_TRY(ctx, hipEventRecord(ctx->back_done[slot], back));
         ctx->back_pending[slot] = true;
     }
+    // A stamped pass with no kernel of the library behind it in the frame: its end is stored by the next kernel the stream runs -- the
+    // next frame's first one while the host runs ahead of the GPU (the reference's loop does, renderer.cpp:103-146), or the one-thread
+    // kernel every call that waits for the stream issues first (vhr_synchronize, GatherPerformanceStatistics, image downloads).
+    // "pass_timestamps" 2 issues that kernel here instead, for hosts that neither run ahead nor wait (+6 us per frame).
+    if (ctx->pending_end && ctx->options[vhr::kOptPassTimestamps] == 2) vhr::launch_stamp(ctx);
     return VHR_OK;
 }
 
@@ -393,11 +401,21 @@ int vhr_graph_gather_performance_statistics(vhr_context *ctx) {
     if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return VHR_OK;
     { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }  // VK_QUERY_RESULT_WAIT_BIT, render_graph.cpp:192-193
+    vhr::PassStampPair host_stamps[vhr::kMaxStampedPasses];
+    bool have_stamps = false;
     for (auto &name : ctx->execution_order) {
         PassDescription &p = ctx->pass_descriptions[name];
         if (!p.timed) continue;
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.ev_begin, p.ev_end) != hipSuccess) continue;
+        if (p.stamped_in_kernel) {
+            if (!have_stamps) {
+                if (hipMemcpy(host_stamps, ctx->d_stamps, sizeof(host_stamps), hipMemcpyDeviceToHost) != hipSuccess) continue;
+                have_stamps = true;
+            }
+            const vhr::PassStampPair &sp = host_stamps[p.stamp_index];
+            if (sp.end < sp.begin) continue;
+            ms = float(double(sp.end - sp.begin) / ctx->wall_clock_khz);
+        } else if (hipEventElapsedTime(&ms, p.ev_begin, p.ev_end) != hipSuccess) continue;
         p.last_ms = ms;
         p.ema_ms = p.ema_ms * 0.95 + double(ms) * 0.05;                        // render_graph.cpp:199
     }

@@ -199,6 +199,27 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
+// Pass time stamps written by the kernels themselves (r3b).  vkCmdWriteTimestamp pairs (render_graph.cpp:167-182) used to ride on the
+// dispatch packets as HIP events; a dispatch that carries a completion signal costs ~5.5 us which the next kernel waits for -- 16.5 us
+// of a 0.5 ms frame for the two passes' four stamps.  Instead every kernel of the library takes a trailing `Stamps` argument (appended
+// by vhr::launch): the first thread of the grid stores the device's wall clock (s_memrealtime, 100 MHz) to `begin` if this is the
+// first kernel of its pass, and to `prev_end` if the kernel before it on the stream was the last one of a pass -- on an in-order
+// stream a kernel starts when its predecessor has drained, so that instant IS the end of the previous pass (plus the launch gap,
+// 1-2 us).  A pass with nothing behind it in the frame gets its end from a one-thread kernel at the end of vhr_graph_execute.
+// Used with one frame in flight; with more, passes of one frame sit on two streams and the event pairs stay.
+struct Stamps { unsigned long long *begin, *prev_end; };
+struct PassStampPair { unsigned long long begin, end; };
+constexpr int kMaxStampedPasses = 64;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void vhr_stamp(const Stamps &st) {
+    if ((st.begin || st.prev_end) && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y | threadIdx.z) == 0u) {
+        const unsigned long long t = wall_clock64();
+        if (st.begin) *st.begin = t;
+        if (st.prev_end) *st.prev_end = t;
+    }
+}
+#endif
+
 struct PassDescription {
     std::string name;
     PassKind kind;
@@ -219,6 +240,8 @@ struct PassDescription {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool timed = false;
     bool begin_stamped = false, end_on_last_dispatch = false;     // per Execute: see vhr_context::dispatch_events
+    bool stamped_in_kernel = false;  // this Execute's stamps are Stamps stores (vhr_context::take_stamps), not events
+    int stamp_index = -1;            // slot of the pass in vhr_context::d_stamps (assigned at Build)
     double ema_ms = 0.0, last_ms = 0.0;
 };
 
@@ -396,6 +419,13 @@ struct vhr_context {
     void time_begin(int kind) { timing_kind = kind; }
     void time_end(int) { timing_kind = -1; }
     void dispatch_events(hipEvent_t &start, hipEvent_t &stop);
+    // in-kernel pass time stamps (see vhr::Stamps)
+    vhr::PassStampPair *d_stamps = nullptr;          // kMaxStampedPasses pairs in device memory
+    unsigned long long *pending_end = nullptr;       // where the next kernel on the stream stores the end of the pass that has just finished
+    bool no_stamps = false;                          // the launch being issued is not on the context's stream (side stream): no stamps
+    double wall_clock_khz = 100000.0;
+    bool in_kernel_stamps() const { return frames_in_flight == 1 && d_stamps != nullptr && options[vhr::kOptPassTimestamps] != 3; }     // 3: event pairs (A-B)
+    vhr::Stamps take_stamps();
 
     vhr::DeviceScene device_scene() const;
     int fail(int code, const std::string &msg) { error = msg; return code; }
@@ -408,8 +438,9 @@ template <typename K, typename... Args>
 inline void launch(vhr_context *ctx, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
     hipEvent_t start = nullptr, stop = nullptr;
     ctx->dispatch_events(start, stop);
-    if (start || stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, start, stop, 0, args...);
-    else hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, args...);
+    const Stamps st = ctx->take_stamps();             // every kernel's last parameter
+    if (start || stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, start, stop, 0, args..., st);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, args..., st);
 }
 
 uint32_t format_stride(int32_t format);   // VkUtils::FormatStride (vulkan_utils.h:128-148)
@@ -436,6 +467,7 @@ int launch_ssao(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &no
 int launch_ssao_blur(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &in, Image &out, uint32_t x_groups, uint32_t y_groups);
 int launch_ssr(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &albedo, const Image &normals, const Image &motion,
                const Image &depth, Image &out, const vhr_ssr_push_constants &pc, uint32_t x_groups, uint32_t y_groups);
+void launch_stamp(vhr_context *ctx);            // a one-thread kernel that takes the pending pass-end stamp (csrc/kernels_svgf.hip)
 int flush_recorded(vhr_context *ctx);          // issue the commands a compute pass recorded (no-op when there are none)
 int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink);
 
