@@ -560,7 +560,7 @@ def main():
             "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1),
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),
-                           "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2),
+                           "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2) if kt["blit"][1] else None,      # None: all three blits are stores of a-trous launches
                            "reflection": round(kt["reflection"][0] / max(1, kt["reflection"][1]) * 1e3, 2) if kt["reflection"][1] else None},
             "passes_ms": passes, "passes_ms_median": passes_median, "passes_ms_p95": passes_p95,
         }

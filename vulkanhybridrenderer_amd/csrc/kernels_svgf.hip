@@ -303,6 +303,7 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(c
     const uint2 texel = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));     // :97-101
     a.out[idx] = texel;
     if (a.out2) a.out2[idx] = texel;
+    if (a.normals_out) a.normals_out[idx] = a.normals[idx];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs
         const uint2 texel = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
         a.out[size_t(cy) * W + cx] = texel;
         if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
+        if (a.normals_out) a.normals_out[size_t(cy) * W + cx] = a.normals[size_t(cy) * W + cx];
     }
 }
 
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArg
         const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
         a.out[size_t(cy) * W + cx] = texel;
         if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
+        if (a.normals_out) a.normals_out[size_t(cy) * W + cx] = a.normals[size_t(cy) * W + cx];
     }
 }
 
@@ -914,6 +917,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
             const uint32_t out_off = texel_offset(cy, cx);
             *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
             if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
+            if (a.normals_out) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.normals_out) + out_off) = *reinterpret_cast<const uint2 *>(nm_base + out_off);
         }
         if (!more) break;
         __syncthreads();                             // every wave is done with this tile's LDS image
@@ -996,6 +1000,7 @@ int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Im
     a.display_w = pfd.display_size[0];
     a.display_h = pfd.display_size[1];
     a.out2 = nullptr;
+    a.normals_out = nullptr;
     SvgfCmd cmd{};
     cmd.kind = SvgfCmd::Atrous;
     cmd.a = a;
@@ -1080,7 +1085,7 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
                     return c.t.integrated_out == p || c.t.moments_out == p ||
                            (!writes_only && (c.t.normals == p || c.t.motion == p || c.t.prev_normals == p || c.t.history == p || c.t.raytraced == p || c.t.moments_in == p));
                 case SvgfCmd::Atrous:
-                    return c.a.out == p || c.a.out2 == p || (!writes_only && (c.a.normals == p || c.a.in == p));
+                    return c.a.out == p || c.a.out2 == p || c.a.normals_out == p || (!writes_only && (c.a.normals == p || c.a.in == p));
                 default:
                     return c.dst_base == p || (!writes_only && c.src_base == p);
             }
@@ -1099,6 +1104,33 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
                 break;
             }
             if (touches(w, dst.ptr, false)) break;                         // a later command uses the destination: the copy cannot move before it
+        }
+    }
+    // ---- ... or a store of the recorded a-trous dispatch that READS its source as its normals / ids image (r3b): the launch copies the
+    // texel of every pixel it computes (hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals; a
+    // copy kernel of its own cost 6 us + a launch gap for 33 MB an a-trous launch fetches anyway).  Whole-image work only; the earliest
+    // dispatch behind the last command that touches the destination takes it, so that the pass's unread dispatch stays unread.
+    if (ctx->options[kOptFuseBlits] && src.bpp == 8 && ctx->row_begin == 0 && ctx->row_end >= src.height && all_cols) {
+        auto uses = [](const SvgfCmd &c, const void *p, bool writes_only) {
+            switch (c.kind) {
+                case SvgfCmd::Temporal:
+                    return c.t.integrated_out == p || c.t.moments_out == p ||
+                           (!writes_only && (c.t.normals == p || c.t.motion == p || c.t.prev_normals == p || c.t.history == p || c.t.raytraced == p || c.t.moments_in == p));
+                case SvgfCmd::Atrous:
+                    return c.a.out == p || c.a.out2 == p || c.a.normals_out == p || (!writes_only && (c.a.normals == p || c.a.in == p));
+                default:
+                    return c.dst_base == p || (!writes_only && c.src_base == p);
+            }
+        };
+        size_t first = ctx->recorded.size();           // commands [first, end) neither touch the destination nor write the source
+        while (first > 0 && !uses(ctx->recorded[first - 1], dst.ptr, false) && !uses(ctx->recorded[first - 1], src.ptr, true)) --first;
+        for (size_t k = first; k < ctx->recorded.size(); ++k) {
+            SvgfCmd &w = ctx->recorded[k];
+            if (w.kind == SvgfCmd::Atrous && w.a.normals == src.ptr && !w.a.normals_out && w.a.row_begin == 0 && w.a.row_end >= src.height && w.a.limit_y >= src.height &&
+                w.a.col_begin == 0 && w.a.limit_x == w.a.width && w.a.width == src.width && w.a.height == src.height) {
+                w.a.normals_out = static_cast<uint2 *>(dst.ptr);
+                return VHR_OK;
+            }
         }
     }
     ctx->recorded.push_back(cmd);
@@ -1226,7 +1258,7 @@ void launch_stamp(vhr_context *ctx) {
 // Everything the pass publishes -- Denoised, history, moments, previous normals -- is bit-identical (tests/test_gpu_svgf.py).
 static bool dead_atrous(const std::vector<SvgfCmd> &rec, size_t k) {
     const SvgfCmd &w = rec[k];
-    if (w.kind != SvgfCmd::Atrous || w.a.out2) return false;
+    if (w.kind != SvgfCmd::Atrous || w.a.out2 || w.a.normals_out) return false;
     const void *img = w.a.out;
     for (size_t j = k + 1; j < rec.size(); ++j) {
         const SvgfCmd &c = rec[j];
@@ -1263,8 +1295,12 @@ static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, s
     // the point where the caller's stream has to wait from the next frame's svgf.comp (which overwrites the ping-pong image) to its
     // first a-trous dispatch (which overwrites this dispatch's output).
     input_copy = nullptr;
+    const void *fused_normals = nullptr;             // ... and the same for the normals: an earlier dispatch's `normals_out`
     for (size_t j = 0; j < k; ++j) {
         const SvgfCmd &c = rec[j];
+        if (c.kind == SvgfCmd::Atrous && c.a.normals == w.a.normals && c.a.normals_out) fused_normals = c.a.normals_out;
+        else if ((c.kind == SvgfCmd::Atrous && (c.a.out == fused_normals || c.a.out2 == fused_normals)) || (c.kind == SvgfCmd::Copy && c.dst_base == fused_normals) ||
+                 (c.kind == SvgfCmd::Temporal && c.t.integrated_out == fused_normals)) fused_normals = nullptr;
         if (c.kind == SvgfCmd::Atrous && c.a.out == w.a.in && c.a.out2 && c.a.row_begin == 0 && c.a.row_end >= c.a.height && c.a.col_begin == 0 && c.a.limit_x >= c.a.width) input_copy = c.a.out2;
         else if (c.kind == SvgfCmd::Atrous && (c.a.out == input_copy || c.a.out2 == input_copy)) input_copy = nullptr;
         else if (c.kind == SvgfCmd::Copy && c.dst_base == input_copy) input_copy = nullptr;
@@ -1272,7 +1308,7 @@ static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, s
     }
     const size_t image_bytes = size_t(w.a.width) * w.a.height * sizeof(uint2);
     if (w.a.row_begin != 0 || w.a.row_end < w.a.height || w.a.col_begin != 0 || w.a.limit_x < w.a.width) return false;      // strips / tiles
-    normals_copy = nullptr;
+    normals_copy = fused_normals;
     for (size_t j = k + 1; j < rec.size(); ++j) {
         const SvgfCmd &c = rec[j];
         switch (c.kind) {
@@ -1282,6 +1318,8 @@ static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, s
             case SvgfCmd::Atrous:
                 if (c.a.out == w.a.in || c.a.out == w.a.out || c.a.out2 == w.a.in || c.a.out2 == w.a.out) return false;
                 if (c.a.out == input_copy || c.a.out2 == input_copy) input_copy = nullptr;
+                if (c.a.out == normals_copy || c.a.out2 == normals_copy || c.a.normals_out == normals_copy) normals_copy = nullptr;
+                if (c.a.normals_out == w.a.in || c.a.normals_out == w.a.out || c.a.normals_out == input_copy) return false;
                 break;
             default:
                 if (c.dst_base == w.a.in || c.dst_base == w.a.out) return false;
@@ -1313,7 +1351,7 @@ int flush_recorded(vhr_context *ctx) {
                 return reads(c.t.normals) || reads(c.t.motion) || reads(c.t.prev_normals) || reads(c.t.history) || reads(c.t.raytraced) || reads(c.t.moments_in) ||
                        writes(c.t.integrated_out) || writes(c.t.moments_out);
             case SvgfCmd::Atrous:
-                return reads(c.a.normals) || reads(c.a.in) || writes(c.a.out) || writes(c.a.out2);
+                return reads(c.a.normals) || reads(c.a.in) || writes(c.a.out) || writes(c.a.out2) || writes(c.a.normals_out);
             default:
                 return reads(c.src_base) || writes(c.dst_base);
         }

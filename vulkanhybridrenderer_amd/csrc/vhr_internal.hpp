@@ -261,6 +261,7 @@ struct AtrousArgs {
     const uint2 *normals, *in;
     uint2 *out;
     uint2 *out2;                  // second destination of the same texels (a blit fused into the launch), or nullptr
+    uint2 *normals_out;           // copy of the normals / ids of the pixels computed (a blit of the launch's `normals` input fused into it), or nullptr
     uint32_t width, height, limit_x, limit_y, row_begin, row_end;
     uint32_t col_begin;           // first column computed (screen tiles); limit_x is the end of the column range
     int32_t step;
