@@ -511,9 +511,10 @@ def main():
                 "kernel": "svgf_atrous_stream_kernel<step, 4 rows per tile at 1080p (8 at 4K), one tile per workgroup, weights in the exponent> (svgf_atrous_filter.comp)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits; "
-                                  "two of the five launches per frame also store the texels a blit would have copied, +8 B/px each = +6.6 MB on this average, "
-                                  "which the 24 B/px of `achieved` do not count)",
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits; mean over the five "
+                                  "launches of a frame.  Three of them also do the work of the pass's three blits -- iteration 0 stores the history copy (+8 B/px) and "
+                                  "copies the normals (+16 B/px), iteration 3 stores the Denoised image (+8 B/px): +13 MB on this average and +1.5 / +0.5 us on those "
+                                  "launches, which the 24 B/px of `achieved` do not count)",
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
                 "launches_note": (f"HIP event pairs on every {ATROUS_TIMING_STRIDE}th a-trous launch of the timed region on the context's stream "
                                   f"({(4 if async_dead else 5) * args.steps * len(t_blocks)} launches, {'steps 1, 2, 4, 8' if async_dead else 'all five step sizes'} sampled evenly); "

@@ -1106,7 +1106,7 @@ int copy_image_rows(vhr_context *ctx, const Image &src, Image &dst) {
             if (touches(w, dst.ptr, false)) break;                         // a later command uses the destination: the copy cannot move before it
         }
     }
-    // ---- ... or a store of the recorded a-trous dispatch that READS its source as its normals / ids image (r3b): the launch copies the
+    // ---- ... or a store of the recorded a-trous dispatch that READS its source as its normals / ids image (r3c): the launch copies the
     // texel of every pixel it computes (hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals; a
     // copy kernel of its own cost 6 us + a launch gap for 33 MB an a-trous launch fetches anyway).  Whole-image work only; the earliest
     // dispatch behind the last command that touches the destination takes it, so that the pass's unread dispatch stays unread.

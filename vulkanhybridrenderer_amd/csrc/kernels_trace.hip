@@ -507,7 +507,7 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
     h1 = tn1 <= tf1;
 }
 
-// Both child boxes of a 32-byte node (BvhNode16, r3b): centres and half extents are HALVES, child 0 in the low and child 1 in the high half of
+// Both child boxes of a 32-byte node (BvhNode16, r3c): centres and half extents are HALVES, child 0 in the low and child 1 in the high half of
 // each word, and v_fma_mix_f32 widens the half operand inside the instruction -- 18 plain FMAs, no unpacking (a packed fp32 FMA
 // occupies the SIMD twice as long as a plain one: the 9 packed FMAs of the fp32 form are the same lane operations).  `noi` is
 // -(o - scene centre) / d: the centres are relative to the scene centre.  Culling only (see BvhNode16).
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             ++n_leaves;
             // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
             // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
-            // ... and the NEXT triangle's loads are in flight while this one is tested (r3b: the leaf's up to three tests were three
+            // ... and the NEXT triangle's loads are in flight while this one is tested (r3c: the leaf's up to three tests were three
             // dependent round trips; the last trip reloads its own triangle, which keeps the loop free of branches; measured -1.3 %
             // on sponza_proc, +0.7 % on bistro_proc: the leaf stage does not wait for memory much)
             {

@@ -32,7 +32,7 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 
-// The same node in 32 bytes = TWO 16-byte loads per visit (r3b): both boxes as centre and half extent in IEEE HALVES, centres
+// The same node in 32 bytes = TWO 16-byte loads per visit (r3c): both boxes as centre and half extent in IEEE HALVES, centres
 // relative to the scene centre (the walker shifts the ray origin once per ray).  The slab distances come straight out of
 // v_fma_mix_f32, which widens a half operand inside the instruction: no unpacking, 18 plain FMAs for the 9 packed ones of the fp32
 // form (the same lane operations).  c is the half nearest to the fp32 box centre, h the smallest normal half for which
@@ -199,7 +199,7 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
-// Pass time stamps written by the kernels themselves (r3b).  vkCmdWriteTimestamp pairs (render_graph.cpp:167-182) used to ride on the
+// Pass time stamps written by the kernels themselves (r3c).  vkCmdWriteTimestamp pairs (render_graph.cpp:167-182) used to ride on the
 // dispatch packets as HIP events; a dispatch that carries a completion signal costs ~5.5 us which the next kernel waits for -- 16.5 us
 // of a 0.5 ms frame for the two passes' four stamps.  Instead every kernel of the library takes a trailing `Stamps` argument (appended
 // by vhr::launch): the first thread of the grid stores the device's wall clock (s_memrealtime, 100 MHz) to `begin` if this is the
