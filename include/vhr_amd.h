@@ -475,10 +475,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      behind the pass's other commands by an event: nothing on the frame's critical path waits for it, and it runs beside
  *                      whatever the context's stream does next (the next frame's ray tracing).  The context's stream waits for it before
  *                      the next compute pass, before storage-image uploads / downloads / vhr_get_storage_image, and in vhr_synchronize.
- *                      Only with "frames_in_flight" 1, whole-image dispatches (no strips / tiles) and when the pass itself copies the
- *                      G-buffer normals the dispatch reads (hybrid_render_path.cpp:319; the copy is read instead, the G-buffer belongs
- *                      to the next frame by then); else the dispatch stays in place.  Every image bit-identical, the dispatch's own
- *                      output included.  0 = every dispatch in recorded order on the context's stream.
+ *                      Only with "frames_in_flight" 1, for dispatches of >= 900 000 pixels (the whole 1080p frame or its half; small
+ *                      screen tiles are not worth the two stream operations) and when the pass itself copies what the dispatch reads of the
+ *                      G-buffer normals (hybrid_render_path.cpp:319; the copy is read instead, the G-buffer belongs to the next frame by
+ *                      then); else the dispatch stays in place.  Every image bit-identical, the dispatch's own
+ *                      output included.  2 = the same whatever the dispatch's size; 0 = every dispatch in recorded order on the context's stream.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None):
     """`world` contexts on one GPU, one thread each, each computing its strip (grid "strips") or screen tile (grid (rows, cols) or None =
     the planner's choice) with host-side copies standing in for the RCCL exchanges.  Returns (plans, per-rank per-frame (raytraced,
     denoised) cut to the owned rectangle)."""
@@ -53,6 +53,10 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
             pc = g.path.push_constants()
             g.ctx.set_option("trace_overlap", 1 if trace_overlap else 0)
             g.ctx.set_option("strip_shrink_overlap", 1 if shrink else 0)
+            for key, val in options:
+                g.ctx.set_option(key, val)
+            if counts is not None:
+                g.ctx.set_kernel_timing(["svgf_atrous", "svgf_atrous_async"])
             if not trace_overlap:
                 g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], (plan.overlap, plan.overlap)))
             g.ctx.set_pass_epilogue("SVGF Denoise Pass", lambda c: exchange(
@@ -61,6 +65,8 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
                 g.frame(pfd)
                 results[rank].append((cut(g.ctx.download(lib.RAYTRACED), plan.rect).copy(), cut(g.ctx.download(lib.DENOISED), plan.rect).copy()))
                 barrier.wait()
+            if counts is not None:
+                counts[rank] = (g.ctx.kernel_time("svgf_atrous")[1], g.ctx.kernel_time("svgf_atrous_async")[1])
         except Exception as e:   # noqa: BLE001
             errors.append(e)
             barrier.abort()
@@ -117,6 +123,21 @@ def test_virtual_screen_tiles_bit_identical(world, grid, trace_overlap, shrink):
     if grid:
         assert (plans[0].grid_rows, plans[0].grid_cols) == grid
     _check_against_reference(plans, results, ref)
+
+
+@pytest.mark.parametrize("world,grid", [(4, (2, 2)), (2, "strips"), (3, (1, 3))])
+def test_virtual_tiles_with_the_dead_dispatch_on_the_side_stream(world, grid):
+    """"svgf_async_unread" on screen tiles and row strips (2 = whatever the size of the dispatch; by default only tiles of >= 900 k pixels
+    take the side stream): the dispatch nobody reads runs on the side stream from the pass's own copy of the tile's normals -- the blit
+    covers the tile grown by the halos, which holds everything the dispatch reads -- and the tiles still compose the single-context frames."""
+    scene = scenes.tiny_scene()
+    W, H = 144, 132
+    pfds = camera.dolly_frames(scene, W, H, 5)
+    ref, mv_rows, mv_cols = _single_context_reference(scene, W, H, pfds)
+    counts = {}
+    plans, results = _run_strips(scene, W, H, world, pfds, mv_rows, True, True, grid=grid, max_motion_cols=mv_cols, options=(("svgf_async_unread", 2),), counts=counts)
+    _check_against_reference(plans, results, ref)
+    assert all(counts[r] == (4 * len(pfds), len(pfds)) for r in range(world)), counts
 
 
 @pytest.mark.parametrize("world,trace_overlap,shrink", [(2, False, False), (3, False, False), (2, True, False), (3, True, False),

@@ -300,7 +300,7 @@ def test_dead_fifth_iteration_on_the_side_stream_changes_no_image():
         c = lib.Context(W, H, device=0)
         try:
             c.upload_scene(scene)
-            c.set_option("svgf_async_unread", mode)
+            c.set_option("svgf_async_unread", 2 * mode)          # 2: whatever the size of the dispatch (1 = only where it pays, >= 900 k pixels)
             path = lib.HybridRenderPath(c, 0, 0, 2, True, 5, lambda cc: cc.standin_gbuffer(0))
             path.build()
             c.set_kernel_timing(["svgf_atrous", "svgf_atrous_async"])

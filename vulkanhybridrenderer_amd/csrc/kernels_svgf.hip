@@ -1283,31 +1283,52 @@ static bool dead_atrous(const std::vector<SvgfCmd> &rec, size_t k) {
 // bound by memory latency and leaves vector issue slots free, while this kernel is bound by vector issue) and waits for the side
 // stream's event before the next command of the library that could touch the images involved (join_side: the next compute pass,
 // image uploads / downloads / queries, vhr_synchronize).  Conditions, all checked here, else the dispatch stays where it was
-// recorded: one stream per frame ("frames_in_flight" 1), whole-image work (no strips / tiles), no later command of the pass writes
-// the dispatch's input or output, and the G-buffer normals it reads are available as a copy made by a later full-image blit of the
-// same pass (hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals) -- the G-buffer itself is
+// recorded: one stream per frame ("frames_in_flight" 1), no later command of the pass writes the dispatch's input or output, and the
+// G-buffer normals it reads are available as a copy, made by the same pass, of everything it reads of them (with screen tiles: the tile
+// grown by the taps' reach; hybrid_render_path.cpp:319: "World Space Normals and Object IDs" -> previous-frame normals) -- the G-buffer itself is
 // rewritten by the next frame's first pass, the copy only by the next SVGF pass, which joins first.  Same kernels on the same
 // inputs: every image, the dead dispatch's own output included, is bit-identical (tests/test_gpu_svgf.py).
 static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, size_t k, const void *&normals_copy, const void *&input_copy) {
     const SvgfCmd &w = rec[k];
-    // The dispatch's input, too, may exist twice: the a-trous dispatch that wrote it may have stored the same texels into a second image
+    // Rectangles (half-open, pixels): what the dispatch READS of its two inputs -- its own rectangle grown by the taps' reach, 2 x step,
+    // and for `in` by one more (the 3x3 variance pre-filter) -- against what a copy holds.  With screen tiles / row strips the pass's
+    // blits cover the tile grown by the halos, its fused stores the launch's own (shrunk) rectangle: a copy counts only if it holds
+    // everything the dispatch reads.
+    struct Rect { int x0, x1, y0, y1; };
+    const int W = int(w.a.width), H = int(w.a.height), reach = 2 * w.a.step;
+    auto clip = [](int v, int hi) { return std::max(0, std::min(v, hi)); };
+    auto rect_of = [&](const AtrousArgs &a) { return Rect{ int(a.col_begin), int(std::min(a.limit_x, a.width)), int(a.row_begin), int(std::min(std::min(a.row_end, a.limit_y), a.height)) }; };
+    auto rect_of_copy = [&](const SvgfCmd &c) {
+        const size_t off = size_t(c.copy_src - static_cast<const char *>(c.src_base)), pitch = c.copy_pitch ? c.copy_pitch : size_t(W) * sizeof(uint2);
+        const int y0 = int(off / pitch), x0 = int((off % pitch) / sizeof(uint2));
+        if (c.copy_rows == 0) return Rect{ x0 == 0 ? 0 : W, W, y0, y0 + int(c.copy_bytes / pitch) };      // whole rows (x0 != 0 cannot happen: an empty rectangle then)
+        return Rect{ x0, x0 + int(c.copy_row_bytes / sizeof(uint2)), y0, y0 + int(c.copy_rows) };
+    };
+    auto covers = [](const Rect &have, const Rect &need) { return have.x0 <= need.x0 && have.x1 >= need.x1 && have.y0 <= need.y0 && have.y1 >= need.y1; };
+    const Rect own = rect_of(w.a);
+    if (own.x1 <= own.x0 || own.y1 <= own.y0) return false;
+    // The event that orders the side stream and the wait for it cost the caller's stream 5-8 us; a dispatch has to be worth that.  Measured
+    // on one GPU (scratch/strip_time.py, 1080p): the whole frame -12 us, half of it (N = 2) -5 us, a quarter 0, an eighth (8.5 us per
+    // launch) +5 us.  900 k pixels = the half-frame tile of 1080p and the eighth of a 4K frame.
+    if (ctx->options[kOptSvgfAsyncUnread] != 2 && size_t(own.x1 - own.x0) * size_t(own.y1 - own.y0) < 900000u) return false;      // (2: whatever the size)
+    const Rect need_n{ clip(own.x0 - reach, W), clip(own.x1 + reach, W), clip(own.y0 - reach, H), clip(own.y1 + reach, H) };
+    const Rect need_in{ clip(need_n.x0 - 1, W), clip(need_n.x1 + 1, W), clip(need_n.y0 - 1, H), clip(need_n.y1 + 1, H) };
+    // The dispatch's input may exist twice: the a-trous dispatch that wrote it may have stored the same texels into a second image
     // (a fused blit: hybrid_render_path.cpp:320-323 publishes iteration 3's image as "Denoised ...").  Reading that copy instead moves
     // the point where the caller's stream has to wait from the next frame's svgf.comp (which overwrites the ping-pong image) to its
-    // first a-trous dispatch (which overwrites this dispatch's output).
+    // first a-trous dispatch (which overwrites this dispatch's output).  The same for the normals: an earlier dispatch's `normals_out`.
     input_copy = nullptr;
-    const void *fused_normals = nullptr;             // ... and the same for the normals: an earlier dispatch's `normals_out`
+    const void *fused_normals = nullptr;
     for (size_t j = 0; j < k; ++j) {
         const SvgfCmd &c = rec[j];
-        if (c.kind == SvgfCmd::Atrous && c.a.normals == w.a.normals && c.a.normals_out) fused_normals = c.a.normals_out;
+        if (c.kind == SvgfCmd::Atrous && c.a.normals == w.a.normals && c.a.normals_out && covers(rect_of(c.a), need_n)) fused_normals = c.a.normals_out;
         else if ((c.kind == SvgfCmd::Atrous && (c.a.out == fused_normals || c.a.out2 == fused_normals)) || (c.kind == SvgfCmd::Copy && c.dst_base == fused_normals) ||
                  (c.kind == SvgfCmd::Temporal && c.t.integrated_out == fused_normals)) fused_normals = nullptr;
-        if (c.kind == SvgfCmd::Atrous && c.a.out == w.a.in && c.a.out2 && c.a.row_begin == 0 && c.a.row_end >= c.a.height && c.a.col_begin == 0 && c.a.limit_x >= c.a.width) input_copy = c.a.out2;
+        if (c.kind == SvgfCmd::Atrous && c.a.out == w.a.in && c.a.out2 && covers(rect_of(c.a), need_in)) input_copy = c.a.out2;
         else if (c.kind == SvgfCmd::Atrous && (c.a.out == input_copy || c.a.out2 == input_copy)) input_copy = nullptr;
         else if (c.kind == SvgfCmd::Copy && c.dst_base == input_copy) input_copy = nullptr;
         else if (c.kind == SvgfCmd::Temporal && c.t.integrated_out == input_copy) input_copy = nullptr;
     }
-    const size_t image_bytes = size_t(w.a.width) * w.a.height * sizeof(uint2);
-    if (w.a.row_begin != 0 || w.a.row_end < w.a.height || w.a.col_begin != 0 || w.a.limit_x < w.a.width) return false;      // strips / tiles
     normals_copy = fused_normals;
     for (size_t j = k + 1; j < rec.size(); ++j) {
         const SvgfCmd &c = rec[j];
@@ -1325,14 +1346,13 @@ static bool async_candidate(vhr_context *ctx, const std::vector<SvgfCmd> &rec, s
                 if (c.dst_base == w.a.in || c.dst_base == w.a.out) return false;
                 if (c.dst_base == normals_copy) normals_copy = nullptr;                    // overwritten again: not a copy any more
                 if (c.dst_base == input_copy) input_copy = nullptr;
-                if (c.src_base == w.a.normals && c.copy_rows == 0 && c.copy_src == static_cast<const char *>(c.src_base) && c.copy_bytes == image_bytes)
-                    normals_copy = c.dst_base;
-                if (c.src_base == w.a.in && c.copy_rows == 0 && c.copy_src == static_cast<const char *>(c.src_base) && c.copy_bytes == image_bytes)
-                    input_copy = c.dst_base;                                               // (the same blit, not fused: "fuse_blits" 0)
+                if (c.src_base == w.a.normals && c.copy_src - static_cast<const char *>(c.src_base) == c.copy_dst - static_cast<const char *>(c.dst_base) &&
+                    covers(rect_of_copy(c), need_n)) normals_copy = c.dst_base;
+                if (c.src_base == w.a.in && c.copy_src - static_cast<const char *>(c.src_base) == c.copy_dst - static_cast<const char *>(c.dst_base) &&
+                    covers(rect_of_copy(c), need_in)) input_copy = c.dst_base;            // (the same blit, not fused: "fuse_blits" 0)
                 break;
         }
     }
-    (void)ctx;
     return normals_copy != nullptr;
 }
 
@@ -1372,11 +1392,7 @@ int flush_recorded(vhr_context *ctx) {
         if (input_copy) cmd.a.in = static_cast<const uint2 *>(input_copy);
         bool ok = true;
         if (!ctx->side_stream) {
-            int prio_lo = 0, prio_hi = 0;            // (numerically lower = higher priority)
-            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            const int mode = ctx->options[kOptSvgfAsyncUnread];
-            const int prio = mode == 2 ? prio_hi : (mode == 3 ? prio_lo : 0);
-            ok = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio) == hipSuccess &&
+            ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
         }
