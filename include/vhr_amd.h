@@ -426,7 +426,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      that one-thread kernel issued at the end of every vhr_graph_execute (hosts that neither run ahead of the GPU nor
  *                      wait for it; +6 us per frame).  3 = HIP event pairs on the dispatch packets (rounds 1-3a; 16 us per frame, and the
  *                      only form with "frames_in_flight" > 1).  0 = off.  External graphics passes are not stamped.
- *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 8 (default), 4 or 2 (measured slower)
+ *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 0 (default) = 8, or 6 for a launch whose 8x8 tiles fill less
+ *                      than 70 % of the chip's wave slots (a 1080p / 8 screen tile: -8 %); 1..8 = that many (4 and 2 lose on whole frames)
  *   "fuse_blits"       1 = a compute pass records its dispatches and blits and issues them when its callback returns; a
  *                      same-extent blit whose source is the output of a recorded a-trous dispatch (and whose destination nothing
  *                      in between touches) becomes a second store of that launch instead of a copy kernel (default; two of the

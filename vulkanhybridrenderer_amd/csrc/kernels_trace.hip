@@ -1956,7 +1956,15 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         // raygen_tile_rows < 8 (A-B only): 8x4- or 8x2-pixel tiles = more, shorter waves.  Measured slower everywhere, thin
         // strips included (1080p / 8: 123 -> 131 us; full frame 452 -> 523 us): a shorter queue keeps fewer lanes busy.
         const uint32_t rows_traced = a.row_end - a.row_begin;
-        const uint32_t tile_rows = uint32_t(std::max(1, std::min(8, ctx->options[kOptRaygenTileRows])));
+        // rows of a wave's tile: 8, or ("raygen_tile_rows" 0 = auto, the default) 6 for a launch whose 8x8 tiles would fill less than 70 % of the
+        // chip's wave slots -- a single partial round of waves lasts as long as its slowest wave, and a wave with three quarters of the rays
+        // lives shorter: the 540 x 570 rectangle of a 1080p / 8 screen tile 97.7 -> 89.9 us (4 rows: 90.2); whole frames and larger tiles keep
+        // 8 rows (a 990 x 570 tile: 122 us either way, 128 with 4 rows)
+        uint32_t tile_rows = uint32_t(std::max(0, std::min(8, ctx->options[kOptRaygenTileRows])));
+        if (tile_rows == 0u) {
+            const uint64_t tiles8 = uint64_t((a.col_end - a.col_begin + 7) / 8) * ((rows_traced + 7) / 8), slots = uint64_t(ctx->cu_count) * 32u;
+            tile_rows = tiles8 * 10u < slots * 7u ? 6u : 8u;
+        }
         const uint32_t tiles_x = (a.col_end - a.col_begin + 7) / 8, tiles_y = (rows_traced + tile_rows - 1) / tile_rows;
         const int waves = ctx->options[kOptWavesPerBlock];
         const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));

@@ -402,7 +402,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 8, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
