@@ -35,3 +35,10 @@ print(json.dumps(out))
 PY
 tail -n 3 $OUT/${TAG}_bench_1gpu.json | cut -c1-600
 grep -E "svgf_atrous|raygen|temporal|copy_rows" $OUT/${TAG}_kernel_stats_bench_1080p.csv | cut -c1-200
+# [4] the same command with every dispatch in recorded order on the one stream (--option svgf_async_unread=0): the kernel summary then has
+#     all five a-trous rows undisturbed (by default the step-16 dispatch runs on the side stream beside raygen_queue_kernel and its row
+#     shows the time it shares the chip)
+cd /tmp
+echo "[4] kernel trace, in order"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_in_order -- python3 $R/bench.py --no-cpu-baseline --no-extras --option svgf_async_unread=0 > $OUT/${TAG}_bench_in_order_under_rocprof.json 2> $OUT/trace_in_order.err || { echo "in-order trace failed"; tail -5 $OUT/trace_in_order.err; exit 1; }
+cp $(find $OUT/trace_in_order -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bench_1080p_in_order.csv
+grep -E "svgf_atrous|raygen|temporal" $OUT/${TAG}_kernel_stats_bench_1080p_in_order.csv | cut -c1-200
