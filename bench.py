@@ -446,6 +446,11 @@ def main():
         ms, mr = one(options={"svgf_async_unread": 0}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
         extras["ms_per_step_all_dispatches_in_order"] = ms
         extras["value_all_dispatches_in_order"] = mr
+        # ... and with svgf.comp run by the ray-tracing kernel in its tiles' epilogues (option "fuse_temporal": one launch and its gap less,
+        # the ray-tracing kernel longer by most of what the dispatch cost)
+        ms, mr = one(options={"fuse_temporal": 1}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
+        extras["ms_per_step_temporal_fused_into_ray_tracing"] = ms
+        extras["value_temporal_fused_into_ray_tracing"] = mr
         # K0 where the reference runs it (resource_manager.cpp:650,692,792 build BLAS / TLAS on the GPU): the device-built tree costs a
         # fraction of the host's SAH build and a few node visits more per ray; the timed region above uses the host tree (the default)
         dk = {}

@@ -481,6 +481,13 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      G-buffer normals (hybrid_render_path.cpp:319; the copy is read instead, the G-buffer belongs to the next frame by
  *                      then); else the dispatch stays in place.  Every image bit-identical, the dispatch's own
  *                      output included.  2 = the same whatever the dispatch's size; 0 = every dispatch in recorded order on the context's stream.
+ *   "fuse_temporal"    1 = a TraceRays of the hybrid path's ray-tracing pass is held back until the next pass shows its first command; if that is
+ *                      svgf.comp on the launch's own images (whole-image work, one frame in flight, no mirror ray, no epilogue hooked to the
+ *                      ray-tracing pass), the queue kernel runs it for each tile in the tile's epilogue -- the visibility goes from LDS into
+ *                      the filter -- and the dispatch is not launched; anything else that enqueues on or waits for the stream first gets the
+ *                      launch as it is.  Every image bit-identical.  Measured: the ray-tracing kernel grows by 20 of the 26 us the kernel
+ *                      and its launch gap cost (0.494 -> 0.490 ms per frame), and "Raytrace Pass" / "SVGF Denoise Pass" times shift by
+ *                      that dispatch: default 0.
  *   "temporal_variant" reserved */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 

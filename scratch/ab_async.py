@@ -8,7 +8,7 @@ from vulkanhybridrenderer_amd import scenes, lib
 from vulkanhybridrenderer_amd.harness import HybridFrameLoop
 names = [a for a in sys.argv[1:] if "=" not in a] or ["sponza_proc"]
 extra = [a.split("=") for a in sys.argv[1:] if "=" in a]
-arms = [dict(svgf_async_unread=0), dict(svgf_async_unread=1), dict(svgf_elide_unread=1), dict(svgf_async_unread=1, fuse_blits=0), dict(svgf_async_unread=0)]
+arms = [dict(fuse_temporal=0), dict(fuse_temporal=1), dict(fuse_temporal=0, svgf_async_unread=0), dict(fuse_temporal=1, svgf_async_unread=0), dict(fuse_temporal=0), dict(fuse_temporal=1)]
 for name in names:
     scene = getattr(scenes, name)()
     ref = None

@@ -322,3 +322,45 @@ def test_dead_fifth_iteration_on_the_side_stream_changes_no_image():
     for s, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with the dead iteration on the side stream"
+
+
+def test_svgf_comp_fused_into_the_ray_tracing_tiles_changes_no_image():
+    """Option "fuse_temporal": the TraceRays launch is held back until the SVGF pass shows svgf.comp, and the ray-tracing queue kernel runs
+    that dispatch in its tiles' epilogues.  The G-buffer is written in place by the stand-in kernel on the context's stream every frame
+    (which issues the held-back launch of nothing: the order G-buffer -> TraceRays -> svgf.comp is what is tested), no synchronisation
+    between frames; after 3 and 10 frames every image of the two passes equals the unfused schedule's, no svgf.comp launch happens, and
+    both passes still report a time."""
+    W, H = 480, 270
+    scene = scenes.sponza_proc()
+    pfds = camera.dolly_frames(scene, W, H, 10)
+    outs = {}
+    for fuse in (0, 1):
+        c = lib.Context(W, H, device=0)
+        try:
+            c.upload_scene(scene)
+            c.set_trace_params(abi.default_trace_params(reflections=False))
+            c.set_option("fuse_temporal", fuse)
+            path = lib.HybridRenderPath(c, 0, 0, 2, True, 5, lambda cc: cc.standin_gbuffer(0))
+            path.build()
+            c.set_kernel_timing(["svgf_temporal", "raygen"])
+            c.kernel_time("svgf_temporal", reset=True); c.kernel_time("raygen", reset=True)
+            snaps = []
+            for i, pfd in enumerate(pfds):
+                c.update_per_frame_ubo(0, pfd)
+                c.execute(0, 0)
+                if i in (2, 9):
+                    pc = path.push_constants()
+                    ids = [int(pc["integrated_shadow_and_ao"][0]), int(pc["integrated_shadow_and_ao"][1]), int(pc["prev_frame_normals_and_object_ids"]),
+                           int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])]
+                    snaps.append([c.download(lib.RAYTRACED), c.download(lib.DENOISED)] + [c.download(k) for k in ids])
+            c.gather_performance_statistics()
+            times = [c.pass_time_ms(n)[1] for n in ("Raytrace Pass", "SVGF Denoise Pass")]
+            outs[fuse] = (snaps, c.kernel_time("svgf_temporal")[1], c.kernel_time("raygen")[1], times)
+            path.destroy()
+        finally:
+            c.close()
+    assert outs[0][1:3] == (10, 10) and outs[1][1:3] == (0, 10)
+    assert all(t > 0.0 for t in outs[0][3] + outs[1][3]), (outs[0][3], outs[1][3])
+    for s, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with svgf.comp fused into the ray-tracing kernel"

@@ -112,6 +112,7 @@ vhr::Stamps vhr_context::take_stamps() {
 
 int vhr_context::sync_streams() {
     if (host_only) return VHR_OK;
+    if (deferred_raygen) { const int drc = vhr::flush_deferred_raygen(this, nullptr); if (drc != VHR_OK) return drc; }
     if (pending_end) vhr::launch_stamp(this);          // the end of the last pass, before the host waits for it
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
     if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
@@ -281,6 +282,7 @@ const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_s
 
 int vhr_get_current_stream(vhr_context *ctx, void **stream) {
     if (!ctx || !stream) return VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // the caller is about to enqueue behind it
     *stream = static_cast<void *>(ctx->stream);       // inside a pass callback of vhr_graph_execute: the stream that pass is ordered on
     return VHR_OK;
 }
@@ -582,7 +584,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -703,6 +705,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     if (!host || bytes != im.bytes()) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "image copy: byte count does not match the image (" + std::to_string(im.bytes()) + ")");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
+    if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
     if (storage || to_device) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // (a side-stream dispatch reads storage images and the pass's published copies)
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));

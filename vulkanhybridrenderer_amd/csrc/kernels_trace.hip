@@ -10,8 +10,11 @@
 //
 // Compiled with -ffp-contract=off: ray setup and Moeller-Trumbore follow the exact-arithmetic contract of
 // device_math.hpp so visibility results are bit-reproducible.
+#include <cstring>
+
 #include "device_math.hpp"
 #include "vhr_internal.hpp"
+#include "svgf_temporal.hpp"
 
 namespace vhr {
 
@@ -362,6 +365,9 @@ struct RaygenArgs {
     uint32_t col_begin, col_end;     // screen tiles (vhr_set_tile): the columns the queue kernels trace -- col_begin a multiple of the tile
                                      // width, [0, width) otherwise; the per-pixel kernels trace whole rows (a superset)
     RayStats *stats;         // nullptr = off
+    // "fuse_temporal": the queue kernel's tile epilogue runs svgf.comp for the tile's pixels (the dispatch the SVGF pass records next)
+    uint32_t fuse_temporal;  // 0 = off
+    TemporalArgs temporal;
 };
 
 __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
@@ -1293,12 +1299,27 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         }
     }
     if (SHARED) __syncthreads(); else wave_lds_sync();
+    float shadow_payload = 1.0f, ao_payload = 1.0f;                                          // rgen:20-21 for a pixel without geometry
     if (covered) {
         const uint32_t vis = s_vis[lane];
-        const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
-        float ao_payload = 1.0f;
+        shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
         if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
+    }
+    // ---- "fuse_temporal": svgf.comp for this tile's pixels, right here (the default kernel only) ----
+    // svgf.comp reads of the CURRENT frame only the pixel's own texels; everything else it gathers is the previous frame's.  So the
+    // wave that has just finished a tile can run it for the tile: the visibility goes from LDS into the filter (rounded to the halves
+    // the image holds, which is also what is stored), the normals are the ones the set-up loaded, and the gathers of 16 200 x 2 waves
+    // spread over the launch instead of forming a kernel of their own that waits on memory.
+    if constexpr (CUT && !STATS && !PACKET && !WIDE && !SHARED && !PREGEN) {
+        if (a.fuse_temporal) {                                                               // (uniform)
+            const TemporalArgs &t = a.temporal;
+            if (in_range && x >= t.col_begin && x < t.limit_x && y >= t.row_begin && y < t.row_end && y < t.limit_y) {
+                const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];
+                const float2 cur = unpack_rg16f(pack_rg16f(shadow_payload, ao_payload));     // what the RG16F image holds
+                svgf_temporal_pixel(t, x, y, unpack_rgba16f(nraw), cur.x, cur.y);
+            }
+        }
     }
     if (stats) {
         const unsigned long long ovf = __ballot(overflow != 0);
@@ -1904,41 +1925,9 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
-                  const Image &depth, Image &shadow_ao, Image *reflections) {
-    if (width != normals.width || height != normals.height || width != depth.width || height != depth.height ||
-        width != shadow_ao.width || height != shadow_ao.height || (reflections && (reflections->width != width || reflections->height != height)))
-        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "TraceRays: launch size must equal the extent of the pass images");
-    RaygenArgs a;
-    a.scene = ctx->device_scene();
-    a.pfd = pfd;
-    a.tp = ctx->trace_params;
-    a.normals = normals.ptr;
-    a.depth = static_cast<const float *>(depth.ptr);
-    a.shadow_ao = shadow_ao.ptr;
-    a.reflections = reflections ? reflections->ptr : nullptr;
-    a.width = width;
-    a.height = height;
-    const uint32_t owned_begin = std::min(ctx->row_begin, height), owned_end = std::min(ctx->row_end, height);
-    a.row_begin = owned_begin;
-    a.row_end = owned_end;
-    // screen tiles: the owned columns, on 16-pixel tile boundaries (a few columns more than owned are harmless: rays are per pixel)
-    const uint32_t owned_col_begin = std::min(ctx->col_begin, width), owned_col_end = std::min(ctx->col_end, width);
-    a.col_begin = owned_col_begin & ~15u;
-    a.col_end = owned_col_end;
-    a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
-    ctx->raytraced_pixels = 0;                 // ray statistics are the hybrid path's again
-    if (a.row_end <= a.row_begin || a.col_end <= a.col_begin) return VHR_OK;
-    if (ctx->options[kOptTraceOverlap]) {      // strips / tiles: trace the margin the denoiser recomputes too (no exchange of raw visibility)
-        a.row_begin = owned_begin > ctx->overlap ? owned_begin - ctx->overlap : 0u;
-        a.row_end = uint32_t(std::min<uint64_t>(height, uint64_t(owned_end) + ctx->overlap));
-        a.col_begin = (owned_col_begin > ctx->overlap ? owned_col_begin - ctx->overlap : 0u) & ~15u;
-        a.col_end = uint32_t(std::min<uint64_t>(width, uint64_t(owned_col_end) + ctx->overlap));
-    }
-    if (a.stats) {
-        if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
-            return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
-    }
+// The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
+static void issue_raygen(vhr_context *ctx, const RaygenArgs &a, const uint32_t width, const uint32_t height) {
+    (void)height;
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
@@ -2056,6 +2045,102 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
     }
     ctx->time_end(kKernelRaygen);
+}
+
+// "fuse_temporal": a TraceRays whose shadow / AO launch was held back (launch_raygen) is issued now -- with svgf.comp fused into the
+// tiles' epilogues if `fuse` is the dispatch the SVGF pass has just recorded for the very images this launch works on, alone otherwise.
+// Called by flush_recorded (with or without `fuse`) and, without, by everything that enqueues on or waits for the stream in between
+// (vhr::launch, sync_streams, image copies, pass epilogues and external callbacks, the end of vhr_graph_execute).
+struct DeferredRaygen { RaygenArgs a; uint32_t width, height; };
+int flush_deferred_raygen(vhr_context *ctx, const TemporalArgs *fuse) {
+    if (!ctx->deferred_raygen) return VHR_OK;
+    DeferredRaygen d;
+    std::memcpy(&d, ctx->deferred_raygen_blob.data(), sizeof(d));
+    ctx->deferred_raygen = false;                      // (first: the launch below goes through vhr::launch, which would flush again)
+    if (fuse) { d.a.fuse_temporal = 1u; d.a.temporal = *fuse; }
+    PassDescription *const running = ctx->cur_pass;
+    ctx->cur_pass = ctx->deferred_pass;               // the stamps (and the time) are the ray-tracing pass's
+    issue_raygen(ctx, d.a, d.width, d.height);
+    if (ctx->deferred_pass && ctx->deferred_pass->stamped_in_kernel) {
+        ctx->pending_end = &ctx->d_stamps[ctx->deferred_pass->stamp_index].end;      // stored by the next kernel on the stream
+        ctx->deferred_pass->timed = true;
+    }
+    ctx->cur_pass = running;
+    ctx->deferred_pass = nullptr;
+    if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
+    return VHR_OK;
+}
+bool deferred_raygen_matches(const vhr_context *ctx, const TemporalArgs &t) {
+    if (!ctx->deferred_raygen) return false;
+    DeferredRaygen d;
+    std::memcpy(&d, ctx->deferred_raygen_blob.data(), sizeof(d));
+    // the dispatch reads this launch's two images and covers exactly the pixels the launch covers (whole-image work)
+    return t.raytraced == d.a.shadow_ao && static_cast<const void *>(t.normals) == d.a.normals && t.width == d.a.width && t.height == d.a.height &&
+           t.col_begin == 0 && t.row_begin == 0 && t.limit_x == d.a.width && t.row_end >= d.a.height && t.limit_y >= d.a.height &&
+           d.a.col_begin == 0 && d.a.row_begin == 0 && d.a.col_end == d.a.width && d.a.row_end == d.a.height;
+}
+
+int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, const Image &normals,
+                  const Image &depth, Image &shadow_ao, Image *reflections) {
+    if (width != normals.width || height != normals.height || width != depth.width || height != depth.height ||
+        width != shadow_ao.width || height != shadow_ao.height || (reflections && (reflections->width != width || reflections->height != height)))
+        return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "TraceRays: launch size must equal the extent of the pass images");
+    RaygenArgs a;
+    a.fuse_temporal = 0u;
+    a.temporal = TemporalArgs{};
+    a.scene = ctx->device_scene();
+    a.pfd = pfd;
+    a.tp = ctx->trace_params;
+    a.normals = normals.ptr;
+    a.depth = static_cast<const float *>(depth.ptr);
+    a.shadow_ao = shadow_ao.ptr;
+    a.reflections = reflections ? reflections->ptr : nullptr;
+    a.width = width;
+    a.height = height;
+    const uint32_t owned_begin = std::min(ctx->row_begin, height), owned_end = std::min(ctx->row_end, height);
+    a.row_begin = owned_begin;
+    a.row_end = owned_end;
+    // screen tiles: the owned columns, on 16-pixel tile boundaries (a few columns more than owned are harmless: rays are per pixel)
+    const uint32_t owned_col_begin = std::min(ctx->col_begin, width), owned_col_end = std::min(ctx->col_end, width);
+    a.col_begin = owned_col_begin & ~15u;
+    a.col_end = owned_col_end;
+    a.stats = ctx->ray_stats_enabled ? ctx->d_ray_stats : nullptr;
+    ctx->raytraced_pixels = 0;                 // ray statistics are the hybrid path's again
+    if (a.row_end <= a.row_begin || a.col_end <= a.col_begin) return VHR_OK;
+    if (ctx->options[kOptTraceOverlap]) {      // strips / tiles: trace the margin the denoiser recomputes too (no exchange of raw visibility)
+        a.row_begin = owned_begin > ctx->overlap ? owned_begin - ctx->overlap : 0u;
+        a.row_end = uint32_t(std::min<uint64_t>(height, uint64_t(owned_end) + ctx->overlap));
+        a.col_begin = (owned_col_begin > ctx->overlap ? owned_col_begin - ctx->overlap : 0u) & ~15u;
+        a.col_end = uint32_t(std::min<uint64_t>(width, uint64_t(owned_col_end) + ctx->overlap));
+    }
+    if (a.stats) {
+        if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
+            return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
+    }
+    // "fuse_temporal" (default): hold the launch back until the next pass shows its first command -- if that is svgf.comp on this launch's
+    // images, the queue kernel runs it in its tiles' epilogues (flush_deferred_raygen).  Only the default kernel has that epilogue, only
+    // whole-image work on one stream qualifies, and only a pass nobody hooked an epilogue to (its owner expects the image when it runs).
+    {
+        const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
+        const bool default_kernel = ctx->options[kOptRaygenVariant] != 0 && ctx->options[kOptRaygenCut] != 0 && !ctx->options[kOptSharedTile] && !ctx->options[kOptShadowPacket] &&
+                                    !(ctx->options[kOptBvhWide] && ctx->d_nodes4) && ctx->options[kOptRaygenTilePixels] != 128 && ctx->options[kOptRaygenTilePixels] != 256 &&
+                                    !(ctx->options[kOptPregen] && kinds >= 1 && kinds <= kMaxPregenKinds);
+        const bool whole = a.row_begin == 0 && a.row_end == height && a.col_begin == 0 && a.col_end == width;
+        const bool mirror = a.reflections && a.tp.reflections;
+        if (ctx->options[kOptFuseTemporal] && ctx->may_defer_raygen && default_kernel && whole && !mirror && !a.stats && ctx->frames_in_flight == 1 &&
+            (ctx->in_kernel_stamps() || !ctx->options[kOptPassTimestamps]) && a.scene.node_count != 0) {
+            a.fuse_temporal = 0u;
+            DeferredRaygen d;
+            std::memset(static_cast<void *>(&d), 0, sizeof(d));
+            d.a = a; d.width = width; d.height = height;
+            ctx->deferred_raygen_blob.resize(sizeof(d));
+            std::memcpy(ctx->deferred_raygen_blob.data(), &d, sizeof(d));
+            ctx->deferred_raygen = true;
+            ctx->deferred_pass = ctx->cur_pass;
+            return VHR_OK;
+        }
+    }
+    issue_raygen(ctx, a, width, height);
     if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {       // not denoised: owned rows (and columns) only
         a.row_begin = owned_begin;
         a.row_end = owned_end;

@@ -356,10 +356,13 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         p.begin_stamped = p.end_on_last_dispatch = p.stamped_in_kernel = false;
         ctx->cur_pass = stamps ? &p : nullptr;
         if (p.kind == PassKind::Graphics) {
+            if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // its owner enqueues on the stream
             if (p.external_cb) p.external_cb(p.user, ctx);
         } else if (p.kind == PassKind::Raytracing) {
             vhr_raytracing_execution_context ec{ ctx, &p, resource_idx };      // ExecuteRaytracingPass, :889-912
+            ctx->may_defer_raygen = !p.epilogue_cb;                            // "fuse_temporal": nobody waits for this pass's image at its end
             p.rt_cb(p.user, &ec);
+            ctx->may_defer_raygen = false;
         } else {
             vhr_compute_execution_context ec{ ctx, &p, resource_idx };         // ExecuteComputePass, :914-919
             ctx->recording = true;                                             // the callback records, like a command buffer
@@ -381,6 +384,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         // ordered between the two (it used to land on the caller's stream, unordered against either).  Whichever it is,
         // vhr_get_current_stream tells the callback.
         ctx->stream = (split && pi + 1 < ctx->front_passes) ? ctx->front_stream : back;
+        if (p.epilogue_cb && ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
         ctx->stream = back;
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
@@ -393,6 +397,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
     // next frame's first one while the host runs ahead of the GPU (the reference's loop does, renderer.cpp:103-146), or the one-thread
     // kernel every call that waits for the stream issues first (vhr_synchronize, GatherPerformanceStatistics, image downloads).
     // "pass_timestamps" 2 issues that kernel here instead, for hosts that neither run ahead nor wait (+6 us per frame).
+    if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // no pass took it: issued as it is
     if (ctx->pending_end && ctx->options[vhr::kOptPassTimestamps] == 2) vhr::launch_stamp(ctx);
     return VHR_OK;
 }

@@ -290,7 +290,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptCount = 33 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptCount = 34 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelAtrousAsync = 8, kKernelKinds = 9 };
@@ -402,7 +402,7 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
@@ -427,6 +427,11 @@ struct vhr_context {
     double wall_clock_khz = 100000.0;
     bool in_kernel_stamps() const { return frames_in_flight == 1 && d_stamps != nullptr && options[vhr::kOptPassTimestamps] != 3; }     // 3: event pairs (A-B)
     vhr::Stamps take_stamps();
+    // "fuse_temporal": a TraceRays launch held back until the next pass shows its first command (csrc/kernels_trace.hip: launch_raygen,
+    // flush_deferred_raygen).  `may_defer_raygen` is set by vhr_graph_execute around a ray-tracing pass that has no epilogue hooked to it.
+    bool deferred_raygen = false, may_defer_raygen = false;
+    std::vector<unsigned char> deferred_raygen_blob;
+    vhr::PassDescription *deferred_pass = nullptr;
 
     vhr::DeviceScene device_scene() const;
     int fail(int code, const std::string &msg) { error = msg; return code; }
@@ -434,9 +439,13 @@ struct vhr_context {
 
 namespace vhr {
 
+int flush_deferred_raygen(vhr_context *ctx, const TemporalArgs *fuse);      // csrc/kernels_trace.hip; no-op without a held-back launch
+bool deferred_raygen_matches(const vhr_context *ctx, const TemporalArgs &t);
+
 // Every kernel launch of the library goes through here (see vhr_context::dispatch_events).
 template <typename K, typename... Args>
 inline void launch(vhr_context *ctx, K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+    if (ctx->deferred_raygen) flush_deferred_raygen(ctx, nullptr);      // a held-back TraceRays goes first (no-op while IT is being issued)
     hipEvent_t start = nullptr, stop = nullptr;
     ctx->dispatch_events(start, stop);
     const Stamps st = ctx->take_stamps();             // every kernel's last parameter
