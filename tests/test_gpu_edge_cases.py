@@ -278,3 +278,31 @@ def test_scene_far_from_the_origin_with_mixed_scales(oracle):
     assert np.array_equal(brute, frames[1]["shadow_ao"])
     shadow = f16(frames[1]["shadow_ao"])[..., 0]
     assert 0.0 < (shadow == 0).mean() < 1.0          # something is lit, something is in shadow
+
+
+def test_scene_wider_than_the_half_range_falls_back_to_the_48_byte_nodes():
+    """The 32-byte nodes (compact_nodes, the default) hold centres and half extents as IEEE halves around the scene centre: a scene wider
+    than +-65 504 has no such form.  The build then marks it unusable (no violation is counted), the queue kernel walks the 48-byte nodes,
+    and the frame is the one compact_nodes 0 gives, bit for bit."""
+    import dataclasses
+    tiny = scenes.tiny_scene()
+    v = tiny.vertices.copy()
+    far_corner = np.zeros(len(v), bool)
+    far_corner[:3] = True                                  # three vertices of the floor go 200 km out: triangles 200 km long
+    v["pos"][far_corner] *= np.float32(5e4)
+    wide = dataclasses.replace(tiny, name="tiny_wide", vertices=v)
+    W, H = 96, 64
+    pfds = camera.dolly_frames(wide, W, H, 2)
+    images = []
+    for compact in (1, 0):
+        g = GpuHybrid(wide, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin", denoise=False)
+        try:
+            g.ctx.set_option("compact_nodes", compact)
+            assert g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+            for pfd in pfds:
+                g.frame(pfd)
+            images.append(g.ctx.download(lib.RAYTRACED))
+        finally:
+            g.close()
+    assert np.array_equal(images[0], images[1])
+    assert 0.0 < (f16(images[0])[..., 0] == 0).mean() < 1.0
