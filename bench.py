@@ -520,6 +520,8 @@ def main():
                                   "launches of a frame.  Three of them also do the work of the pass's three blits -- iteration 0 stores the history copy (+8 B/px) and "
                                   "copies the normals (+16 B/px), iteration 3 stores the Denoised image (+8 B/px): +13 MB on this average and +1.5 / +0.5 us on those "
                                   "launches, which the 24 B/px of `achieved` do not count)",
+                # the same mean without the bytes of the three blits those launches carry (32 B/px per frame over five launches, N = 1 only)
+                "traffic_less_fused_blit_bytes": (None if pmc_traffic(args) is None or world > 1 else int(pmc_traffic(args) - 32 * pixels_owned / 5)),
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
                 "launches_note": (f"HIP event pairs on every {ATROUS_TIMING_STRIDE}th a-trous launch of the timed region on the context's stream "
                                   f"({(4 if async_dead else 5) * args.steps * len(t_blocks)} launches, {'steps 1, 2, 4, 8' if async_dead else 'all five step sizes'} sampled evenly); "
