@@ -33,5 +33,5 @@ for name in scene_names:
         loop.frame(5); torch.cuda.synchronize()
         md5 = hashlib.md5(ctx.download(lib.RAYTRACED).tobytes()).hexdigest()[:12]
         if ref is None: ref = md5
-        print(f"{name} [{arm}]: raygen {min(times):.1f} us ({[round(t, 1) for t in times]}), identical {md5 == ref}", flush=True)
+        print(f"{name} [{arm}]: raygen {min(times):.1f} us ({[round(t, 1) for t in times]}), identical {md5 == ref} md5 {md5}", flush=True)
     loop.close()
