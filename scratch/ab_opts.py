@@ -14,24 +14,28 @@ W, H = [int(v) for v in os.environ.get("VHR_SIZE", "1920x1080").split("x")]
 for name in scene_names:
     loop = HybridFrameLoop(getattr(scenes, name)(), W, H, 12)
     ctx = loop.ctx
+    defaults = {"lds_stack_levels": 8, "raygen_early_exit": 4, "refill_threshold": 16, "raygen_waves_per_block": 2, "raygen_tile_pixels": 64,
+                "shadow_last": 1, "cut_reach": 1, "raygen_cut": 1, "xcd_aware": 0, "raygen_tail_tile_rows": 4, "compact_nodes": 1}
     touched, ref = {}, None
-    for arm in arms:
-        for k, v in touched.items(): ctx.set_option(k, v)           # back to the defaults recorded below
-        kv = [a.split("=") for a in arm.split(",") if a]
-        for k, v in kv:
-            touched.setdefault(k, {"lds_stack_levels": 8, "raygen_early_exit": 4, "refill_threshold": 16, "raygen_waves_per_block": 2, "raygen_tile_pixels": 64,
-                                   "shadow_last": 1, "cut_reach": 1, "raygen_cut": 1, "xcd_aware": 0}.get(k, 0))
-            ctx.set_option(k, int(v))
-        times = []
-        for rep in range(3):
-            for i in range(3): loop.frame(i)
+    parsed = [[a.split("=") for a in arm.split(",") if a] for arm in arms]
+    for kv in parsed:
+        for k, v in kv: touched[k] = defaults.get(k, 0)
+    times = {i: [] for i in range(len(arms))}
+    md5s = {}
+    reps = int(os.environ.get("VHR_REPS", "4"))
+    for rep in range(reps):                       # arms interleaved: the clocks drift over the first seconds of a process
+        for i, kv in enumerate(parsed):
+            for k, v in touched.items(): ctx.set_option(k, v)
+            for k, v in kv: ctx.set_option(k, int(v))
+            for f in range(2): loop.frame(f)
             ctx.set_kernel_timing(["raygen"]); ctx.kernel_time("raygen", reset=True)
-            for i in range(3, 11): loop.frame(i)
+            for f in range(3, 11): loop.frame(f)
             torch.cuda.synchronize()
             ms, k = ctx.kernel_time("raygen"); ctx.set_kernel_timing(False)
-            times.append(ms / 8 * 1e3)
-        loop.frame(5); torch.cuda.synchronize()
-        md5 = hashlib.md5(ctx.download(lib.RAYTRACED).tobytes()).hexdigest()[:12]
-        if ref is None: ref = md5
-        print(f"{name} [{arm}]: raygen {min(times):.1f} us ({[round(t, 1) for t in times]}), identical {md5 == ref} md5 {md5}", flush=True)
+            times[i].append(ms / 8 * 1e3)
+            if rep == 0:
+                loop.frame(5); torch.cuda.synchronize()
+                md5s[i] = hashlib.md5(ctx.download(lib.RAYTRACED).tobytes()).hexdigest()[:12]
+    for i, arm in enumerate(arms):
+        print(f"{name} [{arm}]: raygen {min(times[i]):.1f} us ({[round(t, 1) for t in times[i]]}), identical {md5s[i] == md5s[0]} md5 {md5s[i]}", flush=True)
     loop.close()
