@@ -488,7 +488,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      launch as it is.  Every image bit-identical.  Measured: the ray-tracing kernel grows by 20 of the 26 us the kernel
  *                      and its launch gap cost (0.494 -> 0.490 ms per frame), and "Raytrace Pass" / "SVGF Denoise Pass" times shift by
  *                      that dispatch: default 0.
- *   "temporal_variant" reserved */
+ *   "temporal_variant" 0 = svgf.comp in 32x8-pixel workgroups (default), 1 = 64x4 (rounds 1-3c; A-B) */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 
 /* Per-kernel timing with HIP event pairs attached to every launch of a kernel kind on the context stream (the events ride on

@@ -21,16 +21,17 @@ static int issue_cmd(vhr_context *ctx, const SvgfCmd &cmd);
 
 #pragma clang fp contract(off)      // K3; K4 switches contraction back on below
 
-constexpr int kSvgfBlockX = 64;    // one wave per image row segment: fully coalesced 512-byte row reads
+constexpr int kSvgfBlockX = 64;    // (svgf_atrous_kernel, the direct A-B form) one wave per image row segment: fully coalesced 512-byte row reads
 constexpr int kSvgfBlockY = 4;
 
 // ---------------------------------------------------------------------------------------------
 // K3: svgf.comp -- the per-pixel body lives in svgf_temporal.hpp (shared with the ray-tracing kernel's tile epilogue)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_temporal_kernel(const TemporalArgs a, const Stamps st) {
+template <int BX, int BY>
+__global__ __launch_bounds__(BX *BY) void svgf_temporal_kernel(const TemporalArgs a, const Stamps st) {
     vhr_stamp(st);
-    const uint32_t cx = a.col_begin + blockIdx.x * kSvgfBlockX + threadIdx.x;
-    const uint32_t cy = a.row_begin + blockIdx.y * kSvgfBlockY + threadIdx.y;
+    const uint32_t cx = a.col_begin + blockIdx.x * BX + threadIdx.x;
+    const uint32_t cy = a.row_begin + blockIdx.y * BY + threadIdx.y;
     if (cx >= a.limit_x || cy >= a.row_end || cy >= a.limit_y) return;
     // 32-bit texel indices on the (uniform) image bases: an image is far below 2^29 texels, and a size_t index costs a v_mad_u64_u32 and
     // 64-bit shifts / adds per address (r3c: 27.0 -> 26.x us)
@@ -1046,9 +1047,15 @@ static int issue_copy(vhr_context *ctx, const SvgfCmd &cmd) {
 
 static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
     if (a.row_end > a.row_begin && a.limit_x > a.col_begin && a.limit_y) {
-        const dim3 grid((a.limit_x - a.col_begin + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
         ctx->time_begin(kKernelTemporal);
-        launch(ctx, svgf_temporal_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
+        auto go = [&](auto kern, uint32_t bx, uint32_t by) {
+            launch(ctx, kern, dim3((a.limit_x - a.col_begin + bx - 1) / bx, (a.row_end - a.row_begin + by - 1) / by), dim3(bx, by), 0, a);
+        };
+        // 32x8-pixel blocks (r3d): two rows of 32 pixels per wave.  The three gathered images' border -- one texel around the block -- is
+        // 1.33x the block instead of the 64x4 block's 1.55x: 26.6 -> 25.7 us at 1080p, 95.2 -> 90.1 at 4K (64x8, 32x16, 64x16, 16x16, 128x4,
+        // 32x4, 32x6, 32x12, 16x8 measured too: scratch/ab_temporal.py).  "temporal_variant" 1 = the 64x4 blocks of rounds 1-3c (A-B).
+        if (ctx->options[kOptTemporalVariant] == 1) go(svgf_temporal_kernel<64, 4>, 64, 4);
+        else go(svgf_temporal_kernel<32, 8>, 32, 8);
         ctx->time_end(kKernelTemporal);
         if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
     }
