@@ -1051,9 +1051,9 @@ static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
         auto go = [&](auto kern, uint32_t bx, uint32_t by) {
             launch(ctx, kern, dim3((a.limit_x - a.col_begin + bx - 1) / bx, (a.row_end - a.row_begin + by - 1) / by), dim3(bx, by), 0, a);
         };
-        // 32x8-pixel blocks (r3d): two rows of 32 pixels per wave.  The three gathered images' border -- one texel around the block -- is
-        // 1.33x the block instead of the 64x4 block's 1.55x: 26.6 -> 25.7 us at 1080p, 95.2 -> 90.1 at 4K (64x8, 32x16, 64x16, 16x16, 128x4,
-        // 32x4, 32x6, 32x12, 16x8 measured too: scratch/ab_temporal.py).  "temporal_variant" 1 = the 64x4 blocks of rounds 1-3c (A-B).
+        // 32x8-pixel blocks (r3d): two rows of 32 pixels per wave: 26.6 -> 25.7 us at 1080p, 95.2 -> 90.1 at 4K (64x8, 32x16, 64x16, 16x16, 128x4,
+        // 32x4, 32x6, 32x12, 16x8 measured too: scratch/ab_temporal.py; the counter traffic does not fall, the rate it moves at rises).
+        // "temporal_variant" 1 = the 64x4 blocks of rounds 1-3c (A-B).
         if (ctx->options[kOptTemporalVariant] == 1) go(svgf_temporal_kernel<64, 4>, 64, 4);
         else go(svgf_temporal_kernel<32, 8>, 32, 8);
         ctx->time_end(kKernelTemporal);
