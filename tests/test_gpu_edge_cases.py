@@ -111,7 +111,7 @@ def test_shadows_disabled_extension(oracle):
 @pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)), ("compact_nodes", (0, 1)),
                                            ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)), ("raygen_shared_tile", (0, 1)), ("raygen_pregen", (0, 1)), ("raygen_early_exit", (0, 8, 15)), ("raygen_cut", (0, 1)),
                                            ("shadow_packet", (0, 1)), ("raygen_tile_rows", (0, 8, 6, 4)), ("cut_reach", (0, 1)), ("cut_expand", (0, 1)), ("shadow_last", (0, 1)), ("raygen_tile_pixels", (64, 128, 256)), ("bvh_wide", (0, 1)),
-                                           ("atrous_variant", (0, 1, 2, 3, 4, 5)), ("atrous_blocks_per_cu", (1, 3)), ("atrous_xcd_aware", (0, 1)), ("atrous_small_tiles", (0, 1)), ("temporal_variant", (0, 1))])
+                                           ("atrous_variant", (0, 1, 2, 3, 4, 5)), ("atrous_blocks_per_cu", (1, 3)), ("atrous_xcd_aware", (0, 1)), ("atrous_small_tiles", (0, 1)), ("temporal_variant", (0, 1)), ("raygen_cost_order", (0, 2))])
 def test_every_tuning_option_is_result_neutral(oracle, option, values):
     scene = scenes.tiny_scene()
     W, H = 72, 56

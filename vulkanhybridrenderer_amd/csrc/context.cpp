@@ -272,6 +272,7 @@ void vhr_destroy(vhr_context *ctx) {
     free_scene(ctx);
     hipFree(ctx->d_ray_stats);
     hipFree(ctx->d_tile_counter);
+    for (int i = 0; i < 2; ++i) { hipFree(ctx->d_wave_cost[i]); hipFree(ctx->d_block_order[i]); }
     for (auto &t : ctx->kernel_timers)
         for (hipEvent_t e : t.events) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -584,7 +585,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal", "raygen_cost_order" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }

@@ -368,6 +368,14 @@ struct RaygenArgs {
     // "fuse_temporal": the queue kernel's tile epilogue runs svgf.comp for the tile's pixels (the dispatch the SVGF pass records next)
     uint32_t fuse_temporal;  // 0 = off
     TemporalArgs temporal;
+    // "raygen_cost_order" (the default queue kernel): wave_cost != nullptr -> every wave leaves its lifetime there (index = its block's tiles * WAVES +
+    // wave); block_order != nullptr -> block b works on the tiles of block block_order[b] (the launch before last's blocks, longest-lived first);
+    // order_out != nullptr -> the launch's first block sorts the previous launch's `order_blocks` blocks by `cost_prev` into it before its own tile
+    uint32_t *wave_cost;
+    const uint32_t *block_order;
+    const uint32_t *cost_prev;
+    uint32_t *order_out;
+    uint32_t order_blocks;
 };
 
 __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
@@ -918,6 +926,60 @@ __device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &s
     return occluded;
 }
 
+// "raygen_cost_order": the blocks of an earlier launch sorted by cost, heaviest first, by ONE block of the ray-tracing launch (its first: it starts at
+// once and has the whole launch to finish its own tile afterwards).  A block's cost is its longest-lived wave's lifetime; the blocks fall into 8
+// classes of cost relative to the maximum, and a stable counting sort puts the heaviest class first -- inside a class the blocks keep their
+// row-major order (neighbouring tiles share nodes; a full sort gives that up: round 2's "longest tiles first").  Whatever the lifetimes hold, the
+// result is a permutation of 0 .. n_blocks - 1: the order is a speed hint, never correctness.  `lds`: 8 * 64 * WAVES words of scratch.
+template <int WAVES>
+__device__ __forceinline__ void order_blocks_by_cost(const uint32_t *__restrict__ wave_cost, const uint32_t n_blocks, uint32_t *__restrict__ order, uint32_t *lds) {
+    constexpr uint32_t NT = 64u * WAVES, C = 8u;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n_blocks + NT - 1u) / NT, b0 = min(t * per, n_blocks), b1 = min(b0 + per, n_blocks);     // a contiguous chunk per thread
+    auto cost = [&](uint32_t b) { uint32_t c = 0; for (uint32_t w = 0; w < uint32_t(WAVES); ++w) c = max(c, wave_cost[b * uint32_t(WAVES) + w]); return c; };
+    uint32_t mx = 0;
+    for (uint32_t b = b0; b < b1; ++b) mx = max(mx, cost(b));
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), off)));
+    if ((t & 63u) == 0u) lds[t >> 6] = mx;
+    __syncthreads();
+    for (uint32_t w = 0; w < uint32_t(WAVES); ++w) mx = max(mx, lds[w]);
+    __syncthreads();
+    const float scale = float(C) / float(max(1u, mx));
+    auto cls = [&](uint32_t c) { return (C - 1u) - min(C - 1u, uint32_t(float(c) * scale)); };    // 0 = the heaviest (any deterministic map will do)
+    uint32_t mine[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) mine[c] = 0;
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t k = cls(cost(b));
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) mine[c] += k == c ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) lds[c * NT + t] = mine[c];
+    __syncthreads();
+    for (uint32_t off = 1; off < C * NT; off <<= 1) {         // inclusive scan over (class-major, thread-minor)
+        uint32_t v[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) { const uint32_t i = c * NT + t; v[c] = i >= off ? lds[i - off] : 0u; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) lds[c * NT + t] += v[c];
+        __syncthreads();
+    }
+    uint32_t pos[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; ++c) pos[c] = lds[c * NT + t] - mine[c];       // inclusive -> exclusive
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t k = cls(cost(b));
+        uint32_t p = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < C; ++c) { p = k == c ? pos[c] : p; pos[c] += k == c ? 1u : 0u; }
+        // (rotated by one: the LIGHTEST block goes to the front -- the next launch's first block, which does this sort before its own tile)
+        order[p + 1u == n_blocks ? 0u : p + 1u] = b;
+    }
+    __syncthreads();                                        // the scratch is the waves' traversal stacks from here on
+}
+
 template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false, bool WIDE = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t pregen_kinds, const uint32_t block_tiles_x,
@@ -954,12 +1016,20 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
     constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
     constexpr int kSpillEntries = WIDE ? kWideSpill : kSpillStack;
+    const unsigned long long t_cost0 = a.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if constexpr (CUT && COMPACT && !SHARED && !STATS && !PACKET && !WIDE && !PREGEN) {
+        // "raygen_cost_order": the launch's first block orders the previous launch's blocks for the next one (8 * 64 * WAVES words <= the block's
+        // (stack_levels + 3) * 64 * WAVES words of stack: the host asks for it only with >= 5 stack levels)
+        if (a.order_out && blockIdx.x == 0u) order_blocks_by_cost<WAVES>(a.cost_prev, a.order_blocks, a.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+    }
     int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
     float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + kExtraRows) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
-    const uint32_t block_tile = xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    // "raygen_cost_order": the blocks that lived longest two launches ago start first (a launch ends with its last wave; a long-lived wave that
+    // starts late is what the launch's end waits for)
+    const uint32_t block_tile = a.block_order ? a.block_order[blockIdx.x] : (xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
     if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y, a.col_begin);
     else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y, a.col_begin);
     const bool in_range = x < a.col_end && y < a.row_end && (lane >> 3) < tile_rows;
@@ -1310,6 +1380,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
+    if (a.wave_cost && lane == 0) a.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
     // ---- "fuse_temporal": svgf.comp for this tile's pixels, right here (the default kernel only) ----
     // svgf.comp reads of the CURRENT frame only the pixel's own texels; everything else it gathers is the previous frame's.  So the
     // wave that has just finished a tile can run it for the tile: the visibility goes from LDS into the filter (rounded to the halves
@@ -1930,8 +2001,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 }
 
 // The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
-static void issue_raygen(vhr_context *ctx, const RaygenArgs &a, const uint32_t width, const uint32_t height) {
+static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
     (void)height;
+    RaygenArgs a = a_in;
+    a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
@@ -2024,6 +2097,41 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a, const uint32_t w
 #undef VHR_LAUNCH_WIDE
         }
         else if (compact_cut && !packet && !wide) {     // the default: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of three)
+            {   // "raygen_cost_order" (see vhr_context::d_wave_cost)
+                const uint32_t wv = waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u);
+                const uint32_t n_blocks = ((tiles_x + wv - 1u) / wv) * tiles_y, n_waves = n_blocks * wv;
+                // 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order
+                // connects must have been issued on the same stream -- the order is written and read in stream order, nothing else guards it
+                const int cost_order = ctx->options[kOptRaygenCostOrder];
+                if (cost_order && ctx->cost_stream != ctx->stream) { ctx->cost_stream = ctx->stream; ctx->order_blocks[0] = ctx->order_blocks[1] = ctx->cost_blocks[0] = ctx->cost_blocks[1] = 0; }
+                if (cost_order && !ctx->options[kOptXcdAware] && !a.stats && levels >= 5u && n_blocks >= (cost_order >= 2 ? 2u : 2048u)) {
+                    if (n_waves > ctx->cost_capacity) {
+                        (void)hipDeviceSynchronize();              // (first use / a larger launch: nothing may still read the old buffers)
+                        for (int i = 0; i < 2; ++i) { (void)hipFree(ctx->d_wave_cost[i]); (void)hipFree(ctx->d_block_order[i]); ctx->d_wave_cost[i] = ctx->d_block_order[i] = nullptr; }
+                        ctx->cost_capacity = 0;
+                        ctx->order_blocks[0] = ctx->order_blocks[1] = ctx->cost_blocks[0] = ctx->cost_blocks[1] = 0;
+                        bool ok = true;
+                        for (int i = 0; i < 2; ++i)
+                            ok = ok && hipMalloc(reinterpret_cast<void **>(&ctx->d_wave_cost[i]), size_t(n_waves) * 4) == hipSuccess &&
+                                 hipMalloc(reinterpret_cast<void **>(&ctx->d_block_order[i]), size_t(n_waves) * 4) == hipSuccess;
+                        if (ok) ctx->cost_capacity = n_waves;
+                    }
+                    if (ctx->cost_capacity >= n_waves) {
+                        const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
+                        const uint32_t prev = ctx->cost_slot, slot = prev ^ 1u;
+                        ctx->cost_slot = slot;
+                        a.wave_cost = ctx->d_wave_cost[slot];
+                        if (ctx->order_blocks[slot] == n_blocks && ctx->order_key[slot] == key) a.block_order = ctx->d_block_order[slot];
+                        if (ctx->cost_blocks[prev] == n_blocks && ctx->cost_key[prev] == key) {       // the previous launch had this shape: its blocks get ordered
+                            a.cost_prev = ctx->d_wave_cost[prev]; a.order_out = ctx->d_block_order[prev]; a.order_blocks = n_blocks;
+                            ctx->order_blocks[prev] = n_blocks; ctx->order_key[prev] = key;
+                        } else {
+                            ctx->order_blocks[prev] = 0;
+                        }
+                        ctx->cost_blocks[slot] = n_blocks; ctx->cost_key[slot] = key;
+                    }
+                }
+            }
 #define VHR_LAUNCH_CUT16(WV, SP, ST) launch(ctx, (raygen_queue_kernel<false, WV, true, false, SP, ST, true, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                             stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, cut_flags)
 #define VHR_LAUNCH_CUT16_W(SP, ST) do { if (waves >= 4) VHR_LAUNCH_CUT16(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT16(2, SP, ST); else VHR_LAUNCH_CUT16(1, SP, ST); } while (0)
@@ -2092,6 +2200,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     RaygenArgs a;
     a.fuse_temporal = 0u;
     a.temporal = TemporalArgs{};
+    a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
     a.scene = ctx->device_scene();
     a.pfd = pfd;
     a.tp = ctx->trace_params;

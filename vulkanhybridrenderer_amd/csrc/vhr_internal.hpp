@@ -290,7 +290,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptCount = 34 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptRaygenCostOrder = 34, kOptCount = 35 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelAtrousAsync = 8, kKernelKinds = 9 };
@@ -402,9 +402,18 @@ struct vhr_context {
     vhr::RayStats h_ray_stats = {};
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
+    // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in d_wave_cost[f & 1], and its FIRST block, before it
+    // turns to its own tile, sorts the blocks of launch f - 1 by the lifetimes in d_wave_cost[(f - 1) & 1] into d_block_order[(f + 1) & 1] -- the order
+    // launch f + 1 starts its blocks in.  Everything happens inside the launches the frame has anyway: no kernel, stream or event of its own.
+    uint32_t *d_wave_cost[2] = { nullptr, nullptr }, *d_block_order[2] = { nullptr, nullptr };
+    uint32_t cost_capacity = 0;                    // waves each of the four buffers holds
+    uint32_t cost_slot = 0;                        // the slot the last ray-tracing launch wrote its lifetimes to
+    hipStream_t cost_stream = nullptr;             // ... and the stream it was issued on (an order only connects launches of one stream)
+    uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape d_wave_cost[slot] was written by (0 blocks = nothing)
+    uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape d_block_order[slot] is an order of
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;
