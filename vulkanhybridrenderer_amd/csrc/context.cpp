@@ -272,7 +272,8 @@ void vhr_destroy(vhr_context *ctx) {
     free_scene(ctx);
     hipFree(ctx->d_ray_stats);
     hipFree(ctx->d_tile_counter);
-    for (int i = 0; i < 2; ++i) { hipFree(ctx->d_wave_cost[i]); hipFree(ctx->d_block_order[i]); }
+    for (vhr_context::CostOrder *co : { &ctx->cost_order_raygen, &ctx->cost_order_reflection })
+        for (int i = 0; i < 2; ++i) { hipFree(co->cost[i]); hipFree(co->order[i]); }
     for (auto &t : ctx->kernel_timers)
         for (hipEvent_t e : t.events) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -1869,7 +1869,11 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    const uint32_t tile = blockIdx.x * 2u + wave;
+    // "raygen_cost_order" for this launch (see raygen_queue_kernel): the first block sorts the previous launch's blocks before its own tiles
+    const unsigned long long t_cost0 = a.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if (a.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.cost_prev, a.order_blocks, a.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+    const uint32_t block = a.block_order ? a.block_order[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = block * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[ROWS][kReflRays] = s_ray_all[wave];
     uint8_t (&s_list)[kReflRays] = s_list_all[wave];
@@ -1998,9 +2002,44 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
         if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
     }
+    if (a.wave_cost && lane == 0) a.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
 }
 
 // The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
+// "raygen_cost_order": the cost / order pointers of a queue-kernel launch of `n_blocks` blocks of `wv` waves (see vhr_context::CostOrder).
+// 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order connects must
+// have been issued on the same stream -- the order is written and read in stream order, nothing else guards it.
+static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, RaygenArgs &a) {
+    const int mode = ctx->options[kOptRaygenCostOrder];
+    if (!mode) return;
+    if (co.stream != ctx->stream) { co.stream = ctx->stream; co.order_blocks[0] = co.order_blocks[1] = co.cost_blocks[0] = co.cost_blocks[1] = 0; }
+    if (n_blocks < (mode >= 2 ? 2u : 2048u)) return;
+    const uint32_t n_waves = n_blocks * wv;
+    if (n_waves > co.capacity) {
+        (void)hipDeviceSynchronize();              // (first use / a larger launch: nothing may still read the old buffers)
+        for (int i = 0; i < 2; ++i) { (void)hipFree(co.cost[i]); (void)hipFree(co.order[i]); co.cost[i] = co.order[i] = nullptr; }
+        co.capacity = 0;
+        co.order_blocks[0] = co.order_blocks[1] = co.cost_blocks[0] = co.cost_blocks[1] = 0;
+        bool ok = true;
+        for (int i = 0; i < 2; ++i)
+            ok = ok && hipMalloc(reinterpret_cast<void **>(&co.cost[i]), size_t(n_waves) * 4) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void **>(&co.order[i]), size_t(n_waves) * 4) == hipSuccess;
+        if (!ok) return;
+        co.capacity = n_waves;
+    }
+    const uint32_t prev = co.slot, slot = prev ^ 1u;
+    co.slot = slot;
+    a.wave_cost = co.cost[slot];
+    if (co.order_blocks[slot] == n_blocks && co.order_key[slot] == key) a.block_order = co.order[slot];
+    if (co.cost_blocks[prev] == n_blocks && co.cost_key[prev] == key) {       // the previous launch had this shape: its blocks get ordered
+        a.cost_prev = co.cost[prev]; a.order_out = co.order[prev]; a.order_blocks = n_blocks;
+        co.order_blocks[prev] = n_blocks; co.order_key[prev] = key;
+    } else {
+        co.order_blocks[prev] = 0;
+    }
+    co.cost_blocks[slot] = n_blocks; co.cost_key[slot] = key;
+}
+
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
     (void)height;
     RaygenArgs a = a_in;
@@ -2097,40 +2136,10 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
 #undef VHR_LAUNCH_WIDE
         }
         else if (compact_cut && !packet && !wide) {     // the default: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of three)
-            {   // "raygen_cost_order" (see vhr_context::d_wave_cost)
+            {   // "raygen_cost_order" (see vhr_context::CostOrder)
                 const uint32_t wv = waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u);
-                const uint32_t n_blocks = ((tiles_x + wv - 1u) / wv) * tiles_y, n_waves = n_blocks * wv;
-                // 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order
-                // connects must have been issued on the same stream -- the order is written and read in stream order, nothing else guards it
-                const int cost_order = ctx->options[kOptRaygenCostOrder];
-                if (cost_order && ctx->cost_stream != ctx->stream) { ctx->cost_stream = ctx->stream; ctx->order_blocks[0] = ctx->order_blocks[1] = ctx->cost_blocks[0] = ctx->cost_blocks[1] = 0; }
-                if (cost_order && !ctx->options[kOptXcdAware] && !a.stats && levels >= 5u && n_blocks >= (cost_order >= 2 ? 2u : 2048u)) {
-                    if (n_waves > ctx->cost_capacity) {
-                        (void)hipDeviceSynchronize();              // (first use / a larger launch: nothing may still read the old buffers)
-                        for (int i = 0; i < 2; ++i) { (void)hipFree(ctx->d_wave_cost[i]); (void)hipFree(ctx->d_block_order[i]); ctx->d_wave_cost[i] = ctx->d_block_order[i] = nullptr; }
-                        ctx->cost_capacity = 0;
-                        ctx->order_blocks[0] = ctx->order_blocks[1] = ctx->cost_blocks[0] = ctx->cost_blocks[1] = 0;
-                        bool ok = true;
-                        for (int i = 0; i < 2; ++i)
-                            ok = ok && hipMalloc(reinterpret_cast<void **>(&ctx->d_wave_cost[i]), size_t(n_waves) * 4) == hipSuccess &&
-                                 hipMalloc(reinterpret_cast<void **>(&ctx->d_block_order[i]), size_t(n_waves) * 4) == hipSuccess;
-                        if (ok) ctx->cost_capacity = n_waves;
-                    }
-                    if (ctx->cost_capacity >= n_waves) {
-                        const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
-                        const uint32_t prev = ctx->cost_slot, slot = prev ^ 1u;
-                        ctx->cost_slot = slot;
-                        a.wave_cost = ctx->d_wave_cost[slot];
-                        if (ctx->order_blocks[slot] == n_blocks && ctx->order_key[slot] == key) a.block_order = ctx->d_block_order[slot];
-                        if (ctx->cost_blocks[prev] == n_blocks && ctx->cost_key[prev] == key) {       // the previous launch had this shape: its blocks get ordered
-                            a.cost_prev = ctx->d_wave_cost[prev]; a.order_out = ctx->d_block_order[prev]; a.order_blocks = n_blocks;
-                            ctx->order_blocks[prev] = n_blocks; ctx->order_key[prev] = key;
-                        } else {
-                            ctx->order_blocks[prev] = 0;
-                        }
-                        ctx->cost_blocks[slot] = n_blocks; ctx->cost_key[slot] = key;
-                    }
-                }
+                const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
+                if (!ctx->options[kOptXcdAware] && !a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, ((tiles_x + wv - 1u) / wv) * tiles_y, wv, key, a);
             }
 #define VHR_LAUNCH_CUT16(WV, SP, ST) launch(ctx, (raygen_queue_kernel<false, WV, true, false, SP, ST, true, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                             stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, cut_flags)
@@ -2266,6 +2275,10 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
             const uint32_t tiles_x = (a.col_end - a.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
+            a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
+            if (levels >= 5u && !a.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
+                prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
+                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(a.tp.reflections) << 28) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u), a);
 #define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }

@@ -405,15 +405,19 @@ struct vhr_context {
     int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0, 1 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
-    // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in d_wave_cost[f & 1], and its FIRST block, before it
-    // turns to its own tile, sorts the blocks of launch f - 1 by the lifetimes in d_wave_cost[(f - 1) & 1] into d_block_order[(f + 1) & 1] -- the order
-    // launch f + 1 starts its blocks in.  Everything happens inside the launches the frame has anyway: no kernel, stream or event of its own.
-    uint32_t *d_wave_cost[2] = { nullptr, nullptr }, *d_block_order[2] = { nullptr, nullptr };
-    uint32_t cost_capacity = 0;                    // waves each of the four buffers holds
-    uint32_t cost_slot = 0;                        // the slot the last ray-tracing launch wrote its lifetimes to
-    hipStream_t cost_stream = nullptr;             // ... and the stream it was issued on (an order only connects launches of one stream)
-    uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape d_wave_cost[slot] was written by (0 blocks = nothing)
-    uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape d_block_order[slot] is an order of
+    // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in cost[f & 1], and its FIRST block, before it
+    // turns to its own tile, sorts the blocks of launch f - 1 by the lifetimes in cost[(f - 1) & 1] into order[(f + 1) & 1] -- the order launch
+    // f + 1 starts its blocks in.  Everything happens inside the launches the frame has anyway: no kernel, stream or event of its own.  One set for
+    // the shadow / AO queue kernel, one for the mirror-ray queue kernel (launches of different shapes).
+    struct CostOrder {
+        uint32_t *cost[2] = { nullptr, nullptr }, *order[2] = { nullptr, nullptr };
+        uint32_t capacity = 0;                     // waves each of the four buffers holds
+        uint32_t slot = 0;                         // the slot the last launch wrote its lifetimes to
+        hipStream_t stream = nullptr;              // ... and the stream it was issued on (an order only connects launches of one stream)
+        uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape cost[slot] was written by (0 blocks = nothing)
+        uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
+    };
+    CostOrder cost_order_raygen, cost_order_reflection;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;
