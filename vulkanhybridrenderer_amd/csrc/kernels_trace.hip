@@ -2012,7 +2012,13 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, RaygenArgs &a) {
     const int mode = ctx->options[kOptRaygenCostOrder];
     if (!mode) return;
-    if (co.stream != ctx->stream) { co.stream = ctx->stream; co.order_blocks[0] = co.order_blocks[1] = co.cost_blocks[0] = co.cost_blocks[1] = 0; }
+    if (co.stream != ctx->stream) {
+        // another stream than the last launch's (frames in flight switched on or off, say): whatever of that stream is still in flight may be
+        // writing an order -- wait once, forget both
+        if (co.capacity) (void)hipDeviceSynchronize();
+        co.stream = ctx->stream;
+        co.order_blocks[0] = co.order_blocks[1] = co.cost_blocks[0] = co.cost_blocks[1] = 0;
+    }
     if (n_blocks < (mode >= 2 ? 2u : 2048u)) return;
     const uint32_t n_waves = n_blocks * wv;
     if (n_waves > co.capacity) {
