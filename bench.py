@@ -500,6 +500,10 @@ def main():
                 "schedule": ("reference schedule, every dispatch executed; the fifth a-trous dispatch (output never read, hybrid_render_path.cpp:299-328) is issued on the "
                              "context's side stream beside the next frame's ray tracing (svgf_async_unread, images bit-identical; ms_per_step_all_dispatches_in_order = without)")
                             if async_dead else "reference schedule, every dispatch in recorded order on one stream",
+                # every ray of every frame is traced; only the order the launch's workgroups START in comes from the past (their lifetimes two launches ago)
+                "ray_tracing_block_order": ("row-major" if option_overrides.get("raygen_cost_order", 1) == 0 else
+                                            "longest-lived first (raygen_cost_order: lifetimes two launches ago, sorted by the launch's own first workgroup; images bit-identical; "
+                                            "--option raygen_cost_order=0 = row-major)"),
                 "options": option_overrides or None,
                 "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo_rows, "history_halo_cols": plan.halo_cols if plan.grid_cols > 1 else None,
                 "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
