@@ -489,7 +489,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                      and its launch gap cost (0.494 -> 0.490 ms per frame), and "Raytrace Pass" / "SVGF Denoise Pass" times shift by
  *                      that dispatch: default 0.
  *   "temporal_variant" 0 = svgf.comp in 32x8-pixel workgroups (default), 1 = 64x4 (rounds 1-3c; A-B)
- *   "raygen_cost_order" 1 (default) = the blocks of the shadow / AO ray-tracing launch (and, separately, of the mirror-ray launch) start in the order of their lifetimes two launches ago,
+ *   "raygen_cost_order" 1 (default) = the blocks of the shadow / AO ray-tracing launch (and, separately, of the mirror-ray launch and of the raytraced render path's launch) start in the order of their lifetimes two launches ago,
  *                      longest first: every wave leaves its lifetime, the launch's first block sorts the previous launch's blocks into 8 classes of
  *                      cost (stable inside a class) before it turns to its own tile, the next launch of the same shape on the same stream reads
  *                      the order.  No kernel, stream or event of its own; images bit-identical (any order is a correct one); launches of

@@ -272,7 +272,7 @@ void vhr_destroy(vhr_context *ctx) {
     free_scene(ctx);
     hipFree(ctx->d_ray_stats);
     hipFree(ctx->d_tile_counter);
-    for (vhr_context::CostOrder *co : { &ctx->cost_order_raygen, &ctx->cost_order_reflection })
+    for (vhr_context::CostOrder *co : { &ctx->cost_order_raygen, &ctx->cost_order_reflection, &ctx->cost_order_raytraced })
         for (int i = 0; i < 2; ++i) { hipFree(co->cost[i]); hipFree(co->order[i]); }
     for (auto &t : ctx->kernel_timers)
         for (hipEvent_t e : t.events) hipEventDestroy(e);

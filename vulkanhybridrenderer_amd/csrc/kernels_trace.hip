@@ -352,6 +352,17 @@ __device__ __forceinline__ f4 trace_reflection(const DeviceScene &sc, const vhr_
 // ---------------------------------------------------------------------------------------------
 // K1: raygen.rgen:14-66
 // ---------------------------------------------------------------------------------------------
+// "raygen_cost_order", what a queue kernel's launch gets: wave_cost != nullptr -> every wave leaves its lifetime there (index = its block's tiles *
+// WAVES + wave); block_order != nullptr -> block b works on the tiles of block block_order[b] (the launch before last's blocks, longest-lived
+// first); order_out != nullptr -> the launch's first block sorts the previous launch's `order_blocks` blocks by `cost_prev` into it before its own tile
+struct CostOrderArgs {
+    uint32_t *wave_cost = nullptr;
+    const uint32_t *block_order = nullptr;
+    const uint32_t *cost_prev = nullptr;
+    uint32_t *order_out = nullptr;
+    uint32_t order_blocks = 0;
+};
+
 struct RaygenArgs {
     DeviceScene scene;
     vhr_per_frame_data pfd;
@@ -368,14 +379,7 @@ struct RaygenArgs {
     // "fuse_temporal": the queue kernel's tile epilogue runs svgf.comp for the tile's pixels (the dispatch the SVGF pass records next)
     uint32_t fuse_temporal;  // 0 = off
     TemporalArgs temporal;
-    // "raygen_cost_order" (the default queue kernel): wave_cost != nullptr -> every wave leaves its lifetime there (index = its block's tiles * WAVES +
-    // wave); block_order != nullptr -> block b works on the tiles of block block_order[b] (the launch before last's blocks, longest-lived first);
-    // order_out != nullptr -> the launch's first block sorts the previous launch's `order_blocks` blocks by `cost_prev` into it before its own tile
-    uint32_t *wave_cost;
-    const uint32_t *block_order;
-    const uint32_t *cost_prev;
-    uint32_t *order_out;
-    uint32_t order_blocks;
+    CostOrderArgs co;        // "raygen_cost_order" (the default queue kernel, the mirror-ray queue kernel)
 };
 
 __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
@@ -1016,11 +1020,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
     constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
     constexpr int kSpillEntries = WIDE ? kWideSpill : kSpillStack;
-    const unsigned long long t_cost0 = a.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
     if constexpr (CUT && COMPACT && !SHARED && !STATS && !PACKET && !WIDE && !PREGEN) {
         // "raygen_cost_order": the launch's first block orders the previous launch's blocks for the next one (8 * 64 * WAVES words <= the block's
         // (stack_levels + 3) * 64 * WAVES words of stack: the host asks for it only with >= 5 stack levels)
-        if (a.order_out && blockIdx.x == 0u) order_blocks_by_cost<WAVES>(a.cost_prev, a.order_blocks, a.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+        if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<WAVES>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
     }
     int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     uint32_t x, y;
     // "raygen_cost_order": the blocks that lived longest two launches ago start first (a launch ends with its last wave; a long-lived wave that
     // starts late is what the launch's end waits for)
-    const uint32_t block_tile = a.block_order ? a.block_order[blockIdx.x] : (xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
+    const uint32_t block_tile = a.co.block_order ? a.co.block_order[blockIdx.x] : (xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
     if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y, a.col_begin);
     else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y, a.col_begin);
     const bool in_range = x < a.col_end && y < a.row_end && (lane >> 3) < tile_rows;
@@ -1380,7 +1384,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
-    if (a.wave_cost && lane == 0) a.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
+    if (a.co.wave_cost && lane == 0) a.co.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
     // ---- "fuse_temporal": svgf.comp for this tile's pixels, right here (the default kernel only) ----
     // svgf.comp reads of the CURRENT frame only the pixel's own texels; everything else it gathers is the previous frame's.  So the
     // wave that has just finished a tile can run it for the tile: the visibility goes from LDS into the filter (rounded to the halves
@@ -1870,9 +1874,9 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     // "raygen_cost_order" for this launch (see raygen_queue_kernel): the first block sorts the previous launch's blocks before its own tiles
-    const unsigned long long t_cost0 = a.wave_cost ? __builtin_readcyclecounter() : 0ull;
-    if (a.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.cost_prev, a.order_blocks, a.order_out, reinterpret_cast<uint32_t *>(s_dyn));
-    const uint32_t block = a.block_order ? a.block_order[blockIdx.x] : blockIdx.x;
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+    const uint32_t block = a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x;
     const uint32_t tile = block * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[ROWS][kReflRays] = s_ray_all[wave];
@@ -2002,14 +2006,14 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
         if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
     }
-    if (a.wave_cost && lane == 0) a.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
+    if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
 }
 
 // The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
 // "raygen_cost_order": the cost / order pointers of a queue-kernel launch of `n_blocks` blocks of `wv` waves (see vhr_context::CostOrder).
 // 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order connects must
 // have been issued on the same stream -- the order is written and read in stream order, nothing else guards it.
-static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, RaygenArgs &a) {
+static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, CostOrderArgs &out) {
     const int mode = ctx->options[kOptRaygenCostOrder];
     if (!mode) return;
     if (co.stream != ctx->stream) {
@@ -2035,10 +2039,10 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
     }
     const uint32_t prev = co.slot, slot = prev ^ 1u;
     co.slot = slot;
-    a.wave_cost = co.cost[slot];
-    if (co.order_blocks[slot] == n_blocks && co.order_key[slot] == key) a.block_order = co.order[slot];
+    out.wave_cost = co.cost[slot];
+    if (co.order_blocks[slot] == n_blocks && co.order_key[slot] == key) out.block_order = co.order[slot];
     if (co.cost_blocks[prev] == n_blocks && co.cost_key[prev] == key) {       // the previous launch had this shape: its blocks get ordered
-        a.cost_prev = co.cost[prev]; a.order_out = co.order[prev]; a.order_blocks = n_blocks;
+        out.cost_prev = co.cost[prev]; out.order_out = co.order[prev]; out.order_blocks = n_blocks;
         co.order_blocks[prev] = n_blocks; co.order_key[prev] = key;
     } else {
         co.order_blocks[prev] = 0;
@@ -2049,7 +2053,7 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
     (void)height;
     RaygenArgs a = a_in;
-    a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
+    a.co = CostOrderArgs{};
     const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
@@ -2145,7 +2149,7 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
             {   // "raygen_cost_order" (see vhr_context::CostOrder)
                 const uint32_t wv = waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u);
                 const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
-                if (!ctx->options[kOptXcdAware] && !a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, ((tiles_x + wv - 1u) / wv) * tiles_y, wv, key, a);
+                if (!ctx->options[kOptXcdAware] && !a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, ((tiles_x + wv - 1u) / wv) * tiles_y, wv, key, a.co);
             }
 #define VHR_LAUNCH_CUT16(WV, SP, ST) launch(ctx, (raygen_queue_kernel<false, WV, true, false, SP, ST, true, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
                                             stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, cut_flags)
@@ -2215,7 +2219,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     RaygenArgs a;
     a.fuse_temporal = 0u;
     a.temporal = TemporalArgs{};
-    a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
+    a.co = CostOrderArgs{};
     a.scene = ctx->device_scene();
     a.pfd = pfd;
     a.tp = ctx->trace_params;
@@ -2281,10 +2285,10 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
             const uint32_t tiles_x = (a.col_end - a.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-            a.wave_cost = nullptr; a.block_order = nullptr; a.cost_prev = nullptr; a.order_out = nullptr; a.order_blocks = 0u;
+            a.co = CostOrderArgs{};
             if (levels >= 5u && !a.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
-                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(a.tp.reflections) << 28) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u), a);
+                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(a.tp.reflections) << 28) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u), a.co);
 #define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }
@@ -2372,6 +2376,7 @@ struct RaytracedArgs {
     uint32_t width, height;
     uint32_t row_begin, row_end;
     RayStats *stats;         // nullptr = off; covered_pixels counts the primary hits (= shadow rays)
+    CostOrderArgs co;        // "raygen_cost_order" (the queue kernel)
 };
 
 __device__ __forceinline__ uint32_t unorm8(float f);
@@ -2433,7 +2438,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     __shared__ uint8_t s_list_all[2][kReflRays];
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    const uint32_t tile = blockIdx.x * 2u + wave;
+    // "raygen_cost_order" for this launch (see raygen_queue_kernel): the first block sorts the previous launch's blocks before its own tiles
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+    const uint32_t tile = (a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x) * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[6][kReflRays] = s_ray_all[wave];
     uint8_t (&s_list)[kReflRays] = s_list_all[wave];
@@ -2537,6 +2545,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (nhit) atomicAdd(&a.stats->covered_pixels, (unsigned long long)nhit);
         if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
     }
+    if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
 }
 
 int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t width, uint32_t height, Image &out, bool alpha_test) {
@@ -2563,6 +2572,10 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         const uint32_t tiles_x = (width + 15) / 16, tiles_total = tiles_x * ((a.row_end - a.row_begin + 7) / 8);
         const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
         const bool spill = levels < ctx->bvh_depth + 1u;
+        a.co = CostOrderArgs{};
+        if (levels >= 5u && !a.stats)                      // "raygen_cost_order" for this path's launch (its own lifetimes and orders)
+            prepare_cost_order(ctx, ctx->cost_order_raytraced, (tiles_total + 1u) / 2u, 2u,
+                               (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co);
 #define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }

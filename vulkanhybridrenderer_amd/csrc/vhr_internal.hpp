@@ -408,7 +408,7 @@ struct vhr_context {
     // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in cost[f & 1], and its FIRST block, before it
     // turns to its own tile, sorts the blocks of launch f - 1 by the lifetimes in cost[(f - 1) & 1] into order[(f + 1) & 1] -- the order launch
     // f + 1 starts its blocks in.  Everything happens inside the launches the frame has anyway: no kernel, stream or event of its own.  One set for
-    // the shadow / AO queue kernel, one for the mirror-ray queue kernel (launches of different shapes).
+    // the shadow / AO queue kernel, one for the mirror-ray queue kernel, one for the raytraced path's (launches of different shapes).
     struct CostOrder {
         uint32_t *cost[2] = { nullptr, nullptr }, *order[2] = { nullptr, nullptr };
         uint32_t capacity = 0;                     // waves each of the four buffers holds
@@ -417,7 +417,7 @@ struct vhr_context {
         uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape cost[slot] was written by (0 blocks = nothing)
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
     };
-    CostOrder cost_order_raygen, cost_order_reflection;
+    CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;
