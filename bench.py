@@ -77,7 +77,103 @@ def parse():
                         "Anything set this way is listed under config.options")
     p.add_argument("--allow-degraded", action="store_true",
                    help="N > 1: fall back (per-frame descriptors / no gather) instead of failing when the transport refuses the replayed exchanges")
-    return p.parse_args()
+    p.add_argument("--dry-launch", action="store_true",
+                   help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command the launcher would start (one JSON line) and exit")
+    p.add_argument("--no-c-abi-probe", action="store_true",
+                   help="launcher only: skip the second, time-bounded child that repeats a short run through the library's own RCCL calls (--comm c_abi)")
+    p.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher only: seconds the ranks may take before the launcher ends them")
+    args = p.parse_args()
+    if args.share_device and args.backend == "nccl":
+        args.backend = "gloo"            # RCCL refuses two ranks on one device: ranks that share a GPU talk over gloo
+    return args
+
+
+def visible_devices():
+    """GPUs this process may use.  torch.cuda.device_count() reads the driver's device list without creating a HIP context
+    (the launcher must never touch the GPU: its children do)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _error_line(message, args, **extra):
+    print(json.dumps({"error": message, "n_gpus": args.gpus, "metric": "Mrays/s (unique rays) + ms/frame, Sponza 1080p RT shadows+AO+SVGF",
+                      "value": None, **extra}), flush=True)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process becomes the launcher.  It starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process, relays rank 0's
+    JSON line and returns the child's exit code.  It makes no HIP call itself.  With fewer than N devices visible (and no
+    --share-device) it prints an error line and exits 2: it never falls through to a one-GPU measurement."""
+    import subprocess
+    n = args.gpus
+    have = visible_devices()
+
+    def command(extra):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"] + extra
+    cmd = command([])
+    enough = have >= 1 and (have >= n or args.share_device)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": cmd, "n_gpus": n, "devices_visible": have, "would_run": bool(enough), "share_device": bool(args.share_device),
+                          "backend": args.backend}), flush=True)
+        return 0
+    if not enough:
+        _error_line((f"--gpus {n} but {have} device(s) visible; --share-device runs {n} ranks on one GPU over gloo (a functional check, not a measurement)")
+                    if have >= 1 else "no GPU visible (the product has no CPU path)", args, devices_visible=have)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+
+    def run(cmd, timeout):
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout)
+            return p.returncode, out, False
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(p.pid, signal.SIGTERM)          # exactly the process group started above
+                out, _ = p.communicate(timeout=20)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                out, _ = p.communicate()
+            return 124, out, True
+
+    def json_line(out):
+        for l in reversed((out or "").splitlines()):
+            if l.startswith("{"):
+                try:
+                    return json.loads(l)
+                except ValueError:
+                    continue
+        return None
+    rc, out, timed_out = run(cmd, args.launch_timeout)
+    line = json_line(out)
+    if line is None:
+        sys.stdout.write(out or "")
+        _error_line("the ranks ended without a result line" + (" (launcher timeout)" if timed_out else ""), args, child_exit_code=rc)
+        return rc or 1
+    # The measured route is torch.distributed (backend nccl == RCCL).  The library's own RCCL calls (vhr_comm_*, csrc/comm.cpp) get a
+    # second, short, time-bounded run of their own so that a fault in a route that has never met a second device cannot cost the
+    # measurement above: its outcome is reported as `c_abi_route`, never as `value`.
+    if (rc == 0 and "error" not in line and not args.no_c_abi_probe and args.comm == "auto" and args.backend == "nccl" and not args.share_device):
+        probe = command(["--comm", "c_abi", "--no-extras", "--no-cpu-baseline", "--min-seconds", "0.3"])
+        prc, pout, pto = run(probe, 240.0)
+        pl = json_line(pout)
+        if prc == 0 and pl and "error" not in pl:
+            line["c_abi_route"] = {"exchanges_through": pl["config"]["exchanges_through"], "ms_per_step": pl["ms_per_step"], "value": pl["value"],
+                                   "strips_vs_single_context": pl["config"]["strips_vs_single_context"], "exchanges_note": pl["config"].get("exchanges_note")}
+        else:
+            line["c_abi_route"] = {"error": (pl or {}).get("error", "timed out after 240 s" if pto else f"exit code {prc}"), "exit_code": prc}
+    print(json.dumps(line), flush=True)
+    return rc
 
 
 def _bounces(args):
@@ -213,6 +309,11 @@ def pmc_traffic(args):
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL's peer-to-peer setup needs on this driver (already exported on the GPU boxes)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # not under torchrun: become the launcher (before anything touches the GPU)
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": None, "n_gpus": args.gpus, "note": "nothing to launch: one rank, or already under torch.distributed.run"}), flush=True)
+        return
     import torch
     import torch.distributed as dist
     from vulkanhybridrenderer_amd import abi, scenes
@@ -221,8 +322,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        if rank == 0:
+            _error_line(f"--gpus {args.gpus} but WORLD_SIZE={world}", args)
+        raise SystemExit(2)
+    have = visible_devices()
+    if have < 1 or (have < world and not args.share_device):      # never fall through to fewer GPUs than the line would claim
+        if rank == 0:
+            _error_line(f"{world} rank(s) but {have} device(s) visible (--share-device runs the ranks on one GPU over gloo: a functional check)", args, devices_visible=have)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
     if args.share_device:
@@ -244,8 +352,14 @@ def main():
     n_frames = min(args.steps + args.warmup + (args.verify_frames if world > 1 else 0), args.max_gbuffers)
     common = dict(shadow=True, ao_spp=args.ao_spp, denoise=True, device=local_rank)
     grid = None if args.grid == "auto" else ("strips" if args.grid == "strips" else tuple(int(v) for v in args.grid.lower().split("x")))
-    # who moves the halos: the library's own RCCL calls need one GPU per rank (RCCL refuses two ranks on one device)
-    comm_mode = args.comm if args.comm != "auto" else ("c_abi" if (world > 1 and args.backend == "nccl" and not args.share_device) else "torch")
+    # who moves the halos.  auto = torch.distributed (backend nccl IS RCCL): the route every N > 1 measurement so far has used.  The
+    # library's own RCCL calls (--comm c_abi) need one GPU per rank (RCCL refuses two ranks on one device) and have not met a second
+    # device yet, so they are never chosen silently: the launcher gives them a separate, time-bounded run (launch_ranks: c_abi_route).
+    comm_mode = args.comm if args.comm != "auto" else "torch"
+    if comm_mode == "c_abi" and world > 1 and (args.share_device or args.backend != "nccl"):
+        if rank == 0:
+            _error_line("--comm c_abi needs one GPU per rank and the nccl backend", args)
+        raise SystemExit(2)
     comm_note = None
 
     def make_loop(mode):
@@ -254,20 +368,12 @@ def main():
                                allow_degraded=args.allow_degraded, grid=grid, comm=mode if world > 1 else "torch", **common)
     try:
         loop = make_loop(comm_mode)
-        up = 1
-    except Exception as e:   # noqa: BLE001
-        if not (args.comm == "auto" and comm_mode == "c_abi"):
-            raise
-        loop, up, comm_note = None, 0, f"c_abi did not come up on rank {rank}: {e!r}"
-    if world > 1 and args.comm == "auto" and comm_mode == "c_abi":      # every rank must be on the same route
-        flags = [None] * world
-        dist.all_gather_object(flags, (up, comm_note))
-        if not all(f[0] for f in flags):
-            comm_note = next(f[1] for f in flags if not f[0])
-            if loop is not None:
-                loop.close()
-            comm_mode = "torch"
-            loop = make_loop("torch")
+    except Exception as e:   # noqa: BLE001  (harness.CommBringUpError is raised on EVERY rank or on none: the ranks stay in step)
+        if rank == 0:
+            _error_line(f"the frame loop did not come up: {e!r}", args)
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     ctx = loop.ctx
     build_ms, upload_ms = ctx.build_times_ms()
     option_overrides = {}
@@ -289,18 +395,6 @@ def main():
     strip_check = None
     if world > 1 and args.verify_frames > 0:
         strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
-        if strip_check != "bit-identical" and args.comm == "auto" and comm_mode == "c_abi":
-            # the library's RCCL route has never met a second device before (rounds 1-3 had one GPU per box): if its first frames do not
-            # reproduce the single-context frame, say so and measure the torch.distributed route instead
-            comm_note = "c_abi ran but its tiles differed from the single-context frame; fell back to torch.distributed"
-            barrier()
-            loop.close()
-            comm_mode = "torch"
-            loop = make_loop("torch")
-            ctx = loop.ctx
-            for key, val in option_overrides.items():
-                ctx.set_option(key, val)
-            strip_check = verify_strips(args, scene, loop, dist, rank, world, local_rank)
         f = args.verify_frames
         barrier()
         if strip_check != "bit-identical":
@@ -463,6 +557,7 @@ def main():
         extras[f"value_frames_in_flight_{other}"] = mr
 
     if rank == 0:
+        transport = "RCCL (nccl)" if args.backend == "nccl" else "gloo (host memory)"
         valu = pmc_valu(args)
         # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles of its SIMD-32
         valu_floor_us = valu * 2.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
@@ -475,7 +570,9 @@ def main():
             "metric": "Mrays/s (unique rays) + ms/frame, Sponza 1080p RT shadows+AO+SVGF",
             "value": round(total_rays / dt_max / 1e6, 2),
             "unit": "Mrays/s",
-            "n_gpus": world,
+            # devices the ranks actually ran on: --share-device puts all of them on ONE GPU (a functional check of the tile path over gloo)
+            "n_gpus": 1 if args.share_device else world,
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4),
@@ -494,7 +591,8 @@ def main():
                 "rays_per_covered_pixel": rpp,
                 "reference_issued_rays_per_covered_pixel": rrpp,
                 "parallelism": (f"row strips x{world}" if plan.grid_cols == 1 else f"screen tiles {plan.grid_rows} x {plan.grid_cols} (rows x columns)") if world > 1 else "single GPU",
-                "exchanges_through": None if world == 1 else ("vhr_comm_* (the library's own RCCL calls, csrc/comm.cpp)" if comm_mode == "c_abi" else "torch.distributed P2P (tiling.py)"),
+                "exchanges_through": None if world == 1 else ("vhr_comm_* (the library's own RCCL calls, csrc/comm.cpp)" if comm_mode == "c_abi" else
+                                                              f"torch.distributed P2P (tiling.py), backend {transport}"),
                 "exchanges_note": comm_note,
                 "frames_in_flight": args.frames_in_flight,
                 "schedule": ("reference schedule, every dispatch executed; the fifth a-trous dispatch (output never read, hybrid_render_path.cpp:299-328) is issued on the "
@@ -508,8 +606,11 @@ def main():
                 "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo_rows, "history_halo_cols": plan.halo_cols if plan.grid_cols > 1 else None,
                 "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
-                "multi_gpu_on_hardware": None if world == 1 else "this line IS the measurement; the repository holds no earlier multi-GPU run (rounds 1-2 had one GPU)",
-                "final_gather": ("denoised strips -> rank 0 every frame (point-to-point over RCCL, overlapped with the next frame's ray tracing, "
+                # true only when every rank had a GPU of its own and the bytes moved over RCCL (xGMI between the GPUs of the node)
+                "multi_gpu_on_hardware": None if world == 1 else bool(not args.share_device and args.backend == "nccl"),
+                "multi_gpu_note": None if world == 1 else (f"{world} ranks on ONE GPU over gloo through host memory: a functional check of the tile path, not a scaling measurement"
+                                                           if args.share_device else ("one GPU per rank" + ("" if args.backend == "nccl" else ", exchanges over gloo through host memory"))),
+                "final_gather": (f"denoised tiles -> rank 0 every frame (point-to-point over {transport}, overlapped with the next frame's ray tracing, "
                                  "finished inside the timed region)" if gather_on else ("off" + (f" (disabled at run time: {gather_error})" if gather_error else ""))) if world > 1 else None,
                 "degraded": degraded or None,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "

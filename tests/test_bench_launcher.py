@@ -1,0 +1,62 @@
+"""bench.py --gpus N (N > 1) without WORLD_SIZE must start N ranks itself (a child `python -m torch.distributed.run`), never measure
+one GPU under an N-GPU label, and fail loudly when the devices are not there.  No GPU involved here: the launcher
+itself makes no HIP call, and this container has no device, which is exactly the error path."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=300, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r
+
+
+def test_dry_launch_prints_the_torchrun_command():
+    rc, line, r = run(["--gpus", "4", "--steps", "7", "--warmup", "2", "--dry-launch"])
+    assert rc == 0, r.stderr[-2000:]
+    cmd = line["dry_launch"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(BENCH)
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]           # the same arguments, minus --dry-launch
+    assert line["n_gpus"] == 4
+    import torch
+    assert line["devices_visible"] == torch.cuda.device_count()
+    assert line["would_run"] == (torch.cuda.device_count() >= 4)
+
+
+def test_missing_devices_is_an_error_not_a_one_gpu_run():
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this machine has the devices")
+    rc, line, r = run(["--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert rc == 2
+    assert line is not None and "error" in line and line["n_gpus"] == 8 and line["value"] is None
+    assert line["devices_visible"] == torch.cuda.device_count()
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1         # one line, and it is the error
+
+
+def test_under_torchrun_a_rank_without_a_device_is_an_error_too():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this machine has the devices")
+    rc, line, r = run(["--gpus", "2"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2
+    assert "error" in line and line["n_gpus"] == 2
+    rc, line, r = run(["--gpus", "2"], env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})      # --gpus and WORLD_SIZE disagree
+    assert rc == 2 and "WORLD_SIZE" in line["error"]
+
+
+def test_one_rank_needs_no_launcher():
+    rc, line, r = run(["--gpus", "1", "--dry-launch"])
+    assert rc == 0 and line["dry_launch"] is None

@@ -28,6 +28,11 @@ def alias_tensor(info):
     return torch.as_tensor(_DeviceArray(info), device="cuda")
 
 
+class CommBringUpError(RuntimeError):
+    """The library's own RCCL route (vhr_comm_*) did not come up.  Raised on EVERY rank of the job or on none, so the ranks stay in step
+    and may all take another route (or all stop)."""
+
+
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
                  atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True,
@@ -70,10 +75,7 @@ class HybridFrameLoop:
         if world > 1:
             p = self.plan
             if comm == "c_abi":          # vhr_comm_create_tiled sets the tile itself
-                ids = [lib.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                cplan = lib.tile_plan(width, height, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps)
-                self.comm = lib.Comm(self.ctx, cplan, ids[0])
+                self._bring_up_c_abi(p, atrous_steps)
             elif p.grid_cols == 1:
                 self.ctx.set_strip(p.row_begin, p.row_end, p.overlap, p.halo_rows)
             else:
@@ -97,6 +99,40 @@ class HybridFrameLoop:
                 if denoise:
                     self.ctx.set_pass_epilogue("SVGF Denoise Pass", self._comm_after_svgf)
         self.pc = self.path.push_constants() if denoise else None
+
+    def _bring_up_c_abi(self, p, atrous_steps):
+        """Collective-safe bring-up of vhr_comm_*: every rank first probes what can fail locally (RCCL loads and hands out an id, the C
+        planner accepts this rank's tile), the ranks exchange those verdicts, and only if all are good does rank 0's id travel and
+        ncclCommInitRank run.  After the create call the verdicts are exchanged once more.  Any failure raises CommBringUpError on all
+        ranks (with the context closed), never on one rank alone while the others wait in a collective."""
+        dist, rank, world = self.dist, self.rank, self.world
+        uid, cplan, why = None, None, None
+        try:
+            uid = lib.Comm.unique_id()                       # loads librccl.so, resolves its symbols, ncclGetUniqueId
+            cplan = lib.tile_plan(self.W, self.H, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps)
+            if cplan is None:
+                why = "the C planner refuses this rank's tile"
+        except Exception as e:   # noqa: BLE001
+            why = repr(e)
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, why)
+        bad = [(r, w) for r, w in enumerate(verdicts) if w]
+        if not bad:
+            ids = [uid if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                self.comm = lib.Comm(self.ctx, cplan, ids[0])
+            except Exception as e:   # noqa: BLE001
+                why = repr(e)
+            dist.all_gather_object(verdicts, why)
+            bad = [(r, w) for r, w in enumerate(verdicts) if w]
+        if bad:
+            if self.comm:
+                self.comm.destroy()
+                self.comm = None
+            self.path.destroy()
+            self.ctx.close()
+            raise CommBringUpError("; ".join(f"rank {r}: {w}" for r, w in bad))
 
     # ---- stand-in for the raster G-buffer stage ----
     def _precompute_gbuffers(self):
