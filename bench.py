@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate -- the level the (cache-resident) tree is read from
 ATROUS_BYTES_PER_PIXEL = 24      # read integrated 8 + normals/id 8, write 8
 TEMPORAL_BYTES_PER_PIXEL = 52    # normals 8 + motion 8 + current 4 + previous normals 8 + history 8 + moments 4, integrated 8 + moments 4 out
 
@@ -276,6 +277,38 @@ def pmc_address_unit(args, raygen_ms):
         return None
 
 
+def reflection_block(ctx, loop, frame_index, sync):
+    """`traversal_reflection`: the mirror-ray launch's own counters and time (reflection_queue_kernel: raygen.rgen:59-65 + reflection_hit.rchit).
+    One untimed frame with the in-kernel statistics on, eight more with an event pair on the launch."""
+    ctx.set_kernel_timing(["reflection"])
+    ctx.kernel_time("reflection", reset=True)
+    for i in range(frame_index, frame_index + 8):
+        loop.frame(i)
+    sync()
+    ms, n = ctx.kernel_time("reflection")
+    ctx.set_kernel_timing(False)
+    ctx.set_ray_statistics(True)
+    loop.frame(frame_index + 8)
+    sync()
+    st = ctx.reflection_statistics()
+    ctx.set_ray_statistics(False)
+    if not n or not st["rays"]:
+        return None
+    launch_ms = ms / n
+    visits, tests, rays = st["node_visits"], st["triangle_tests"], st["rays"]
+    gbs = (visits * 48 + tests * 48) / launch_ms / 1e6            # 48-byte nodes (three loads per visit), 48-byte triangle records
+    return {"kernel": "reflection_queue_kernel (closest-hit walk of the mirror rays on the 48-byte nodes + reflection_hit.rchit per tile)",
+            "avg_launch_ms": round(launch_ms, 4), "rays": int(rays), "second_bounce_rays": int(st["second_bounce_rays"]),
+            "mrays_per_s": round(rays / launch_ms / 1e3, 1),
+            "node_visits_per_ray": round(visits / rays, 2), "triangle_tests_per_ray": round(tests / rays, 2), "leaf_visits_per_ray": round(st["leaf_visits"] / rays, 2),
+            "active_lane_utilisation": round(st["active_lane_utilisation"], 3),
+            "refills_per_wave": round(st["refills"] / max(1, st["waves"]), 2),
+            "walk_share_of_wave_lifetime": round(st["cycles_walk"] / max(1, st["cycles_total"]), 3),
+            "effective_traversal_gbs": round(gbs, 1), "l2_frac": round(gbs / L2_PEAK_GBS, 4),
+            "note": "utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops); l2_frac = effective_traversal_gbs / the L2's 34.5 TB/s "
+                    "(MI355X_MICROARCH.md: the tree is cache resident, HBM is not the level it is read from)"}
+
+
 def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
     """Blocks of exactly `steps` frames, each bracketed by barrier + synchronize, until `min_seconds` have been measured.
     Returns (block seconds, next frame index)."""
@@ -461,6 +494,10 @@ def main():
     barrier()
     ray_stats, trav_stats = ctx.ray_statistics(), ctx.traversal_statistics()
     ctx.set_ray_statistics(False)
+    refl_block = None
+    if _bounces(args) and world == 1:
+        refl_block = reflection_block(ctx, loop, f, barrier)
+        f += 9
     y0, y1 = loop.owned_rows()
     # pixels an a-trous launch computes, averaged over the 5 launches of a frame: strips / tiles shrink the overlap per iteration
     # (tiling.atrous_output_extent: 28, 24, 16, 0, 0 of E = 30); at N = 1 this is W x H
@@ -504,7 +541,7 @@ def main():
     # always-on mirror ray, and the same workload with two frames in flight ----
     extras = {}
     if world == 1 and not args.no_extras:
-        def one(options=None, device_k0=None, **kw):
+        def one(options=None, device_k0=None, refl_out=None, **kw):
             lp = HybridFrameLoop(scene, W, H, n_frames, **common, **kw)
             for key, val in {**option_overrides, **(options or {})}.items():
                 lp.ctx.set_option(key, val)
@@ -521,15 +558,19 @@ def main():
             for i in range(args.warmup + 1):
                 lp.frame(i)
             first = args.warmup + 1
-            ts, _ = time_blocks(lp, sync, first, args.steps, min(args.min_seconds, 0.5))
+            ts, nf = time_blocks(lp, sync, first, args.steps, min(args.min_seconds, 0.5))
             b = int(np.argsort(ts)[len(ts) // 2])                        # the median block and its own rays
             rays = sum(lp.rays_in_frame(i) for i in range(first + b * args.steps, first + (b + 1) * args.steps))
+            if refl_out is not None:
+                refl_out["block"] = reflection_block(lp.ctx, lp, nf, sync)
             lp.close()
             return round(ts[b] / args.steps * 1e3, 4), round(rays / ts[b] / 1e6, 2)
         if not _bounces(args):
-            ms, mr = one(reflections=1, frames_in_flight=args.frames_in_flight)
+            ro = {}
+            ms, mr = one(reflections=1, frames_in_flight=args.frames_in_flight, refl_out=ro)
             extras["ms_per_step_with_mirror_ray"] = ms                   # raygen.rgen:59-65 always traces it
             extras["value_with_mirror_ray"] = mr
+            extras["traversal_reflection"] = ro.get("block")             # the mirror-ray launch of THAT frame
         # the reference's fifth a-trous iteration is dead work (its output is overwritten before anything reads it); the
         # timed region above executes it like the reference does, this is the same frame with it elided (opt-in "svgf_elide_unread")
         ms, mr = one(options={"svgf_elide_unread": 1}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
@@ -557,6 +598,8 @@ def main():
         extras[f"value_frames_in_flight_{other}"] = mr
 
     if rank == 0:
+        node_bytes = 32 if option_overrides.get("compact_nodes", 1) else 48
+        trav_gbs = (trav_stats["node_visits"] * node_bytes + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6
         transport = "RCCL (nccl)" if args.backend == "nccl" else "gloo (host memory)"
         valu = pmc_valu(args)
         # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles of its SIMD-32
@@ -663,7 +706,10 @@ def main():
                 "active_lane_utilisation": round(trav_stats["active_lane_utilisation"], 3),
                 "node_visits_per_ray": round(trav_stats["node_visits"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
                 "triangle_tests_per_ray": round(trav_stats["triangle_tests"] / max(1, ray_stats["covered_pixels"] * (1 + args.ao_spp)), 2),
-                "effective_traversal_gbs": round((trav_stats["node_visits"] * 64 + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6, 1),
+                # bytes the walk asks for: a 32-byte half-precision node per visit (48-byte nodes with compact_nodes 0), a 48-byte record per triangle test
+                "effective_traversal_gbs": round(trav_gbs, 1),
+                # against the level the cache-resident tree is read from (L2 ~34.5 TB/s), not HBM
+                "l2_frac": round(trav_gbs / L2_PEAK_GBS, 4),
                 "stack_overflows": int(ray_stats["stack_overflows"]),
                 "address_unit": pmc_address_unit(args, raygen_ms),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
@@ -677,6 +723,8 @@ def main():
                            "reflection": round(kt["reflection"][0] / max(1, kt["reflection"][1]) * 1e3, 2) if kt["reflection"][1] else None},
             "passes_ms": passes, "passes_ms_median": passes_median, "passes_ms_p95": passes_p95,
         }
+        if refl_block is not None:
+            out["traversal_reflection"] = refl_block
         out.update(extras)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, tp, args.cpu_frames, rpp)

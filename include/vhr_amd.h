@@ -512,6 +512,12 @@ int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64
  * loops (node steps + triangle tests) counted once per wave, i.e. by the slowest lane of each round.
  * Active-lane utilisation of the traversal loops = (out[0] + out[2]) / (64 * out[3]). */
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
+/* The same for the mirror-ray launch of the last vhr_trace_rays (raygen.rgen:59-65 + reflection_hit.rchit; the queue kernel, statistics
+ * enabled): out[0] = rays walked (first + second bounce), out[1] = second-bounce rays among them, out[2] = inner-node visits summed over
+ * lanes, out[3] = leaf visits, out[4] = ray/triangle tests, out[5] = trips of the two inner loops counted once per wave (lane
+ * utilisation = (out[2] + out[4]) / (64 * out[5])), out[6] = queue refills, out[7] = waves, out[8] = s_memtime ticks summed over the
+ * waves' lifetimes, out[9] = of those, inside the walks (the rest is ray set-up and shading). */
+int vhr_get_reflection_statistics(vhr_context *ctx, uint64_t out[10]);
 
 /* Where the waves of the last work-queue raygen launch spent their time (statistics enabled; s_memtime ticks summed
  * over waves): out[0] = whole kernel, out[1] = per-tile pixel setup, out[2] = queue refills (ray generation),

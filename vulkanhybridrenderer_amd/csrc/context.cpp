@@ -116,6 +116,7 @@ int vhr_context::sync_streams() {
     if (pending_end) vhr::launch_stamp(this);          // the end of the last pass, before the host waits for it
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
     if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
+    if (mirror_stream && hipStreamSynchronize(mirror_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(mirror stream) failed");
     side_pending = false;
     if (hipStreamSynchronize(stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize failed");     // (a null handle is the default stream)
     return VHR_OK;
@@ -224,7 +225,7 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, info->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
-    if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), sizeof(RayStats)) != hipSuccess ||
+    if (upload_srgb_lut(lut) != 0 || hipMalloc(reinterpret_cast<void **>(&ctx->d_ray_stats), 2 * sizeof(RayStats)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_tile_counter), sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), sizeof(vhr::PassStampPair) * vhr::kMaxStampedPasses) != hipSuccess ||
         hipMemset(ctx->d_stamps, 0, sizeof(vhr::PassStampPair) * vhr::kMaxStampedPasses) != hipSuccess) {
@@ -259,6 +260,9 @@ void vhr_destroy(vhr_context *ctx) {
     vhr_graph_destroy_resources(ctx);
     if (ctx->front_stream) hipStreamDestroy(ctx->front_stream);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->mirror_stream) hipStreamDestroy(ctx->mirror_stream);
+    if (ctx->mirror_ready) hipEventDestroy(ctx->mirror_ready);
+    if (ctx->mirror_done) hipEventDestroy(ctx->mirror_done);
     if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
     if (ctx->side_done) hipEventDestroy(ctx->side_done);
     hipFree(ctx->d_stamps);
@@ -586,7 +590,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal", "raygen_cost_order" };
+                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal", "raygen_cost_order", "reflection_concurrent" };
     static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
     for (int i = 0; i < vhr::kOptCount; ++i)
         if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
@@ -623,6 +627,15 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     out[0] = ctx->h_ray_stats.node_visits; out[1] = ctx->h_ray_stats.leaf_visits;
     out[2] = ctx->h_ray_stats.triangle_tests; out[3] = ctx->h_ray_stats.wave_iterations;
+    return VHR_OK;
+}
+
+int vhr_get_reflection_statistics(vhr_context *ctx, uint64_t out[10]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
+    const RayStats &r = ctx->h_refl_stats;
+    out[0] = r.unique_rays; out[1] = r.second_bounce_rays; out[2] = r.node_visits; out[3] = r.leaf_visits; out[4] = r.triangle_tests;
+    out[5] = r.wave_iterations; out[6] = r.refills; out[7] = r.waves; out[8] = r.cycles_total; out[9] = r.cycles_nodes;
     return VHR_OK;
 }
 

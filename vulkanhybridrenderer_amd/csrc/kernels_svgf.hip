@@ -105,13 +105,6 @@ int launch_svgf_temporal(vhr_context *ctx, const vhr_per_frame_data &pfd, const 
 // ---------------------------------------------------------------------------------------------
 #pragma clang fp contract(fast)
 
-// Knock-out builds of the streaming a-trous kernel (timing experiments only, results are wrong by construction): -DVHR_ATROUS_KO=n
-// removes one ingredient of the tap loop -- 1 the two v_exp_f32, 2 the pow(., 128) chain, 3 the id compare, 4 the variance sums,
-// 5 the LDS tap reads, 6 the taps altogether, 7 the whole luminance term, 8 the whole normal / id weight.  profiles/r3_atrous_knockouts.txt
-#ifndef VHR_ATROUS_KO
-#define VHR_ATROUS_KO 0
-#endif
-
 __device__ __forceinline__ float pow128(float x) {      // max(0, pow(x, 128)); pow of x <= 0 defined as 0
     x = fmaxf(x, 0.0f);
     x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
@@ -178,169 +171,42 @@ __global__ __launch_bounds__(kSvgfBlockX *kSvgfBlockY) void svgf_atrous_kernel(c
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4, LDS-tiled form.
+// K4, the default: comb tiles in LDS, weights in the exponent.
 //
-// The direct kernel above issues 58 cached loads per pixel and is bound by the CU's L1 (TCP) line rate
-// (PMC: 33 M line accesses per 1080p launch ~ 54 us at one line per clock per CU), not by HBM.  An a-trous
-// pass with step s only ever combines pixels that are s apart, so a block here owns a COMB of rows:
-// output rows y0 + k*s (k = 0..R-1) over 64 consecutive columns.  It stages rows y0 + (k-2..R+1)*s over columns
-// [x0 - 2s, x0 + 64 + 2s) of both inputs into LDS once -- (R+4)/R * (64+4s)/64 = 1.3x .. 2.5x the compulsory
-// bytes instead of 25x -- plus three rows of the variance channels per output row for the 3x3 pre-filter
-// (svgf_atrous_filter.comp:17-38), and every one of the 25 taps of every output is then an LDS read
-// (ds_read_b64, lanes on consecutive 8-byte slots: conflict free).  Different blocks take the s row phases.
-//
-// While staging, the normals/id texel is preprocessed once per texel instead of once per tap: the object id
-// is truncated like int() (svgf_atrous_filter.comp:57,83) and kept as a half next to nz, out-of-image texels
-// get an id no pixel can have (a NaN pattern) so that their weight is exactly 0, which is what the shader's
-// `continue` amounts to.  The normal dot product uses v_dot2_f32_f16 on the packed halves.
+// The direct kernel above issues 58 cached loads per pixel and is bound by the CU's L1 line rate, not by HBM.  An a-trous pass with
+// step s only ever combines pixels that are s apart, so a workgroup here owns a COMB of rows: output rows y0 + k*s (k = 0..R-1) over
+// 64 consecutive columns (different workgroups take the s row phases).  It stages rows y0 + (k-2..R+1)*s over columns
+// [x0 - 2s, x0 + 64 + 2s) of both inputs into LDS once -- (R+4)/R * (64+4s)/64 = 1.3x .. 4x the compulsory bytes instead of 25x -- and
+// every one of the 24 taps of every output is then two LDS reads (ds_read_b128 + ds_read_b32, conflict free).
+//   * All of a tile's global loads are issued up front into registers (32-bit byte offsets on the uniform image bases; a tile whose
+//     halo lies inside the image -- nine in ten at 1080p, a workgroup-uniform test -- loads without bounds tests), converted ONCE per
+//     texel and parked in LDS: shadow / AO as fp32, the two variances as the halves they are (they enter the sums through
+//     v_fma_mix_f32), (nx, ny) as halves for v_dot2, and one word with nz (high half) and the truncated object id (low half: int(w)
+//     of svgf_atrous_filter.comp:57,83 as a half; out-of-image texels get a NaN pattern no id equals, so their weight is exactly 0,
+//     which is what the shader's `continue` amounts to).  20 bytes per staged texel: eight workgroups per CU at every step size.
+//   * The 3x3 variance pre-filter (:17-38, separable) reads three rows per output pixel straight from memory (they are not comb
+//     rows) and takes the horizontal neighbours from the adjacent lanes (DPP wave shifts; the tile's two edge lanes load theirs).
+//   * The weight of a tap leaves the exponent only once.  The shader's
+//       w_ch = k * max(0, n.n')^128 * [id == id'] * exp(-|l - l'| / (4 sqrt(var) + 1e-6))                      (:40-51, 86-89)
+//     is evaluated as exp2(L - |l - l'| * inv_ch) with L = 128 * log2(max(0, n.n')) + log2(k), or -inf where the ids differ
+//     (exp2(-inf) = 0 and log2(0) = -inf: the zeros the product form gives).  On this chip a packed fp32 instruction occupies the
+//     SIMD for 4 cycles, a plain one for 2, a transcendental for 8 (profiles/r3_atrous_knockouts.txt: the kernel's time follows lane
+//     operations): one v_log_f32 + one v_fma_f32 stand for the 7 squarings, the kernel constant and the product with the luminance
+//     weight.  v_log_f32 / v_exp_f32 are 1-ulp instructions; 128 * log2(x) moves a weight by <= 1e-5 relative, far below the fp16
+//     step of the output (tests/test_gpu_svgf.py: <= 2 fp16 steps per dispatch, RMSE <= 1e-4 per frame).
+//   * One tile per workgroup, tiles dealt to the XCDs in contiguous bands (xcd_remap: neighbouring tiles share halo texels in one L2;
+//     it halved the HBM-side traffic: profiles/traffic.json).
+// Same operation order per channel as svgf_atrous_filter.comp:72-94, fp32 sums.  The fused stores: `out2` = a blit of the output
+// (hybrid_render_path.cpp:310-315, 322-325), `normals_out` = the blit of the normals image (:321) for the pixels this launch computes.
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ half2_t as_half2(uint32_t u) { return *reinterpret_cast<const half2_t *>(&u); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 constexpr int kTileX = 64;
 constexpr uint32_t kInvalidId = 0xffffu;     // NaN half: never equal to a truncated object id
-
-template <int STEP, int R>
-__global__ __launch_bounds__(256) void svgf_atrous_tiled_kernel(const AtrousArgs a, const Stamps st) {
-    vhr_stamp(st);
-    constexpr int TW = kTileX + 4 * STEP;            // staged columns
-    constexpr int TH = R + 4;                        // staged comb rows
-    constexpr int VW = kTileX + 2;                   // variance columns
-    __shared__ uint2 s_in[TH][TW];
-    __shared__ uint2 s_nm[TH][TW];
-    __shared__ uint32_t s_var[R][3][VW];
-    const int W = int(a.width), H = int(a.height);
-    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
-    const int x0 = int(blockIdx.x) * kTileX;
-    const int group = int(blockIdx.y) / STEP, phase = int(blockIdx.y) - group * STEP;
-    const int y0 = int(a.row_begin) + group * (R * STEP) + phase;
-    const int tid = int(threadIdx.x);
-
-    // ---- stage the comb tile ----
-    for (int i = tid; i < TH * TW; i += 256) {
-        const int kk = i / TW, c = i - kk * TW;
-        const int sx = x0 - 2 * STEP + c, sy = y0 + (kk - 2) * STEP;
-        uint2 vin = make_uint2(0u, 0u), vnm = make_uint2(0u, kInvalidId << 16);
-        if (sx >= 0 && sx < max_x && sy >= 0 && sy < max_y) {
-            const size_t sidx = size_t(sy) * W + sx;
-            vin = a.in[sidx];
-            const uint2 n = a.normals[sidx];
-            // int(w) as a half: trunc toward zero, -0 folded into +0 (both are int 0)
-            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
-            uint32_t idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
-            if ((idb & 0x7fffu) == 0u) idb = 0u;
-            if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;          // NaN: int(NaN) = 0 in the oracle; keep it unequal to real ids
-            vnm = make_uint2(n.x, (n.y & 0xffffu) | (idb << 16));
-        }
-        s_in[kk][c] = vin;
-        s_nm[kk][c] = vnm;
-    }
-    for (int i = tid; i < R * 3 * VW; i += 256) {
-        const int k = i / (3 * VW), rem = i - k * (3 * VW), j = rem / VW, c = rem - j * VW;
-        const int sx = x0 - 1 + c, sy = y0 + k * STEP + (j - 1);
-        uint32_t v = 0u;
-        if (sx >= 0 && sx < max_x && sy >= 0 && sy < max_y) v = a.in[size_t(sy) * W + sx].y;      // .zw = the two variances
-        s_var[k][j][c] = v;
-    }
-    __syncthreads();
-
-    const int tx = tid & 63, ty = tid >> 6;
-    const int cx = x0 + tx;
-#pragma unroll 1
-    for (int k = ty; k < R; k += 4) {
-        const int cy = y0 + k * STEP;
-        if (uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
-        const uint2 pin = s_in[k + 2][tx + 2 * STEP];
-        const uint2 pnm = s_nm[k + 2][tx + 2 * STEP];
-        const f4 p = unpack_rgba16f(pin);
-        const half2_t np_xy = as_half2(pnm.x);
-        const half2_t np_z0 = as_half2(pnm.y & 0xffffu);            // (nz, 0): the id lane must not enter the dot product
-        const uint32_t idp = pnm.y >> 16;
-
-        float var_s = 0.0f, var_a = 0.0f;                                                   // :17-38
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float w = (c == 1 ? 0.5f : 0.25f) * (j == 1 ? 0.5f : 0.25f);
-                const float2 q = unpack_rg16f(s_var[k][j][tx + c]);
-                var_s += w * q.x;
-                var_a += w * q.y;
-            }
-        const float inv_s = __frcp_rn(4.0f * sqrtf(var_s) + 1e-6f) * 1.44269504088896341f;  // :48-50, log2(e) folded in
-        const float inv_a = __frcp_rn(4.0f * sqrtf(var_a) + 1e-6f) * 1.44269504088896341f;
-
-        float sw_s = 1.0f, sw_a = 1.0f;                                                     // :70-71
-        float s0 = p.x, s1 = p.y, s2 = p.z, s3 = p.w;
-#pragma unroll
-        for (int y = -2; y <= 2; ++y)
-#pragma unroll
-            for (int x = -2; x <= 2; ++x) {                                                 // :72-94
-                if (x == 0 && y == 0) continue;
-                const uint2 qin = s_in[k + 2 + y][tx + 2 * STEP + x * STEP];
-                const uint2 qnm = s_nm[k + 2 + y][tx + 2 * STEP + x * STEP];
-                const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
-                const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
-                const float kernel = kx * ky;                                               // :62-68
-                float d = __builtin_amdgcn_fdot2(np_z0, as_half2(qnm.y), 0.0f, false);
-                d = __builtin_amdgcn_fdot2(np_xy, as_half2(qnm.x), d, false);              // :44-46
-                const float wn = pow128(d);
-                const float w = ((qnm.y >> 16) == idp) ? kernel * wn : 0.0f;                // :40-42, :87
-                const f4 q = unpack_rgba16f(qin);
-                const float wx = w * __builtin_amdgcn_exp2f(-(fabsf(p.x - q.x) * inv_s));   // :88
-                const float wy = w * __builtin_amdgcn_exp2f(-(fabsf(p.y - q.y) * inv_a));   // :89
-                sw_s += wx; sw_a += wy;                                                     // :91
-                s0 += wx * q.x; s1 += wy * q.y; s2 += (wx * wx) * q.z; s3 += (wy * wy) * q.w;   // :92
-            }
-        const float rs = __frcp_rn(sw_s), ra = __frcp_rn(sw_a);
-        const uint2 texel = pack_rgba16f(s0 * rs, s1 * ra, s2 * (rs * rs), s3 * (ra * ra));            // :97-101
-        a.out[size_t(cy) * W + cx] = texel;
-        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
-        if (a.normals_out) a.normals_out[size_t(cy) * W + cx] = a.normals[size_t(cy) * W + cx];
-    }
-}
-
-template <int STEP, int R>
-static void launch_atrous_tiled(vhr_context *ctx, const AtrousArgs &a) {
-    const uint32_t rows = a.row_end - a.row_begin;
-    const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
-    const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
-    launch(ctx, (svgf_atrous_tiled_kernel<STEP, R>), grid, dim3(256), 0, a);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4, LDS-tiled + packed-math form (the default).
-//
-// The tiled kernel above is bound by VALU issue (PMC: ~800 wave instructions per pixel, ~34 per tap), not by
-// LDS or HBM.  This form keeps its comb tiling and halves the per-tap instruction count:
-//   * the staged texel is converted ONCE: shadow/AO as fp32 (so the taps need no v_cvt), the two variances stay
-//     packed halves and enter the sums through v_fma_mix_f32, nz (fp32) and the truncated id (16 bit) sit in side arrays
-//     (an extra ds_read is free for a VALU-bound kernel; it replaces the shift/xor of the packed word);
-//   * shadow and AO are one float2: difference, scale, weight, both sums -> v_pk_add/mul/fma_f32;
-//   * taps are processed in pairs so the 7 squarings of pow(n.n', 128) and the B3 kernel factor are v_pk_mul_f32.
-// Same operation order per channel as svgf_atrous_filter.comp:72-94, fp32 throughout.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
-
-// One row of the two variance channels, 3-tap vertical Gaussian (svgf_atrous_filter.comp:17-38 is separable:
-// its weights are the outer product of (1/4, 1/2, 1/4)); taps outside the image are skipped = contribute 0.
-__device__ __forceinline__ f2v variance_column(const AtrousArgs &a, int x, int y, int max_x, int max_y) {
-    f2v acc = f2v{ 0.0f, 0.0f };
-    if (x >= 0 && x < max_x) {
-#pragma unroll
-        for (int j = -1; j <= 1; ++j) {
-            const int sy = y + j;
-            if (sy >= 0 && sy < max_y) {
-                const float2 q = unpack_rg16f(a.in[size_t(sy) * a.width + x].y);            // .zw = the two variances
-                const float w = j == 0 ? 0.5f : 0.25f;
-                acc += f2v{ w * q.x, w * q.y };
-            }
-        }
-    }
-    return acc;
-}
 
 // lane i receives lane i-1's (i+1's) value; lane 0 (63) keeps `edge`
 __device__ __forceinline__ float wave_shr1(float edge, float v) {
@@ -351,176 +217,19 @@ __device__ __forceinline__ float wave_shl1(float edge, float v) {
 }
 
 template <int STEP, int R>
-__global__ __launch_bounds__(256) void svgf_atrous_packed_kernel(const AtrousArgs a, const Stamps st) {
+__global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total, const Stamps st) {
     vhr_stamp(st);
     constexpr int TW = kTileX + 4 * STEP;            // staged columns
     constexpr int TH = R + 4;                        // staged comb rows
-    constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block (TW <= 128 columns each)
-    static_assert(TW <= 256, "one thread per staged column");
-    __shared__ uint4 s_a[TH][TW];                    // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
-    __shared__ float s_nz[TH][TW];                   // nz (fp32: its product with the centre's nz is one v_mul)
-    __shared__ uint16_t s_id[TH][TW];                // int(id) as a half bit pattern; kInvalidId outside the image
-    const int W = int(a.width), H = int(a.height);
-    const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
-    const int x0 = int(blockIdx.x) * kTileX;
-    const int group = int(blockIdx.y) / STEP, phase = int(blockIdx.y) - group * STEP;
-    const int y0 = int(a.row_begin) + group * (R * STEP) + phase;
-    const int tid = int(threadIdx.x);
-    const int tx = tid & 63, ty = tid >> 6;
-    const int cx = x0 + tx;
-
-    // ---- the 3x3 variance pre-filter of this thread's output pixels (:17-38): vertical taps are three coalesced
-    // row reads per lane, horizontal taps come from the neighbouring lanes (DPP), the two tile-edge lanes also read
-    // the column just outside.  Issued before the tile staging so that their latency hides behind it. ----
-    f2v var_p[(R + 3) / 4];
-#pragma unroll
-    for (int kq = 0; kq < (R + 3) / 4; ++kq) {
-        const int cy = y0 + (ty + 4 * kq) * STEP;
-        const f2v own = variance_column(a, cx, cy, max_x, max_y);
-        f2v edge = f2v{ 0.0f, 0.0f };
-        if (tx == 0 || tx == 63) edge = variance_column(a, tx == 0 ? cx - 1 : cx + 1, cy, max_x, max_y);
-        const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
-        const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
-        var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
-    }
-
-    // ---- stage the comb tile: thread = (column, row within the pass) ----
-    {
-        const int c = tid % TW, r0 = tid / TW;
-        const int sx = x0 - 2 * STEP + c;
-        const bool col_ok = tid < PASS * TW && sx >= 0 && sx < max_x;
-#pragma unroll
-        for (int kk0 = 0; kk0 < TH; kk0 += PASS) {
-            const int kk = kk0 + r0;
-            const int sy = y0 + (kk - 2) * STEP;
-            uint4 va = make_uint4(0u, 0u, 0u, 0u);
-            float nz = 0.0f;
-            uint32_t idb = kInvalidId;
-            if (col_ok && sy >= 0 && sy < max_y && kk < TH) {
-                const size_t sidx = size_t(sy) * W + sx;
-                const uint2 vin = a.in[sidx];
-                const uint2 n = a.normals[sidx];
-                const float2 xy = unpack_rg16f(vin.x);
-                va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
-                nz = float(as_half2(n.y).x);
-                // int(w) as a half: trunc toward zero, -0 folded into +0 (both are int 0)
-                _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
-                idb = uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
-                if ((idb & 0x7fffu) == 0u) idb = 0u;
-                if ((idb & 0x7fffu) > 0x7c00u) idb = 0x7e00u;      // NaN: int(NaN) = 0 in the oracle; keep it unequal to real ids
-            }
-            if (tid < PASS * TW && kk < TH) {
-                s_a[kk][c] = va;
-                s_nz[kk][c] = nz;
-                s_id[kk][c] = uint16_t(idb);
-            }
-        }
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int kq = 0; kq < (R + 3) / 4; ++kq) {
-        const int k = ty + 4 * kq;
-        const int cy = y0 + k * STEP;
-        if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
-        const uint4 pa = s_a[k + 2][tx + 2 * STEP];
-        const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
-        const float2 p_zw = unpack_rg16f(pa.z);
-        const half2_t np_xy = as_half2(pa.w);
-        const float np_z = s_nz[k + 2][tx + 2 * STEP];
-        const uint32_t idp = s_id[k + 2][tx + 2 * STEP];
-        // :48-50, log2(e) folded in.  v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the correctly rounded expansions (~10
-        // instructions each): the quotient only scales the exponent of a weight
-        const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
-                             __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
-
-        f2v sw = f2v{ 1.0f, 1.0f };                                                         // :70-71
-        f2v s01 = p_xy;
-        float s2 = p_zw.x, s3 = p_zw.y;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {                                                       // :72-94, four taps per trip
-            uint4 qa[4];
-            f2v d[2];
-            bool same[4];
-            float kern[4];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                          // skip the centre (:77)
-                const int y = idx / 5 - 2, x = idx % 5 - 2;
-                const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
-                qa[h] = s_a[row][col];
-                const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
-                const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
-                kern[h] = kx * ky;                                                          // :62-68
-                // n.n' = nz*nz' (exact in fp32: both are widened halves) + v_dot2 over the packed (nx, ny)
-                float dd = np_z * s_nz[row][col];
-                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);          // :44-46
-                d[h >> 1][h & 1] = fmaxf(dd, 0.0f);
-                same[h] = uint32_t(s_id[row][col]) == idp;                                  // :40-42
-            }
-            // pow(., 128): two packed chains of 7 squarings, interleaved so that neither waits on its own result
-#pragma unroll
-            for (int sq = 0; sq < 7; ++sq) { d[0] *= d[0]; d[1] *= d[1]; }
-            d[0] *= f2v{ kern[0], kern[1] };
-            d[1] *= f2v{ kern[2], kern[3] };
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const float w = same[h] ? d[h >> 1][h & 1] : 0.0f;                          // :87
-                const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
-                const f2v tt = (p_xy - q_xy) * inv;
-                const f2v e = f2v{ __builtin_amdgcn_exp2f(-fabsf(tt.x)), __builtin_amdgcn_exp2f(-fabsf(tt.y)) };   // :88-89
-                const f2v w2 = e * f2v{ w, w };
-                sw += w2;                                                                   // :91
-                s01 = __builtin_elementwise_fma(w2, q_xy, s01);                             // :92
-                const f2v wq = w2 * w2;
-                const half2_t q_zw = as_half2(qa[h].z);
-                s2 = fmaf(wq.x, float(q_zw.x), s2);
-                s3 = fmaf(wq.y, float(q_zw.y), s3);
-            }
-        }
-        const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
-        const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
-        a.out[size_t(cy) * W + cx] = texel;
-        if (a.out2) a.out2[size_t(cy) * W + cx] = texel;
-        if (a.normals_out) a.normals_out[size_t(cy) * W + cx] = a.normals[size_t(cy) * W + cx];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4, streaming form of the packed kernel (the default): persistent workgroups walk over the comb tiles and fetch
-// the NEXT tile's texels into registers while the taps of the current tile run out of LDS.  The one-tile-per-block
-// form above launches ~2 rounds of resident blocks that all load, then all compute: its global-load phases are
-// exposed (PMC: VALU busy 75 %).  Same arithmetic, same tile geometry; only the schedule differs.
-// ---------------------------------------------------------------------------------------------
-// ONE_TILE: the grid has a workgroup per tile (the default launch): no tile loop, and the prefetch registers die before the
-// taps start instead of carrying the next tile through them.
-// LOGW (r3, "atrous_variant" 5, the default): the weight of a tap leaves the exponent only once.  The shader's
-//   w_ch = k * max(0, n.n')^128 * [id == id'] * exp(-|l - l'| / (4 sqrt(var) + 1e-6))                 (svgf_atrous_filter.comp:40-51, 86-89)
-// is evaluated as exp2(L - |l - l'| * inv_ch) with L = 128 * log2(max(0, n.n')) + log2(k), or -inf where the ids differ (exp2(-inf) = 0,
-// log2(0) = -inf: the same zeros the product form gives).  Per tap that is one v_log_f32 and one v_fma_f32 for the 3.5 + 0.5 + 1 packed
-// multiplies of the squaring chain, the kernel constant and e * w, and two v_fma_f32 (|.| and sign as operand modifiers) for the packed
-// multiply by inv.  On this chip a packed fp32 instruction occupies the SIMD for 4 cycles, a plain one for 2, a transcendental for 8
-// (profiles/r3_atrous_knockouts.txt: the kernel's time follows lane operations, not instructions): 34 instead of 39 units per tap.
-// v_log_f32 / v_exp_f32 are 1-ulp instructions; 128 * log2(x) moves a weight by <= ~1e-5 relative, far below the fp16 step of the output.
-template <int STEP, int R, bool ONE_TILE, bool LOGW = false>
-__global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArgs a, const uint32_t tiles_x, const uint32_t tiles_total,
-                                                                 const uint32_t xcd_aware, const Stamps st) {
-    vhr_stamp(st);
-    constexpr int TW = kTileX + 4 * STEP;            // staged columns
-    constexpr int TH = R + 4;                        // staged comb rows
-    constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the block
-    constexpr int NP = (TH + PASS - 1) / PASS;       // passes = texels prefetched per thread
+    constexpr int PASS = 256 / TW > 0 ? 256 / TW : 1;   // comb rows staged per pass of the workgroup
+    constexpr int NP = (TH + PASS - 1) / PASS;       // passes = texels loaded per thread
     constexpr int NK = (R + 3) / 4;                  // output pixels per thread
     static_assert(TW <= 256, "one thread per staged column");
     // (a plain 16-byte vector type: the tap's texel is then ONE ds_read_b128; as HIP's uint4 struct the compiler fetched it as
-    // ds_read2_b64 = two 8-byte reads at a 16-byte lane stride, each a two-way bank conflict: 44.4 -> 43.5 us.  Packing nz and the id
-    // into one word as well -- two LDS reads per tap instead of three -- was measured slower, 44.8 us: the id compare then needs a mask)
+    // ds_read2_b64 = two 8-byte reads at a 16-byte lane stride, each a two-way bank conflict)
     typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
     __shared__ lds_u4 s_a[TH][TW];                   // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
-    // the truncated id's half pattern (low 16 bits: a 16-bit compare reads just those) and nz as the half it is (high 16 bits; its
-    // product with the centre's fp32 nz joins the dot product through one v_fma_mix_f32) in ONE word: two LDS reads per tap instead of three, 20 bytes per staged texel -- the step-16 tile
-    // (8 x 128 texels) then takes 20 KB and eight workgroups stay resident per CU like for the smaller steps (r3)
-    __shared__ uint32_t s_ni[TH][TW];
+    __shared__ uint32_t s_ni[TH][TW];                // nz (high half) | truncated id as a half (low half)
     const int W = int(a.width), H = int(a.height);
     const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
     const int tid = int(threadIdx.x);
@@ -528,59 +237,50 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
     const int c = tid % TW, r0 = tid / TW;
     const bool stager = tid < PASS * TW;
 
-    // prefetch registers: the raw texels of the next tile and the raw variance columns of this thread's pixels
-    uint2 pf_in[NP], pf_nm[NP];
-    uint32_t pf_ok = 0;
-    uint32_t pv_own[NK][3], pv_edge[NK][3];
+    // ---- the tile ----
+    const uint32_t t = xcd_remap(blockIdx.x, tiles_total);
+    const uint32_t by = t / tiles_x, bx = t - by * tiles_x;
+    const int group = int(by) / STEP, phase = int(by) - group * STEP;
+    const int x0 = int(a.col_begin) + int(bx) * kTileX;
+    const int y0 = int(a.row_begin) + group * (R * STEP) + phase;
 
-    auto tile_origin = [&](uint32_t v, int &x0, int &y0) {
-        const uint32_t t = xcd_aware ? xcd_remap(v, tiles_total) : v;
-        const uint32_t by = t / tiles_x, bx = t - by * tiles_x;
-        const int group = int(by) / STEP, phase = int(by) - group * STEP;
-        x0 = int(a.col_begin) + int(bx) * kTileX;
-        y0 = int(a.row_begin) + group * (R * STEP) + phase;
-    };
+    // ---- every global load of the tile, up front: the raw texels this thread stages and the raw variance columns of its pixels ----
     // Addresses are 32-bit byte offsets from the (uniform) image bases -- an image is far below 4 GiB, rows below 2^24 bytes: one
-    // v_mad_u32_u24 per texel instead of the two v_mad_u64_u32 + 64-bit shifts and adds a size_t index costs (r3: the per-tile fixed
-    // part was a third of the kernel's vector instructions).
+    // v_mad_u32_u24 per texel instead of the two v_mad_u64_u32 + 64-bit shifts and adds a size_t index costs.
     const char *const in_base = reinterpret_cast<const char *>(a.in), *const nm_base = reinterpret_cast<const char *>(a.normals);
     const uint32_t row_bytes = uint32_t(W) * 8u;
     auto texel_offset = [&](int sy, int sx) { return __umul24(uint32_t(sy), row_bytes) + uint32_t(sx) * 8u; };
-    auto prefetch = [&](uint32_t v) {
-        int x0, y0;
-        tile_origin(v, x0, y0);
-        const int sx = x0 - 2 * STEP + c;
-        // A tile whose halo lies inside the image (nine in ten at 1080p; a workgroup-uniform test) loads without per-texel bounds tests,
-        // zero fills and exec-mask regions: the general path below spends more scalar and vector instructions on those than on the loads.
-        const bool interior = x0 - 2 * STEP >= 0 && x0 + kTileX + 2 * STEP <= max_x && y0 - 2 * STEP >= 0 && y0 + (TH - 3) * STEP < max_y;
-        if (interior) {
-            pf_ok = (1u << NP) - 1u;
-            if (stager) {
-                const uint32_t off0 = texel_offset(y0 + (r0 - 2) * STEP, sx);
+    uint2 pf_in[NP], pf_nm[NP];
+    uint32_t pf_ok = 0;
+    uint32_t pv_own[NK][3], pv_edge[NK][3];
+    const bool interior = x0 - 2 * STEP >= 0 && x0 + kTileX + 2 * STEP <= max_x && y0 - 2 * STEP >= 0 && y0 + (TH - 3) * STEP < max_y;
+    if (interior) {
+        pf_ok = (1u << NP) - 1u;
+        if (stager) {
+            const uint32_t off0 = texel_offset(y0 + (r0 - 2) * STEP, x0 - 2 * STEP + c);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    if (p * PASS + r0 < TH) {
-                        const uint32_t off = off0 + uint32_t(p * PASS * STEP) * row_bytes;
-                        pf_in[p] = *reinterpret_cast<const uint2 *>(in_base + off);
-                        pf_nm[p] = *reinterpret_cast<const uint2 *>(nm_base + off);
-                    }
+            for (int p = 0; p < NP; ++p) {
+                if (p * PASS + r0 < TH) {
+                    const uint32_t off = off0 + uint32_t(p * PASS * STEP) * row_bytes;
+                    pf_in[p] = *reinterpret_cast<const uint2 *>(in_base + off);
+                    pf_nm[p] = *reinterpret_cast<const uint2 *>(nm_base + off);
                 }
             }
-            const bool edge_lane = tx == 0 || tx == 63;
-#pragma unroll
-            for (int kq = 0; kq < NK; ++kq) {
-                const uint32_t off = texel_offset(y0 + (ty + 4 * kq) * STEP - 1, x0 + tx) + 4u;       // .zw = the two variances
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    pv_own[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + off + uint32_t(j) * row_bytes);
-                    pv_edge[kq][j] = 0u;
-                    if (edge_lane) pv_edge[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u) + uint32_t(j) * row_bytes);
-                }
-            }
-            return;
         }
+        const bool edge_lane = tx == 0 || tx == 63;
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq) {
+            const uint32_t off = texel_offset(y0 + (ty + 4 * kq) * STEP - 1, x0 + tx) + 4u;       // .zw = the two variances
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                pv_own[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + off + uint32_t(j) * row_bytes);
+                pv_edge[kq][j] = 0u;
+                if (edge_lane) pv_edge[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u) + uint32_t(j) * row_bytes);
+            }
+        }
+    } else {
+        const int sx = x0 - 2 * STEP + c;
         const bool col_ok = stager && sx >= 0 && sx < max_x;
-        pf_ok = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int kk = p * PASS + r0;
@@ -609,231 +309,132 @@ __global__ __launch_bounds__(256) void svgf_atrous_stream_kernel(const AtrousArg
                 pv_edge[kq][j] = (row_ok && edge_lane) ? *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u)) : 0u;
             }
         }
-    };
+    }
 
-    uint32_t v = blockIdx.x;
-    if (v >= tiles_total) return;
-    prefetch(v);
-    for (;;) {
-        int x0, y0;
-        tile_origin(v, x0, y0);
-        // ---- the 3x3 variance pre-filter (:17-38) from the prefetched columns: vertical taps in-lane, horizontal via DPP ----
-        f2v var_p[NK];
+    // ---- the 3x3 variance pre-filter (:17-38): vertical taps in-lane, horizontal via DPP ----
+    f2v var_p[NK];
 #pragma unroll
-        for (int kq = 0; kq < NK; ++kq) {
-            f2v own = f2v{ 0.0f, 0.0f }, edge = f2v{ 0.0f, 0.0f };
+    for (int kq = 0; kq < NK; ++kq) {
+        f2v own = f2v{ 0.0f, 0.0f }, edge = f2v{ 0.0f, 0.0f };
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float w = j == 1 ? 0.5f : 0.25f;
-                const float2 qo = unpack_rg16f(pv_own[kq][j]), qe = unpack_rg16f(pv_edge[kq][j]);
-                own += f2v{ w * qo.x, w * qo.y };
-                edge += f2v{ w * qe.x, w * qe.y };
-            }
-            const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
-            const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
-            var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
+        for (int j = 0; j < 3; ++j) {
+            const float w = j == 1 ? 0.5f : 0.25f;
+            const float2 qo = unpack_rg16f(pv_own[kq][j]), qe = unpack_rg16f(pv_edge[kq][j]);
+            own += f2v{ w * qo.x, w * qo.y };
+            edge += f2v{ w * qe.x, w * qe.y };
         }
-        // ---- registers -> LDS (converted once per texel) ----
-        if (stager) {
-            auto stage = [&](const bool all_loaded) {
+        const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
+        const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
+        var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
+    }
+    // ---- registers -> LDS (converted once per texel) ----
+    if (stager) {
+        auto stage = [&](const bool all_loaded) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int kk = p * PASS + r0;
-                    if (kk < TH) {
-                        uint4 va = make_uint4(0u, 0u, 0u, 0u);
-                        uint32_t ni = kInvalidId;
-                        if (all_loaded || (pf_ok & (1u << p))) {
-                            const uint2 vin = pf_in[p], n = pf_nm[p];
-                            const float2 xy = unpack_rg16f(vin.x);
-                            va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
-                            // int(w) as a half (:57, :83).  The taps compare ids as HALVES (v_cmp_eq_f16): -0 == +0 like int(-0.x) == 0, and a
-                            // NaN id becomes 0 here, which is what int(NaN) is in the oracle (decision viii)
-                            _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
-                            idh = idh == idh ? idh : _Float16(0.0f);
-                            ni = (n.y << 16) | uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
-                        }
-                        s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
-                        s_ni[kk][c] = ni;
+            for (int p = 0; p < NP; ++p) {
+                const int kk = p * PASS + r0;
+                if (kk < TH) {
+                    uint4 va = make_uint4(0u, 0u, 0u, 0u);
+                    uint32_t ni = kInvalidId;
+                    if (all_loaded || (pf_ok & (1u << p))) {
+                        const uint2 vin = pf_in[p], n = pf_nm[p];
+                        const float2 xy = unpack_rg16f(vin.x);
+                        va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
+                        // int(w) as a half (:57, :83).  The taps compare ids as HALVES (v_cmp_eq_f16): -0 == +0 like int(-0.x) == 0, and a
+                        // NaN id becomes 0 here, which is what int(NaN) is in the oracle (decision viii)
+                        _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
+                        idh = idh == idh ? idh : _Float16(0.0f);
+                        ni = (n.y << 16) | uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
                     }
-                }
-            };
-            if (pf_ok == (1u << NP) - 1u) stage(true); else stage(false);       // (an interior tile: workgroup-uniform)
-        }
-        __syncthreads();
-        const uint32_t vn = v + gridDim.x;
-        const bool more = !ONE_TILE && vn < tiles_total;          // block-uniform
-        if (more) prefetch(vn);                      // in flight while the taps below run
-
-        const int cx = x0 + tx;
-#pragma unroll
-        for (int kq = 0; kq < NK; ++kq) {
-            const int k = ty + 4 * kq;
-            const int cy = y0 + k * STEP;
-            if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
-            const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
-            const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
-            const float2 p_zw = unpack_rg16f(pa.z);
-            const half2_t np_xy = as_half2(pa.w);
-            const uint32_t nip = s_ni[k + 2][tx + 2 * STEP];
-            const float np_z = float(as_half2(nip).y);
-            const _Float16 idp = as_half2(nip).x;
-            const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
-                                 __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
-            f2v sw = f2v{ 1.0f, 1.0f };                                                     // :70-71
-            f2v s01 = p_xy;
-            float s2 = p_zw.x, s3 = p_zw.y;
-#pragma unroll
-            for (int g = 0; g < (VHR_ATROUS_KO == 6 ? 0 : 6); ++g) {                        // :72-94, four taps per trip
-                lds_u4 qa[4];
-                f2v d[2];
-                bool same[4];
-                float kern[4];
-                if constexpr (LOGW) {
-                    float L[4];
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                  // skip the centre (:77)
-                        const int y = idx / 5 - 2, x = idx % 5 - 2;
-                        const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
-                        qa[h] = s_a[row][col];
-                        // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
-                        const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
-                        const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
-                        const uint32_t niq = s_ni[row][col];
-                        float dd;                                                           // :44-46: nz nz' (the half widened by the instruction) ...
-                        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(niq), "v"(np_z));
-                        dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);  // ... + nx nx' + ny ny'
-                        const float lg = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));           // log2; -inf at 0
-                        L[h] = as_half2(niq).x == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();    // :40-42, :87 (out of the image: a NaN id)
-                    }
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
-                        const f2v dl = p_xy - q_xy;
-                        const f2v w2 = f2v{ __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.x), inv.x, L[h])),
-                                            __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.y), inv.y, L[h])) };          // :88-89 with :87 in the exponent
-                        sw += w2;                                                           // :91
-                        s01 = __builtin_elementwise_fma(w2, q_xy, s01);                     // :92
-                        const f2v wq = w2 * w2;
-                        const half2_t q_zw = as_half2(qa[h].z);
-                        s2 = fmaf(wq.x, float(q_zw.x), s2);
-                        s3 = fmaf(wq.y, float(q_zw.y), s3);
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int t = 4 * g + h, idx = t < 12 ? t : t + 1;                      // skip the centre (:77)
-                    const int y = idx / 5 - 2, x = idx % 5 - 2;
-                    const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
-#if VHR_ATROUS_KO == 5
-                    qa[h] = pa; (void)row; (void)col;
-#else
-                    qa[h] = s_a[row][col];
-#endif
-                    const float kx = (x == 0) ? 0.375f : ((x == 1 || x == -1) ? 0.25f : 0.0625f);
-                    const float ky = (y == 0) ? 0.375f : ((y == 1 || y == -1) ? 0.25f : 0.0625f);
-                    kern[h] = kx * ky;                                                      // :62-68
-                    const uint32_t niq = s_ni[row][col];
-#if VHR_ATROUS_KO == 5
-                    float dd = np_z * np_z;
-#elif VHR_ATROUS_KO == 8
-                    float dd = 1.0f;
-#else
-                    float dd = np_z * float(as_half2(niq).y);
-#endif
-#if VHR_ATROUS_KO != 8
-                    dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // :44-46
-                    d[h >> 1][h & 1] = fmaxf(dd, 0.0f);
-#else
-                    d[h >> 1][h & 1] = dd;
-#endif
-#if VHR_ATROUS_KO == 5 || VHR_ATROUS_KO == 3 || VHR_ATROUS_KO == 8
-                    same[h] = true;
-#else
-                    same[h] = as_half2(niq).x == idp;                                       // :40-42
-#endif
-                }
-#if VHR_ATROUS_KO != 2 && VHR_ATROUS_KO != 8
-#pragma unroll
-                for (int sq = 0; sq < 7; ++sq) { d[0] *= d[0]; d[1] *= d[1]; }              // pow(., 128), interleaved chains
-#endif
-                d[0] *= f2v{ kern[0], kern[1] };
-                d[1] *= f2v{ kern[2], kern[3] };
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const float w = same[h] ? d[h >> 1][h & 1] : 0.0f;                      // :87
-                    const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
-                    const f2v tt = (p_xy - q_xy) * inv;
-#if VHR_ATROUS_KO == 1
-                    const f2v e = tt;
-#elif VHR_ATROUS_KO == 7
-                    const f2v e = f2v{ 1.0f, 1.0f }; (void)tt;
-#else
-                    const f2v e = f2v{ __builtin_amdgcn_exp2f(-fabsf(tt.x)), __builtin_amdgcn_exp2f(-fabsf(tt.y)) };   // :88-89
-#endif
-                    const f2v w2 = e * f2v{ w, w };
-                    sw += w2;                                                               // :91
-                    s01 = __builtin_elementwise_fma(w2, q_xy, s01);                         // :92
-#if VHR_ATROUS_KO != 4
-                    const f2v wq = w2 * w2;
-                    const half2_t q_zw = as_half2(qa[h].z);
-                    s2 = fmaf(wq.x, float(q_zw.x), s2);
-                    s3 = fmaf(wq.y, float(q_zw.y), s3);
-#endif
+                    s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
+                    s_ni[kk][c] = ni;
                 }
             }
-            const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
-            const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
-            const uint32_t out_off = texel_offset(cy, cx);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
-            if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
-            if (a.normals_out) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.normals_out) + out_off) = *reinterpret_cast<const uint2 *>(nm_base + out_off);
+        };
+        if (pf_ok == (1u << NP) - 1u) stage(true); else stage(false);       // (an interior tile: workgroup-uniform)
+    }
+    __syncthreads();
+
+    const int cx = x0 + tx;
+#pragma unroll
+    for (int kq = 0; kq < NK; ++kq) {
+        const int k = ty + 4 * kq;
+        const int cy = y0 + k * STEP;
+        if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
+        const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
+        const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
+        const float2 p_zw = unpack_rg16f(pa.z);
+        const half2_t np_xy = as_half2(pa.w);
+        const uint32_t nip = s_ni[k + 2][tx + 2 * STEP];
+        const float np_z = float(as_half2(nip).y);
+        const _Float16 idp = as_half2(nip).x;
+        // 1 / (4 sqrt(var) + 1e-6) (:48-50), times log2(e): the luminance weight is an exp2
+        const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
+                             __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
+        f2v sw = f2v{ 1.0f, 1.0f };                                                     // :70-71
+        f2v s01 = p_xy;
+        float s2 = p_zw.x, s3 = p_zw.y;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
+            lds_u4 qa[4];
+            float L[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int tp = 4 * g + h, idx = tp < 12 ? tp : tp + 1;                  // skip the centre (:77)
+                const int y = idx / 5 - 2, x = idx % 5 - 2;
+                const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+                qa[h] = s_a[row][col];
+                // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
+                const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
+                const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
+                const uint32_t niq = s_ni[row][col];
+                float dd;                                                               // :44-46: nz nz' (the half widened by the instruction) ...
+                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(niq), "v"(np_z));
+                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // ... + nx nx' + ny ny'
+                const float lg = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));               // log2; -inf at 0
+                L[h] = as_half2(niq).x == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();    // :40-42, :87 (out of the image: a NaN id)
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
+                const f2v dl = p_xy - q_xy;
+                const f2v w2 = f2v{ __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.x), inv.x, L[h])),
+                                    __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.y), inv.y, L[h])) };          // :88-89 with :87 in the exponent
+                sw += w2;                                                               // :91
+                s01 = __builtin_elementwise_fma(w2, q_xy, s01);                         // :92
+                const f2v wq = w2 * w2;
+                const half2_t q_zw = as_half2(qa[h].z);
+                s2 = fmaf(wq.x, float(q_zw.x), s2);
+                s3 = fmaf(wq.y, float(q_zw.y), s3);
+            }
         }
-        if (!more) break;
-        __syncthreads();                             // every wave is done with this tile's LDS image
-        v = vn;
+        const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
+        const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
+        const uint32_t out_off = texel_offset(cy, cx);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
+        if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
+        if (a.normals_out) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.normals_out) + out_off) = *reinterpret_cast<const uint2 *>(nm_base + out_off);
     }
 }
 
+// 4-row tiles (one pixel per thread, twice the workgroups, 2/3 of the LDS each) or 8-row tiles (two pixels per thread, a quarter less
+// staging per pixel).  Thin launches -- the screen tile of one GPU out of 4 or 8 -- need the smaller tile to fill the chip, and so does
+// the whole 1080p frame (214.5 -> 209.2 us for the five launches, r2), while at 4K (63 8-row tiles per CU) the 8-row tile stays ahead
+// (154.7 vs 159.2 us per launch).  "atrous_small_tiles" -1 (auto): 4-row tiles below 32 8-row tiles per CU; 0 never, 1 always.
 template <int STEP, int R>
-static void launch_atrous_stream(vhr_context *ctx, const AtrousArgs &a) {
+static void launch_atrous_tiles(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
     const uint32_t tiles_x = (a.limit_x - a.col_begin + kTileX - 1) / kTileX, tiles_total = tiles_x * groups * STEP;
-    const uint32_t per_cu = uint32_t(std::max(1, std::min(64, ctx->options[kOptAtrousBlocksPerCu])));
-    const uint32_t grid = std::min<uint32_t>(tiles_total, uint32_t(ctx->cu_count) * per_cu);
-    const bool logw = ctx->options[kOptAtrousVariant] == 5;      // 4: the product form of the weights (A-B)
-    const uint32_t xcd = uint32_t(ctx->options[kOptAtrousXcdAware]);
-    if (grid == tiles_total) {
-        if (logw) launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
-        else launch(ctx, (svgf_atrous_stream_kernel<STEP, R, true, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
-    } else {
-        if (logw) launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false, true>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
-        else launch(ctx, (svgf_atrous_stream_kernel<STEP, R, false, false>), dim3(grid), dim3(256), 0, a, tiles_x, tiles_total, xcd);
-    }
+    launch(ctx, (svgf_atrous_tile_kernel<STEP, R>), dim3(tiles_total), dim3(256), 0, a, tiles_x, tiles_total);
 }
-
-// 4-row tiles (one pixel per thread, twice the blocks, 2/3 of the LDS per block) or 8-row tiles (two pixels per thread, a quarter less
-// staging per pixel).  Thin launches -- the row strip of one GPU out of 4 or 8: 195 rows x 1920 are 750 8-row tiles for 256 CUs -- need
-// the smaller tile to fill the chip; measured in r2 (scratch/ab_atrous_tiles.py) the whole 1080p frame does too, 214.5 -> 209.2 us for
-// the five launches (the step-16 launch, whose 8-row tile takes 30 KB of LDS, 48.8 -> 44.6 us), while at 4K (63 8-row tiles per CU)
-// the 8-row tile stays ahead, 154.7 vs 159.2 us per launch.  "atrous_small_tiles" -1 (auto): 4-row tiles below 32 8-row tiles per CU.
 template <int STEP>
-static void launch_atrous_stream_auto(vhr_context *ctx, const AtrousArgs &a) {
+static void launch_atrous_tiles_auto(vhr_context *ctx, const AtrousArgs &a) {
     const uint32_t rows = a.row_end - a.row_begin;
     const uint32_t tiles8 = ((a.limit_x - a.col_begin + kTileX - 1) / kTileX) * ((rows + 8 * STEP - 1) / (8 * STEP)) * STEP;
-    const int small = ctx->options[kOptAtrousSmallTiles];        // -1 auto, 0 never, 1 always
-    if (small == 1 || (small == 2 && STEP >= 16) || (small == 3 && STEP >= 8) || (small < 0 && tiles8 < 32u * uint32_t(ctx->cu_count))) launch_atrous_stream<STEP, 4>(ctx, a);
-    else launch_atrous_stream<STEP, 8>(ctx, a);
-}
-
-template <int STEP, int R>
-static void launch_atrous_packed(vhr_context *ctx, const AtrousArgs &a) {
-    const uint32_t rows = a.row_end - a.row_begin;
-    const uint32_t groups = (rows + R * STEP - 1) / (R * STEP);
-    const dim3 grid((a.limit_x + kTileX - 1) / kTileX, groups * STEP);
-    launch(ctx, (svgf_atrous_packed_kernel<STEP, R>), grid, dim3(256), 0, a);
+    const int small = ctx->options[kOptAtrousSmallTiles];
+    if (small == 1 || (small < 0 && tiles8 < 32u * uint32_t(ctx->cu_count))) launch_atrous_tiles<STEP, 4>(ctx, a);
+    else launch_atrous_tiles<STEP, 8>(ctx, a);
 }
 
 int launch_svgf_atrous(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &normals, const Image &in, Image &out,
@@ -1053,9 +654,7 @@ static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
         };
         // 32x8-pixel blocks (r3d): two rows of 32 pixels per wave: 26.6 -> 25.7 us at 1080p, 95.2 -> 90.1 at 4K (64x8, 32x16, 64x16, 16x16, 128x4,
         // 32x4, 32x6, 32x12, 16x8 measured too: scratch/ab_temporal.py; the counter traffic does not fall, the rate it moves at rises).
-        // "temporal_variant" 1 = the 64x4 blocks of rounds 1-3c (A-B).
-        if (ctx->options[kOptTemporalVariant] == 1) go(svgf_temporal_kernel<64, 4>, 64, 4);
-        else go(svgf_temporal_kernel<32, 8>, 32, 8);
+        go(svgf_temporal_kernel<32, 8>, 32, 8);
         ctx->time_end(kKernelTemporal);
         if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf temporal kernel launch failed");
     }
@@ -1068,40 +667,23 @@ static int issue_temporal(vhr_context *ctx, const TemporalArgs &a) {
 static int issue_atrous(vhr_context *ctx, const AtrousArgs &a) {
     const int32_t step = a.step;
     if (a.row_end <= a.row_begin || a.limit_x <= a.col_begin || !a.limit_y) return VHR_OK;
-    // (only the default streaming kernel starts at col_begin; the A-B variants compute the rows from column 0: a superset)
-    const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
     ctx->time_begin(ctx->async_atrous ? kKernelAtrousAsync : kKernelAtrous);
-    const int variant = ctx->options[kOptAtrousVariant];
-    bool tiled = variant != 0;
-    if (variant == 4 || variant == 5) {
-        switch (step) {
-            case 1: launch_atrous_stream_auto<1>(ctx, a); break;
-            case 2: launch_atrous_stream_auto<2>(ctx, a); break;
-            case 4: launch_atrous_stream_auto<4>(ctx, a); break;
-            case 8: launch_atrous_stream_auto<8>(ctx, a); break;
-            case 16: launch_atrous_stream_auto<16>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
-        }
-    } else if (variant == 3) {
-        switch (step) {
-            case 1: launch_atrous_packed<1, 8>(ctx, a); break;
-            case 2: launch_atrous_packed<2, 8>(ctx, a); break;
-            case 4: launch_atrous_packed<4, 8>(ctx, a); break;
-            case 8: launch_atrous_packed<8, 8>(ctx, a); break;
-            case 16: launch_atrous_packed<16, 8>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
-        }
-    } else if (tiled) {
-        switch (step) {
-            case 1: if (variant == 2) launch_atrous_tiled<1, 8>(ctx, a); else launch_atrous_tiled<1, 16>(ctx, a); break;
-            case 2: if (variant == 2) launch_atrous_tiled<2, 8>(ctx, a); else launch_atrous_tiled<2, 16>(ctx, a); break;
-            case 4: if (variant == 2) launch_atrous_tiled<4, 8>(ctx, a); else launch_atrous_tiled<4, 16>(ctx, a); break;
-            case 8: if (variant == 2) launch_atrous_tiled<8, 8>(ctx, a); else launch_atrous_tiled<8, 16>(ctx, a); break;
-            case 16: if (variant == 2) launch_atrous_tiled<16, 8>(ctx, a); else launch_atrous_tiled<16, 16>(ctx, a); break;
-            default: tiled = false; break;       // other steps: the direct kernel
+    bool tiled = ctx->options[kOptAtrousVariant] != 0;          // 0: the literal form of the shader (svgf_atrous_kernel), every step size
+    if (tiled) {
+        switch (step) {                                          // the step sizes of the reference's schedule (hybrid_render_path.cpp:299-319)
+            case 1: launch_atrous_tiles_auto<1>(ctx, a); break;
+            case 2: launch_atrous_tiles_auto<2>(ctx, a); break;
+            case 4: launch_atrous_tiles_auto<4>(ctx, a); break;
+            case 8: launch_atrous_tiles_auto<8>(ctx, a); break;
+            case 16: launch_atrous_tiles_auto<16>(ctx, a); break;
+            default: tiled = false; break;                       // any other step: the literal kernel
         }
     }
-    if (!tiled) launch(ctx, svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
+    if (!tiled) {
+        // (the literal kernel computes the rows from column 0: a superset of a screen tile's columns)
+        const dim3 grid((a.limit_x + kSvgfBlockX - 1) / kSvgfBlockX, (a.row_end - a.row_begin + kSvgfBlockY - 1) / kSvgfBlockY);
+        launch(ctx, svgf_atrous_kernel, grid, dim3(kSvgfBlockX, kSvgfBlockY), 0, a);
+    }
     ctx->time_end(kKernelAtrous);
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "svgf atrous kernel launch failed");
     return VHR_OK;

@@ -1729,11 +1729,15 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kNoHit = 0xffffffffu;
 
-template <bool SPILL, bool ALPHA, typename Fetch, typename Commit>
+// what a walk did (STATS builds only): node visits, leaf visits and triangle tests summed over lanes, and the trips of the two inner loops
+// counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
+struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
+
+template <bool SPILL, bool ALPHA, bool STATS = false, typename Fetch, typename Commit>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
-                                                const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit) {
+                                                const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit, WalkCounters *wc = nullptr) {
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
@@ -1752,6 +1756,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {                 // wave-uniform
             const uint32_t r = next + lane_rank(idle);
             next += n_idle;
+            if (STATS && lane == 0) ++wc->refills;
             if (!has && r < total) {
                 fetch(r, pix, ro, rd);
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
@@ -1780,8 +1785,10 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         if (!__any(has)) break;
         // ---- inner nodes ----
         const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
+        uint32_t my_nodes = 0, my_tris = 0;               // (STATS) this lane's trips of the two inner loops in this round
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
+            if (STATS) ++my_nodes;
             const Node48Words nw = load_node48(sc.nodes48, cur);
             const float4 q0 = nw.q0, q1 = nw.q1, q2 = nw.q2;
             const int2 links = nw.links;
@@ -1809,10 +1816,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             const uint32_t vv = ~uint32_t(cur);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             bool done = false;
+            if (STATS) ++wc->leaves;
             for (uint32_t i = 0; i < count; ++i) {
                 const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + first + i);
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 float t, uu, ww;
+                if (STATS) ++my_tris;
                 if (ray_triangle_nb(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
                     const uint32_t flat = __float_as_uint(tc.w);
@@ -1843,6 +1852,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             has = false;
             commit(pix, best_tri, best_u, best_v);
         }
+        if (STATS) {
+            wc->nodes += my_nodes; wc->triangles += my_tris;
+            uint32_t tn = my_nodes, tt = my_tris;
+            for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
+            wc->wave_trips += tn + tt;
+        }
     }
 }
 
@@ -1860,7 +1875,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
 // ---------------------------------------------------------------------------------------------
 constexpr int kReflRays = 128;
 
-template <bool SPILL, int BOUNCES>
+template <bool SPILL, int BOUNCES, bool STATS = false>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
     const uint32_t early_exit, const uint32_t use_cut, const Stamps st) {
@@ -1927,12 +1942,16 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 
     // ---- phase 2: the queue (once per bounce) ----
     uint32_t overflow = 0, second_rays = 0;
+    WalkCounters wc;
+    const unsigned long long t_walk0 = STATS ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_walk = 0;
 #pragma unroll 1
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
     // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
     const uint32_t cut_n = use_cut && total && bounce == 0 ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
-    wave_queue_walk<SPILL, false>(
+    const unsigned long long tw0 = STATS ? __builtin_readcyclecounter() : 0ull;
+    wave_queue_walk<SPILL, false, STATS>(
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
@@ -1941,8 +1960,9 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
-        });
+        }, &wc);
     wave_lds_sync();
+    if (STATS) t_walk += __builtin_readcyclecounter() - tw0;
     if constexpr (BOUNCES > 1) if (bounce == 0) {
         // ---- second-bounce rays (trace_reflection's arithmetic), whole wave: a mirror ray from every first hit ----
         uint32_t n2 = 0;
@@ -2005,6 +2025,25 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     if (a.stats && lane == 0) {
         if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
         if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
+    }
+    if constexpr (STATS) {
+        // the mirror-ray launch's own counters: the second RayStats of the buffer (vhr_get_reflection_statistics)
+        RayStats *const rs = a.stats + 1;
+        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles;
+        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
+        if (lane == 0) {
+            atomicAdd(&rs->node_visits, (unsigned long long)n_nodes);
+            atomicAdd(&rs->leaf_visits, (unsigned long long)n_leaves);
+            atomicAdd(&rs->triangle_tests, (unsigned long long)n_tris);
+            atomicAdd(&rs->wave_iterations, (unsigned long long)wc.wave_trips);
+            atomicAdd(&rs->unique_rays, (unsigned long long)(ncov + second_rays));
+            atomicAdd(&rs->covered_pixels, (unsigned long long)ncov);
+            atomicAdd(&rs->second_bounce_rays, (unsigned long long)second_rays);
+            atomicAdd(&rs->refills, (unsigned long long)wc.refills);
+            atomicAdd(&rs->waves, 1ull);
+            atomicAdd(&rs->cycles_total, __builtin_readcyclecounter() - t_walk0);          // set-up + walks + shading, this wave
+            atomicAdd(&rs->cycles_nodes, t_walk);                                           // the walks alone (both bounces)
+        }
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
 }
@@ -2246,7 +2285,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         a.col_end = uint32_t(std::min<uint64_t>(width, uint64_t(owned_col_end) + ctx->overlap));
     }
     if (a.stats) {
-        if (hipMemsetAsync(ctx->d_ray_stats, 0, sizeof(RayStats), ctx->stream) != hipSuccess)
+        if (hipMemsetAsync(ctx->d_ray_stats, 0, 2 * sizeof(RayStats), ctx->stream) != hipSuccess)     // [0] shadow / AO launch, [1] mirror-ray launch
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
     }
     // "fuse_temporal" (default): hold the launch back until the next pass shows its first command -- if that is svgf.comp on this launch's
@@ -2272,36 +2311,72 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             return VHR_OK;
         }
     }
-    issue_raygen(ctx, a, width, height);
-    if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {       // not denoised: owned rows (and columns) only
-        a.row_begin = owned_begin;
-        a.row_end = owned_end;
-        a.col_begin = owned_col_begin & ~15u;
-        a.col_end = owned_col_end;
+    // The mirror ray's launch (raygen.rgen:59-65): not denoised, so owned rows (and columns) only.  "reflection_concurrent" (1: issued first,
+    // 2: issued second) puts it on the context's mirror stream beside the shadow / AO launch -- both read the G-buffer, they write different
+    // images -- and the caller's stream waits for it before the TraceRays returns: every later command sees both images complete.
+    const bool mirror = ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections;
+    auto issue_mirror = [&](RaygenArgs m) {
+        m.row_begin = owned_begin;
+        m.row_end = owned_end;
+        m.col_begin = owned_col_begin & ~15u;
+        m.col_end = owned_col_end;
         ctx->time_begin(kKernelReflection);
-        if (a.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
+        if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
-            const uint32_t tiles_x = (a.col_end - a.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
+            const uint32_t tiles_x = (m.col_end - m.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-            a.co = CostOrderArgs{};
-            if (levels >= 5u && !a.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
+            m.co = CostOrderArgs{};
+            if (levels >= 5u && !m.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
-                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(a.tp.reflections) << 28) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u), a.co);
-#define VHR_LAUNCH_REFL(SP, B) launch(ctx, (reflection_queue_kernel<SP, B>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
+                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co);
+#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
+#define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
-            if (a.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL(true, 2); else VHR_LAUNCH_REFL(false, 2); }
-            else { if (spill) VHR_LAUNCH_REFL(true, 1); else VHR_LAUNCH_REFL(false, 1); }
+            if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }
+            else { if (spill) VHR_LAUNCH_REFL_S(true, 1); else VHR_LAUNCH_REFL_S(false, 1); }
+#undef VHR_LAUNCH_REFL_S
 #undef VHR_LAUNCH_REFL
         } else {
-            launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, a);
+            launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m);
         }
         ctx->time_end(kKernelReflection);
+    };
+    int concurrent = mirror && ctx->frames_in_flight == 1 ? ctx->options[kOptReflectionConcurrent] : 0;
+    if (concurrent) {
+        bool ok = true;
+        if (!ctx->mirror_stream)
+            ok = hipStreamCreateWithFlags(&ctx->mirror_stream, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->mirror_ready, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->mirror_done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventRecord(ctx->mirror_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->mirror_stream, ctx->mirror_ready, 0) == hipSuccess;
+        if (!ok) concurrent = 0;                         // no second stream: in order after all
+    }
+    auto on_mirror_stream = [&]() {
+        hipStream_t const main_stream = ctx->stream;
+        PassDescription *const pass = ctx->cur_pass;
+        ctx->stream = ctx->mirror_stream;
+        ctx->cur_pass = nullptr;                         // the pass's time stamps stay on the caller's stream
+        ctx->no_stamps = true;
+        issue_mirror(a);
+        ctx->no_stamps = false;
+        ctx->cur_pass = pass;
+        (void)hipEventRecord(ctx->mirror_done, ctx->mirror_stream);
+        ctx->stream = main_stream;
+    };
+    if (concurrent == 1) on_mirror_stream();
+    issue_raygen(ctx, a, width, height);
+    if (concurrent >= 2) on_mirror_stream();
+    if (concurrent) {
+        if (hipStreamWaitEvent(ctx->stream, ctx->mirror_done, 0) != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "hipStreamWaitEvent(mirror stream) failed");
+    } else if (mirror) {
+        issue_mirror(a);
     }
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {
-        if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        if (hipMemcpyAsync(&ctx->h_ray_stats, ctx->d_ray_stats, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&ctx->h_refl_stats, ctx->d_ray_stats + 1, sizeof(RayStats), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemcpyAsync(ray stats) failed");
     }
     return VHR_OK;

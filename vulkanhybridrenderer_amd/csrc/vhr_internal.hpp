@@ -290,7 +290,7 @@ struct RayStats {
 };
 
 // tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptRaygenCostOrder = 34, kOptCount = 35 };
+enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptRaygenCostOrder = 34, kOptReflectionConcurrent = 35, kOptCount = 36 };
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelAtrousAsync = 8, kKernelKinds = 9 };
@@ -394,15 +394,20 @@ struct vhr_context {
     bool side_pending = false;
     const void *side_reads[2] = { nullptr, nullptr }, *side_writes = nullptr;      // the images the pending dispatch reads / writes (hazard checks)
     bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
+    // "reflection_concurrent": the mirror-ray launch of a TraceRays is issued on `mirror_stream`, beside the shadow / AO launch on the caller's
+    // stream (both read the G-buffer, they write different images); the caller's stream waits for it at the end of the TraceRays
+    hipStream_t mirror_stream = nullptr;
+    hipEvent_t mirror_ready = nullptr, mirror_done = nullptr;
     int join_side();                   // the current stream waits for the side stream's pending dispatch (no-op without one)
 
     // statistics
     bool ray_stats_enabled = false;
     vhr::RayStats *d_ray_stats = nullptr;
     vhr::RayStats h_ray_stats = {};
+    vhr::RayStats h_refl_stats = {};      // the mirror-ray launch's counters (d_ray_stats[1])
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0, 1 };     // see vhr_set_option
+    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0, 1, 0 };     // see vhr_set_option
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in cost[f & 1], and its FIRST block, before it

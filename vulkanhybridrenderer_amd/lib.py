@@ -33,7 +33,7 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
@@ -218,6 +218,7 @@ def load():
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_reflection_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_build_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.vhr_atrous_overlap.restype = u32
@@ -533,6 +534,15 @@ class Context:
         self.check(self.L.vhr_get_traversal_statistics(self.handle, out), "traversal_statistics")
         d = dict(node_visits=out[0], leaf_visits=out[1], triangle_tests=out[2], wave_iterations=out[3])
         d["active_lane_utilisation"] = (out[0] + out[2]) / (64.0 * out[3]) if out[3] else 0.0
+        return d
+
+    def reflection_statistics(self):
+        """The mirror-ray launch's counters (reflection_queue_kernel with statistics enabled)."""
+        out = (C.c_uint64 * 10)()
+        self.check(self.L.vhr_get_reflection_statistics(self.handle, out), "reflection_statistics")
+        d = dict(rays=out[0], second_bounce_rays=out[1], node_visits=out[2], leaf_visits=out[3], triangle_tests=out[4], wave_iterations=out[5],
+                 refills=out[6], waves=out[7], cycles_total=out[8], cycles_walk=out[9])
+        d["active_lane_utilisation"] = (out[2] + out[4]) / (64.0 * out[5]) if out[5] else 0.0
         return d
 
     def traversal_cycles(self):
