@@ -511,6 +511,10 @@ int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64
  * visits summed over lanes, out[1] = leaf visits, out[2] = ray/triangle tests, out[3] = trips of the two inner
  * loops (node steps + triangle tests) counted once per wave, i.e. by the slowest lane of each round.
  * Active-lane utilisation of the traversal loops = (out[0] + out[2]) / (64 * out[3]). */
+/* A hash of the sources this library was built from (16 hex digits).  profiles/pmc_*.json carry the fingerprint of the library their
+ * counters were collected on; bench.py quotes them only when it equals the loaded library's. */
+const char *vhr_source_fingerprint(void);
+
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 /* The same for the mirror-ray launch of the last vhr_trace_rays (raygen.rgen:59-65 + reflection_hit.rchit; the queue kernel, statistics
  * enabled): out[0] = rays walked (first + second bounce), out[1] = second-bounce rays among them, out[2] = inner-node visits summed over

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "vhr_internal.hpp"
+#include "fingerprint.h"      // build/fingerprint.h, written by the Makefile
 
 namespace vhr {
 int upload_srgb_lut(const float *lut);
@@ -266,6 +267,7 @@ void vhr_destroy(vhr_context *ctx) {
     if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
     if (ctx->side_done) hipEventDestroy(ctx->side_done);
     hipFree(ctx->d_stamps);
+    hipFree(ctx->d_hit_records);
     for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
         if (!im.used) continue;
         hipFree(im.ptr);
@@ -669,6 +671,8 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
     out[3] = uint64_t(ctx->node_count) * sizeof(BvhNode); out[4] = uint64_t(ctx->tri_count) * sizeof(BvhTri);
     return VHR_OK;
 }
+
+const char *vhr_source_fingerprint(void) { return VHR_SOURCE_FINGERPRINT; }
 
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;

@@ -1020,16 +1020,16 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
     constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
     constexpr int kSpillEntries = WIDE ? kWideSpill : kSpillStack;
-    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
     if constexpr (CUT && COMPACT && !SHARED && !STATS && !PACKET && !WIDE && !PREGEN) {
         // "raygen_cost_order": the launch's first block orders the previous launch's blocks for the next one (8 * 64 * WAVES words <= the block's
         // (stack_levels + 3) * 64 * WAVES words of stack: the host asks for it only with >= 5 stack levels)
         if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<WAVES>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
     }
     int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
-    stack[0] = kStackSentinel;
     float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + kExtraRows) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
     const uint32_t W = a.width, H = a.height;
+    stack[0] = kStackSentinel;
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
     uint32_t x, y;
     // "raygen_cost_order": the blocks that lived longest two launches ago start first (a launch ends with its last wave; a long-lived wave that
     // starts late is what the launch's end waits for)
@@ -1733,7 +1733,7 @@ constexpr uint32_t kNoHit = 0xffffffffu;
 // counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
 struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
 
-template <bool SPILL, bool ALPHA, bool STATS = false, typename Fetch, typename Commit>
+template <bool SPILL, bool ALPHA, bool STATS = false, bool COMPACT = false, typename Fetch, typename Commit>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
@@ -1761,9 +1761,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 fetch(r, pix, ro, rd);
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
-                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
+                if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
+                const f3 noi_cut = noi;               // (the cut's boxes are absolute fp32 boxes whatever the node format)
+                if (COMPACT)                          // the half-precision boxes are relative to the scene centre: shift the origin the slab test uses (only)
+                    noi = f3{ -((ro.x - sc.centre[0]) * rinv.x), -((ro.y - sc.centre[1]) * rinv.y), -((ro.z - sc.centre[2]) * rinv.z) };
                 if (cut_n) {
                     // the ray against the tile's cut (build_tile_cut): the subtrees it hits go on its stack, the deepest -- the
                     // one closest to the origin -- on top; the (t, flat index) order of the commit makes the result independent
@@ -1772,7 +1775,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                     for (uint32_t e = 0; e < cut_n; ++e) {
                         const float4 b0 = cut[e][0], b1 = cut[e][1];
                         float tnu;
-                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
+                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
                             if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
                             else emask |= 1u << e;
                         }
@@ -1789,12 +1792,20 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
             if (STATS) ++my_nodes;
-            const Node48Words nw = load_node48(sc.nodes48, cur);
-            const float4 q0 = nw.q0, q1 = nw.q1, q2 = nw.q2;
-            const int2 links = nw.links;
             float tn0, tn1;
             bool h0, h1;
-            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
+            int2 links;
+            if constexpr (COMPACT) {
+                // `cur` is the node's BYTE offset (index * 32); two 16-byte loads per visit; conservative half-precision boxes (BvhNode16)
+                const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes16) + uint32_t(cur));
+                const uint4 c0 = np[0], c1 = np[1];
+                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
+                links = int2{ int(c1.z), int(c1.w) };
+            } else {
+                const Node48Words nw = load_node48(sc.nodes48, cur);
+                links = nw.links;
+                box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
+            }
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
@@ -2046,6 +2057,137 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         }
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mirror ray, walk and shading in two launches ("reflection_variant" 2, one bounce).
+//
+// reflection_queue_kernel's register budget is set by reflection_hit.rchit (vertex fetches, two bilinear texture samples, the BRDF), which it
+// runs in its tiles' epilogues: 5-6 waves per SIMD for a walk that waits on memory for 60 % of its cycles (profiles/r4b_refl_pmc_*.txt).
+// Here the walk is a kernel of its own -- the same queue, the same node step on the 32-byte half-precision nodes where the tree has them
+// (two loads per visit instead of three; boxes only cull), 64 registers -- that leaves one 16-byte hit record per pixel (triangle, u, v;
+// kNoHit for a miss and for pixels without geometry) in a buffer of the context; reflection_shade_kernel then runs the shader one pixel per
+// lane with every lane busy.  Same rays, same intersection arithmetic, same shader: the image is reflection_queue_kernel's bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <bool SPILL, bool COMPACT, bool STATS>
+__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(7, 8))) void reflection_walk_kernel(
+    const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
+    const uint32_t early_exit, uint4 *__restrict__ records, const Stamps st) {
+    vhr_stamp(st);
+    extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
+    // rows 0-2: P (raygen.rgen:26) -> the hit record (triangle, u, v); rows 3-4: the G-buffer normal as the halves it is.  Origin and direction
+    // are recomputed from them at refill (rgen:29, 60-61: the same operations on the same operands): 2.5 KB per wave instead of 3 KB, which
+    // with a six-level LDS stack lets seven waves per SIMD stay resident
+    __shared__ float s_ray_all[2][5][kReflRays];
+    __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
+    __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut)
+    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
+    const uint32_t block = a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = block * 2u + wave;
+    if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
+    float (&s_ray)[5][kReflRays] = s_ray_all[wave];
+    uint8_t (&s_list)[kReflRays] = s_list_all[wave];
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
+    stack[0] = kStackSentinel;
+    const uint32_t W = a.width, H = a.height;
+    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+    // ---- phase 1: per-pixel ray setup, whole wave (raygen.rgen:15-29, 60-61) ----
+    uint32_t ncov = 0;
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const bool in_range = x < a.col_end && y < a.row_end;
+        const float depth = in_range ? a.depth[size_t(y) * W + x] : 0.0f;                    // rgen:19
+        const bool covered = depth != 0.0f;
+        const uint32_t p = sub * 64u + lane;
+        s_ray[0][p] = __uint_as_float(kNoHit);                                               // rgen:22 / reflection_miss.rmiss:7 unless a hit is committed
+        if (covered) {
+            const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);  // rgen:15-16
+            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
+            const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];    // rgen:28 (R16G16B16A16: nx ny | nz id)
+            const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
+            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29 (here for the bounds of the tile's origins)
+            s_ray[0][p] = P.x; s_ray[1][p] = P.y; s_ray[2][p] = P.z;
+            s_ray[3][p] = __uint_as_float(nraw.x); s_ray[4][p] = __uint_as_float(nraw.y);
+            omin = f3{ fminf(omin.x, origin.x), fminf(omin.y, origin.y), fminf(omin.z, origin.z) };
+            omax = f3{ fmaxf(omax.x, origin.x), fmaxf(omax.y, origin.y), fmaxf(omax.z, origin.z) };
+        }
+        const unsigned long long m = __ballot(covered);
+        if (covered) s_list[ncov + lane_rank(m)] = uint8_t(p);
+        ncov += uint32_t(__popcll(m));
+    }
+    wave_lds_sync();
+    const uint32_t total = a.scene.node_count == 0 ? 0u : ncov;
+    // ---- phase 2: the queue ----
+    uint32_t overflow = 0;
+    WalkCounters wc;
+    const unsigned long long t_walk0 = STATS ? __builtin_readcyclecounter() : 0ull;
+    const uint32_t cut_n = total ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane, 3.0e38f, kCutMax, 0u, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48))) : 0u;
+    wave_queue_walk<SPILL, false, STATS, COMPACT>(
+        a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
+        [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
+            pix = s_list[r];
+            const f3 P = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
+            const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nzw = __float_as_uint(s_ray[4][pix]);
+            const f3 N = f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) };
+            ro = P + N * a.tp.normal_bias;                                                   // rgen:29
+            const f3 I = normalize3(P - cam);                                                // rgen:60
+            const float ni2 = 2.0f * dot3(N, I);
+            rd = I - N * ni2;                                                                // rgen:61 reflect(I, N)
+        },
+        [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
+            s_ray[0][pix] = __uint_as_float(tri); s_ray[1][pix] = u; s_ray[2][pix] = v;
+        }, &wc);
+    wave_lds_sync();
+    // ---- phase 3: the tile's records, whole wave ----
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2; ++sub) {
+        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        if (x >= a.col_end || y >= a.row_end) continue;
+        const uint32_t p = sub * 64u + lane;
+        const uint32_t tri = total ? __float_as_uint(s_ray[0][p]) : kNoHit;                  // (no tree: every ray misses; the origins are still there)
+        records[size_t(y) * W + x] = make_uint4(tri, __float_as_uint(s_ray[1][p]), __float_as_uint(s_ray[2][p]), 0u);
+    }
+    if (a.stats && lane == 0 && overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
+    if constexpr (STATS) {
+        RayStats *const rs = a.stats + 1;
+        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles;
+        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
+        if (lane == 0) {
+            atomicAdd(&rs->node_visits, (unsigned long long)n_nodes);
+            atomicAdd(&rs->leaf_visits, (unsigned long long)n_leaves);
+            atomicAdd(&rs->triangle_tests, (unsigned long long)n_tris);
+            atomicAdd(&rs->wave_iterations, (unsigned long long)wc.wave_trips);
+            atomicAdd(&rs->unique_rays, (unsigned long long)ncov);
+            atomicAdd(&rs->covered_pixels, (unsigned long long)ncov);
+            atomicAdd(&rs->refills, (unsigned long long)wc.refills);
+            atomicAdd(&rs->waves, 1ull);
+            atomicAdd(&rs->cycles_total, __builtin_readcyclecounter() - t_cost0);
+            atomicAdd(&rs->cycles_nodes, __builtin_readcyclecounter() - t_walk0);
+        }
+    }
+    if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
+}
+
+// reflection_hit.rchit / reflection_miss.rmiss on the hit records, one pixel per lane (8x8 pixels per wave, 4 waves per workgroup)
+__global__ __launch_bounds__(kTraceBlock) void reflection_shade_kernel(const RaygenArgs a, const uint4 *__restrict__ records, const Stamps st) {
+    vhr_stamp(st);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = a.col_begin + blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t y = a.row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    if (x >= a.col_end || y >= a.row_end) return;
+    const uint4 rec = records[size_t(y) * a.width + x];
+    f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                               // rgen:22, reflection_miss.rmiss:7
+    if (rec.x != kNoHit) {
+        Hit h;
+        h.t = 0.0f; h.u = __uint_as_float(rec.y); h.v = __uint_as_float(rec.z); h.tri_index = rec.x; h.flat = 0;
+        payload = shade_reflection_hit(a.scene, a.pfd, h);
+    }
+    store_rgba16f(a.reflections, a.width, x, y, payload.x, payload.y, payload.z, payload.w);    // rgen:65
 }
 
 // The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
@@ -2321,7 +2463,28 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         m.col_begin = owned_col_begin & ~15u;
         m.col_end = owned_col_end;
         ctx->time_begin(kKernelReflection);
-        if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
+        if (m.tp.reflections == 1 && ctx->options[kOptReflectionVariant] == 2 && ctx->hit_records(size_t(width) * height)) {
+            // walk and shading in two launches (see reflection_walk_kernel)
+            const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
+            const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
+            const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
+            const uint32_t tiles_x = (m.col_end - m.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
+            const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
+            m.co = CostOrderArgs{};
+            if (levels >= 5u && !m.stats)
+                prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
+                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (3u << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co);
+            const bool spill = levels < ctx->bvh_depth + 1u;
+            const bool compact = ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
+#define VHR_LAUNCH_WALK(SP, C, ST) launch(ctx, (reflection_walk_kernel<SP, C, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, ctx->d_hit_records)
+#define VHR_LAUNCH_WALK_S(SP, C) do { if (m.stats) VHR_LAUNCH_WALK(SP, C, true); else VHR_LAUNCH_WALK(SP, C, false); } while (0)
+            if (compact) { if (spill) VHR_LAUNCH_WALK_S(true, true); else VHR_LAUNCH_WALK_S(false, true); }
+            else { if (spill) VHR_LAUNCH_WALK_S(true, false); else VHR_LAUNCH_WALK_S(false, false); }
+#undef VHR_LAUNCH_WALK_S
+#undef VHR_LAUNCH_WALK
+            m.co = CostOrderArgs{};
+            launch(ctx, reflection_shade_kernel, dim3((m.col_end - m.col_begin + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m, static_cast<const uint4 *>(ctx->d_hit_records));
+        } else if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));

@@ -423,6 +423,18 @@ struct vhr_context {
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
     };
     CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
+    // the mirror ray's hit records between reflection_walk_kernel and reflection_shade_kernel ("reflection_variant" 2): 16 bytes per pixel
+    uint4 *d_hit_records = nullptr;
+    size_t hit_record_capacity = 0;
+    bool hit_records(size_t pixels) {
+        if (pixels <= hit_record_capacity) return true;
+        (void)hipDeviceSynchronize();
+        (void)hipFree(d_hit_records);
+        d_hit_records = nullptr; hit_record_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&d_hit_records), pixels * sizeof(uint4)) != hipSuccess) return false;
+        hit_record_capacity = pixels;
+        return true;
+    }
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;

@@ -33,7 +33,7 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
@@ -117,6 +117,11 @@ RAYTRACING_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 COMPUTE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 _lib = None
+
+
+def source_fingerprint():
+    """vhr_source_fingerprint(): the hash of the sources the loaded library was built from."""
+    return load().vhr_source_fingerprint().decode()
 
 
 def load():
@@ -219,6 +224,8 @@ def load():
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_reflection_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_source_fingerprint.restype = C.c_char_p
+    L.vhr_source_fingerprint.argtypes = []
     L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_build_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.vhr_atrous_overlap.restype = u32
