@@ -78,6 +78,7 @@ def parse():
                         "Anything set this way is listed under config.options")
     p.add_argument("--allow-degraded", action="store_true",
                    help="N > 1: fall back (per-frame descriptors / no gather) instead of failing when the transport refuses the replayed exchanges")
+    p.add_argument("--print-workload-key", action="store_true", help="print the name profiles/pmc_<key>.json goes by for this workload and exit (tools/pmc_workload.sh)")
     p.add_argument("--dry-launch", action="store_true",
                    help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command the launcher would start (one JSON line) and exit")
     p.add_argument("--no-c-abi-probe", action="store_true",
@@ -246,35 +247,38 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
 SIMDS, CLOCK_HZ = 1024, 2.4e9     # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2400 MHz max clock
 
 
-def pmc_valu(args):
-    """Wave-level VALU instructions per a-trous launch from the committed PMC run (SQ_INSTS_VALU, profiles/atrous_valu.json).  A
-    wave64 VALU instruction occupies its SIMD for 4 cycles, so insts x 4 / (SIMDs x clock) is the time the launch needs at 100 %
-    issue: the floor of THIS formulation of the shader's arithmetic (the kernel is arithmetic bound, not HBM bound)."""
-    if (args.width, args.height, args.scene, args.gpus) != (1920, 1080, "sponza_proc", 1):
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "atrous_valu.json")) as f:
-            return int(json.load(f)["svgf_atrous_valu_insts_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def workload_key(args):
+    """What a PMC file is collected for: scene, size, rays.  One GPU only (the counters are per launch of the whole frame)."""
+    scene = os.path.splitext(os.path.basename(args.gltf))[0] if args.gltf else args.scene
+    return f"{scene}_{args.width}x{args.height}_ao{args.ao_spp}_refl{_bounces(args)}"
 
 
-def pmc_address_unit(args, raygen_ms):
-    """What bounds the ray-tracing kernel is the CU's address unit (TA): ~20 busy cycles per wave-level load instruction whatever its
-    width or the number of active lanes (profiles/r2_pmc_memory.txt).  The committed PMC run of this workload
-    (tools/pmc_ta.sh -> profiles/raygen_ta.json) gives the load instructions per launch and the TA's busy cycles; `floor_us` is the time
-    the launch needs with the address units of all 256 CUs busy every cycle, `frac` that floor over the launch time measured here."""
-    if (args.width, args.height, args.scene, args.gpus, args.ao_spp) != (1920, 1080, "sponza_proc", 1, 2):
-        return None
+def load_pmc(args, fingerprint):
+    """profiles/pmc_<workload>.json (tools/pmc_workload.sh): the counters behind roofline.traffic, roofline.valu and traversal.address_unit.
+    Quoted only when the file was collected on THIS library (vhr_source_fingerprint) and for THIS workload at N = 1; else (None, why)."""
+    if args.gpus != 1:
+        return None, "PMC files are per whole-frame launch: not quoted for N > 1"
+    name = f"pmc_{workload_key(args)}.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "raygen_ta.json")) as f:
-            ta = json.load(f)
-        floor_us = ta["ta_busy_cycles_sum"] / 256.0 / CLOCK_HZ * 1e6
-        return {"load_instructions_per_launch": ta["wave_level_load_instructions"], "ta_busy_cycles_per_load": ta["ta_cycles_per_load_instruction"],
-                "ta_busy_frac_under_profiler": ta["ta_busy_frac"], "floor_us": round(floor_us, 1), "frac": round(floor_us / max(raygen_ms * 1e3, 1e-9), 4),
-                "source": "profiles/raygen_ta.json (rocprofv3 --pmc TA_TA_BUSY_sum, TA_FLAT_READ_WAVEFRONTS_sum; tools/pmc_ta.sh); floor = TA busy cycles / 256 CUs / 2.4 GHz"}
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, f"no profiles/{name} (tools/pmc_workload.sh)"
+    if d.get("fingerprint") != fingerprint:
+        return None, f"profiles/{name} was collected on library {d.get('fingerprint')}; the loaded library is {fingerprint}: stale, not quoted"
+    return d, None
+
+
+def address_unit_block(pmc, raygen_ms):
+    """What the ray-tracing kernel's memory path does: ~20 busy cycles of the CU's address unit (TA) per wave-level load instruction whatever its
+    width or the number of active lanes.  `floor_us` is the time the launch needs with the address units of all 256 CUs busy every cycle."""
+    ta = (pmc or {}).get("raygen_ta")
+    if not ta:
         return None
+    floor_us = ta["ta_busy_cycles_sum"] / 256.0 / CLOCK_HZ * 1e6
+    return {"load_instructions_per_launch": ta["wave_level_load_instructions"], "ta_busy_cycles_per_load": ta["ta_cycles_per_load_instruction"],
+            "ta_busy_frac_under_profiler": ta["ta_busy_frac"], "floor_us": round(floor_us, 1), "frac": round(floor_us / max(raygen_ms * 1e3, 1e-9), 4),
+            "source": "rocprofv3 --pmc TA_TA_BUSY_sum, TA_FLAT_READ_WAVEFRONTS_sum (tools/pmc_workload.sh); floor = TA busy cycles / 256 CUs / 2.4 GHz"}
 
 
 def reflection_block(ctx, loop, frame_index, sync):
@@ -327,21 +331,12 @@ def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
             return times, f
 
 
-def pmc_traffic(args):
-    """HBM-side bytes per a-trous launch from the committed PMC run (tools/profile_traffic.sh -> profiles/traffic.json:
-    FETCH_SIZE x the calibrated gfx950 correction + WRITE_SIZE, separate --pmc passes).  Only valid for the default workload."""
-    if (args.width, args.height, args.scene, args.gpus) != (1920, 1080, "sponza_proc", 1):
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return int(json.load(f)["svgf_atrous_mean_traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL's peer-to-peer setup needs on this driver (already exported on the GPU boxes)
+    if args.print_workload_key:
+        print(workload_key(args))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # not under torchrun: become the launcher (before anything touches the GPU)
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
     if args.dry_launch:
@@ -601,7 +596,12 @@ def main():
         node_bytes = 32 if option_overrides.get("compact_nodes", 1) else 48
         trav_gbs = (trav_stats["node_visits"] * node_bytes + trav_stats["triangle_tests"] * 48) / max(raygen_ms, 1e-9) / 1e6
         transport = "RCCL (nccl)" if args.backend == "nccl" else "gloo (host memory)"
-        valu = pmc_valu(args)
+        from vulkanhybridrenderer_amd import lib as _lib
+        fingerprint = _lib.source_fingerprint()
+        pmc, pmc_note = load_pmc(args, fingerprint)
+        valu = (pmc or {}).get("svgf_atrous_valu_insts_per_launch")
+        traffic = (pmc or {}).get("svgf_atrous_mean_traffic_bytes_per_launch")
+        traffic = int(traffic) if traffic else None
         # MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles of its SIMD-32
         valu_floor_us = valu * 2.0 / (SIMDS * CLOCK_HZ) * 1e6 if valu else None
         temporal_us = kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3
@@ -661,15 +661,18 @@ def main():
                         "ms_per_step_with_mirror_ray is the frame with it",
             },
             "roofline": {
-                "kernel": "svgf_atrous_stream_kernel<step, 4 rows per tile at 1080p (8 at 4K), one tile per workgroup, weights in the exponent> (svgf_atrous_filter.comp)",
+                "kernel": "svgf_atrous_tile_kernel<step, 4 rows per tile at 1080p (8 at 4K)> (svgf_atrous_filter.comp: LDS comb tiles, weights in the exponent)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2.0 calibrated + WRITE_SIZE; includes Infinity-Cache hits; mean over the five "
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # the PMC-derived fields (traffic, valu, traversal.address_unit) come from profiles/pmc_<workload>.json and are quoted only when that
+                # file was collected on the library loaded here (vhr_source_fingerprint) for this very workload; else null and the reason
+                "pmc_file": None if pmc is None else f"profiles/pmc_{workload_key(args)}.json", "pmc_note": pmc_note, "library_fingerprint": fingerprint,
+                "traffic_source": "tools/pmc_workload.sh (rocprofv3 --pmc FETCH_SIZE x the correction calibrated in the same run + WRITE_SIZE; includes Infinity-Cache hits; mean over the five "
                                   "launches of a frame.  Three of them also do the work of the pass's three blits -- iteration 0 stores the history copy (+8 B/px) and "
                                   "copies the normals (+16 B/px), iteration 3 stores the Denoised image (+8 B/px): +13 MB on this average and +1.5 / +0.5 us on those "
                                   "launches, which the 24 B/px of `achieved` do not count)",
                 # the same mean without the bytes of the three blits those launches carry (32 B/px per frame over five launches, N = 1 only)
-                "traffic_less_fused_blit_bytes": (None if pmc_traffic(args) is None or world > 1 else int(pmc_traffic(args) - 32 * pixels_owned / 5)),
+                "traffic_less_fused_blit_bytes": (None if traffic is None or world > 1 else int(traffic - 32 * pixels_owned / 5)),
                 "avg_launch_us": round(atrous_us, 2), "launches": int(kt["svgf_atrous"][1]),
                 "launches_note": (f"HIP event pairs on every {ATROUS_TIMING_STRIDE}th a-trous launch of the timed region on the context's stream "
                                   f"({(4 if async_dead else 5) * args.steps * len(t_blocks)} launches, {'steps 1, 2, 4, 8' if async_dead else 'all five step sizes'} sampled evenly); "
@@ -684,7 +687,7 @@ def main():
                 # what actually bounds the kernel: issue of its vector instructions (PMC: lanes 96-97 % active, traffic 1.2-1.3 x algorithmic)
                 "valu": None if not valu else {
                     "insts_per_launch": valu, "floor_us": round(valu_floor_us, 2), "frac": round(valu_floor_us / atrous_us, 4) if atrous_us > 0 else None,
-                    "source": "profiles/atrous_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 2 cycles / (1024 SIMDs x 2.4 GHz), "
+                    "source": "tools/pmc_workload.sh (rocprofv3 --pmc SQ_INSTS_VALU, wave-level instructions per launch); floor = insts x 2 cycles / (1024 SIMDs x 2.4 GHz), "
                               "a wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md).  The knock-out builds (profiles/r3_atrous_knockouts.txt) price the kernel's mix higher: a packed "
                               "fp32 instruction 4 cycles, a transcendental 8"},
             },
@@ -711,7 +714,7 @@ def main():
                 # against the level the cache-resident tree is read from (L2 ~34.5 TB/s), not HBM
                 "l2_frac": round(trav_gbs / L2_PEAK_GBS, 4),
                 "stack_overflows": int(ray_stats["stack_overflows"]),
-                "address_unit": pmc_address_unit(args, raygen_ms),
+                "address_unit": address_unit_block(pmc, raygen_ms),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
             },
             # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); here a host

@@ -8,10 +8,24 @@
  * vhr_last_error() returns the message.  The reference has no error returns (VK_CHECK asserts,
  * vulkan_common.h:4-7); pool exhaustion returns -1 like resource_manager.cpp:847-848,876-877.
  *
- * Threading: like the reference (renderer.cpp:184-235) one host thread drives one context; all device
-
- * work of a context is issued in order on ONE HIP stream (the one given at creation, or an internal one
- * with VHR_CREATE_INTERNAL_STREAM).  One context per GPU / per process for multi-GPU (row strips, vhr_set_strip).
+ * Threading and streams: like the reference (renderer.cpp:184-235) one host thread drives one context.  Everything a frame PUBLISHES is
+ * issued in order on the context's stream (the one given at creation, or an internal one with VHR_CREATE_INTERNAL_STREAM): after
+ * vhr_graph_execute returns, work the caller enqueues on that stream sees every image the graph's passes declare as outputs.  Two things
+ * leave that stream, both owned and joined by the library:
+ *   - "svgf_async_unread" (default 1): a compute pass's a-trous dispatch whose output nothing reads (the reference's fifth iteration,
+ *     hybrid_render_path.cpp:299-328) runs on a library-owned SIDE stream beside whatever the context's stream does next; the context's
+ *     stream waits for it before the next compute pass, before storage-image uploads / downloads / vhr_get_storage_image and in
+ *     vhr_synchronize.  A caller that reads that dispatch's storage image itself on the context's stream must call vhr_synchronize first
+ *     or set the option to 0 (every dispatch in recorded order on the one stream).
+ *   - "frames_in_flight" 2 / 3 (opt-in): the front of a frame (up to its last ray-tracing pass) runs on a second stream; vhr_get_current_stream
+ *     tells an external pass which stream to enqueue on.
+ * Pass time stamps ("pass_timestamps", vhr_graph_gather_performance_statistics) cover what the CONTEXT'S stream executes between a pass's
+ * first kernel and the next kernel behind it: with the side stream on, "SVGF Denoise Pass" covers 1 temporal + 4 a-trous dispatches + the
+ * blits where the reference's vkCmdWriteTimestamp pair covers five a-trous dispatches (render_graph.cpp:167-182); with "svgf_async_unread" 0
+ * it covers all five.  In mode 1 the END of a pass is stored by the next LIBRARY kernel on the stream, so GPU work an external (graphics)
+ * pass's callback enqueues on the stream right behind a library pass is charged to that pass; mode 2 closes the pass in front of every such
+ * callback and at the end of vhr_graph_execute (a one-thread kernel, +6 us each).
+ * One context per GPU / per process for multi-GPU (screen tiles, vhr_set_tile; row strips, vhr_set_strip).
  */
 #ifndef VHR_AMD_H
 #define VHR_AMD_H
@@ -377,124 +391,74 @@ int vhr_comm_finish_frame_exchanges(vhr_comm *comm);
 int vhr_set_ray_statistics(vhr_context *ctx, int32_t enable);
 int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
 
-/* Tuning knobs for A/B measurements; every setting computes identical results.
- *   "raygen_variant"   0 = one thread per pixel tracing its rays in sequence, 1 = block work queue (default)
- *   "refill_threshold" idle lanes per wave that trigger a queue refill (default 16)
- *   "lds_stack_levels" traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 8)
- *   "raygen_early_exit" n/16: the inner-node loop is left once the walking lanes have dropped to that fraction of
- *                      those that entered it (0 = only when all are done; default 4)
- *   "raygen_pregen"    1 = every pixel pre-generates its ray directions into LDS, 0 = generated at refill (default)
- *   "raygen_waves_per_block" 1, 2 or 4 waves per workgroup (default 2)
- *   "raygen_shared_tile" 1 = the waves of a workgroup split ONE 8x8-pixel tile's ray queue, 0 = one tile per wave
- *   "trace_overlap"    strips only: 1 = the shadow/AO rays of the overlap rows are traced by this context as well, so
- *                      the raw visibility needs no neighbour exchange before svgf.comp (default 0: owned rows only)
- *   "compact_nodes"    1 (default) = the any-hit queue kernel walks 32-byte nodes: both child boxes as centre and half extent in IEEE halves
- *                      relative to the scene centre, widened until they contain the fp32 boxes in exact arithmetic (vhr_get_bvh_form_checks),
- *                      read straight into v_fma_mix_f32 -- two 16-byte loads per visit instead of three, no unpacking; 0 = the 48-byte
- *                      nodes (fp32 centres, truncated fp32 half extents).  Boxes only cull: bit-identical.  A scene whose extent
- *                      does not fit the half range around its centre has no such nodes and is walked on the 48-byte ones.
- *   "xcd_aware"        1 = workgroups sharing an XCD (b mod 8) own one contiguous band of screen tiles (default 0)
- *   "bvh_leaf_triangles" 1..4, leaf size of the next acceleration-structure build (default 3)
- *   "bvh_builder"      builder of the next vhr_update_geometry: 0 = binned SAH on the host (default: the better tree), 1 = an LBVH built on
- *                      the device like the reference's BLAS / TLAS (resource_manager.cpp:650,692,792): Morton sort, Karras hierarchy,
- *                      bottom-up boxes, the same node forms -- one-time cost 20-40x lower, a tree the walkers need more visits in.
- *                      Images are bit-identical with either (any-hit results do not depend on the tree, closest hits commit by (t, index)).
- *   "bvh_build_threads" host threads of the next build: 0 = up to 16 of the machine's (default), 1 = the serial build; subtrees below
- *                      the top of the tree are built by a pool and spliced in -- the tree is the same whatever the count
- *   "atrous_variant"   K4: 0 direct cached loads, 1 / 2 LDS comb tiles (16 / 8 rows), 3 packed-math tiles, 4 = 3 with
- *                      persistent workgroups that prefetch the next tile into registers, 5 = 4 with a tap's normal / id / kernel
- *                      weight carried in the exponent of its luminance weight (one v_log_f32 for the squaring chain; default)
- *   "atrous_blocks_per_cu" (1..64, default 64: more workgroups than tiles per CU at 1080p and 4K, i.e. one tile per workgroup --
- *                      measured faster than 8 persistent ones by 5 % at 1080p and 10 % at 4K), "atrous_xcd_aware" (default 1):
- *                      launch shape of variant 4
- *   "atrous_small_tiles" variant 4: -1 = 4-row instead of 8-row tiles when the launch has < 32 8-row tiles per CU (default: a 1080p
- *                      frame and every strip use 4-row tiles, a 4K frame 8-row ones), 0 = never, 1 = always, 2 / 3 = for step 16 / steps 8 and 16 only
- *   "strip_shrink_overlap" strips only (vhr_set_strip): 1 = an a-trous launch with step s computes the owned rows extended by
- *                      overlap - (4s - 2) rows instead of the full overlap -- all that can be valid, and all that is needed,
- *                      after the reference's doubling schedule 1, 2, 4, ... s (hybrid_render_path.cpp:299-319); only for callers
- *                      that run that schedule (default 0).  Owned rows are bit-identical either way.
- *   "reflection_variant" the mirror ray (one bounce): 1 = work-queue kernel, closest-hit walk per 16x8 tile + shading with the
- *                      whole wave (default), 0 = one pixel per thread (also what two bounces use)
- *   "raytraced_variant" the raytraced render path's "Raytracing Pass": 1 = work-queue kernel (primary closest-hit walk, shadow
- *                      any-hit walk, shading with the whole wave; default), 0 = one pixel per thread
- *   "pass_timestamps"  1 (default) = every ray-tracing / compute pass carries begin / end timestamps for
- *                      vhr_graph_gather_performance_statistics (the reference's vkCmdWriteTimestamp pair, render_graph.cpp:167-182),
- *                      written by the kernels themselves: the first thread of a pass's first kernel stores the device's wall clock as the
- *                      begin, the first thread of the NEXT kernel on the (in-order) stream stores it as the end -- for the frame's last
- *                      pass that is the next frame's first kernel, or a one-thread kernel issued by whatever call waits for the stream
- *                      first (vhr_synchronize, vhr_graph_gather_performance_statistics, downloads); ~3 us per frame.  2 = the same with
- *                      that one-thread kernel issued at the end of every vhr_graph_execute (hosts that neither run ahead of the GPU nor
- *                      wait for it; +6 us per frame).  3 = HIP event pairs on the dispatch packets (rounds 1-3a; 16 us per frame, and the
- *                      only form with "frames_in_flight" > 1).  0 = off.  External graphics passes are not stamped.
- *   "raygen_tile_rows" rows of the 8-pixel-wide tile a wave of the queue kernel owns: 0 (default) = 8, or 6 for a launch whose 8x8 tiles fill less
- *                      than 70 % of the chip's wave slots (a 1080p / 8 screen tile: -8 %); 1..8 = that many (4 and 2 lose on whole frames)
- *   "fuse_blits"       1 = a compute pass records its dispatches and blits and issues them when its callback returns; a
- *                      same-extent blit whose source is the output of a recorded a-trous dispatch (and whose destination nothing
- *                      in between touches) becomes a second store of that launch instead of a copy kernel (default; two of the
- *                      three blits of hybrid_render_path.cpp:310-325), 0 = every blit is a copy
- *   "raygen_cut"       1 = each tile of the queue kernel descends the BVH once from the root along the children that
- *                      contain the box of its ray origins and keeps the siblings it passes (at most 16) in LDS; a ray tests
- *                      those boxes when it is fetched and starts below them instead of at the root (default; same
- *                      triangles tested in a different order, visibility bit-identical), 0 = every ray starts at the root.
- *                      Ignored with the shared-tile variant and pre-generated rays.
- *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair
- *                      (default 1 = every launch).  A timed dispatch costs ~6 us that the next kernel waits for; bench.py samples
- *                      the a-trous launches with stride 6 (coprime with the 5 launches of a frame, so every step size is sampled).
- *   "shadow_packet"    with "raygen_cut": 1 = the shadow rays of a tile (one per pixel, within 0.18 degrees of the light direction,
- *                      raygen.rgen:32-35) are walked as ONE wave-uniform packet before the tile's queue starts -- the node arrives
- *                      through scalar loads, every lane tests its own ray, the stack is wave-uniform -- and the queue carries the
- *                      AO rays only; 0 = shadow rays share the per-ray queue.  Visibility bit-identical (any hit = OR over triangles).
- *   "cut_reach"        with "raygen_cut", whenever the queue holds AO rays only (shadow rays off or walked as a packet): 1 = a
- *                      subtree whose box lies farther from the bounds of the tile's ray origins than any of its AO rays can
- *                      reach (ao_tmax * an upper bound of |d|: the G-buffer normal is not a unit vector) is left out of the
- *                      tile's cut (default), 0 = all siblings kept.  Box tests only cull: bit-identical.
- *   "shadow_last"      order of a tile's ray queue (kind-major either way): 1 (default) = AO samples first, the shadow rays LAST; 0 = shadow
- *                      rays first.  What a wave loses is the drain of its queue, and the near-parallel shadow rays end together: wave-level
- *                      trips -5 %, ray-tracing kernel -3.5 %.  Visibility is accumulated as integers: bit-identical.
- *   "cut_expand"       with "raygen_cut": 1 = after the shared descent, inner entries of the cut whose box overlaps the bounds of the
- *                      tile's ray origins are replaced by their two children (largest first) until the cut's 16 entries are used:
- *                      fewer node visits per ray (7.9 -> 6.9) for more box tests at refill; measured +1 % time: default 0.  Bit-identical.
- *   "raygen_tile_pixels" pixels per wave of the work-queue raygen kernel: 64 = one 8x8 tile (default), 128 / 256 = 16x8 / 16x16 pixels
- *                      with ONE ray queue over all of them (raygen_wide_kernel: fewer lanes idle while a queue drains -- 45 / 50 %
- *                      instead of 37 % active lanes -- but half / a quarter as many waves per launch; measured -2 % at 4K, +4 % at
- *                      1080p).  Bit-identical.
- *   "frames_in_flight" 1 (default), 2 or 3; read by vhr_graph_build.  n > 1: frame f uses resource index f mod n (as the
- *                      reference's frame loop does, vulkan_common.h:9 / renderer.cpp:103-146); the passes up to and including the
- *                      last ray-tracing pass are issued on a second stream beside the previous frame's remaining passes, every
- *                      graph-owned transient image exists once per index, an external binding (vhr_graph_bind_external_image)
- *                      belongs to the index being executed, and the two streams are ordered by events derived from the pass
- *                      declarations.  External graphics passes before the ray-tracing pass must enqueue on the stream current
- *                      during their callback: vhr_get_current_stream.  Images bit-identical to n = 1.
- *   "bvh_wide"         1 = the any-hit queue kernel walks the four-wide tree (48-byte nodes, child boxes quantised to 8 bits per plane,
- *                      rounded outward; vhr_get_bvh_wide_checks): half the node visits and 38 % fewer load instructions for 35 % more
- *                      vector instructions -- measured slower (sponza_proc 1080p 404 vs 318 us): default 0.  Bit-identical.
- *   "svgf_elide_unread" 1 = an a-trous dispatch of a compute pass whose output image nothing later in that pass reads or publishes is
- *                      not launched -- the reference's fifth a-trous iteration (hybrid_render_path.cpp:299-328 publishes the fourth;
- *                      SURVEY 8 a5).  Everything the pass publishes is bit-identical; the skipped dispatch's storage image keeps older
- *                      contents, which is why this is opt-in (default 0).
- *   "svgf_async_unread" 1 (default) = that same dispatch, when it is launched, is issued last and on a side stream of the context, ordered
- *                      behind the pass's other commands by an event: nothing on the frame's critical path waits for it, and it runs beside
- *                      whatever the context's stream does next (the next frame's ray tracing).  The context's stream waits for it before
- *                      the next compute pass, before storage-image uploads / downloads / vhr_get_storage_image, and in vhr_synchronize.
- *                      Only with "frames_in_flight" 1, for dispatches of >= 900 000 pixels (the whole 1080p frame or its half; small
- *                      screen tiles are not worth the two stream operations) and when the pass itself copies what the dispatch reads of the
- *                      G-buffer normals (hybrid_render_path.cpp:319; the copy is read instead, the G-buffer belongs to the next frame by
- *                      then); else the dispatch stays in place.  Every image bit-identical, the dispatch's own
- *                      output included.  2 = the same whatever the dispatch's size; 0 = every dispatch in recorded order on the context's stream.
- *   "fuse_temporal"    1 = a TraceRays of the hybrid path's ray-tracing pass is held back until the next pass shows its first command; if that is
- *                      svgf.comp on the launch's own images (whole-image work, one frame in flight, no mirror ray, no epilogue hooked to the
- *                      ray-tracing pass), the queue kernel runs it for each tile in the tile's epilogue -- the visibility goes from LDS into
- *                      the filter -- and the dispatch is not launched; anything else that enqueues on or waits for the stream first gets the
- *                      launch as it is.  Every image bit-identical.  Measured: the ray-tracing kernel grows by 20 of the 26 us the kernel
- *                      and its launch gap cost (0.494 -> 0.490 ms per frame), and "Raytrace Pass" / "SVGF Denoise Pass" times shift by
- *                      that dispatch: default 0.
- *   "temporal_variant" 0 = svgf.comp in 32x8-pixel workgroups (default), 1 = 64x4 (rounds 1-3c; A-B)
- *   "raygen_cost_order" 1 (default) = the blocks of the shadow / AO ray-tracing launch (and, separately, of the mirror-ray launch and of the raytraced render path's launch) start in the order of their lifetimes two launches ago,
- *                      longest first: every wave leaves its lifetime, the launch's first block sorts the previous launch's blocks into 8 classes of
- *                      cost (stable inside a class) before it turns to its own tile, the next launch of the same shape on the same stream reads
- *                      the order.  No kernel, stream or event of its own; images bit-identical (any order is a correct one); launches of
- *                      >= 2 048 blocks only.  2 = any launch (tests), 0 = blocks in row-major order.  -1.5 .. -2 % per frame at 1080p. */
+/* Options.  One table in the library (csrc/vhr_internal.hpp: VHR_OPTION_TABLE) holds every option's name, default, smallest and largest value;
+ * vhr_option_count / vhr_option_info enumerate it, vhr_set_option refuses a value outside the range (VHR_ERROR_INVALID_ARGUMENT) and an
+ * unknown name (VHR_ERROR_NOT_FOUND).  Every setting publishes identical images (the literal forms of the a-trous filter and of the mirror
+ * ray within the float tolerance of tests/); what changes is which kernel runs or what is launched where.
+ *  Forms of a shader -- 0 = the literal one-pixel-per-thread form (the in-tree cross-check of the default), 1 = the default:
+ *   "raygen_variant"     raygen.rgen's shadow + AO rays: raygen_kernel / raygen_queue_kernel (a ray queue per 8x8-pixel tile and wave)
+ *   "reflection_variant" the mirror ray + reflection_hit.rchit: reflection_kernel / reflection_queue_kernel (closest-hit queue per 16x8 tile,
+ *                        shading with the whole wave; one or two bounces)
+ *   "raytraced_variant"  the raytraced render path's pass: raytraced_kernel / raytraced_queue_kernel
+ *   "atrous_variant"     svgf_atrous_filter.comp: svgf_atrous_kernel (direct cached loads, product-form weights) / svgf_atrous_tile_kernel
+ *                        (LDS comb tiles, weights in the exponent)
+ *  The queue kernels:
+ *   "refill_threshold"   idle lanes per wave that trigger a queue refill (default 16)
+ *   "lds_stack_levels"   traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 8)
+ *   "raygen_early_exit"  n/16: the inner-node loop is left once the walking lanes have dropped to that fraction of those that entered it
+ *                        (0 = only when all are done; default 4)
+ *   "raygen_waves_per_block" 1, 2 or 4 tiles (= waves) per workgroup (default 2)
+ *   "compact_nodes"      1 (default) = the any-hit queue kernel walks 32-byte nodes: both child boxes as centre and half extent in IEEE halves
+ *                        relative to the scene centre, widened until they contain the fp32 boxes in exact arithmetic (vhr_get_bvh_form_checks),
+ *                        read straight into v_fma_mix_f32 -- two 16-byte loads per visit instead of three, no unpacking; 0 = the 48-byte
+ *                        nodes (fp32 centres, truncated fp32 half extents).  Boxes only cull: bit-identical.  A scene whose extent does not
+ *                        fit the half range around its centre has no such nodes and is walked on the 48-byte ones.
+ *   "raygen_tile_rows"   rows of the 8-pixel-wide tile a wave owns: 0 (default) = 8, or 6 for a launch whose 8x8 tiles fill less than 70 % of
+ *                        the chip's wave slots (a 1080p / 8 screen tile: -8 %); 1..8 = that many (4 and 2 lose on whole frames)
+ *   "raygen_cost_order"  1 (default) = the workgroups of a queue kernel's launch start in the order of their lifetimes two launches ago, longest
+ *                        first: every wave leaves its lifetime, the launch's first workgroup sorts the previous launch's into 8 classes of cost
+ *                        (stable inside a class) before it turns to its own tile, the next launch of the same shape on the same stream reads the
+ *                        order.  No kernel, stream or event of its own; launches of >= 2 048 workgroups only.  2 = any launch (tests), 0 = row-major.
+ *  The a-trous kernel:
+ *   "atrous_small_tiles" -1 (default) = 4-row instead of 8-row tiles when the launch has < 32 8-row tiles per CU (a 1080p frame and every screen
+ *                        tile use 4-row tiles, a 4K frame 8-row ones), 0 = never, 1 = always
+ *  The frame's schedule:
+ *   "fuse_blits"         1 (default) = a compute pass records its dispatches and blits and issues them when its callback returns; a same-extent
+ *                        blit whose source is the output (or the normals input) of a recorded a-trous dispatch becomes a second store of that
+ *                        launch instead of a copy kernel (all three blits of hybrid_render_path.cpp:310-325); 0 = every blit is a copy
+ *   "svgf_elide_unread"  1 = an a-trous dispatch whose output image nothing later in its pass reads or publishes is not launched -- the
+ *                        reference's fifth iteration (hybrid_render_path.cpp:299-328 publishes the fourth).  Everything the pass
+ *                        publishes is bit-identical; the skipped dispatch's storage image keeps older contents: opt-in (default 0)
+ *   "svgf_async_unread"  1 (default) = that dispatch is issued last, on the side stream (see "Threading and streams" at the top); only with one
+ *                        frame in flight, for dispatches of >= 900 000 pixels, and when the pass itself copies what the dispatch reads of the
+ *                        G-buffer normals (hybrid_render_path.cpp:319); 2 = whatever the size; 0 = every dispatch in recorded order
+ *   "fuse_temporal"      1 = svgf.comp runs in the ray-tracing kernel's tile epilogues when the SVGF pass's first command is that dispatch on the
+ *                        launch's own images (whole-image work, one frame in flight, no mirror ray, no epilogue hooked to the ray-tracing pass);
+ *                        the pass times shift by that dispatch: default 0
+ *   "frames_in_flight"   1 (default), 2 or 3; read by vhr_graph_build.  n > 1: frame f uses resource index f mod n (vulkan_common.h:9,
+ *                        renderer.cpp:103-146); the passes up to and including the last ray-tracing pass are issued on a second stream beside the
+ *                        previous frame's remaining passes, every graph-owned transient image exists once per index, an external binding belongs
+ *                        to the index being executed, the two streams are ordered by events derived from the pass declarations
+ *  Screen tiles / row strips (one process per GPU; vhr_set_tile, vhr_set_strip):
+ *   "trace_overlap"      1 = the shadow / AO rays of the overlap margin are traced by this context as well, so the raw visibility needs no
+ *                        neighbour exchange before svgf.comp (default 0: owned pixels only)
+ *   "strip_shrink_overlap" 1 = an a-trous launch with step s computes the owned rectangle extended by overlap - (4s - 2) instead of the full
+ *                        overlap -- all that can be valid, and all that is needed, after the reference's doubling schedule 1, 2, 4, ... s
+ *                        (hybrid_render_path.cpp:299-319); only for callers that run that schedule (default 0)
+ *  Instrumentation:
+ *   "pass_timestamps"    1 (default) = begin / end stamps per ray-tracing / compute pass, written by the kernels themselves (see "Threading and
+ *                        streams"); 2 = + the one-thread stamp kernel in front of external passes and at the end of vhr_graph_execute; 3 = HIP
+ *                        event pairs on the dispatch packets (16 us per frame; the only form with "frames_in_flight" > 1); 0 = off
+ *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair (a timed dispatch
+ *                        costs ~6 us that the next kernel waits for)
+ *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 3); "bvh_builder" 0 = binned SAH on the
+ *  host (default: the better tree), 1 = Morton sort + PLOC on the device like the reference's BLAS / TLAS (resource_manager.cpp:650,692,792;
+ *  20-40x faster to build, a tree the walkers need more visits in; images bit-identical); "bvh_build_threads" 0 = up to 16 host threads
+ *  (default), 1 = serial -- the tree is the same whatever the count. */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
+int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);
+int32_t vhr_option_count(void);
+int vhr_option_info(int32_t index, const char **name, int32_t *default_value, int32_t *min_value, int32_t *max_value);
 
 /* Per-kernel timing with HIP event pairs attached to every launch of a kernel kind on the context stream (the events ride on
  * the dispatch packet -- hipExtLaunchKernelGGL's start / stop events, the dispatch's own begin / end timestamps -- instead of
@@ -514,6 +478,9 @@ int vhr_get_kernel_time(vhr_context *ctx, int32_t kind, double *total_ms, uint64
 /* A hash of the sources this library was built from (16 hex digits).  profiles/pmc_*.json carry the fingerprint of the library their
  * counters were collected on; bench.py quotes them only when it equals the loaded library's. */
 const char *vhr_source_fingerprint(void);
+/* Diagnostics: the lifetimes (shader clock ticks) of the last ray-tracing launch's waves, as left for "raygen_cost_order"
+ * (index = tile pair * waves per workgroup + wave); *count = entries written. */
+int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity, uint32_t *count);
 
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 /* The same for the mirror-ray launch of the last vhr_trace_rays (raygen.rgen:59-65 + reflection_hit.rchit; the queue kernel, statistics
@@ -528,13 +495,10 @@ int vhr_get_reflection_statistics(vhr_context *ctx, uint64_t out[10]);
  * out[3] = inner-node loop, out[4] = leaf (triangle) stage, out[5] = refills, out[6] = waves, out[7] = 0. */
 int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]);
 
-/* Shadow packets of the last work-queue raygen launch (option "shadow_packet", statistics enabled): out[0] = waves that walked
- * one (tiles with covered pixels), out[1] = wave-level inner-node visits, out[2] = wave-level triangle tests, out[3] = still
- * undecided lanes summed over those steps (active-lane utilisation of the packets = out[3] / (64 * (out[1] + out[2]))),
- * out[4] = s_memtime ticks spent in the packets; out[5] = entries of the tiles' tree cuts ("raygen_cut"), summed over the
- * waves of the launch (traversal cycles out[6]): what "cut_reach" prunes; out[6..8] = wave-level trips made after the tile's queue
- * had run dry with at most 4 / 8 / 16 of the wave's rays still in flight (the tail of the drain). */
-int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[9]);
+/* The drain of the tiles' queues in the last shadow / AO launch (statistics enabled): out[0] = entries of the tiles' tree cuts summed over
+ * the launch's waves (vhr_get_traversal_cycles out[6]), out[1..3] = wave-level trips made after the tile's queue had run dry with at most
+ * 4 / 8 / 16 of the wave's rays still in flight. */
+int vhr_get_drain_statistics(vhr_context *ctx, uint64_t out[4]);
 
 /* Profiling aid: streams a storage image once with 4, 8 or 16 bytes per lane (a read of exactly width * height *
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */
@@ -555,11 +519,6 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]);
  * out[3] = half-precision ("compact_nodes") boxes that do not contain theirs.  All three must be 0: the walkers' bit-identity with the
  * oracle rests on box tests that only cull. */
 int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]);
-/* The same for the four-wide tree the "bvh_wide" walkers read (a collapse of the same BVH2, child boxes quantised to 8 bits per plane
- * on a per-node power-of-two grid, rounded outward): out[0] = wide nodes, out[1] = child boxes checked, out[2] = quantised boxes that do
- * NOT contain the binary tree's padded box of the same subtree in exact arithmetic, out[3] = structural errors (links that differ from
- * the binary tree's, malformed grid words, triangles not covered exactly once).  out[2] and out[3] must be 0. */
-int vhr_get_bvh_wide_checks(vhr_context *ctx, uint64_t out[4]);
 /* A 64-bit hash of the last build's nodes and leaf triangles in their final order: two builds of the same input must agree whatever
  * "bvh_build_threads" was. */
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out);

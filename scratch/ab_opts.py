@@ -14,8 +14,7 @@ W, H = [int(v) for v in os.environ.get("VHR_SIZE", "1920x1080").split("x")]
 for name in scene_names:
     loop = HybridFrameLoop(getattr(scenes, name)(), W, H, 12)
     ctx = loop.ctx
-    defaults = {"lds_stack_levels": 8, "raygen_early_exit": 4, "refill_threshold": 16, "raygen_waves_per_block": 2, "raygen_tile_pixels": 64,
-                "shadow_last": 1, "cut_reach": 1, "raygen_cut": 1, "xcd_aware": 0, "raygen_tail_tile_rows": 4, "compact_nodes": 1}
+    defaults = {k: v[0] for k, v in lib.option_table().items()}
     touched, ref = {}, None
     parsed = [[a.split("=") for a in arm.split(",") if a] for arm in arms]
     for kv in parsed:

@@ -9,7 +9,7 @@ for name in ("sponza_proc", "bistro_proc"):
     ctx = loop.ctx
     for i in range(3): loop.frame(i)
     ctx.set_ray_statistics(True); loop.frame(5); ctx.synchronize()
-    ts, ps, cy = ctx.traversal_statistics(), ctx.packet_statistics(), ctx.traversal_cycles()
+    ts, ps, cy = ctx.traversal_statistics(), ctx.drain_statistics(), ctx.traversal_cycles()
     T = ts["wave_iterations"]
     print(f"{name}: trips {T}, drain {cy['drain_iterations']/T:.3f}, with <= 16 rays left {ps['drain_trips_le16']/T:.3f}, <= 8 {ps['drain_trips_le8']/T:.3f}, <= 4 {ps['drain_trips_le4']/T:.3f}", flush=True)
     loop.close()

@@ -88,18 +88,16 @@ def test_axis_parallel_light_and_rays(oracle):
 
 @pytest.mark.parametrize("ao_spp", [0, 1, 4, 16, 20])
 def test_ao_sample_counts(oracle, ao_spp):
-    """BASELINE.json configs 3 and 5 use 4 and 16 AO samples; 20 exceeds the pre-generation limit (other code path)."""
+    """BASELINE.json configs 3 and 5 use 4 and 16 AO samples."""
     tp = abi.default_trace_params(ao_spp=ao_spp, reflections=False)
-    for pregen in (0, 1):
-        frames, _, _ = oracle_frames(oracle, scenes.tiny_scene(), 64, 40, 2, tp, denoise=False)
-        g = GpuHybrid(scenes.tiny_scene(), 64, 40, denoise=False, trace_params=tp, reflections=False)
-        try:
-            g.ctx.set_option("raygen_pregen", pregen)
-            for fr in frames:
-                g.frame(fr["pfd"], fr["gbuf"])
-                assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"])
-        finally:
-            g.close()
+    frames, _, _ = oracle_frames(oracle, scenes.tiny_scene(), 64, 40, 2, tp, denoise=False)
+    g = GpuHybrid(scenes.tiny_scene(), 64, 40, denoise=False, trace_params=tp, reflections=False)
+    try:
+        for fr in frames:
+            g.frame(fr["pfd"], fr["gbuf"])
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"])
+    finally:
+        g.close()
 
 
 def test_shadows_disabled_extension(oracle):
@@ -108,10 +106,45 @@ def test_shadows_disabled_extension(oracle):
     assert (f16(frames[1]["shadow_ao"])[..., 0] == 1.0).all()
 
 
-@pytest.mark.parametrize("option,values", [("raygen_waves_per_block", (1, 2, 4)), ("lds_stack_levels", (1, 3, 32)), ("compact_nodes", (0, 1)),
-                                           ("xcd_aware", (0, 1)), ("refill_threshold", (1, 64)), ("raygen_shared_tile", (0, 1)), ("raygen_pregen", (0, 1)), ("raygen_early_exit", (0, 8, 15)), ("raygen_cut", (0, 1)),
-                                           ("shadow_packet", (0, 1)), ("raygen_tile_rows", (0, 8, 6, 4)), ("cut_reach", (0, 1)), ("cut_expand", (0, 1)), ("shadow_last", (0, 1)), ("raygen_tile_pixels", (64, 128, 256)), ("bvh_wide", (0, 1)),
-                                           ("atrous_variant", (0, 1, 2, 3, 4, 5)), ("atrous_blocks_per_cu", (1, 3)), ("atrous_xcd_aware", (0, 1)), ("atrous_small_tiles", (0, 1)), ("temporal_variant", (0, 1)), ("raygen_cost_order", (0, 2))])
+def _option_cases():
+    """Every option of the library's table (vhr_option_info) with its smallest, its largest and its default value (+ a value in between for
+    the wide ranges).  frames_in_flight is read at graph build (its own tests: test_gpu_frames_in_flight.py); kernel_timing_stride only
+    thins event pairs.  No device needed to list them."""
+    table = lib.option_table()
+    cases = []
+    for name, (default, lo, hi) in sorted(table.items()):
+        if name == "frames_in_flight":
+            continue
+        values = sorted({lo, hi, default} | ({(lo + hi) // 2} if hi - lo > 2 and hi - lo < 100 else set()) | ({6} if name == "kernel_timing_stride" else set()))
+        if name == "kernel_timing_stride":
+            values = [1, 6]
+        cases.append((name, tuple(values)))
+    return cases
+
+
+def test_the_option_table_is_what_the_neutrality_test_covers():
+    table = lib.option_table()
+    assert set(n for n, _ in _option_cases()) == set(table) - {"frames_in_flight"}
+    for name, (default, lo, hi) in table.items():
+        assert lo <= default <= hi, name
+
+
+def test_options_outside_their_range_are_refused():
+    c = lib.Context(32, 32)
+    try:
+        for name, (default, lo, hi) in lib.option_table().items():
+            assert c.get_option(name) == default
+            for bad in (lo - 1, hi + 1):
+                with pytest.raises(lib.VhrError):
+                    c.set_option(name, bad)
+            assert c.get_option(name) == default
+        with pytest.raises(lib.VhrError):
+            c.set_option("no_such_option", 1)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("option,values", _option_cases())
 def test_every_tuning_option_is_result_neutral(oracle, option, values):
     scene = scenes.tiny_scene()
     W, H = 72, 56
@@ -126,7 +159,7 @@ def test_every_tuning_option_is_result_neutral(oracle, option, values):
                 g.frame(fr["pfd"], fr["gbuf"])
                 assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), (option, v)
             outs.append(g.ctx.download(lib.DENOISED))
-            if option in ("lds_stack_levels", "compact_nodes", "raygen_cut", "shadow_packet", "raygen_tile_pixels", "bvh_wide"):
+            if option in ("lds_stack_levels", "compact_nodes", "raygen_waves_per_block", "raygen_tile_rows"):
                 g.ctx.set_ray_statistics(True)
                 g.frame(frames[-1]["pfd"], frames[-1]["gbuf"])
                 assert g.ctx.ray_statistics()["stack_overflows"] == 0
@@ -159,9 +192,9 @@ def test_scene_through_the_gltf_host(oracle, tmp_path):
     _check(oracle, scene, 96, 64, 2, abi.default_trace_params())
 
 
-def test_packet_and_wide_tiles_on_odd_sizes_and_ao_only(oracle):
-    """The shadow-packet stage (with the AO-only queue's reach-pruned cut) and the 16x8 / 16x16 wide-tile kernel on image sizes
-    that leave partial tiles, with and without shadow rays, 1 and 4 AO samples: visibility bit-identical to the oracle."""
+def test_odd_sizes_and_ao_only_queues(oracle):
+    """Image sizes that leave partial tiles, with and without shadow rays (the AO-only queue's cut is pruned to the rays' reach; with shadow
+    rays in the queue the AO rays skip the cut's far entries), 1 and 4 AO samples, every tile height: visibility bit-identical to the oracle."""
     scene = scenes.sponza_proc(detail=0.25) if hasattr(scenes, "sponza_proc") else scenes.tiny_scene()
     W, H = 150, 93
     for shadow, ao in ((True, 1), (False, 4), (True, 0)):
@@ -169,9 +202,7 @@ def test_packet_and_wide_tiles_on_odd_sizes_and_ao_only(oracle):
         frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
         g = GpuHybrid(scene, W, H, shadow=shadow, ao=bool(ao), trace_params=tp, reflections=False, denoise=False)
         try:
-            for key, val in (("shadow_packet", 1), ("raygen_tile_pixels", 128), ("raygen_tile_pixels", 256)):
-                g.ctx.set_option("shadow_packet", 0)
-                g.ctx.set_option("raygen_tile_pixels", 64)
+            for key, val in (("raygen_tile_rows", 8), ("raygen_tile_rows", 5), ("raygen_waves_per_block", 4), ("lds_stack_levels", 2)):
                 g.ctx.set_option(key, val)
                 for fr in frames:
                     g.frame(fr["pfd"], fr["gbuf"])

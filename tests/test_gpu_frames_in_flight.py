@@ -84,10 +84,12 @@ def test_graph_owned_gbuffer_instances_and_per_frame_results(oracle):
         assert np.array_equal(rt, rt1) and np.array_equal(den, den1), f"frame {i}"
 
 
-def test_option_is_read_at_build_and_clamped():
+def test_option_is_read_at_build_and_bounded():
     c = lib.Context(64, 64)
     try:
-        c.set_option("frames_in_flight", 7)
+        with pytest.raises(lib.VhrError):
+            c.set_option("frames_in_flight", 7)                    # beyond MAX_FRAMES_IN_FLIGHT (vulkan_common.h:9): refused by the option table
+        c.set_option("frames_in_flight", 3)
         path = lib.HybridRenderPath(c, 0, 0, 2, True, 5, lambda ctx: ctx.standin_gbuffer(0))
         path.build()
         sc = scenes.tiny_scene()
@@ -95,7 +97,7 @@ def test_option_is_read_at_build_and_clamped():
         pfds = camera.dolly_frames(sc, 64, 64, 4)
         for i, pfd in enumerate(pfds):
             c.update_per_frame_ubo(i % 3, pfd)
-            c.execute(i % 3, 0)                                    # three slots exist (the option is clamped to MAX_FRAMES_IN_FLIGHT)
+            c.execute(i % 3, 0)                                    # three slots exist
         c.synchronize()
         assert np.isfinite(c.download(lib.DENOISED).view(np.float16).astype(np.float32)).all()
         path.destroy()

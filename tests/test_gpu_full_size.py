@@ -43,16 +43,14 @@ def test_config2_1080p_whole_frames_against_the_oracle(oracle):
             assert out[..., :2].min() >= 0.0 and out[..., :2].max() <= 1.0 + 2.0 ** -10
             if i == 3:                                                # every traversal flavour, same bits
                 for key, val in (("raygen_variant", 0), ("lds_stack_levels", 32), ("refill_threshold", 1), ("raygen_early_exit", 0),
-                                 ("raygen_cut", 0), ("lds_stack_levels", 2),        # 2 levels with the cut on: cut entries wait in the mask
-                                 ("shadow_packet", 1),                              # shadow rays as one packet per tile instead of through the per-ray queue
-                                 ("cut_expand", 1),                                 # the tile's cut expanded around the origins
-                                 ("shadow_last", 0),                                # the queue with the shadow rays first
-                                 ("bvh_wide", 1)):                                  # the four-wide tree with 8-bit child boxes
+                                 ("lds_stack_levels", 2),                           # 2 levels: cut entries wait in the mask
+                                 ("compact_nodes", 0),                              # the 48-byte fp32 nodes
+                                 ("raygen_cost_order", 0), ("raygen_waves_per_block", 4)):
                     g.ctx.set_option(key, val)
                     g.ctx.execute(0, 0)
                     g.ctx.synchronize()
                     assert np.array_equal(g.ctx.download(lib.RAYTRACED), sa), key
-                    g.ctx.set_option(key, {"raygen_variant": 1, "lds_stack_levels": 8, "refill_threshold": 16, "raygen_early_exit": 4, "raygen_cut": 1, "shadow_packet": 0, "cut_expand": 0, "shadow_last": 1, "bvh_wide": 0}[key])
+                    g.ctx.set_option(key, lib.option_table()[key][0])
     finally:
         g.close()
 

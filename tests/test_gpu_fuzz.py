@@ -50,7 +50,6 @@ def test_random_triangle_soup_matches_oracle_bvh_and_brute_force(oracle, seed, n
     g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
     try:
         assert g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
-        assert g.ctx.bvh_wide_checks()[2:] == (0, 0)
         for i, fr in enumerate(frames):
             g.frame(fr["pfd"], fr["gbuf"])
             got = g.ctx.download(lib.RAYTRACED)
@@ -59,8 +58,8 @@ def test_random_triangle_soup_matches_oracle_bvh_and_brute_force(oracle, seed, n
                 brute = osc.raygen(fr["pfd"], tp, fr["gbuf"][0], fr["gbuf"][2], use_bvh=False, want_reflections=False)[0]
                 assert np.array_equal(got, brute), f"frame {i}: visibility differs from the oracle's brute force"
             if i == 1:                             # and every walker flavour, same bits
-                for key, val, back in (("raygen_variant", 0, 1), ("raygen_cut", 0, 1), ("compact_nodes", 0, 1), ("shadow_packet", 1, 0),
-                                       ("raygen_tile_pixels", 128, 64), ("cut_expand", 1, 0), ("shadow_last", 0, 1), ("lds_stack_levels", 2, 8), ("bvh_wide", 1, 0)):
+                for key, val, back in (("raygen_variant", 0, 1), ("compact_nodes", 0, 1), ("raygen_tile_rows", 5, 0), ("raygen_waves_per_block", 1, 2),
+                                       ("lds_stack_levels", 2, 8), ("refill_threshold", 64, 16)):
                     g.ctx.set_option(key, val)
                     g.ctx.execute(0, 0)
                     g.ctx.synchronize()

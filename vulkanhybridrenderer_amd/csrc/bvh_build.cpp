@@ -421,12 +421,8 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     out.nodes16.clear();
     out.nodes_ch.clear();
     out.nodes48.clear();
-    out.nodes4.clear();
-    out.wide_root.clear();
-    out.wide_child_ref.clear();
     out.tris.clear();
     out.max_depth = 0;
-    out.wide_depth = 0;
     if (n == 0) return;
 
     b.tri_box.resize(n);
@@ -454,54 +450,17 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     lap("tree");
     out.max_depth = b.max_depth;
 
-    // ---- the four-wide collapse (BvhNode4): a wide node is a binary inner node X with its two children, of which the inner one
-    // with the largest box is opened (replaced by ITS two children, in place) until there are four or only leaves are left.
-    // Breadth-first numbering; a node's inner children are appended together, so they are consecutive nodes.
-    struct WideTmp { int32_t root; int32_t child[4]; int n; uint32_t depth; };
-    std::vector<WideTmp> wide;
-    {
-        std::vector<std::pair<int32_t, uint32_t>> queue;      // (binary node, depth), breadth first
-        if (b.nodes[0].left >= 0) queue.emplace_back(0, 1u);
-        else { WideTmp w{ -1, { 0, -1, -1, -1 }, 1, 1u }; wide.push_back(w); out.wide_depth = 1; }      // the whole scene is one leaf
-        for (size_t head = 0; head < queue.size(); ++head) {
-            const int32_t id = queue[head].first;
-            const uint32_t depth = queue[head].second;
-            WideTmp w{ id, { b.nodes[id].left, b.nodes[id].right, -1, -1 }, 2, depth };
-            while (w.n < 4) {
-                int best = -1;
-                float best_area = -1.0f;
-                for (int c = 0; c < w.n; ++c) {
-                    const TmpNode &t = b.nodes[w.child[c]];
-                    if (t.left < 0) continue;
-                    const float area = t.box.half_area();
-                    if (area > best_area) { best_area = area; best = c; }
-                }
-                if (best < 0) break;
-                const TmpNode &t = b.nodes[w.child[best]];
-                for (int c = w.n; c > best + 1; --c) w.child[c] = w.child[c - 1];
-                w.child[best] = t.left;
-                w.child[best + 1] = t.right;
-                ++w.n;
-            }
-            for (int c = 0; c < w.n; ++c)
-                if (b.nodes[w.child[c]].left >= 0) queue.emplace_back(w.child[c], depth + 1u);
-            out.wide_depth = std::max(out.wide_depth, depth);
-            wide.push_back(w);
-        }
-    }
-    // Triangle order: the leaf children of a wide node are consecutive in `tris`, in slot order (a leaf of the binary tree is a leaf
-    // child of exactly one wide node, so this is a permutation of the binary tree's leaves; their links follow it)
+    // Triangle order: the leaves in the breadth-first order of the inner nodes that own them, left child first (the order the inner
+    // nodes are numbered in below): the leaves under one node are neighbours in `tris`
     std::vector<uint32_t> leaf_pos(b.nodes.size(), 0u);
-    std::vector<uint32_t> wide_first(wide.size(), 0u);
-    {
+    if (b.nodes[0].left >= 0) {
         uint32_t pos = 0;
-        for (size_t k = 0; k < wide.size(); ++k) {
-            wide_first[k] = pos;
-            for (int c = 0; c < wide[k].n; ++c) {
-                const TmpNode &t = b.nodes[wide[k].child[c]];
-                if (t.left >= 0) continue;
-                leaf_pos[wide[k].child[c]] = pos;
-                pos += t.count;
+        std::vector<int32_t> queue{ 0 };
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const TmpNode &t = b.nodes[queue[head]];
+            for (const int32_t c : { t.left, t.right }) {
+                if (b.nodes[c].left >= 0) queue.push_back(c);
+                else { leaf_pos[c] = pos; pos += b.nodes[c].count; }
             }
         }
     }
@@ -513,7 +472,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             for (uint32_t j = 0; j < t.count; ++j) out.tris[leaf_pos[i] + j] = b.tris[b.order[t.first + j]];
         }
     });
-    lap("wide collapse + triangle order");
+    lap("triangle order");
 
     const float inf = std::numeric_limits<float>::infinity();
     auto set_child = [&](BvhNode &node, int which, const TmpNode &child, int32_t link) {
@@ -610,96 +569,6 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         out.nodes16_valid = overflow == 0 && out.nodes.size() * sizeof(BvhNode16) < (size_t(1) << 31);
     };
 
-    // ---- the wide nodes themselves: per axis a grid (origin, power-of-two scale) that reaches from the lowest lower plane to the
-    // highest upper plane of the children in 255 steps; lower planes rounded down, upper planes up
-    auto emit_wide = [&](const std::vector<int32_t> &bfs_index_of) {
-        // wide index of a binary inner node = its position in `wide` (same breadth-first queue order)
-        std::vector<int32_t> wide_index(b.nodes.size(), -1);
-        for (size_t k = 0; k < wide.size(); ++k) if (wide[k].root >= 0) wide_index[wide[k].root] = int32_t(k);
-        // parent of every binary node (for the cross references of the checker: which box0 / box1 holds a child's box)
-        std::vector<int32_t> parent(b.nodes.size(), -1);
-        for (size_t i = 0; i < b.nodes.size(); ++i)
-            if (b.nodes[i].left >= 0) { parent[b.nodes[i].left] = int32_t(i); parent[b.nodes[i].right] = int32_t(i); }
-        out.nodes4.resize(wide.size());
-        out.wide_root.resize(wide.size());
-        out.wide_child_ref.assign(wide.size() * 4, 0xffffffffu);
-        parallel_for(wide.size(), hw, [&](size_t k0, size_t k1) {
-        for (size_t k = k0; k < k1; ++k) {
-            const WideTmp &w = wide[k];
-            BvhNode4 nd{};
-            float lo[4][3], hi[4][3];
-            for (int c = 0; c < w.n; ++c) padded(b.nodes[w.child[c]].box, lo[c], hi[c]);
-            uint8_t qlo[3][4], qhi[3][4];
-            for (int a = 0; a < 3; ++a) {
-                float lo_min = lo[0][a], hi_max = hi[0][a];
-                for (int c = 1; c < w.n; ++c) { lo_min = std::min(lo_min, lo[c][a]); hi_max = std::max(hi_max, hi[c][a]); }
-                // smallest exponent byte e whose grid, anchored at the largest fp32 <= lo_min with the low nine bits (0, e), reaches hi_max
-                int ex = 0;
-                std::frexp(double(hi_max) - double(lo_min), &ex);          // extent < 2^ex
-                int e = std::max(1, std::min(254, 127 + ex - 8));         // 2^ex / 256 per step: at most one too small
-                uint32_t obits = 0;
-                for (;; ++e) {
-                    uint32_t bits;
-                    std::memcpy(&bits, &lo_min, 4);
-                    if (!(bits & 0x80000000u)) {                           // lo_min >= +0: truncate the magnitude, step down if that went up
-                        uint32_t cand = (bits & ~0x1ffu) | uint32_t(e);
-                        if (cand > bits) cand = (bits >> 9) ? cand - 0x200u : (0x80000000u | uint32_t(e));     // (below the smallest step: a tiny negative number)
-                        obits = cand;
-                    } else {                                               // negative: the magnitude may only grow
-                        const uint32_t mag = bits & 0x7fffffffu;
-                        uint32_t cand = (mag & ~0x1ffu) | uint32_t(e);
-                        if (cand < mag) cand += 0x200u;
-                        obits = 0x80000000u | cand;
-                    }
-                    float of;
-                    std::memcpy(&of, &obits, 4);
-                    const long double steps = std::ceil((static_cast<long double>(hi_max) - static_cast<long double>(of)) / std::ldexp(1.0L, e - 127));
-                    if (steps <= 255.0L || e >= 254) break;
-                }
-                float of;
-                std::memcpy(&of, &obits, 4);
-                const long double O = of, S = std::ldexp(1.0L, e - 127);
-                nd.origin[a] = obits;
-                for (int c = 0; c < 4; ++c) {
-                    if (c >= w.n) { qlo[a][c] = 255; qhi[a][c] = 0; continue; }      // absent: never entered
-                    long double ql = std::floor((static_cast<long double>(lo[c][a]) - O) / S), qh = std::ceil((static_cast<long double>(hi[c][a]) - O) / S);
-                    ql = std::max(0.0L, std::min(255.0L, ql));
-                    qh = std::max(0.0L, std::min(255.0L, qh));
-                    while (ql > 0.0L && O + ql * S > static_cast<long double>(lo[c][a])) ql -= 1.0L;
-                    while (qh < 255.0L && O + qh * S < static_cast<long double>(hi[c][a])) qh += 1.0L;
-                    qlo[a][c] = uint8_t(ql);
-                    qhi[a][c] = uint8_t(qh);
-                }
-                nd.qlo[a] = uint32_t(qlo[a][0]) | uint32_t(qlo[a][1]) << 8 | uint32_t(qlo[a][2]) << 16 | uint32_t(qlo[a][3]) << 24;
-                nd.qhi[a] = uint32_t(qhi[a][0]) | uint32_t(qhi[a][1]) << 8 | uint32_t(qhi[a][2]) << 16 | uint32_t(qhi[a][3]) << 24;
-            }
-            // links: inner children are consecutive wide nodes, leaf children consecutive triangles
-            int32_t first_inner = -1;
-            uint32_t inner_rank = 0, off = 0;
-            nd.meta = 0;
-            for (int c = 0; c < w.n; ++c) {
-                const TmpNode &t = b.nodes[w.child[c]];
-                int8_t byte;
-                if (t.left >= 0) {
-                    if (first_inner < 0) first_inner = wide_index[w.child[c]];
-                    byte = int8_t(inner_rank++);
-                } else {
-                    byte = int8_t(-1 - int((off << 2) | (t.count - 1)));
-                    off += t.count;
-                }
-                nd.meta |= uint32_t(uint8_t(byte)) << (8 * c);
-                const int32_t par = parent[w.child[c]];
-                if (par >= 0) out.wide_child_ref[k * 4 + c] = uint32_t(bfs_index_of[par]) << 1 | (b.nodes[par].right == w.child[c] ? 1u : 0u);
-                else out.wide_child_ref[k * 4 + c] = 0u;                   // the single-leaf scene: box0 of node 0
-            }
-            nd.child_base = std::max(first_inner, 0);
-            nd.leaf_base = -int32_t(wide_first[k] << 2);
-            out.nodes4[k] = nd;
-            out.wide_root[k] = w.root >= 0 ? uint32_t(bfs_index_of[w.root]) : 0u;
-        }
-        });
-    };
-
     const TmpNode &root = b.nodes[0];
     if (root.left < 0) {                       // whole scene fits one leaf
         BvhNode node{};
@@ -708,7 +577,6 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
         node.child1 = node.child0;
         out.nodes.push_back(node);
         finalize16();
-        emit_wide(std::vector<int32_t>(b.nodes.size(), 0));
         return;
     }
     // breadth-first numbering of the inner nodes
@@ -739,8 +607,6 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     lap("numbering + (lo, hi) nodes");
     finalize16();
     lap("derived node forms");
-    emit_wide(bfs_index);
-    lap("wide nodes");
 }
 
 // A 64-bit multiplicative hash over the (lo, hi) nodes and the leaf triangles in their final order, eight bytes at a time: the
@@ -814,61 +680,6 @@ bool nodes16_in_range(const HostBvh &bvh) {
             if (ec == 31 || (ec == 0 && n.c[i] != 0) || eh == 31 || eh == 0) return false;
         }
     return true;
-}
-
-// The wide tree against the binary one (what the wide walkers' bit-identity rests on).  out: wide nodes; child boxes checked; child
-// boxes whose quantised planes -- O + q * 2^(e - 127) in exact arithmetic, O and e read from the node as a walker reads them -- do
-// NOT contain the padded (lo, hi) box the binary tree stores for the same subtree; structural errors (a link that does not lead
-// where the binary tree's link leads, an origin word with bit 8 set or a zero exponent byte, triangles not covered exactly once).
-void check_wide_nodes(const HostBvh &bvh, uint64_t out[4], int threads) {
-    out[0] = bvh.nodes4.size();
-    out[1] = out[2] = out[3] = 0;
-    if (bvh.nodes4.empty()) return;
-    if (bvh.wide_root.size() != bvh.nodes4.size() || bvh.wide_child_ref.size() != bvh.nodes4.size() * 4) { out[3] = 1; return; }
-    // binary node index -> wide node index (collapse roots only)
-    std::vector<int32_t> wide_of(bvh.nodes.size(), -1);
-    for (size_t k = 0; k < bvh.nodes4.size(); ++k) if (bvh.wide_root[k] < bvh.nodes.size()) wide_of[bvh.wide_root[k]] = int32_t(k);
-    std::atomic<uint64_t> boxes{ 0 }, bad_boxes{ 0 }, bad_links{ 0 }, leaf_tris{ 0 };
-    parallel_for(bvh.nodes4.size(), host_threads(threads), [&](size_t k0, size_t k1) {
-        uint64_t nb = 0, bb = 0, bl = 0, lt = 0;
-        for (size_t k = k0; k < k1; ++k) {
-            const BvhNode4 &nd = bvh.nodes4[k];
-            long double O[3], S[3];
-            for (int a = 0; a < 3; ++a) {
-                float of;
-                std::memcpy(&of, &nd.origin[a], 4);
-                O[a] = of;
-                const uint32_t e = nd.origin[a] & 0xffu;
-                if ((nd.origin[a] & 0x100u) || e == 0u || e == 255u) ++bl;
-                S[a] = std::ldexp(1.0L, int(e) - 127);
-            }
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t ref = bvh.wide_child_ref[k * 4 + c];
-                bool absent = true;
-                for (int a = 0; a < 3; ++a) if (((nd.qlo[a] >> (8 * c)) & 0xffu) <= ((nd.qhi[a] >> (8 * c)) & 0xffu)) absent = false;
-                if (ref == 0xffffffffu) { if (!absent) ++bl; continue; }
-                ++nb;
-                const BvhNode &bn = bvh.nodes[ref >> 1];
-                const float *box = (ref & 1u) ? bn.box1 : bn.box0;
-                const int32_t blink = (ref & 1u) ? bn.child1 : bn.child0;
-                bool contains = true;
-                for (int a = 0; a < 3; ++a) {
-                    const long double ql = (nd.qlo[a] >> (8 * c)) & 0xffu, qh = (nd.qhi[a] >> (8 * c)) & 0xffu;
-                    if (O[a] + ql * S[a] > static_cast<long double>(box[2 * a]) || O[a] + qh * S[a] < static_cast<long double>(box[2 * a + 1])) contains = false;
-                }
-                if (!contains) ++bb;
-                const int byte = int(int8_t((nd.meta >> (8 * c)) & 0xffu));
-                const int32_t link = (byte < 0 ? nd.leaf_base : nd.child_base) + byte;
-                if (blink < 0) {                                          // a leaf: the very same code
-                    if (link != blink) ++bl;
-                    lt += uint64_t((~uint32_t(blink)) & 3u) + 1u;
-                } else if (byte < 0 || link < 0 || size_t(link) >= bvh.nodes4.size() || wide_of[size_t(blink)] != link) ++bl;
-            }
-        }
-        boxes += nb; bad_boxes += bb; bad_links += bl; leaf_tris += lt;
-    });
-    out[1] = boxes; out[2] = bad_boxes; out[3] = bad_links;
-    if (leaf_tris != bvh.tris.size()) ++out[3];
 }
 
 }  // namespace vhr

@@ -106,6 +106,9 @@ struct vhr_comm {
     // staging for rectangles that are not whole rows (RCCL moves contiguous bytes): one buffer per direction, grown on demand
     char *send_stage = nullptr, *recv_stage = nullptr;
     size_t send_capacity = 0, recv_capacity = 0;
+    // the rectangle the context had before create applied the plan's (col_begin, col_end, row_begin, row_end, overlap, halo rows, halo cols)
+    bool tile_applied = false;
+    uint32_t saved_tile[7] = { 0, 0, 0, 0, 0, 0, 0 };
     std::string error;
     int fail(int code, const std::string &msg) { error = msg; if (ctx) ctx->error = msg; return code; }
 };
@@ -281,8 +284,11 @@ int vhr_comm_create_tiled(vhr_context *ctx, const vhr_tile_plan *plan, const uin
         hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess)
         return bail(VHR_ERROR_DEVICE, "vhr_comm_create: stream / event creation failed");
     // the context computes its tile from now on: owned rectangle + overlap recomputed, blits extended by the halos
+    const uint32_t saved[7] = { ctx->col_begin, ctx->col_end, ctx->row_begin, ctx->row_end, ctx->overlap, ctx->halo, ctx->halo_cols };
     const int src = vhr_set_tile(ctx, plan->col_begin, plan->col_end, plan->row_begin, plan->row_end, plan->overlap, plan->halo_rows, plan->halo_cols);
     if (src != VHR_OK) { const std::string msg = ctx->error; return bail(src, msg); }
+    for (int i = 0; i < 7; ++i) c->saved_tile[i] = saved[i];
+    c->tile_applied = true;
     *out = c;
     return VHR_OK;
 }
@@ -307,7 +313,10 @@ void vhr_comm_destroy(vhr_comm *c) {
     if (c->stream) hipStreamDestroy(c->stream);
     hipFree(c->send_stage);
     hipFree(c->recv_stage);
-    if (c->ctx) vhr_set_tile(c->ctx, 0, c->ctx->width, 0, c->ctx->height, 0, 0, 0);       // the context owns the whole image again
+    // the context gets the rectangle back it had before vhr_comm_create[_tiled] applied the plan's (a create that failed before that
+    // point leaves whatever the caller had set -- a strip for the torch.distributed route, say -- alone)
+    if (c->ctx && c->tile_applied)
+        vhr_set_tile(c->ctx, c->saved_tile[0], c->saved_tile[1], c->saved_tile[2], c->saved_tile[3], c->saved_tile[4], c->saved_tile[5], c->saved_tile[6]);
     delete c;
 }
 
@@ -344,7 +353,16 @@ int grow_stage(vhr_comm *c, char *&buf, size_t &capacity, size_t need) {
 // Everything of one frame in ONE group: packs, sends and receives, unpacks.  The first failure inside the group is remembered, the
 // group is closed all the same (a return between ncclGroupStart and ncclGroupEnd would leave every later RCCL call of this thread,
 // ncclCommDestroy included, queued into it -- ADVICE r2), and the communicator refuses further work: its peers may be out of step.
+int run_pieces_unguarded(vhr_comm *c, std::vector<Piece> &pieces, hipStream_t stream);
+// Any failure in here -- a staging buffer that did not grow, a pack or unpack copy that was refused, RCCL itself -- leaves this rank out
+// of step with its peers (they have posted, or will post, the matching sends and receives): the communicator is marked unusable on EVERY
+// error path, and the job has to be torn down (the peers' pending receives do not complete: vhr_comm.h says so).
 int run_pieces(vhr_comm *c, std::vector<Piece> &pieces, hipStream_t stream) {
+    const int rc = run_pieces_unguarded(c, pieces, stream);
+    if (rc != VHR_OK) c->broken = true;
+    return rc;
+}
+int run_pieces_unguarded(vhr_comm *c, std::vector<Piece> &pieces, hipStream_t stream) {
     if (pieces.empty()) return VHR_OK;
     Rccl &r = rccl();
     size_t send_need = 0, recv_need = 0;

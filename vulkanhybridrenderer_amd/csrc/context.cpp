@@ -43,9 +43,6 @@ vhr::DeviceScene vhr_context::device_scene() const {
     s.nodes16 = d_nodes16;
     s.nodes_ch = d_nodes_ch;
     s.nodes48 = d_nodes48;
-    s.nodes4 = d_nodes4;
-    s.node4_count = node4_count;
-    s.pad1[0] = s.pad1[1] = s.pad1[2] = 0;
     s.centre[0] = bvh_centre[0]; s.centre[1] = bvh_centre[1]; s.centre[2] = bvh_centre[2];
     s.pad0 = 0.0f;
     s.tris = d_tris;
@@ -101,6 +98,7 @@ void vhr_context::dispatch_events(hipEvent_t &start, hipEvent_t &stop) {
 // The stamps of the next kernel launch (vhr::launch): the end of the pass that finished last, the begin of the running pass's first kernel.
 vhr::Stamps vhr_context::take_stamps() {
     vhr::Stamps st{ nullptr, nullptr };
+    if (!in_kernel_stamps()) pending_end = nullptr;      // (stamps switched to event pairs while an end was pending: nothing will store it)
     if (no_stamps || !in_kernel_stamps()) return st;
     if (pending_end) { st.prev_end = pending_end; pending_end = nullptr; }
     if (cur_pass && options[vhr::kOptPassTimestamps] && cur_pass->stamp_index >= 0 && !cur_pass->begin_stamped) {
@@ -117,7 +115,6 @@ int vhr_context::sync_streams() {
     if (pending_end) vhr::launch_stamp(this);          // the end of the last pass, before the host waits for it
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
     if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
-    if (mirror_stream && hipStreamSynchronize(mirror_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(mirror stream) failed");
     side_pending = false;
     if (hipStreamSynchronize(stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize failed");     // (a null handle is the default stream)
     return VHR_OK;
@@ -242,10 +239,9 @@ int vhr_create(const vhr_create_info *info, vhr_context **out) {
 
 static void free_scene(vhr_context *ctx) {
     hipFree(ctx->d_vertices); hipFree(ctx->d_indices); hipFree(ctx->d_primitives); hipFree(ctx->d_normal_matrices);
-    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_nodes4); hipFree(ctx->d_tris);
+    hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
     ctx->d_vertices = nullptr; ctx->d_indices = nullptr; ctx->d_primitives = nullptr; ctx->d_normal_matrices = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_nodes4 = nullptr; ctx->d_tris = nullptr;
-    ctx->node4_count = 0;
+    ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_tris = nullptr;
     ctx->vertex_count = ctx->index_count = ctx->primitive_count = ctx->node_count = ctx->tri_count = 0;
 }
 
@@ -261,13 +257,9 @@ void vhr_destroy(vhr_context *ctx) {
     vhr_graph_destroy_resources(ctx);
     if (ctx->front_stream) hipStreamDestroy(ctx->front_stream);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
-    if (ctx->mirror_stream) hipStreamDestroy(ctx->mirror_stream);
-    if (ctx->mirror_ready) hipEventDestroy(ctx->mirror_ready);
-    if (ctx->mirror_done) hipEventDestroy(ctx->mirror_done);
     if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
     if (ctx->side_done) hipEventDestroy(ctx->side_done);
     hipFree(ctx->d_stamps);
-    hipFree(ctx->d_hit_records);
     for (auto &im : ctx->storage_images) {      // {ptr, alt} hold both allocations of a double-buffered image
         if (!im.used) continue;
         hipFree(im.ptr);
@@ -413,14 +405,11 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
     const auto t_build1 = std::chrono::steady_clock::now();       // K0 proper ends here; the self-checks below are timed apart
     check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
-    check_wide_nodes(bvh, ctx->bvh_wide_checks, ctx->bvh_build_threads);
     ctx->nodes16_valid = bvh.nodes16_valid && ctx->bvh_form_checks[3] == 0;      // else the walkers stay on the 48-byte nodes
     ctx->bvh_fingerprint = bvh_fingerprint(bvh);
     ctx->bvh_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
-    ctx->bvh_wide_depth = bvh.wide_depth;
     if (ctx->host_only) {
         ctx->node_count = uint32_t(bvh.nodes.size());
-        ctx->node4_count = uint32_t(bvh.nodes4.size());
         ctx->tri_count = uint32_t(bvh.tris.size());
         ctx->bvh_depth = bvh.max_depth;
         ctx->geometry_upload_ms = 0.0;
@@ -432,16 +421,12 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes16), bvh.nodes16.data(), sizeof(BvhNode16) * bvh.nodes16.size()));
         HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes_ch), bvh.nodes_ch.data(), sizeof(BvhNodeCH) * bvh.nodes_ch.size()));
         HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes48), bvh.nodes48.data(), sizeof(BvhNode48) * bvh.nodes48.size()));
-        HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_nodes4), bvh.nodes4.data(), sizeof(BvhNode4) * bvh.nodes4.size()));
         HIP_TRY(ctx, upload(reinterpret_cast<void **>(&ctx->d_tris), bvh.tris.data(), sizeof(BvhTri) * bvh.tris.size()));
         for (int a = 0; a < 3; ++a) ctx->bvh_centre[a] = bvh.centre[a];
         ctx->node_count = uint32_t(bvh.nodes.size());
-        ctx->node4_count = uint32_t(bvh.nodes4.size());
         ctx->tri_count = uint32_t(bvh.tris.size());
         ctx->bvh_depth = bvh.max_depth;
         upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload0).count();
-    } else {
-        ctx->node4_count = 0;                  // (the four-wide collapse is the host builder's: "bvh_wide" falls back to the binary walker)
     }
     ctx->vertex_count = vertex_count;
     ctx->index_count = index_count;
@@ -591,11 +576,33 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         ctx->bvh_build_threads = value;
         return VHR_OK;
     }
-    static const char *const names[] = { "raygen_variant", "refill_threshold", "atrous_variant", "temporal_variant", "raygen_blocks_per_cu",
-                                         "lds_stack_levels", "raygen_pregen", "raygen_waves_per_block", "compact_nodes", "xcd_aware", "raygen_shared_tile", "trace_overlap", "atrous_blocks_per_cu", "atrous_xcd_aware", "raygen_early_exit", "atrous_small_tiles", "strip_shrink_overlap", "reflection_variant", "raytraced_variant", "pass_timestamps", "raygen_tile_rows", "fuse_blits", "raygen_cut", "kernel_timing_stride", "shadow_packet", "cut_reach", "raygen_tile_pixels", "frames_in_flight", "cut_expand", "shadow_last", "bvh_wide", "svgf_elide_unread", "svgf_async_unread", "fuse_temporal", "raygen_cost_order", "reflection_concurrent" };
-    static_assert(sizeof(names) / sizeof(names[0]) == vhr::kOptCount, "one name per option");
+    for (int i = 0; i < vhr::kOptCount; ++i) {
+        const vhr::OptionInfo &o = vhr::kOptionInfo[i];
+        if (std::strcmp(key, o.name)) continue;
+        if (value < o.lo || value > o.hi)
+            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, std::string(o.name) + " must be " + std::to_string(o.lo) + ".." + std::to_string(o.hi));
+        ctx->options[i] = value;
+        return VHR_OK;
+    }
+    return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");
+}
+
+int32_t vhr_option_count(void) { return vhr::kOptCount; }
+
+int vhr_option_info(int32_t index, const char **name, int32_t *default_value, int32_t *min_value, int32_t *max_value) {
+    if (index < 0 || index >= vhr::kOptCount) return VHR_ERROR_INVALID_ARGUMENT;
+    const vhr::OptionInfo &o = vhr::kOptionInfo[index];
+    if (name) *name = o.name;
+    if (default_value) *default_value = o.def;
+    if (min_value) *min_value = o.lo;
+    if (max_value) *max_value = o.hi;
+    return VHR_OK;
+}
+
+int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value) {
+    if (!ctx || !key || !value) return VHR_ERROR_INVALID_ARGUMENT;
     for (int i = 0; i < vhr::kOptCount; ++i)
-        if (!std::strcmp(key, names[i])) { ctx->options[i] = value; return VHR_OK; }
+        if (!std::strcmp(key, vhr::kOptionInfo[i].name)) { *value = ctx->options[i]; return VHR_OK; }
     return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("unknown option '") + key + "'");
 }
 
@@ -650,12 +657,11 @@ int vhr_get_traversal_cycles(vhr_context *ctx, uint64_t out[8]) {
     return VHR_OK;
 }
 
-int vhr_get_packet_statistics(vhr_context *ctx, uint64_t out[9]) {
+int vhr_get_drain_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
     const RayStats &r = ctx->h_ray_stats;
-    out[0] = r.packets; out[1] = r.packet_nodes; out[2] = r.packet_triangles; out[3] = r.packet_lane_tests; out[4] = r.cycles_packet; out[5] = r.cut_entries;
-    out[6] = r.drain_le4; out[7] = r.drain_le8; out[8] = r.drain_le16;
+    out[0] = r.cut_entries; out[1] = r.drain_le4; out[2] = r.drain_le8; out[3] = r.drain_le16;
     return VHR_OK;
 }
 
@@ -674,17 +680,23 @@ int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
 
 const char *vhr_source_fingerprint(void) { return VHR_SOURCE_FINGERPRINT; }
 
+/* Diagnostics: the waves' lifetimes (s_memtime ticks) the last ray-tracing launch left for "raygen_cost_order" (index = tile pair * waves + wave). */
+int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity, uint32_t *count) {
+    if (!ctx || !out || !count) return VHR_ERROR_INVALID_ARGUMENT;
+    const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_;
+    const vhr_context::CostOrder &co = ctx->cost_order_raygen;
+    const uint32_t n = std::min<uint32_t>(capacity, co.cost_blocks[co.slot] * uint32_t(std::max(1, std::min(4, ctx->options[vhr::kOptWavesPerBlock]))));
+    *count = n;
+    if (n && hipMemcpy(out, co.cost[co.slot], size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "wave lifetimes: copy failed");
+    return VHR_OK;
+}
+
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     *out = ctx->bvh_fingerprint;
     return VHR_OK;
 }
 
-int vhr_get_bvh_wide_checks(vhr_context *ctx, uint64_t out[4]) {
-    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    for (int i = 0; i < 4; ++i) out[i] = ctx->bvh_wide_checks[i];
-    return VHR_OK;
-}
 
 int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;

@@ -591,7 +591,6 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
 
 constexpr int kQueueBlock = 64;
 constexpr int kStackSentinel = int(0x80000000u);   // not a node (>= 0) and not a leaf code the builder can emit
-constexpr uint32_t kMaxPregenKinds = 17;       // 1 shadow + up to 16 AO samples pre-generated into LDS (13 KB)
 
 // raygen.rgen:32-53 for one (pixel, kind): the ray direction, exact arithmetic
 __device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t seed, uint32_t kind, f3 L, f3 N) {
@@ -623,21 +622,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PREGEN: every pixel generates all of its rays up front with the whole wave active (ray generation costs
-// several hundred instructions -- divisions, sqrt, the sin/cos polynomial -- and would otherwise run inside
-// the refill with a fraction of the lanes); the queue refill then only fetches 3 floats.  !PREGEN (more than
-// kMaxPregenKinds ray kinds): directions are generated inside the refill.
-// SHARED: the WAVES waves of a block split the queue of ONE 8x8 tile between them (queue head in LDS) instead of
-// owning a tile each: a wave then lives for about a third as long, which matters whenever few waves are in flight
-// (the end of a launch, or a thin strip of a multi-GPU run), at the price of one block-wide barrier on either side.
-// CUT: the rays of a tile all start within centimetres of each other, and each of them would spend most of its ~16 node
-// visits walking from the root down to the boxes around that spot -- every box on the way contains the origin, so every ray
+// The shared descent ("the cut"): the rays of a tile all start within centimetres of each other, and each of them would spend most of its
+// ~16 node visits walking from the root down to the boxes around that spot -- every box on the way contains the origin, so every ray
 // hits it whatever its direction.  The wave therefore makes that descent ONCE per tile (uniformly: follow the inner child whose
 // box contains the bounding box of the tile's ray origins, keep the other child) and leaves a CUT of the tree in LDS: up to
 // kCutMax subtrees that together cover all geometry.  A ray then starts by testing the cut's boxes (a short uniform loop over
 // LDS broadcasts, every refilled lane busy) and walks only the subtrees it hits.  Box tests only cull, so results are unchanged.
-constexpr int kCutMax = 16;
-constexpr int kWideCutMax = 12;      // raygen_wide_kernel (LDS budget; 12 and 24 entries measured flat around 16 on the 8x8 kernel)
+constexpr int kCutMax = 16;          // (12 and 24 entries measured flat around 16)
 
 // An upper bound of |onb_transform(n, v)| / |v|, i.e. of the largest singular value of the Frisvad basis (c0, c1, n) that
 // common.glsl:80-93 builds around the G-buffer normal.  The normal is a rounded half vector, not a unit vector, and near
@@ -674,23 +665,27 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
 // `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
+// `short_reach` (in: this lane's contribution; out: the wave's maximum, uniform): the same bound for the SHORT rays of a tile whose queue also holds
+// long ones (AO rays beside shadow rays).  Entries are not dropped for it; every entry carries the squared gap between its box and the bounds of
+// the origins in its last word, and a short ray skips the entries whose gap exceeds short_reach^2 without a box test.
 __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
-                                                   const int max_entries = kCutMax, const uint32_t expand = 0u, const int link_bytes = int(sizeof(BvhNode48))) {
+                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), float *short_reach = nullptr) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
         omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
         reach = fmaxf(reach, __shfl_xor(reach, off));
+        if (short_reach) *short_reach = fmaxf(*short_reach, __shfl_xor(*short_reach, off));
     }
     // wave-uniform from here on, and told so: the descent then runs on scalar registers and scalar branches
     auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
+    if (short_reach) *short_reach = uni(*short_reach);
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
     reach = uni(reach);
     const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
-    // The cut while it is being built: entry e lives in lane e (box, link, and a key: the half area of an inner node's box that
-    // overlaps the bounds of the origins -- what the expansion below picks by -- or 0).
-    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f, e_key = 0.0f;
+    // The cut while it is being built: entry e lives in lane e (box, link, squared gap to the bounds of the origins).
+    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f, e_gap2 = 0.0f;
     int e_link = 0;
     uint32_t cut_n = 0;
     auto gap2_of = [&](float lx, float hx, float ly, float hy, float lz, float hz) {
@@ -699,9 +694,7 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
         return (gx * gx + gy * gy) + gz * gz;
     };
     auto put = [&](uint32_t slot, float lx, float hx, float ly, float hy, float lz, float hz, int link, float gap2) {
-        const float dx = hx - lx, dy = hy - ly, dz = hz - lz;
-        const float key = (link >= 0 && gap2 == 0.0f) ? fmaxf((dx * dy + dy * dz) + dz * dx, 1.0e-30f) : 0.0f;
-        if (lane == slot) { e_lx = lx; e_hx = hx; e_ly = ly; e_hy = hy; e_lz = lz; e_hz = hz; e_link = link; e_key = key; }
+        if (lane == slot) { e_lx = lx; e_hx = hx; e_ly = ly; e_hy = hy; e_lz = lz; e_hz = hz; e_link = link; e_gap2 = gap2; }
     };
     auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
         const float g2 = gap2_of(lx, hx, ly, hy, lz, hz);
@@ -739,195 +732,12 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
         }
     }
     if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
-    // ---- expansion ("cut_expand"): the descent stops where the origins straddle both children, usually with half the entries
-    // unused.  Every ray that STARTS inside an entry's box enters it, so an inner entry overlapping the origins' bounds costs most
-    // rays a node visit in memory; replacing it by its two children trades that visit for one more box test out of LDS at refill.
-    // Largest overlapping box first, until the entries are used up.  The cut still covers everything within reach.
-    if (expand) {
-        for (int it = 0; it < max_entries && int(cut_n) < max_entries; ++it) {
-            uint32_t k = (lane < cut_n && e_key > 0.0f) ? ((__float_as_uint(e_key) & ~63u) | lane) : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) k = max(k, uint32_t(__shfl_xor(int(k), off)));
-            k = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
-            if (k == 0u) break;
-            const uint32_t e = k & 63u;
-            const int link = __builtin_amdgcn_readlane(e_link, e);
-            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(nodes + link);
-            const v4f q0 = np[0], q1 = np[1], q2 = np[2];
-            const v4i vl = ((uniform_i4_ptr)np)[3];
-            const float g0 = gap2_of(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y), g1 = gap2_of(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-            const bool keep0 = !(g0 > reach2), keep1 = !(g1 > reach2);
-            if (keep0) put(e, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, vl.x, g0);
-            if (keep1) { put(keep0 ? cut_n : e, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, vl.y, g1); if (keep0) ++cut_n; }
-            if (!keep0 && !keep1) {                                                        // nothing of it within reach: the last entry takes its place
-                --cut_n;
-                const float mlx = __shfl(e_lx, int(cut_n)), mhx = __shfl(e_hx, int(cut_n)), mly = __shfl(e_ly, int(cut_n)), mhy = __shfl(e_hy, int(cut_n)),
-                            mlz = __shfl(e_lz, int(cut_n)), mhz = __shfl(e_hz, int(cut_n)), mkey = __shfl(e_key, int(cut_n));
-                const int mlink = __shfl(e_link, int(cut_n));
-                if (lane == e) { e_lx = mlx; e_hx = mhx; e_ly = mly; e_hy = mhy; e_lz = mlz; e_hz = mhz; e_key = mkey; e_link = mlink; }
-            }
-        }
-    }
     if (lane < cut_n) {
         s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
-        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
+        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), e_gap2);
     }
     wave_lds_sync();
     return cut_n;
-}
-
-// The shared descent on the FOUR-WIDE tree (BvhNode4, option "bvh_wide"): the same idea, one wide node per level -- the child whose
-// box contains the bounds of the tile's ray origins is followed, the node's other children (up to three) join the cut.  Child boxes
-// are decoded from the node's 8-bit grid (fp32, rounded to nearest: they are used by the same padded-box slab test as everything
-// else); links are the wide tree's (inner: wide node index, leaf: the shared leaf code).
-constexpr int kWideSpill = 64;       // scratch part of a wide walk's stack: 3 pending subtrees per level of the wide tree (launch_raygen checks)
-
-__device__ __forceinline__ uint32_t build_tile_cut_wide(const BvhNode4 *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach,
-                                                        const int max_entries) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
-        omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
-        reach = fmaxf(reach, __shfl_xor(reach, off));
-    }
-    auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
-    omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
-    reach = uni(reach);
-    const float reach2 = reach * reach;
-    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f;      // entry e lives in lane e until the end
-    int e_link = 0;
-    uint32_t cut_n = 0;
-    auto add_entry = [&](const float b[6], int link) {
-        const float gx = fmaxf(fmaxf(b[0] - omax.x, omin.x - b[1]), 0.0f), gy = fmaxf(fmaxf(b[2] - omax.y, omin.y - b[3]), 0.0f),
-                    gz = fmaxf(fmaxf(b[4] - omax.z, omin.z - b[5]), 0.0f);
-        if ((gx * gx + gy * gy) + gz * gz > reach2) return;                               // out of every ray's reach
-        if (lane == cut_n) { e_lx = b[0]; e_hx = b[1]; e_ly = b[2]; e_hy = b[3]; e_lz = b[4]; e_hz = b[5]; e_link = link; }
-        ++cut_n;
-    };
-    int node = 0;
-    float fb[6] = { -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f };
-    bool open = true;
-    while (int(cut_n) + 4 <= max_entries) {            // a node adds at most three entries on the way down, four where the descent ends
-        const uniform_i4_ptr np = (uniform_i4_ptr)(uintptr_t)(nodes + node);
-        const v4i w0 = np[0], w1 = np[1], w2 = np[2];
-        const float O[3] = { __int_as_float(w0.x), __int_as_float(w0.y), __int_as_float(w0.z) };
-        const float S[3] = { __uint_as_float(uint32_t(w0.x) << 23), __uint_as_float(uint32_t(w0.y) << 23), __uint_as_float(uint32_t(w0.z) << 23) };
-        const uint32_t qlo[3] = { uint32_t(w0.w), uint32_t(w1.x), uint32_t(w1.y) }, qhi[3] = { uint32_t(w1.z), uint32_t(w1.w), uint32_t(w2.x) };
-        float box[4][6];
-        int link[4];
-        bool valid[4], inside[4];
-        int follow = -1;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            valid[c] = ((qlo[0] >> (8 * c)) & 0xffu) <= ((qhi[0] >> (8 * c)) & 0xffu);      // an absent child has 255 > 0
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                box[c][2 * ax] = __builtin_fmaf(float((qlo[ax] >> (8 * c)) & 0xffu), S[ax], O[ax]);
-                box[c][2 * ax + 1] = __builtin_fmaf(float((qhi[ax] >> (8 * c)) & 0xffu), S[ax], O[ax]);
-            }
-            const int byte = int(uint32_t(w2.w) << (24 - 8 * c)) >> 24;
-            link[c] = (byte < 0 ? w2.z : w2.y) + byte;
-            inside[c] = valid[c] && byte >= 0 && box[c][0] <= omin.x && omax.x <= box[c][1] && box[c][2] <= omin.y && omax.y <= box[c][3] &&
-                        box[c][4] <= omin.z && omax.z <= box[c][5];
-            if (follow < 0 && inside[c]) follow = c;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (valid[c] && c != follow) add_entry(box[c], link[c]);
-        if (follow < 0) { open = false; break; }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c == follow) { for (int k = 0; k < 6; ++k) fb[k] = box[c][k]; node = link[c]; }
-    }
-    if (open) add_entry(fb, node);
-    if (lane < cut_n) {
-        s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
-        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link), 0.0f);
-    }
-    wave_lds_sync();
-    return cut_n;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Shadow rays as a PACKET (option "shadow_packet").  The shadow rays of an 8x8-pixel tile leave from origins centimetres
-// apart in directions that differ by less than 0.18 degrees (one cone sample around the light direction, raygen.rgen:32-35):
-// walking the tree once per RAY repeats the same node sequence 64 times at whatever lane occupancy divergence leaves.  Here
-// the WAVE walks the tree once for its tile: the current node is wave-uniform and arrives through scalar loads (s_load_dwordx8
-// x 2 per node, the boxes then sit in SGPR pairs that v_pk_fma_f32 takes directly), every lane tests ITS ray against both
-// child boxes, a child is entered when any still-undecided lane hits it (the near one by majority first), the traversal
-// stack is wave-uniform (one VGPR: lane i holds entry i), leaves test their triangles against all lanes at once with a
-// branch-free Moeller-Trumbore, and a lane leaves the packet at its first accepted triangle (terminateOnFirstHit).  No LDS,
-// no vector memory, no divergence.  Results are those of the per-ray walk bit for bit: box tests only cull (padded boxes,
-// the per-ray arithmetic of box_test_pk), a lane whose ray meets a triangle passes the tests of every box above it, so the
-// packet visits that leaf, and any-hit visibility is an OR over triangles in any order.
-// ---------------------------------------------------------------------------------------------
-
-struct PacketCounters { uint32_t nodes, triangles, lane_tests; };
-
-template <bool STATS>
-__device__ __forceinline__ unsigned long long shadow_packet(const DeviceScene &sc, unsigned long long active, const f3 ro, const f3 rd, const float tmin,
-                                                            const float tmax, const uint32_t lane, PacketCounters &pc) {
-    const f3 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
-    const f3 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
-    const f3 ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
-    float tmin_v = tmin, tmax_v = tmax;               // VGPR copies for the asm-operand min / max of the slab test
-    asm volatile("" : "+v"(tmin_v), "+v"(tmax_v));
-    unsigned long long occluded = 0;
-    int stackv = 0;                                   // wave-uniform stack: lane i holds entry i (depth <= kMaxBvhDepth < 64)
-    uint32_t sp = 0;
-    int node = 0;
-    for (;;) {
-        if (node >= 0) {
-            const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(sc.nodes_ch + node);
-            const v4f q0 = np[0], q1 = np[1], q2 = np[2];
-            const v4i links = *(uniform_i4_ptr)(np + 3);
-            float tn0, tn1;
-            bool h0, h1;
-            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax_v, h0, h1, tn0, tn1);
-            const unsigned long long m0 = __ballot(h0) & active, m1 = __ballot(h1) & active;
-            if (STATS) { ++pc.nodes; pc.lane_tests += uint32_t(__popcll(active)); }
-            if (m0 != 0 && m1 != 0) {
-                // both children hold work: the one most undecided lanes meet first goes first, the other waits on the stack
-                const unsigned long long zero_nearer = __ballot(tn0 <= tn1) & m0;
-                const bool first0 = uint32_t(__popcll(zero_nearer | (m0 & ~m1))) * 2u >= uint32_t(__popcll(m0 | m1));
-                const int farc = first0 ? links.y : links.x;
-                stackv = (lane == sp) ? farc : stackv;
-                ++sp;
-                node = first0 ? links.x : links.y;
-                continue;
-            }
-            if (m0 != 0) { node = links.x; continue; }
-            if (m1 != 0) { node = links.y; continue; }
-        } else {
-            const uint32_t vv = ~uint32_t(node);
-            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const uniform_f4_ptr tp = (uniform_f4_ptr)(uintptr_t)(sc.tris + first + i);
-                const v4f ta = tp[0], tb = tp[1], tc = tp[2];
-                if (STATS) { ++pc.triangles; pc.lane_tests += uint32_t(__popcll(active)); }
-                // ray_triangle() without its early returns (same operations in the same order on the same operands; a lane
-                // the branching form would have sent home early computes on and fails the same comparison at the end)
-                const f3 e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
-                const f3 pvec = cross3(rd, e2);
-                const float det = dot3(e1, pvec);
-                const float inv = 1.0f / det;
-                const f3 tvec = ro - f3{ ta.x, ta.y, ta.z };
-                const float uu = dot3(tvec, pvec) * inv;
-                const f3 qvec = cross3(tvec, e1);
-                const float vv2 = dot3(rd, qvec) * inv;
-                const float tt = dot3(e2, qvec) * inv;
-                const bool hit = det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv2 >= 0.0f && !(uu + vv2 > 1.0f) && tt > tmin && tt < tmax;
-                const unsigned long long hm = __ballot(hit) & active;
-                occluded |= hm;
-                active &= ~hm;
-            }
-            if (active == 0) break;                   // every ray of the tile has met an occluder
-        }
-        if (sp == 0) break;
-        --sp;
-        node = __builtin_amdgcn_readlane(stackv, int(sp));
-    }
-    return occluded;
 }
 
 // "raygen_cost_order": the blocks of an earlier launch sorted by cost, heaviest first, by ONE block of the ray-tracing launch (its first: it starts at
@@ -984,76 +794,64 @@ __device__ __forceinline__ void order_blocks_by_cost(const uint32_t *__restrict_
     __syncthreads();                                        // the scratch is the waves' traversal stacks from here on
 }
 
-template <bool PREGEN, int WAVES, bool COMPACT, bool SHARED, bool SPILL, bool STATS, bool CUT = false, bool PACKET = false, bool WIDE = false>
+// raygen_queue_kernel<WAVES, COMPACT, SPILL, STATS>: every wave owns one 8x8-pixel tile (tile_rows < 8: fewer rows) and runs its own queue of
+// `covered x (1 + ao_spp)` rays, kind-major, the shadow rays last.  COMPACT: the walk reads the 32-byte half-precision nodes (BvhNode16, two loads
+// per visit; trees whose boxes do not fit the half range walk the 48-byte fp32 nodes instead).  SPILL: stack entries beyond the LDS levels
+// live in scratch.  STATS: in-kernel counters and timers (vhr_set_ray_statistics).  Per covered pixel the wave keeps 5 words in LDS -- the ray
+// origin and the G-buffer normal as the halves it is -- and recomputes the pixel's seed and the ray's direction at refill with raygen.rgen's
+// exact arithmetic.
+template <int WAVES, bool COMPACT, bool SPILL, bool STATS>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
-                                                                          const uint32_t pregen_kinds, const uint32_t block_tiles_x,
-                                                                          const uint32_t xcd_aware, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t cut_reach, const Stamps st) {
+                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t tile_rows, const Stamps st) {
     vhr_stamp(st);
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
-    extern __shared__ int s_dyn[];                    // per wave: stack_levels x 64 ints, then (PREGEN) kinds x 3 x 64 floats
+    extern __shared__ int s_dyn[];                    // per wave: (stack_levels + 3) x 64 ints
     const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
-    constexpr int COPIES = SHARED ? 1 : WAVES;
-    __shared__ uint32_t s_vis_all[COPIES][kQueueBlock];   // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
-    // per covered pixel: ray origin (3), normal (3), RNG seed (1).  The cut kernels (the default) keep 5 words instead -- the normal as the
-    // G-buffer's own half bits (2 words), the seed recomputed from the pixel at refill: with 512 bytes less per wave 16 workgroups
-    // (8 waves per SIMD) fit a CU's LDS at 8 stack levels instead of 15
-#ifdef VHR_RAY_WORDS7          // (A-B builds only)
-    constexpr int RAYW = 7;
-#else
-    constexpr int RAYW = (CUT && !PREGEN && !SHARED) ? 5 : 7;
-#endif
-    __shared__ float s_ray_all[COPIES][RAYW][kQueueBlock];
-    __shared__ uint8_t s_list_all[COPIES][kQueueBlock];   // compacted covered pixels
-    __shared__ uint32_t s_next, s_ncov;                   // SHARED: queue head and covered-pixel count of the tile
-    __shared__ float4 s_cut_all[CUT ? COPIES : 1][CUT ? kCutMax : 1][2];   // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
+    __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
+    __shared__ float s_ray_all[WAVES][5][kQueueBlock];    // per covered pixel: ray origin (3), the normal's half bits (2)
+    __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
+    __shared__ float4 s_cut_all[WAVES][kCutMax][2];       // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, gap^2)
     // (the compiler cannot know that threadIdx.x >> 6 is the same in every lane of a wave: said explicitly, what derives
     // from it -- the LDS bases, the wave's tile -- stays in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    uint32_t (&s_vis)[kQueueBlock] = s_vis_all[SHARED ? 0 : wave];
-    float (&s_ray)[RAYW][kQueueBlock] = s_ray_all[SHARED ? 0 : wave];
-    uint8_t (&s_list)[kQueueBlock] = s_list_all[SHARED ? 0 : wave];
-    float4 (&s_cut)[CUT ? kCutMax : 1][2] = s_cut_all[CUT ? (SHARED ? 0 : wave) : 0];
-    // dynamic LDS: per wave stack_levels x 64 ints; then the pre-generated directions (per wave, or one set if SHARED)
+    uint32_t (&s_vis)[kQueueBlock] = s_vis_all[wave];
+    float (&s_ray)[5][kQueueBlock] = s_ray_all[wave];
+    uint8_t (&s_list)[kQueueBlock] = s_list_all[wave];
+    float4 (&s_cut)[kCutMax][2] = s_cut_all[wave];
     // LDS stack rows: [0] = sentinel (what a pop of the empty stack returns), [1 .. stack_levels] = entries
     // 0 .. stack_levels-1, [stack_levels+1, +2] = dummies that absorb the accesses of entries living in scratch
-    // WIDE: a visit makes four unconditional writes to rows top + 1 .. top + 4 (see the node step): four more dummy rows
-    constexpr uint32_t kExtraRows = WIDE ? 6u : 3u;
-    constexpr int kSpillEntries = WIDE ? kWideSpill : kSpillStack;
-    if constexpr (CUT && COMPACT && !SHARED && !STATS && !PACKET && !WIDE && !PREGEN) {
+    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    if constexpr (!STATS) {
         // "raygen_cost_order": the launch's first block orders the previous launch's blocks for the next one (8 * 64 * WAVES words <= the block's
         // (stack_levels + 3) * 64 * WAVES words of stack: the host asks for it only with >= 5 stack levels)
         if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<WAVES>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
     }
-    int *stack = s_dyn + wave * (stack_levels + kExtraRows) * kQueueBlock + lane;
-    float *s_dir = reinterpret_cast<float *>(s_dyn + WAVES * (stack_levels + kExtraRows) * kQueueBlock) + (SHARED ? 0u : wave) * pregen_kinds * 3u * kQueueBlock;
-    const uint32_t W = a.width, H = a.height;
+    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
-    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
+    const uint32_t W = a.width, H = a.height;
     uint32_t x, y;
     // "raygen_cost_order": the blocks that lived longest two launches ago start first (a launch ends with its last wave; a long-lived wave that
     // starts late is what the launch's end waits for)
-    const uint32_t block_tile = a.co.block_order ? a.co.block_order[blockIdx.x] : (xcd_aware ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x);
-    if (SHARED) tile_pixel<1>(block_tile, block_tiles_x, 0, lane, a.row_begin, tile_rows, x, y, a.col_begin);
-    else tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y, a.col_begin);
+    const uint32_t block_tile = a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x;
+    tile_pixel<WAVES>(block_tile, block_tiles_x, wave, lane, a.row_begin, tile_rows, x, y, a.col_begin);
     const bool in_range = x < a.col_end && y < a.row_end && (lane >> 3) < tile_rows;
-    const bool setup_wave = !SHARED || wave == 0;         // SHARED: wave 0 prepares the tile, the others join at the barrier
     bool covered = false;
     float depth = 0.0f;
-    if (in_range && setup_wave) {
+    if (in_range) {
         depth = a.depth[size_t(y) * W + x];                                                  // rgen:19
         covered = depth != 0.0f;
         if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                         // rgen:20-21
     }
-    if (setup_wave) s_vis[lane] = 0;
-    const uint32_t first_kind = (a.tp.shadow_enable && !PACKET) ? 0u : 1u;       // PACKET: the shadow rays never enter the queue
+    s_vis[lane] = 0;
+    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
-    // the queue holds AO rays only (shadow rays off, or walked as a packet): the cut is pruned to their reach ("cut_reach")
-    const bool ao_only = first_kind != 0u && (cut_reach & 1u) != 0u;      // cut_reach: bit 0 = prune by reach, bit 1 = expand the cut
+    // without shadow rays the queue holds AO rays only and the cut is pruned to their reach; with them it keeps every entry and an AO ray skips
+    // those beyond its reach (build_tile_cut)
+    const bool ao_only = first_kind != 0u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
-    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // CUT: bounds of the tile's ray origins
-    f3 pk_origin = f3{ 0.0f, 0.0f, 0.0f }, pk_dir = f3{ 0.0f, 0.0f, 1.0f };              // PACKET: this pixel's shadow ray
-    float ao_reach = 0.0f;                                                                   // CUT: bound of tmax * |d| over this pixel's AO rays
+    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of the tile's ray origins
+    float ao_reach = 0.0f;                                                                   // bound of tmax * |d| over this pixel's AO rays
     if (covered) {
         // ---- raygen.rgen:15-29 once per pixel (shared by all of the pixel's rays) ----
         const float u = (float(x) + 0.5f) / float(W);
@@ -1062,52 +860,26 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];    // rgen:28 (R16G16B16A16: nx ny | nz id)
         const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
-        const uint32_t seed = seed_thread((y * H + x) * a.pfd.frame_index);                  // rgen:17
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
-        if (PACKET && a.tp.shadow_enable) { pk_origin = origin; pk_dir = ray_direction(a.tp, seed, 0u, L, N); }   // rgen:32-35, whole wave
-        if (CUT && ao_only) ao_reach = a.tp.ao_tmax * onb_norm_bound(N);      // (wave-uniform condition)
-        if (CUT) { omin = origin; omax = origin; }
-        if (PREGEN) {
-            for (uint32_t kind = first_kind; kind <= last_kind; ++kind) {
-                const f3 d = ray_direction(a.tp, seed, kind, L, N);
-                float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + lane;
-                slot[0] = d.x; slot[kQueueBlock] = d.y; slot[2 * kQueueBlock] = d.z;
-            }
-        } else if constexpr (RAYW == 5) {
-            s_ray[3][lane] = __uint_as_float(nraw.x); s_ray[4][lane] = __uint_as_float(nraw.y);
-        } else {
-            s_ray[3][lane] = N.x; s_ray[4][lane] = N.y; s_ray[5][lane] = N.z;
-            s_ray[6][lane] = __uint_as_float(seed);
-        }
+        s_ray[3][lane] = __uint_as_float(nraw.x); s_ray[4][lane] = __uint_as_float(nraw.y);
+        ao_reach = a.tp.ao_tmax * onb_norm_bound(N);
+        omin = origin; omax = origin;
     }
     const unsigned long long cov_mask = __ballot(covered);
-    uint32_t ncov = uint32_t(__popcll(cov_mask));
+    const uint32_t ncov = uint32_t(__popcll(cov_mask));
     if (covered) s_list[lane_rank(cov_mask)] = uint8_t(lane);
-    if (SHARED) {
-        if (threadIdx.x == 0) { s_ncov = ncov; s_next = 0; }
-        __syncthreads();
-        ncov = s_ncov;
-    } else {
-        wave_lds_sync();
-    }
+    wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
-    PacketCounters pkc = { 0u, 0u, 0u };
-    uint32_t n_cut_entries = 0;
-    unsigned long long t_packet = 0;
-    if (PACKET && a.tp.shadow_enable && a.scene.node_count != 0 && cov_mask != 0) {
-        const unsigned long long tp0 = stats ? __builtin_readcyclecounter() : 0ull;
-        const unsigned long long occluded = shadow_packet<STATS>(a.scene, cov_mask, pk_origin, pk_dir, a.tp.tmin, a.tp.tmax, lane, pkc);
-        if ((occluded >> lane) & 1ull) s_vis[lane] = 1u;                                     // miss.rmiss:7 leaves 1.0 for the others
-        wave_lds_sync();
-        if (stats) t_packet = __builtin_readcyclecounter() - tp0;
-    }
     uint32_t cut_n = 0;
-    if (CUT && total) {
-        if constexpr (WIDE) cut_n = build_tile_cut_wide(a.scene.nodes4, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax);
-        else cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, cut_reach & 2u, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)));
+    if (total) {
+        float short_reach = ao_only ? 0.0f : ao_reach;
+        cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)),
+                               ao_only ? nullptr : &short_reach);
+        ao_reach = short_reach;                       // (uniform: the tile's maximum)
     }
-    if (STATS) n_cut_entries = cut_n;
-    uint32_t emask = 0;                               // CUT: cut entries this lane's ray hits that did not fit its LDS stack
+    const float ao_reach2 = ao_only ? 3.0e38f : ao_reach * ao_reach;
+    const uint32_t n_cut_entries = cut_n;
+    uint32_t emask = 0;                               // cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
 
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
@@ -1115,14 +887,14 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     int cur = 0, sp = 0;
     uint32_t pix = 0, kind = 0;
     bool has = false;
-    uint32_t next = 0;                                // queue head: wave-uniform, lives in a register (one wave per block)
+    uint32_t next = 0;                                // queue head: wave-uniform, lives in a register
     uint32_t overflow = 0;
     uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;      // statistics (only flushed when stats)
     uint32_t n_drain_le4 = 0, n_drain_le8 = 0, n_drain_le16 = 0;
     // Stack entries beyond the LDS levels spill to a small private (scratch) array: any-hit walks rarely hold more than
     // a dozen pending subtrees, so the LDS part can be much shallower than the tree -- more waves per CU -- without
     // giving up the guarantee that kTraceStack entries can never overflow (the builder bounds the depth).
-    int spill[SPILL ? kSpillEntries : 1];
+    int spill[SPILL ? kSpillStack : 1];
     const float tmin = a.tp.tmin;
     float tmin_v = tmin;                              // one VGPR copy for the asm-operand min/max of the slab test
     asm volatile("" : "+v"(tmin_v));
@@ -1134,45 +906,34 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
             __builtin_amdgcn_s_setprio(0);            // (see below)
             ++n_refills;
-            if (SHARED) {                             // one LDS atomic per refill, issued by the first idle lane
-                const int leader = __ffsll((long long)idle) - 1;
-                uint32_t base = 0;
-                if (int(lane) == leader) base = atomicAdd(&s_next, n_idle);
-                next = __shfl(base, leader);
-            }
             const uint32_t r = next + lane_rank(idle);
             next += n_idle;
             if (!has && r < total) {
                 // k = r / ncov without the integer division (~25 instructions): the queue is kind-major, k < kinds
                 uint32_t k = 0, rr = r;
                 while (rr >= ncov) { rr -= ncov; ++k; }
-                kind = (cut_reach & 4u) ? last_kind - k : k + first_kind;     // "shadow_last": the shadow rays at the END of the queue
+                kind = last_kind - k;                 // the shadow rays (kind 0) at the END of the queue (r2: the AO rays' long drains overlap them)
                 pix = s_list[rr];
                 ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
-                if (PREGEN) {
-                    const float *slot = s_dir + (kind - first_kind) * 3u * kQueueBlock + pix;
-                    rd = f3{ slot[0], slot[kQueueBlock], slot[2 * kQueueBlock] };
-                } else if constexpr (RAYW == 5) {
-                    const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nzw = __float_as_uint(s_ray[4][pix]);
-                    const uint32_t px = x - (lane & 7u) + (pix & 7u), py = y - (lane >> 3) + (pix >> 3);     // the tile's origin + the pixel's place in it
-                    rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                            // rgen:17
-                                       f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) });
-                } else {
-                    rd = ray_direction(a.tp, __float_as_uint(s_ray[6][pix]), kind, L, f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] });
-                }
+                const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nzw = __float_as_uint(s_ray[4][pix]);
+                const uint32_t px = x - (lane & 7u) + (pix & 7u), py = y - (lane >> 3) + (pix >> 3);     // the tile's origin + the pixel's place in it
+                rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                            // rgen:17
+                                   f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) });
                 tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 // COMPACT boxes are relative to the scene centre: shift the origin used by the slab test (only)
                 const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
-                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
+                if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 cur = 0; sp = 0;
-                if (CUT) {                            // the ray against the tile's cut: hit subtrees go on its stack
+                {   // the ray against the tile's cut: hit subtrees go on its stack
                     emask = 0;
                     // (the cut's boxes are absolute fp32 boxes whatever the node format)
                     const f3 noi_cut = COMPACT ? f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) } : noi;
                     for (uint32_t e = 0; e < cut_n; ++e) {
-                        const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
+                        const float4 b1 = s_cut[e][1];
+                        if (kind != 0u && b1.w > ao_reach2) continue;         // out of every AO ray's reach (a whole refill of AO rays skips the test)
+                        const float4 b0 = s_cut[e][0];
                         float tnu;
                         if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
                             if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
@@ -1203,75 +964,6 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;   // ballot(true) = the walkers left; early_exit in 0..15 sixteenths, so the first trip always runs
             ++n_nodes;
-            if constexpr (WIDE) {
-                // ---- one FOUR-WIDE node (BvhNode4): three loads, the ray moved into the node's 8-bit grid, four boxes ----
-                const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.scene.nodes4) + uint32_t(cur) * uint32_t(sizeof(BvhNode4)));
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                // plane = O + q * S  =>  t = q * (S / d) + (O - o) / d; S is the word's low byte moved into the exponent field
-                const float idx = rinv.x * __uint_as_float(n0.x << 23), idy = rinv.y * __uint_as_float(n0.y << 23), idz = rinv.z * __uint_as_float(n0.z << 23);
-                const float oqx = __builtin_fmaf(__uint_as_float(n0.x), rinv.x, noi.x), oqy = __builtin_fmaf(__uint_as_float(n0.y), rinv.y, noi.y),
-                            oqz = __builtin_fmaf(__uint_as_float(n0.z), rinv.z, noi.z);
-                // the planes a ray meets first are the lower ones where it travels upward, the upper ones where it travels downward
-                const bool ngx = rinv.x < 0.0f, ngy = rinv.y < 0.0f, ngz = rinv.z < 0.0f;
-                const uint32_t nxw = ngx ? n1.z : n0.w, fxw = ngx ? n0.w : n1.z;
-                const uint32_t nyw = ngy ? n1.w : n1.x, fyw = ngy ? n1.x : n1.w;
-                const uint32_t nzw = ngz ? n2.x : n1.y, fzw = ngz ? n1.y : n2.x;
-                auto ub = [](uint32_t w, int c) { return float((w >> (8 * c)) & 0xffu); };                 // v_cvt_f32_ubyteN
-                auto pair = [&](uint32_t w, int c, float id, float oq) {
-                    return __builtin_elementwise_fma(f2v{ ub(w, c), ub(w, c + 1) }, f2v{ id, id }, f2v{ oq, oq });
-                };
-                const f2v nx01 = pair(nxw, 0, idx, oqx), nx23 = pair(nxw, 2, idx, oqx), fx01 = pair(fxw, 0, idx, oqx), fx23 = pair(fxw, 2, idx, oqx);
-                const f2v ny01 = pair(nyw, 0, idy, oqy), ny23 = pair(nyw, 2, idy, oqy), fy01 = pair(fyw, 0, idy, oqy), fy23 = pair(fyw, 2, idy, oqy);
-                const f2v nz01 = pair(nzw, 0, idz, oqz), nz23 = pair(nzw, 2, idz, oqz), fz01 = pair(fzw, 0, idz, oqz), fz23 = pair(fzw, 2, idz, oqz);
-                const float tnc[4] = { hw_max3(nx01.x, ny01.x, hw_max(nz01.x, tmin_v)), hw_max3(nx01.y, ny01.y, hw_max(nz01.y, tmin_v)),
-                                       hw_max3(nx23.x, ny23.x, hw_max(nz23.x, tmin_v)), hw_max3(nx23.y, ny23.y, hw_max(nz23.y, tmin_v)) };
-                const float tfc[4] = { hw_min3(fx01.x, fy01.x, hw_min(fz01.x, tmax)), hw_min3(fx01.y, fy01.y, hw_min(fz01.y, tmax)),
-                                       hw_min3(fx23.x, fy23.x, hw_min(fz23.x, tmax)), hw_min3(fx23.y, fy23.y, hw_min(fz23.y, tmax)) };
-                // the nearest hit child is entered, the others wait on the stack.  Key = entry distance with the slot in its two low
-                // bits (positive floats order like integers; the keys of a node are distinct), all ones for a child that is missed.
-                uint32_t key[4];
-                int link[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    key[c] = tnc[c] <= tfc[c] ? ((__float_as_uint(tnc[c]) & ~3u) | uint32_t(c)) : 0xffffffffu;
-                    const int byte = int(n2.w << (24 - 8 * c)) >> 24;
-                    link[c] = (byte < 0 ? int(n2.z) : int(n2.y)) + byte;
-                }
-                const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-                const bool any_hit_child = kmin != 0xffffffffu;
-                // Row min(sp, L + 1) holds the top entry (the sentinel when the stack is empty).  The four links are written one after
-                // the other from the row above it; the write position only advances past a link that has to wait, so the entered
-                // child and the missed ones are overwritten or stay above the new top (rows L + 2 .. L + 5 absorb the rest).
-                int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
-                int top = row[0];
-                uint32_t wo = kQueueBlock;
-                bool wait[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    wait[c] = key[c] != 0xffffffffu && key[c] != kmin;
-                    row[wo] = link[c];
-                    wo += wait[c] ? uint32_t(kQueueBlock) : 0u;
-                }
-                const int pushed = int(wo / kQueueBlock) - 1;
-                if (__any(uint32_t(sp) + 3u > stack_levels)) {          // (wave-uniform, rare) entries beyond the LDS levels live in scratch
-                    if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
-                    uint32_t e = uint32_t(sp);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (wait[c]) {
-                            if (e >= stack_levels) {
-                                if (SPILL && e - stack_levels < uint32_t(kSpillEntries)) spill[e - stack_levels] = link[c];
-                                else overflow |= 1u;                                  // cannot happen (launch_raygen checks the wide depth); counted
-                            }
-                            ++e;
-                        }
-                    }
-                }
-                const int entered = key[0] == kmin ? link[0] : (key[1] == kmin ? link[1] : (key[2] == kmin ? link[2] : link[3]));
-                cur = any_hit_child ? entered : top;
-                sp += any_hit_child ? pushed : -1;
-                continue;
-            }
             float tn0, tn1;
             bool h0, h1;
             int2 links;
@@ -1300,9 +992,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             // deep entries: behind a wave-uniform test, so that the hot path keeps plain ds_read / ds_write (an
             // if-converted "LDS or scratch" access becomes a flat load plus ten instructions of pointer selection)
             if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
+                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillEntries)) spill[uint32_t(sp) - stack_levels] = farc;
+                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillStack)) spill[uint32_t(sp) - stack_levels] = farc;
                     else overflow |= both ? 1u : 0u;                              // cannot happen (builder depth bound); counted
                 }
             }
@@ -1344,12 +1036,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             if (!found) {                                                          // pop (the sentinel if nothing is pending)
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillEntries - 1)];
+                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 }
                 --sp;
             }
         }
-        if (CUT && has && !found && cur == kStackSentinel && emask) {          // overflowed cut entries: next subtree
+        if (has && !found && cur == kStackSentinel && emask) {                 // overflowed cut entries: next subtree
             const int e = __ffs(int(emask)) - 1;
             emask &= emask - 1u;
             cur = __float_as_int(s_cut[e][1].z);
@@ -1376,7 +1068,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             }
         }
     }
-    if (SHARED) __syncthreads(); else wave_lds_sync();
+    wave_lds_sync();
     float shadow_payload = 1.0f, ao_payload = 1.0f;                                          // rgen:20-21 for a pixel without geometry
     if (covered) {
         const uint32_t vis = s_vis[lane];
@@ -1385,12 +1077,12 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
-    // ---- "fuse_temporal": svgf.comp for this tile's pixels, right here (the default kernel only) ----
+    // ---- "fuse_temporal": svgf.comp for this tile's pixels, right here ----
     // svgf.comp reads of the CURRENT frame only the pixel's own texels; everything else it gathers is the previous frame's.  So the
     // wave that has just finished a tile can run it for the tile: the visibility goes from LDS into the filter (rounded to the halves
     // the image holds, which is also what is stored), the normals are the ones the set-up loaded, and the gathers of 16 200 x 2 waves
     // spread over the launch instead of forming a kernel of their own that waits on memory.
-    if constexpr (CUT && !STATS && !PACKET && !WIDE && !SHARED && !PREGEN) {
+    if constexpr (!STATS) {
         if (a.fuse_temporal) {                                                               // (uniform)
             const TemporalArgs &t = a.temporal;
             if (in_range && x >= t.col_begin && x < t.limit_x && y >= t.row_begin && y < t.row_end && y < t.limit_y) {
@@ -1418,264 +1110,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             atomicAdd(&stats->refills, n_refills);
             atomicAdd(&stats->waves, 1ull);
             atomicAdd(&stats->cut_entries, (unsigned long long)n_cut_entries);
-            if (PACKET && pkc.nodes) {
-                atomicAdd(&stats->packets, 1ull);
-                atomicAdd(&stats->packet_nodes, (unsigned long long)pkc.nodes);
-                atomicAdd(&stats->packet_triangles, (unsigned long long)pkc.triangles);
-                atomicAdd(&stats->packet_lane_tests, (unsigned long long)pkc.lane_tests);
-                atomicAdd(&stats->cycles_packet, t_packet);
-            }
         }
         // wave-reduced first: 64 same-address atomics per wave serialise at the memory side (the diagnostic launch took 3.4 ms)
-        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
-        if (lane == 0) {
-            atomicAdd(&stats->node_visits, (unsigned long long)n_nodes);
-            atomicAdd(&stats->leaf_visits, (unsigned long long)n_leaves);
-            atomicAdd(&stats->triangle_tests, (unsigned long long)n_tris);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1, work-queue form with WIDE tiles (option "raygen_tile_pixels" 128 / 256): the kernel above with SUB 8x8-pixel sub-tiles
-// per wave (16x8 or 16x16 pixels) and ONE queue over all of their rays.  What the lanes of a wave lose is set by the length
-// of the queue they share: a wave works through its rays greedily, and when the queue has run dry the slowest rays finish
-// with ever fewer lanes (PMC / in-kernel counters on the 8x8 kernel: 47 % of the wave trips after the drain began, AO rays
-// alone at 27 % of the lanes).  Twice or four times the rays per queue halve / quarter the share of that drain.  Per-pixel
-// set-up (raygen.rgen:15-29) runs SUB times with the whole wave; the tree cut is built once over all origins.  Same rays,
-// same arithmetic, integer visibility accumulated in LDS: bit-identical to the 8x8 form.
-// ---------------------------------------------------------------------------------------------
-template <int SUB, int WAVES, bool SPILL, bool STATS>
-__global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_wide_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
-                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t cut_reach, const Stamps st) {
-    vhr_stamp(st);
-    static_assert(SUB == 2 || SUB == 4, "16x8 or 16x16 pixels per wave");
-    constexpr int PIX = kQueueBlock * SUB;
-    constexpr uint32_t TW = 16u, TH = SUB == 4 ? 16u : 8u;
-    RayStats *const stats = STATS ? a.stats : nullptr;
-    extern __shared__ int s_dyn[];                    // per wave: (stack_levels + 3) x 64 ints (see raygen_queue_kernel)
-    const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
-    // LDS per wave is what decides the waves per SIMD here (7 need <= 5.7 KB): two pixels share a visibility word, the normal
-    // stays in the G-buffer's own half bits (2 words), the RNG seed is recomputed from the pixel at refill, 12 cut entries
-    __shared__ uint32_t s_vis_all[WAVES][PIX / 2];    // per pixel 16 bits: bit 0 shadow ray occluded, bits 4..: AO rays that escaped
-    __shared__ float s_ray_all[WAVES][5][PIX];        // per covered pixel: ray origin (3), normal as stored in the G-buffer (2)
-    __shared__ uint8_t s_list_all[WAVES][PIX];        // compacted covered pixels
-    __shared__ float4 s_cut_all[WAVES][kWideCutMax][2];
-    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    uint32_t (&s_vis)[PIX / 2] = s_vis_all[wave];
-    float (&s_ray)[5][PIX] = s_ray_all[wave];
-    uint8_t (&s_list)[PIX] = s_list_all[wave];
-    float4 (&s_cut)[kWideCutMax][2] = s_cut_all[wave];
-    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
-    stack[0] = kStackSentinel;
-    const uint32_t W = a.width, H = a.height;
-    const uint32_t by = blockIdx.x / block_tiles_x, bx = blockIdx.x - by * block_tiles_x;
-    const uint32_t tile_x0 = (bx * WAVES + wave) * TW, tile_y0 = a.row_begin + by * TH;
-    const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
-    const uint32_t last_kind = a.tp.ao_spp;
-    const bool ao_only = first_kind != 0u && (cut_reach & 1u) != 0u;      // cut_reach: bit 0 = prune by reach, bit 1 = expand the cut
-    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
-    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
-    float ao_reach = 0.0f;
-    unsigned long long cov_masks[SUB];
-    uint32_t ncov = 0;
-#pragma unroll
-    for (uint32_t sub = 0; sub < uint32_t(SUB); ++sub) {
-        const uint32_t x = tile_x0 + (sub & 1u) * 8u + (lane & 7u), y = tile_y0 + (sub >> 1) * 8u + (lane >> 3);
-        const uint32_t p = sub * kQueueBlock + lane;
-        bool covered = false;
-        float depth = 0.0f;
-        if (x < W && y < a.row_end) {
-            depth = a.depth[size_t(y) * W + x];                                              // rgen:19
-            covered = depth != 0.0f;
-            if (!covered) store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);                     // rgen:20-21
-        }
-        if ((sub & 1u) == 0u) s_vis[(sub >> 1) * kQueueBlock + lane] = 0;
-        if (covered) {
-            // ---- raygen.rgen:15-29 once per pixel ----
-            const float u = (float(x) + 0.5f) / float(W);
-            const float v = (float(y) + 0.5f) / float(H);
-            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
-            const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];  // rgen:28
-            const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
-            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
-            s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
-            s_ray[3][p] = __uint_as_float(nraw.x); s_ray[4][p] = __uint_as_float(nraw.y);
-            omin = f3{ fminf(omin.x, origin.x), fminf(omin.y, origin.y), fminf(omin.z, origin.z) };
-            omax = f3{ fmaxf(omax.x, origin.x), fmaxf(omax.y, origin.y), fmaxf(omax.z, origin.z) };
-            if (ao_only) ao_reach = fmaxf(ao_reach, a.tp.ao_tmax * onb_norm_bound(N));
-        }
-        const unsigned long long m = __ballot(covered);
-        cov_masks[sub] = m;
-        if (covered) s_list[ncov + lane_rank(m)] = uint8_t(p);
-        ncov += uint32_t(__popcll(m));
-    }
-    wave_lds_sync();
-    const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
-    uint32_t cut_n = 0;
-    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kWideCutMax, cut_reach & 2u);
-    uint32_t emask = 0;
-    if (stats) t_setup = __builtin_readcyclecounter() - t_start;
-
-    f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
-    float tmax = 0.0f;
-    int cur = 0, sp = 0;
-    uint32_t pix = 0, kind = 0;
-    bool has = false;
-    uint32_t next = 0;
-    uint32_t overflow = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, n_tris = 0, n_wave_trips = 0, n_drain_trips = 0;
-    volatile int spill[SPILL ? kSpillStack : 1];     // volatile: stays in scratch (see wave_queue_walk)
-    const float tmin = a.tp.tmin;
-    float tmin_v = tmin;
-    asm volatile("" : "+v"(tmin_v));
-    for (;;) {
-        // ---- refill idle lanes from the tile's ray queue (ranks from the idle ballot) ----
-        const unsigned long long idle = __ballot(!has);
-        const uint32_t n_idle = uint32_t(__popcll(idle));
-        const unsigned long long t0 = stats ? __builtin_readcyclecounter() : 0ull;
-        if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
-            ++n_refills;
-            const uint32_t r = next + lane_rank(idle);
-            next += n_idle;
-            if (!has && r < total) {
-                uint32_t k = 0, rr = r;
-                while (rr >= ncov) { rr -= ncov; ++k; }                                      // kind-major queue, k < kinds
-                kind = k + first_kind;
-                pix = s_list[rr];
-                ro = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
-                const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nz = __float_as_uint(s_ray[4][pix]);
-                const uint32_t px = tile_x0 + ((pix >> 6) & 1u) * 8u + (pix & 7u), py = tile_y0 + (pix >> 7) * 8u + ((pix >> 3) & 7u);
-                rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                        // rgen:17
-                                   f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nz & 0xffffu)) });
-                tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
-                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
-                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
-                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
-                cur = 0; sp = 0;
-                emask = 0;
-                for (uint32_t e = 0; e < cut_n; ++e) {                                       // the ray against the tile's cut
-                    const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
-                    float tnu;
-                    if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
-                        if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
-                        else emask |= 1u << e;
-                    }
-                }
-                if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
-                has = true;
-            }
-        }
-        if (!__any(has)) break;
-        const unsigned long long t1 = stats ? __builtin_readcyclecounter() : 0ull;
-        // ---- inner nodes (the node step of raygen_queue_kernel) ----
-        bool found = false;
-        const uint32_t nodes_before = n_nodes, tris_before = n_tris;
-        const uint32_t walkers_in = uint32_t(__popcll(__ballot(has && cur >= 0)));
-        while (has && cur >= 0) {
-            if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
-            ++n_nodes;
-            const Node48Words nw = load_node48(a.scene.nodes48, cur);
-            const float4 q0 = nw.q0, q1 = nw.q1, q2 = nw.q2;
-            const int2 links = nw.links;
-            float tn0, tn1;
-            bool h0, h1;
-            box_pair_ch(q0, q1, q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
-            const bool both = h0 && h1, none = !(h0 || h1);
-            const bool first0 = tn0 <= tn1;
-            const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
-            int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
-            int top = row[0];
-            row[kQueueBlock] = farc;
-            if (__any(uint32_t(sp) >= stack_levels)) {
-                if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
-                if (uint32_t(sp) >= stack_levels) {
-                    if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillStack)) spill[uint32_t(sp) - stack_levels] = farc;
-                    else overflow |= both ? 1u : 0u;
-                }
-            }
-            cur = both ? nearc : (none ? top : (h0 ? links.x : links.y));
-            sp += (both ? 1 : 0) - (none ? 1 : 0);
-        }
-        const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
-        // ---- leaf ----
-        if (has && cur < 0 && cur != kStackSentinel) {
-            const uint32_t vv = ~uint32_t(cur);
-            const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
-            ++n_leaves;
-            // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
-            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
-            for (uint32_t i = 0; i < count; ++i) {
-                ++n_tris;
-                const float4 *tp = reinterpret_cast<const float4 *>(a.scene.tris + first + i);
-                const float4 ta = tp[0], tb = tp[1];
-                const float tcx = reinterpret_cast<const float *>(tp)[8];
-                if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
-                    found = true;
-                    break;
-                }
-            }
-            if (!found) {
-                cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
-                if (SPILL && __any(uint32_t(sp) > stack_levels)) {
-                    if (uint32_t(sp) > stack_levels) cur = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
-                }
-                --sp;
-            }
-        }
-        if (has && !found && cur == kStackSentinel && emask) {                 // overflowed cut entries: next subtree
-            const int e = __ffs(int(emask)) - 1;
-            emask &= emask - 1u;
-            cur = __float_as_int(s_cut[e][1].z);
-            sp = 0;
-        }
-        const bool finished = found || cur == kStackSentinel;
-        if (has && finished) {
-            has = false;
-            // pixel p = 64 * sub + l lives in word 64 * (sub >> 1) + l, half (sub & 1)
-            uint32_t *const word = &s_vis[(pix >> 7) * kQueueBlock + (pix & 63u)];
-            const uint32_t shift = ((pix >> 6) & 1u) * 16u;
-            if (kind == 0) { if (found) atomicOr(word, 1u << shift); }                       // miss.rmiss:7 leaves 1.0
-            else if (!found) atomicAdd(word, 16u << shift);
-        }
-        if (stats) {
-            const unsigned long long t3 = __builtin_readcyclecounter();
-            t_refill += t1 - t0; t_nodes += t2 - t1; t_leaves += t3 - t2;
-            uint32_t tn = n_nodes - nodes_before, tt = n_tris - tris_before;
-            for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
-            n_wave_trips += tn + tt;
-            if (next >= total) n_drain_trips += tn + tt;
-        }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (uint32_t sub = 0; sub < uint32_t(SUB); ++sub) {
-        if (!((cov_masks[sub] >> lane) & 1ull)) continue;
-        const uint32_t x = tile_x0 + (sub & 1u) * 8u + (lane & 7u), y = tile_y0 + (sub >> 1) * 8u + (lane >> 3);
-        const uint32_t vis = (s_vis[(sub >> 1) * kQueueBlock + lane] >> ((sub & 1u) * 16u)) & 0xffffu;
-        const float shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
-        float ao_payload = 1.0f;
-        if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 4)) / float(a.tp.ao_spp);   // rgen:55
-        store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
-    }
-    if (stats) {
-        const unsigned long long ovf = __ballot(overflow != 0);
-        if (lane == 0) {
-            if (ncov) atomicAdd(&stats->covered_pixels, (unsigned long long)ncov);
-            if (ovf) atomicAdd(&stats->stack_overflows, (unsigned long long)__popcll(ovf));
-            atomicAdd(&stats->wave_iterations, (unsigned long long)n_wave_trips);
-            atomicAdd(&stats->drain_iterations, (unsigned long long)n_drain_trips);
-            atomicAdd(&stats->cycles_total, __builtin_readcyclecounter() - t_start);
-            atomicAdd(&stats->cycles_setup, t_setup);
-            atomicAdd(&stats->cycles_refill, t_refill);
-            atomicAdd(&stats->cycles_nodes, t_nodes);
-            atomicAdd(&stats->cycles_leaves, t_leaves);
-            atomicAdd(&stats->refills, n_refills);
-            atomicAdd(&stats->waves, 1ull);
-            atomicAdd(&stats->cut_entries, (unsigned long long)cut_n);
-        }
-        // wave-reduced before the atomics (64 same-address atomics per wave serialise at the memory side)
         for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
         if (lane == 0) {
             atomicAdd(&stats->node_visits, (unsigned long long)n_nodes);
@@ -1733,7 +1169,7 @@ constexpr uint32_t kNoHit = 0xffffffffu;
 // counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
 struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
 
-template <bool SPILL, bool ALPHA, bool STATS = false, bool COMPACT = false, typename Fetch, typename Commit>
+template <bool SPILL, bool ALPHA, bool STATS = false, typename Fetch, typename Commit>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
@@ -1761,12 +1197,9 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 fetch(r, pix, ro, rd);
                 rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
                 noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
-                if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
+                ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
-                const f3 noi_cut = noi;               // (the cut's boxes are absolute fp32 boxes whatever the node format)
-                if (COMPACT)                          // the half-precision boxes are relative to the scene centre: shift the origin the slab test uses (only)
-                    noi = f3{ -((ro.x - sc.centre[0]) * rinv.x), -((ro.y - sc.centre[1]) * rinv.y), -((ro.z - sc.centre[2]) * rinv.z) };
                 if (cut_n) {
                     // the ray against the tile's cut (build_tile_cut): the subtrees it hits go on its stack, the deepest -- the
                     // one closest to the origin -- on top; the (t, flat index) order of the commit makes the result independent
@@ -1775,7 +1208,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                     for (uint32_t e = 0; e < cut_n; ++e) {
                         const float4 b0 = cut[e][0], b1 = cut[e][1];
                         float tnu;
-                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
+                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
                             if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
                             else emask |= 1u << e;
                         }
@@ -1792,20 +1225,13 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;
             if (STATS) ++my_nodes;
+            // (the 48-byte fp32 nodes: the 32-byte half-precision ones were measured here too -- r3c, and r4 with the walk as a kernel of its
+            // own at 58 registers -- and make no difference to this walk)
+            const Node48Words nw = load_node48(sc.nodes48, cur);
+            const int2 links = nw.links;
             float tn0, tn1;
             bool h0, h1;
-            int2 links;
-            if constexpr (COMPACT) {
-                // `cur` is the node's BYTE offset (index * 32); two 16-byte loads per visit; conservative half-precision boxes (BvhNode16)
-                const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes16) + uint32_t(cur));
-                const uint4 c0 = np[0], c1 = np[1];
-                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
-                links = int2{ int(c1.z), int(c1.w) };
-            } else {
-                const Node48Words nw = load_node48(sc.nodes48, cur);
-                links = nw.links;
-                box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
-            }
+            box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tbest, h0, h1, tn0, tn1);
             const bool both = h0 && h1, none = !(h0 || h1);
             const bool first0 = tn0 <= tn1;
             const int nearc = first0 ? links.x : links.y, farc = first0 ? links.y : links.x;
@@ -1889,7 +1315,7 @@ constexpr int kReflRays = 128;
 template <bool SPILL, int BOUNCES, bool STATS = false>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const uint32_t use_cut, const Stamps st) {
+    const uint32_t early_exit, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
     // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
@@ -1960,7 +1386,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
     // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
-    const uint32_t cut_n = use_cut && total && bounce == 0 ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    const uint32_t cut_n = total && bounce == 0 ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     const unsigned long long tw0 = STATS ? __builtin_readcyclecounter() : 0ull;
     wave_queue_walk<SPILL, false, STATS>(
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
@@ -2059,137 +1485,6 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
 }
 
-// ---------------------------------------------------------------------------------------------
-// Mirror ray, walk and shading in two launches ("reflection_variant" 2, one bounce).
-//
-// reflection_queue_kernel's register budget is set by reflection_hit.rchit (vertex fetches, two bilinear texture samples, the BRDF), which it
-// runs in its tiles' epilogues: 5-6 waves per SIMD for a walk that waits on memory for 60 % of its cycles (profiles/r4b_refl_pmc_*.txt).
-// Here the walk is a kernel of its own -- the same queue, the same node step on the 32-byte half-precision nodes where the tree has them
-// (two loads per visit instead of three; boxes only cull), 64 registers -- that leaves one 16-byte hit record per pixel (triangle, u, v;
-// kNoHit for a miss and for pixels without geometry) in a buffer of the context; reflection_shade_kernel then runs the shader one pixel per
-// lane with every lane busy.  Same rays, same intersection arithmetic, same shader: the image is reflection_queue_kernel's bit for bit.
-// ---------------------------------------------------------------------------------------------
-template <bool SPILL, bool COMPACT, bool STATS>
-__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(7, 8))) void reflection_walk_kernel(
-    const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, uint4 *__restrict__ records, const Stamps st) {
-    vhr_stamp(st);
-    extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
-    // rows 0-2: P (raygen.rgen:26) -> the hit record (triangle, u, v); rows 3-4: the G-buffer normal as the halves it is.  Origin and direction
-    // are recomputed from them at refill (rgen:29, 60-61: the same operations on the same operands): 2.5 KB per wave instead of 3 KB, which
-    // with a six-level LDS stack lets seven waves per SIMD stay resident
-    __shared__ float s_ray_all[2][5][kReflRays];
-    __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
-    __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut)
-    const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
-    if (a.co.order_out && blockIdx.x == 0u) order_blocks_by_cost<2>(a.co.cost_prev, a.co.order_blocks, a.co.order_out, reinterpret_cast<uint32_t *>(s_dyn));
-    const uint32_t block = a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x;
-    const uint32_t tile = block * 2u + wave;
-    if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
-    float (&s_ray)[5][kReflRays] = s_ray_all[wave];
-    uint8_t (&s_list)[kReflRays] = s_list_all[wave];
-    int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
-    stack[0] = kStackSentinel;
-    const uint32_t W = a.width, H = a.height;
-    const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
-    // ---- phase 1: per-pixel ray setup, whole wave (raygen.rgen:15-29, 60-61) ----
-    uint32_t ncov = 0;
-    f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };
-#pragma unroll
-    for (uint32_t sub = 0; sub < 2; ++sub) {
-        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
-        const bool in_range = x < a.col_end && y < a.row_end;
-        const float depth = in_range ? a.depth[size_t(y) * W + x] : 0.0f;                    // rgen:19
-        const bool covered = depth != 0.0f;
-        const uint32_t p = sub * 64u + lane;
-        s_ray[0][p] = __uint_as_float(kNoHit);                                               // rgen:22 / reflection_miss.rmiss:7 unless a hit is committed
-        if (covered) {
-            const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);  // rgen:15-16
-            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
-            const uint2 nraw = reinterpret_cast<const uint2 *>(a.normals)[size_t(y) * W + x];    // rgen:28 (R16G16B16A16: nx ny | nz id)
-            const f3 N = f3{ half_bits_to_float(uint16_t(nraw.x & 0xffffu)), half_bits_to_float(uint16_t(nraw.x >> 16)), half_bits_to_float(uint16_t(nraw.y & 0xffffu)) };
-            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29 (here for the bounds of the tile's origins)
-            s_ray[0][p] = P.x; s_ray[1][p] = P.y; s_ray[2][p] = P.z;
-            s_ray[3][p] = __uint_as_float(nraw.x); s_ray[4][p] = __uint_as_float(nraw.y);
-            omin = f3{ fminf(omin.x, origin.x), fminf(omin.y, origin.y), fminf(omin.z, origin.z) };
-            omax = f3{ fmaxf(omax.x, origin.x), fmaxf(omax.y, origin.y), fmaxf(omax.z, origin.z) };
-        }
-        const unsigned long long m = __ballot(covered);
-        if (covered) s_list[ncov + lane_rank(m)] = uint8_t(p);
-        ncov += uint32_t(__popcll(m));
-    }
-    wave_lds_sync();
-    const uint32_t total = a.scene.node_count == 0 ? 0u : ncov;
-    // ---- phase 2: the queue ----
-    uint32_t overflow = 0;
-    WalkCounters wc;
-    const unsigned long long t_walk0 = STATS ? __builtin_readcyclecounter() : 0ull;
-    const uint32_t cut_n = total ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane, 3.0e38f, kCutMax, 0u, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48))) : 0u;
-    wave_queue_walk<SPILL, false, STATS, COMPACT>(
-        a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
-        [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
-            pix = s_list[r];
-            const f3 P = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
-            const uint32_t nxy = __float_as_uint(s_ray[3][pix]), nzw = __float_as_uint(s_ray[4][pix]);
-            const f3 N = f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) };
-            ro = P + N * a.tp.normal_bias;                                                   // rgen:29
-            const f3 I = normalize3(P - cam);                                                // rgen:60
-            const float ni2 = 2.0f * dot3(N, I);
-            rd = I - N * ni2;                                                                // rgen:61 reflect(I, N)
-        },
-        [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
-            s_ray[0][pix] = __uint_as_float(tri); s_ray[1][pix] = u; s_ray[2][pix] = v;
-        }, &wc);
-    wave_lds_sync();
-    // ---- phase 3: the tile's records, whole wave ----
-#pragma unroll
-    for (uint32_t sub = 0; sub < 2; ++sub) {
-        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
-        if (x >= a.col_end || y >= a.row_end) continue;
-        const uint32_t p = sub * 64u + lane;
-        const uint32_t tri = total ? __float_as_uint(s_ray[0][p]) : kNoHit;                  // (no tree: every ray misses; the origins are still there)
-        records[size_t(y) * W + x] = make_uint4(tri, __float_as_uint(s_ray[1][p]), __float_as_uint(s_ray[2][p]), 0u);
-    }
-    if (a.stats && lane == 0 && overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
-    if constexpr (STATS) {
-        RayStats *const rs = a.stats + 1;
-        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles;
-        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
-        if (lane == 0) {
-            atomicAdd(&rs->node_visits, (unsigned long long)n_nodes);
-            atomicAdd(&rs->leaf_visits, (unsigned long long)n_leaves);
-            atomicAdd(&rs->triangle_tests, (unsigned long long)n_tris);
-            atomicAdd(&rs->wave_iterations, (unsigned long long)wc.wave_trips);
-            atomicAdd(&rs->unique_rays, (unsigned long long)ncov);
-            atomicAdd(&rs->covered_pixels, (unsigned long long)ncov);
-            atomicAdd(&rs->refills, (unsigned long long)wc.refills);
-            atomicAdd(&rs->waves, 1ull);
-            atomicAdd(&rs->cycles_total, __builtin_readcyclecounter() - t_cost0);
-            atomicAdd(&rs->cycles_nodes, __builtin_readcyclecounter() - t_walk0);
-        }
-    }
-    if (a.co.wave_cost && lane == 0) a.co.wave_cost[tile] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
-}
-
-// reflection_hit.rchit / reflection_miss.rmiss on the hit records, one pixel per lane (8x8 pixels per wave, 4 waves per workgroup)
-__global__ __launch_bounds__(kTraceBlock) void reflection_shade_kernel(const RaygenArgs a, const uint4 *__restrict__ records, const Stamps st) {
-    vhr_stamp(st);
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = a.col_begin + blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = a.row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    if (x >= a.col_end || y >= a.row_end) return;
-    const uint4 rec = records[size_t(y) * a.width + x];
-    f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                               // rgen:22, reflection_miss.rmiss:7
-    if (rec.x != kNoHit) {
-        Hit h;
-        h.t = 0.0f; h.u = __uint_as_float(rec.y); h.v = __uint_as_float(rec.z); h.tri_index = rec.x; h.flat = 0;
-        payload = shade_reflection_hit(a.scene, a.pfd, h);
-    }
-    store_rgba16f(a.reflections, a.width, x, y, payload.x, payload.y, payload.z, payload.w);    // rgen:65
-}
-
 // The shadow / AO launch itself, by the options in force (everything launch_raygen decided is in `a`).
 // "raygen_cost_order": the cost / order pointers of a queue-kernel launch of `n_blocks` blocks of `wv` waves (see vhr_context::CostOrder).
 // 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order connects must
@@ -2235,22 +1530,15 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
     (void)height;
     RaygenArgs a = a_in;
     a.co = CostOrderArgs{};
-    const dim3 grid((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16);
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
-        launch(ctx, raygen_kernel, grid, dim3(kTraceBlock), 0, a);
+        launch(ctx, raygen_kernel, dim3((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16), dim3(kTraceBlock), 0, a);
     } else {
-        // the traversal stack is sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU
-        // LDS part of the traversal stack; deeper entries spill to scratch (see the kernel)
+        // LDS part of the traversal stack, sized by the tree actually built (depth <= kMaxBvhDepth): less LDS, more waves per CU; deeper
+        // entries spill to scratch (see the kernel)
         const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
         const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
-        const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
-        const bool pregen = kinds >= 1 && kinds <= kMaxPregenKinds && ctx->options[kOptPregen];
-        const uint32_t pregen_kinds = pregen ? kinds : 0u;
-        const bool shared_tile = ctx->options[kOptSharedTile] != 0;
-        const size_t stack_bytes = size_t(levels + 3) * kQueueBlock * sizeof(int), dir_bytes = size_t(pregen_kinds) * 3 * kQueueBlock * sizeof(float);
-        // raygen_tile_rows < 8 (A-B only): 8x4- or 8x2-pixel tiles = more, shorter waves.  Measured slower everywhere, thin
-        // strips included (1080p / 8: 123 -> 131 us; full frame 452 -> 523 us): a shorter queue keeps fewer lanes busy.
+        const size_t stack_bytes = size_t(levels + 3) * kQueueBlock * sizeof(int);
         const uint32_t rows_traced = a.row_end - a.row_begin;
         // rows of a wave's tile: 8, or ("raygen_tile_rows" 0 = auto, the default) 6 for a launch whose 8x8 tiles would fill less than 70 % of the
         // chip's wave slots -- a single partial round of waves lasts as long as its slowest wave, and a wave with three quarters of the rays
@@ -2263,98 +1551,33 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
         }
         const uint32_t tiles_x = (a.col_end - a.col_begin + 7) / 8, tiles_y = (rows_traced + tile_rows - 1) / tile_rows;
         const int waves = ctx->options[kOptWavesPerBlock];
+        const uint32_t wv = waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u);
         const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
-#define VHR_LAUNCH_QUEUE(P, WV, C, SP, ST)                                                                                        \
-    do {                                                                                                                          \
-        if (shared_tile)                                                                                                          \
-            launch(ctx, (raygen_queue_kernel<P, WV, C, true, SP, ST>), dim3(tiles_x * tiles_y), dim3(kQueueBlock * WV), stack_bytes * WV + dir_bytes, \
-                               a, levels, threshold, pregen_kinds, tiles_x, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, 0u);    \
-        else                                                                                                                      \
-            launch(ctx, (raygen_queue_kernel<P, WV, C, false, SP, ST>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-                               (stack_bytes + dir_bytes) * WV, a, levels, threshold, pregen_kinds, (tiles_x + WV - 1) / WV,      \
-                               uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, 0u);                                   \
-    } while (0)
-#define VHR_LAUNCH_QUEUE_W(P, C, SP, ST)                                                                                           \
-    do { if (waves >= 4) VHR_LAUNCH_QUEUE(P, 4, C, SP, ST); else if (waves >= 2) VHR_LAUNCH_QUEUE(P, 2, C, SP, ST); else VHR_LAUNCH_QUEUE(P, 1, C, SP, ST); } while (0)
-        // the shared descent ("raygen_cut", default): own-tile waves on the plain fp32 nodes
-        const bool cut = ctx->options[kOptRaygenCut] != 0 && !pregen && !shared_tile;
-        const bool compact_cut = cut && ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
-        const bool packet = ctx->options[kOptShadowPacket] != 0 && a.tp.shadow_enable;
-        const uint32_t cut_flags = (ctx->options[kOptCutReach] != 0 ? 1u : 0u) | (ctx->options[kOptCutExpand] != 0 ? 2u : 0u) | (ctx->options[kOptShadowLast] != 0 ? 4u : 0u);
-#define VHR_LAUNCH_CUT_P(WV, SP, ST, PK)                                                                                          \
-    launch(ctx, (raygen_queue_kernel<false, WV, false, false, SP, ST, true, PK>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-           stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
-           cut_flags)
-        // "bvh_wide": the same kernel on the four-wide tree (BvhNode4).  Its LDS stack is three levels shallower by default (a wide
-        // visit needs four more dummy rows; 5 + 6 rows keep the LDS per wave -- and with it 7 waves per SIMD -- where the binary
-        // walker's 8 + 3 are); a wide walk holds at most three pending subtrees per level of the wide tree, which the scratch part of
-        // the stack must cover, else the binary walker runs.
-        const uint32_t wide_levels = std::max<uint32_t>(1u, uint32_t(std::max(4, ctx->options[kOptLdsStackLevels])) - 3u);
-        const size_t wide_stack_bytes = size_t(wide_levels + 6) * kQueueBlock * sizeof(int);
-        const bool wide = ctx->options[kOptBvhWide] != 0 && ctx->d_nodes4 && ctx->node4_count != 0 && !packet &&
-                          3u * ctx->bvh_wide_depth <= uint32_t(kWideSpill);
-#define VHR_LAUNCH_CUT_WIDE(WV, ST)                                                                                               \
-    launch(ctx, (raygen_queue_kernel<false, WV, false, false, true, ST, true, false, true>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-           wide_stack_bytes * WV, a, wide_levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, \
-           cut_flags)
-#define VHR_LAUNCH_CUT(WV, SP, ST) do { if (wide) VHR_LAUNCH_CUT_WIDE(WV, ST); else if (packet) VHR_LAUNCH_CUT_P(WV, SP, ST, true); else VHR_LAUNCH_CUT_P(WV, SP, ST, false); } while (0)
-#define VHR_LAUNCH_CUT_W(SP, ST) \
-    do { if (waves >= 4) VHR_LAUNCH_CUT(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT(2, SP, ST); else VHR_LAUNCH_CUT(1, SP, ST); } while (0)
-        const bool compact = ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
-        // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
-        const bool spill = levels < ctx->bvh_depth + 1u;
-        // A/B variants (pre-generated directions, compact nodes) exist in the diagnostic flavour only
-        const int tile_pixels = ctx->options[kOptRaygenTilePixels];
-        if (cut && tile_rows == 8u && (tile_pixels == 128 || tile_pixels == 256)) {
-            // wide tiles: 16x8 / 16x16 pixels per wave, one queue over all their rays (raygen_wide_kernel)
-            const uint32_t th = tile_pixels == 256 ? 16u : 8u;
-            const uint32_t wtiles_x = (width + 15u) / 16u, wtiles_y = (rows_traced + th - 1u) / th;
-            const int wv = waves >= 2 ? 2 : 1;
-            const uint32_t blocks_x = (wtiles_x + wv - 1) / wv;
-            // 6 LDS stack levels at most: with 5.6 KB of LDS per wave 7 waves per SIMD stay resident (deeper entries spill)
-            const uint32_t wlevels = std::min<uint32_t>(levels, 6u);
-            const size_t wstack_bytes = size_t(wlevels + 3) * kQueueBlock * sizeof(int);
-            const bool wspill = wlevels < ctx->bvh_depth + 1u;
-#define VHR_LAUNCH_WIDE(SUBT, WV, SP, ST) \
-    launch(ctx, (raygen_wide_kernel<SUBT, WV, SP, ST>), dim3(blocks_x * wtiles_y), dim3(kQueueBlock * WV), wstack_bytes * WV, a, wlevels, threshold, blocks_x, \
-           early_exit, cut_flags)
-#define VHR_LAUNCH_WIDE_S(SUBT, WV) \
-    do { if (a.stats) { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, true); else VHR_LAUNCH_WIDE(SUBT, WV, false, true); } \
-         else { if (wspill) VHR_LAUNCH_WIDE(SUBT, WV, true, false); else VHR_LAUNCH_WIDE(SUBT, WV, false, false); } } while (0)
-            if (tile_pixels == 256) { if (wv == 2) VHR_LAUNCH_WIDE_S(4, 2); else VHR_LAUNCH_WIDE_S(4, 1); }
-            else { if (wv == 2) VHR_LAUNCH_WIDE_S(2, 2); else VHR_LAUNCH_WIDE_S(2, 1); }
-#undef VHR_LAUNCH_WIDE_S
-#undef VHR_LAUNCH_WIDE
+        const bool compact = ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;      // the 32-byte half-precision nodes (two loads per visit instead of three)
+        const bool spill = levels < ctx->bvh_depth + 1u;           // the whole stack in LDS (no scratch) whenever the tree's depth fits the configured LDS levels
+        const uint32_t n_blocks = ((tiles_x + wv - 1u) / wv) * tiles_y;
+        {   // "raygen_cost_order" (see vhr_context::CostOrder)
+            const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
+            if (!a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, n_blocks, wv, key, a.co);
         }
-        else if (compact_cut && !packet && !wide) {     // the default: the cut kernel on the 32-byte half-precision nodes (two loads per visit instead of three)
-            {   // "raygen_cost_order" (see vhr_context::CostOrder)
-                const uint32_t wv = waves >= 4 ? 4u : (waves >= 2 ? 2u : 1u);
-                const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
-                if (!ctx->options[kOptXcdAware] && !a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, ((tiles_x + wv - 1u) / wv) * tiles_y, wv, key, a.co);
+        auto go = [&](auto kernel) { launch(ctx, kernel, dim3(n_blocks), dim3(kQueueBlock * wv), stack_bytes * wv, a, levels, threshold, (tiles_x + wv - 1u) / wv, early_exit, tile_rows); };
+        auto by_flags = [&](auto waves_c) {
+            constexpr int WV = decltype(waves_c)::value;
+            const int sel = (compact ? 4 : 0) | (spill ? 2 : 0) | (a.stats ? 1 : 0);
+            switch (sel) {
+                case 0: go(raygen_queue_kernel<WV, false, false, false>); break;
+                case 1: go(raygen_queue_kernel<WV, false, false, true>); break;
+                case 2: go(raygen_queue_kernel<WV, false, true, false>); break;
+                case 3: go(raygen_queue_kernel<WV, false, true, true>); break;
+                case 4: go(raygen_queue_kernel<WV, true, false, false>); break;
+                case 5: go(raygen_queue_kernel<WV, true, false, true>); break;
+                case 6: go(raygen_queue_kernel<WV, true, true, false>); break;
+                default: go(raygen_queue_kernel<WV, true, true, true>); break;
             }
-#define VHR_LAUNCH_CUT16(WV, SP, ST) launch(ctx, (raygen_queue_kernel<false, WV, true, false, SP, ST, true, false>), dim3(((tiles_x + WV - 1) / WV) * tiles_y), dim3(kQueueBlock * WV), \
-                                            stack_bytes * WV, a, levels, threshold, 0u, (tiles_x + WV - 1) / WV, uint32_t(ctx->options[kOptXcdAware]), early_exit, tile_rows, cut_flags)
-#define VHR_LAUNCH_CUT16_W(SP, ST) do { if (waves >= 4) VHR_LAUNCH_CUT16(4, SP, ST); else if (waves >= 2) VHR_LAUNCH_CUT16(2, SP, ST); else VHR_LAUNCH_CUT16(1, SP, ST); } while (0)
-            if (a.stats) { if (spill) VHR_LAUNCH_CUT16_W(true, true); else VHR_LAUNCH_CUT16_W(false, true); }
-            else { if (spill) VHR_LAUNCH_CUT16_W(true, false); else VHR_LAUNCH_CUT16_W(false, false); }
-#undef VHR_LAUNCH_CUT16_W
-#undef VHR_LAUNCH_CUT16
-        }
-        else if (cut) {
-            if (a.stats) { if (spill) VHR_LAUNCH_CUT_W(true, true); else VHR_LAUNCH_CUT_W(false, true); }
-            else { if (spill) VHR_LAUNCH_CUT_W(true, false); else VHR_LAUNCH_CUT_W(false, false); }
-        }
-        else if (pregen) { if (compact) VHR_LAUNCH_QUEUE_W(true, true, true, true); else VHR_LAUNCH_QUEUE_W(true, false, true, true); }
-        else if (compact) VHR_LAUNCH_QUEUE_W(false, true, true, true);
-        else if (a.stats) { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, true); else VHR_LAUNCH_QUEUE_W(false, false, false, true); }
-        else { if (spill) VHR_LAUNCH_QUEUE_W(false, false, true, false); else VHR_LAUNCH_QUEUE_W(false, false, false, false); }
-#undef VHR_LAUNCH_CUT_W
-#undef VHR_LAUNCH_CUT
-#undef VHR_LAUNCH_CUT_WIDE
-#undef VHR_LAUNCH_CUT_P
-#undef VHR_LAUNCH_QUEUE_W
-#undef VHR_LAUNCH_QUEUE
-        // mirror rays: traced only when enabled (with the extension switch off the image keeps its cleared contents)
+        };
+        if (wv == 4u) by_flags(std::integral_constant<int, 4>{});
+        else if (wv == 2u) by_flags(std::integral_constant<int, 2>{});
+        else by_flags(std::integral_constant<int, 1>{});
     }
     ctx->time_end(kKernelRaygen);
 }
@@ -2430,14 +1653,11 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         if (hipMemsetAsync(ctx->d_ray_stats, 0, 2 * sizeof(RayStats), ctx->stream) != hipSuccess)     // [0] shadow / AO launch, [1] mirror-ray launch
             return ctx->fail(VHR_ERROR_DEVICE, "hipMemsetAsync(ray stats) failed");
     }
-    // "fuse_temporal" (default): hold the launch back until the next pass shows its first command -- if that is svgf.comp on this launch's
+    // "fuse_temporal" (opt-in): hold the launch back until the next pass shows its first command -- if that is svgf.comp on this launch's
     // images, the queue kernel runs it in its tiles' epilogues (flush_deferred_raygen).  Only the default kernel has that epilogue, only
     // whole-image work on one stream qualifies, and only a pass nobody hooked an epilogue to (its owner expects the image when it runs).
     {
-        const uint32_t kinds = (a.tp.shadow_enable ? 1u : 0u) + a.tp.ao_spp;
-        const bool default_kernel = ctx->options[kOptRaygenVariant] != 0 && ctx->options[kOptRaygenCut] != 0 && !ctx->options[kOptSharedTile] && !ctx->options[kOptShadowPacket] &&
-                                    !(ctx->options[kOptBvhWide] && ctx->d_nodes4) && ctx->options[kOptRaygenTilePixels] != 128 && ctx->options[kOptRaygenTilePixels] != 256 &&
-                                    !(ctx->options[kOptPregen] && kinds >= 1 && kinds <= kMaxPregenKinds);
+        const bool default_kernel = ctx->options[kOptRaygenVariant] != 0;
         const bool whole = a.row_begin == 0 && a.row_end == height && a.col_begin == 0 && a.col_end == width;
         const bool mirror = a.reflections && a.tp.reflections;
         if (ctx->options[kOptFuseTemporal] && ctx->may_defer_raygen && default_kernel && whole && !mirror && !a.stats && ctx->frames_in_flight == 1 &&
@@ -2453,38 +1673,18 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             return VHR_OK;
         }
     }
-    // The mirror ray's launch (raygen.rgen:59-65): not denoised, so owned rows (and columns) only.  "reflection_concurrent" (1: issued first,
-    // 2: issued second) puts it on the context's mirror stream beside the shadow / AO launch -- both read the G-buffer, they write different
-    // images -- and the caller's stream waits for it before the TraceRays returns: every later command sees both images complete.
-    const bool mirror = ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections;
-    auto issue_mirror = [&](RaygenArgs m) {
+    issue_raygen(ctx, a, width, height);
+    // The mirror ray's launch (raygen.rgen:59-65): not denoised, so owned rows (and columns) only.  It runs BEHIND the shadow / AO launch: beside it
+    // (a second stream) the two take as long as one after the other, and with walk and shading in two launches the walk is no faster
+    // (profiles/r4_reflection_concurrent.txt, r4d/r4e logs in profiles/r4_reflection_split.txt).
+    if (ctx->options[kOptRaygenVariant] != 0 && a.reflections && a.tp.reflections) {
+        RaygenArgs m = a;
         m.row_begin = owned_begin;
         m.row_end = owned_end;
         m.col_begin = owned_col_begin & ~15u;
         m.col_end = owned_col_end;
         ctx->time_begin(kKernelReflection);
-        if (m.tp.reflections == 1 && ctx->options[kOptReflectionVariant] == 2 && ctx->hit_records(size_t(width) * height)) {
-            // walk and shading in two launches (see reflection_walk_kernel)
-            const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
-            const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
-            const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
-            const uint32_t tiles_x = (m.col_end - m.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
-            const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
-            m.co = CostOrderArgs{};
-            if (levels >= 5u && !m.stats)
-                prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
-                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (3u << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co);
-            const bool spill = levels < ctx->bvh_depth + 1u;
-            const bool compact = ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
-#define VHR_LAUNCH_WALK(SP, C, ST) launch(ctx, (reflection_walk_kernel<SP, C, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, ctx->d_hit_records)
-#define VHR_LAUNCH_WALK_S(SP, C) do { if (m.stats) VHR_LAUNCH_WALK(SP, C, true); else VHR_LAUNCH_WALK(SP, C, false); } while (0)
-            if (compact) { if (spill) VHR_LAUNCH_WALK_S(true, true); else VHR_LAUNCH_WALK_S(false, true); }
-            else { if (spill) VHR_LAUNCH_WALK_S(true, false); else VHR_LAUNCH_WALK_S(false, false); }
-#undef VHR_LAUNCH_WALK_S
-#undef VHR_LAUNCH_WALK
-            m.co = CostOrderArgs{};
-            launch(ctx, reflection_shade_kernel, dim3((m.col_end - m.col_begin + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m, static_cast<const uint4 *>(ctx->d_hit_records));
-        } else if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
+        if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptEarlyExit])));
@@ -2494,7 +1694,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             if (levels >= 5u && !m.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
                                    (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co);
-#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
+#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }
@@ -2505,36 +1705,6 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m);
         }
         ctx->time_end(kKernelReflection);
-    };
-    int concurrent = mirror && ctx->frames_in_flight == 1 ? ctx->options[kOptReflectionConcurrent] : 0;
-    if (concurrent) {
-        bool ok = true;
-        if (!ctx->mirror_stream)
-            ok = hipStreamCreateWithFlags(&ctx->mirror_stream, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&ctx->mirror_ready, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&ctx->mirror_done, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventRecord(ctx->mirror_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->mirror_stream, ctx->mirror_ready, 0) == hipSuccess;
-        if (!ok) concurrent = 0;                         // no second stream: in order after all
-    }
-    auto on_mirror_stream = [&]() {
-        hipStream_t const main_stream = ctx->stream;
-        PassDescription *const pass = ctx->cur_pass;
-        ctx->stream = ctx->mirror_stream;
-        ctx->cur_pass = nullptr;                         // the pass's time stamps stay on the caller's stream
-        ctx->no_stamps = true;
-        issue_mirror(a);
-        ctx->no_stamps = false;
-        ctx->cur_pass = pass;
-        (void)hipEventRecord(ctx->mirror_done, ctx->mirror_stream);
-        ctx->stream = main_stream;
-    };
-    if (concurrent == 1) on_mirror_stream();
-    issue_raygen(ctx, a, width, height);
-    if (concurrent >= 2) on_mirror_stream();
-    if (concurrent) {
-        if (hipStreamWaitEvent(ctx->stream, ctx->mirror_done, 0) != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "hipStreamWaitEvent(mirror stream) failed");
-    } else if (mirror) {
-        issue_mirror(a);
     }
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {
@@ -2668,7 +1838,7 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
 template <bool SPILL, bool ALPHA>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void raytraced_queue_kernel(
     const RaytracedArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const uint32_t use_cut, const Stamps st) {
+    const uint32_t early_exit, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints
     // rows 0-2: primary direction -> primary hit record (triangle, u, v); rows 3-5: shadow-ray origin -> row 3 = its answer
@@ -2717,7 +1887,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     uint32_t overflow = 0;
     // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
     // (one origin for every ray: the shared descent follows the boxes around the camera)
-    uint32_t cut_n = use_cut && traced && total ? build_tile_cut(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
+    uint32_t cut_n = traced && total ? build_tile_cut(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
@@ -2753,7 +1923,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
     wave_lds_sync();
     // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
-    cut_n = use_cut && nhit ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    cut_n = nhit ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
@@ -2814,7 +1984,7 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         if (levels >= 5u && !a.stats)                      // "raygen_cost_order" for this path's launch (its own lifetimes and orders)
             prepare_cost_order(ctx, ctx->cost_order_raytraced, (tiles_total + 1u) / 2u, 2u,
                                (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co);
-#define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptRaygenCut] != 0))
+#define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
 #undef VHR_LAUNCH_RT

@@ -357,6 +357,11 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         ctx->cur_pass = stamps ? &p : nullptr;
         if (p.kind == PassKind::Graphics) {
             if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // its owner enqueues on the stream
+            // An in-kernel END stamp still pending belongs to the library pass in front of this one; whatever the owner's callback enqueues
+            // on the stream would be charged to that pass (the stamp is stored by the NEXT library kernel).  "pass_timestamps" 2 closes the
+            // pass here with the one-thread stamp kernel (+6 us per external pass with work behind a library pass); mode 1 leaves it open --
+            // right for callbacks that only bind images, as the harness's do.
+            if (p.external_cb && ctx->pending_end && ctx->options[vhr::kOptPassTimestamps] == 2) vhr::launch_stamp(ctx);
             if (p.external_cb) p.external_cb(p.user, ctx);
         } else if (p.kind == PassKind::Raytracing) {
             vhr_raytracing_execution_context ec{ ctx, &p, resource_idx };      // ExecuteRaytracingPass, :889-912

@@ -78,32 +78,6 @@ struct BvhNode48 {
 };
 static_assert(sizeof(BvhNode48) == 48, "BvhNode48");
 
-// The WIDE tree (r3, option "bvh_wide"): a four-wide collapse of the same BVH2 -- a node holds up to four child boxes, so a ray makes
-// about half as many dependent node round trips -- in 48 bytes = THREE 16-byte loads per visit (the same three the binary node costs:
-// the walk is bound by wave-level load instructions, ~20 cycles of the CU's address unit each).  The child boxes are quantised to
-// 8 bits per plane on a per-node grid:
-//   plane = O[axis] + q * 2^(e[axis] - 127),   O[axis] = the fp32 number whose bit pattern is origin[axis] AS IT STANDS,
-//   e[axis] = origin[axis] & 0xff, bit 8 of origin[axis] is zero  (so that origin[axis] << 23 IS the fp32 scale: one shift).
-// Lower planes are rounded DOWN, upper planes UP, against the padded (lo, hi) box the binary tree stores for the same subtree:
-// the quantised box contains it in exact arithmetic (checked on the host after every build, check_wide_nodes), boxes only cull,
-// results are unchanged.  A walker never builds the planes: it moves the RAY into the node's grid (three multiplies, three
-// FMAs) and evaluates t = q * (scale / d) + (O - o) / d per plane.
-//   q0 = (origin.x, origin.y, origin.z, qlo.x)   q1 = (qlo.y, qlo.z, qhi.x, qhi.y)   q2 = (qhi.z, child_base, leaf_base, meta)
-//   qlo.a / qhi.a: byte c = child c's lower / upper plane on axis a.  An absent child has qlo = 255, qhi = 0 on every axis.
-//   meta: byte c, signed.  >= 0: inner child, link = child_base + byte (a node's inner children are consecutive nodes, in slot
-//   order).  < 0: leaf, byte = -1 - ((off << 2) | (count - 1)), link = leaf_base + byte with leaf_base = -(first << 2) where
-//   `first` is the first triangle of the node's leaf children (consecutive in `tris`, in slot order) -- which is the binary
-//   tree's leaf code ~(((first + off) << 2) | (count - 1)), so the leaf stage of the walkers is shared.
-struct BvhNode4 {
-    uint32_t origin[3];
-    uint32_t qlo[3];
-    uint32_t qhi[3];
-    int32_t child_base;
-    int32_t leaf_base;
-    uint32_t meta;
-};
-static_assert(sizeof(BvhNode4) == 48, "BvhNode4");
-
 // Leaf triangle, 48 B = 3 x dwordx4: Moeller-Trumbore operands precomputed in world space
 // (resource_manager.cpp:608-617 bakes the primitive transform into the BLAS geometry).
 struct BvhTri {
@@ -137,7 +111,6 @@ struct DeviceScene {
     const BvhNode16 *nodes16;
     const BvhNodeCH *nodes_ch;       // centre / half-extent form of `nodes` (same indices, same links)
     const BvhNode48 *nodes48;        // the same in 48 bytes (same indices, same links)
-    const BvhNode4 *nodes4;          // the four-wide collapse of the same tree (its own indices; leaf codes shared)
     float centre[3];                 // origin of the half-precision boxes
     float pad0;
     const BvhTri *tris;
@@ -147,7 +120,6 @@ struct DeviceScene {
     const float *normal_matrices;    // 9 floats per primitive, column-major inverseTranspose(mat3(transform))
     const DeviceTexture *textures;
     uint32_t node_count, tri_count, primitive_count, texture_count;
-    uint32_t node4_count, pad1[3];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -174,21 +146,14 @@ struct HostBvh {
     std::vector<BvhNode16> nodes16;
     std::vector<BvhNodeCH> nodes_ch;
     std::vector<BvhNode48> nodes48;
-    std::vector<BvhNode4> nodes4;
-    // host-side cross references of the wide tree, for check_wide_nodes only (never uploaded): wide node -> the binary node it was
-    // collapsed from; wide child slot -> (binary node << 1 | which) whose box0 / box1 is that child's box
-    std::vector<uint32_t> wide_root;
-    std::vector<uint32_t> wide_child_ref;      // 4 per wide node, 0xffffffff for an absent child
     float centre[3] = { 0, 0, 0 };
     bool nodes16_valid = false;        // false: some box does not fit the half range around `centre` (the walkers then stay on nodes48)
     std::vector<BvhTri> tris;
     uint32_t max_depth = 0;
-    uint32_t wide_depth = 0;          // levels of the four-wide tree (a walk holds at most 3 pending subtrees per level)
 };
 
 // builds the BVH2 (csrc/bvh_build.cpp)
 void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads = 0);
-void check_wide_nodes(const HostBvh &bvh, uint64_t out[4], int threads = 0);
 bool nodes16_in_range(const HostBvh &bvh);      // no inf / NaN / subnormal half in the 32-byte form (a device-built tree: the host decides)
 uint64_t bvh_fingerprint(const HostBvh &bvh);
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
@@ -283,14 +248,54 @@ struct SvgfCmd {
 struct RayStats {
     unsigned long long unique_rays, covered_pixels, stack_overflows, node_visits, leaf_visits, triangle_tests, wave_iterations, second_bounce_rays;
     unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, drain_iterations;   // per-wave s_memtime sums
-    // shadow packets ("shadow_packet"): waves that walked one, wave-level node visits and triangle tests, undecided lanes summed
-    // over those steps (lane utilisation = packet_lane_tests / (64 * (packet_nodes + packet_triangles))), s_memtime ticks
-    unsigned long long packets, packet_nodes, packet_triangles, packet_lane_tests, cycles_packet, cut_entries;
+    unsigned long long cut_entries;
     unsigned long long drain_le4, drain_le8, drain_le16;     // drain trips made with at most 4 / 8 / 16 rays of the wave still in flight
 };
 
-// tuning knobs (vhr_set_option): every variant computes identical results
-enum Option { kOptRaygenVariant = 0, kOptRefillThreshold = 1, kOptAtrousVariant = 2, kOptTemporalVariant = 3, kOptBlocksPerCu = 4, kOptLdsStackLevels = 5, kOptPregen = 6, kOptWavesPerBlock = 7, kOptCompactNodes = 8, kOptXcdAware = 9, kOptSharedTile = 10, kOptTraceOverlap = 11, kOptAtrousBlocksPerCu = 12, kOptAtrousXcdAware = 13, kOptEarlyExit = 14, kOptAtrousSmallTiles = 15, kOptShrinkOverlap = 16, kOptReflectionVariant = 17, kOptRaytracedVariant = 18, kOptPassTimestamps = 19, kOptRaygenTileRows = 20, kOptFuseBlits = 21, kOptRaygenCut = 22, kOptKernelTimingStride = 23, kOptShadowPacket = 24, kOptCutReach = 25, kOptRaygenTilePixels = 26, kOptFramesInFlight = 27, kOptCutExpand = 28, kOptShadowLast = 29, kOptBvhWide = 30, kOptSvgfElideUnread = 31, kOptSvgfAsyncUnread = 32, kOptFuseTemporal = 33, kOptRaygenCostOrder = 34, kOptReflectionConcurrent = 35, kOptCount = 36 };
+// Options (vhr_set_option): ONE table -- name, default, smallest and largest value -- that vhr_set_option, vhr_get_option, vhr_option_info
+// (the Python binding, the neutrality test) and the context's defaults all read.  Every setting computes identical results (the a-trous
+// and mirror-ray forms within the float tolerance of tests/); the schedule options change what is launched, never what is published.
+#define VHR_OPTION_TABLE(X)                                                                                                             \
+    /* which form of a shader runs: 0 = the literal per-pixel form (the in-tree cross-check), 1 = the default */                        \
+    X(kOptRaygenVariant, "raygen_variant", 1, 0, 1)             /* raygen.rgen's shadow + AO rays: raygen_kernel / raygen_queue_kernel */ \
+    X(kOptReflectionVariant, "reflection_variant", 1, 0, 1)     /* the mirror ray: reflection_kernel / reflection_queue_kernel */       \
+    X(kOptRaytracedVariant, "raytraced_variant", 1, 0, 1)       /* the raytraced render path: raytraced_kernel / raytraced_queue_kernel */ \
+    X(kOptAtrousVariant, "atrous_variant", 1, 0, 1)             /* svgf_atrous_filter.comp: svgf_atrous_kernel / svgf_atrous_tile_kernel */ \
+    /* the queue kernels */                                                                                                             \
+    X(kOptRefillThreshold, "refill_threshold", 16, 1, 64)       /* idle lanes that trigger a refill from the tile's ray queue */        \
+    X(kOptLdsStackLevels, "lds_stack_levels", 8, 1, 32)         /* traversal stack entries kept in LDS (deeper ones live in scratch) */ \
+    X(kOptWavesPerBlock, "raygen_waves_per_block", 2, 1, 4)     /* tiles (= waves) per workgroup of raygen_queue_kernel: 1, 2 or 4 */    \
+    X(kOptCompactNodes, "compact_nodes", 1, 0, 1)               /* the 32-byte half-precision nodes where the tree has them */          \
+    X(kOptEarlyExit, "raygen_early_exit", 4, 0, 15)             /* sixteenths of the walkers that entered below which the node loop is left */ \
+    X(kOptRaygenTileRows, "raygen_tile_rows", 0, 0, 8)          /* rows of a wave's tile; 0 = auto (6 for launches that fill < 70 % of the wave slots) */ \
+    X(kOptRaygenCostOrder, "raygen_cost_order", 1, 0, 2)        /* start the longest-lived tiles first: 1 = launches of >= 2 048 workgroups, 2 = any */ \
+    /* the a-trous kernel */                                                                                                            \
+    X(kOptAtrousSmallTiles, "atrous_small_tiles", -1, -1, 1)    /* 4-row tiles: -1 auto (below 32 8-row tiles per CU), 0 never, 1 always */ \
+    /* the frame's schedule */                                                                                                          \
+    X(kOptFuseBlits, "fuse_blits", 1, 0, 1)                     /* a pass's blits as stores of its a-trous launches */                   \
+    X(kOptSvgfElideUnread, "svgf_elide_unread", 0, 0, 1)        /* do not launch an a-trous dispatch nothing reads (the reference's fifth) */ \
+    X(kOptSvgfAsyncUnread, "svgf_async_unread", 1, 0, 2)        /* ... or issue it on the side stream: 1 = where it pays, 2 = always */  \
+    X(kOptFuseTemporal, "fuse_temporal", 0, 0, 1)               /* svgf.comp in the ray-tracing kernel's tile epilogues */              \
+    X(kOptFramesInFlight, "frames_in_flight", 1, 1, 3)          /* read by vhr_graph_build */                                            \
+    /* screen tiles / row strips (one process per GPU) */                                                                               \
+    X(kOptTraceOverlap, "trace_overlap", 0, 0, 1)               /* trace the overlap margin locally instead of exchanging raw visibility */ \
+    X(kOptShrinkOverlap, "strip_shrink_overlap", 0, 0, 1)       /* later a-trous iterations compute only the margin still needed */     \
+    /* instrumentation */                                                                                                               \
+    X(kOptPassTimestamps, "pass_timestamps", 1, 0, 3)           /* 0 off, 1 in-kernel stamps, 2 + a stamp in front of external passes, 3 event pairs */ \
+    X(kOptKernelTimingStride, "kernel_timing_stride", 1, 1, 1000000)   /* every n-th launch of a timed kind carries an event pair */
+
+enum Option {
+#define X(e, n, d, lo, hi) e,
+    VHR_OPTION_TABLE(X)
+#undef X
+    kOptCount
+};
+struct OptionInfo { const char *name; int def, lo, hi; };
+inline constexpr OptionInfo kOptionInfo[kOptCount] = {
+#define X(e, n, d, lo, hi) { n, d, lo, hi },
+    VHR_OPTION_TABLE(X)
+#undef X
+};
 
 // optional per-kernel timing with HIP events on the context stream (vhr_set_kernel_timing)
 enum KernelKind { kKernelRaygen = 0, kKernelTemporal = 1, kKernelAtrous = 2, kKernelCopy = 3, kKernelReflection = 4, kKernelSsao = 5, kKernelSsaoBlur = 6, kKernelSsr = 7, kKernelAtrousAsync = 8, kKernelKinds = 9 };
@@ -342,9 +347,6 @@ struct vhr_context {
     vhr::BvhNode16 *d_nodes16 = nullptr;
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
     vhr::BvhNode48 *d_nodes48 = nullptr;
-    vhr::BvhNode4 *d_nodes4 = nullptr;
-    uint32_t node4_count = 0, bvh_wide_depth = 0;
-    uint64_t bvh_wide_checks[4] = { 0, 0, 0, 0 };   // check_wide_nodes of the last build (vhr_get_bvh_wide_checks)
     uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
     float bvh_centre[3] = { 0, 0, 0 };
@@ -394,10 +396,6 @@ struct vhr_context {
     bool side_pending = false;
     const void *side_reads[2] = { nullptr, nullptr }, *side_writes = nullptr;      // the images the pending dispatch reads / writes (hazard checks)
     bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
-    // "reflection_concurrent": the mirror-ray launch of a TraceRays is issued on `mirror_stream`, beside the shadow / AO launch on the caller's
-    // stream (both read the G-buffer, they write different images); the caller's stream waits for it at the end of the TraceRays
-    hipStream_t mirror_stream = nullptr;
-    hipEvent_t mirror_ready = nullptr, mirror_done = nullptr;
     int join_side();                   // the current stream waits for the side stream's pending dispatch (no-op without one)
 
     // statistics
@@ -407,7 +405,8 @@ struct vhr_context {
     vhr::RayStats h_refl_stats = {};      // the mirror-ray launch's counters (d_ray_stats[1])
     uint64_t raytraced_pixels = 0;      // != 0: the last TraceRays was the raytraced render path's (primary rays launched)
 
-    int options[vhr::kOptCount] = { 1, 16, 5, 0, 6, 8, 0, 2, 1, 0, 0, 0, 64, 1, 4, -1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 64, 1, 0, 1, 0, 0, 1, 0, 1, 0 };     // see vhr_set_option
+    int options[vhr::kOptCount];       // vhr_set_option; defaults from vhr::kOptionInfo (the constructor)
+    vhr_context() { for (int i = 0; i < vhr::kOptCount; ++i) options[i] = vhr::kOptionInfo[i].def; }
     int cu_count = 256;
     uint32_t *d_tile_counter = nullptr;
     // "raygen_cost_order" (csrc/kernels_trace.hip): ray-tracing launch f leaves its waves' lifetimes in cost[f & 1], and its FIRST block, before it
@@ -423,18 +422,6 @@ struct vhr_context {
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
     };
     CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
-    // the mirror ray's hit records between reflection_walk_kernel and reflection_shade_kernel ("reflection_variant" 2): 16 bytes per pixel
-    uint4 *d_hit_records = nullptr;
-    size_t hit_record_capacity = 0;
-    bool hit_records(size_t pixels) {
-        if (pixels <= hit_record_capacity) return true;
-        (void)hipDeviceSynchronize();
-        (void)hipFree(d_hit_records);
-        d_hit_records = nullptr; hit_record_capacity = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&d_hit_records), pixels * sizeof(uint4)) != hipSuccess) return false;
-        hit_record_capacity = pixels;
-        return true;
-    }
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;

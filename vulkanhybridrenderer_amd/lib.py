@@ -32,8 +32,8 @@ EXPORTS = [
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip", "vhr_set_tile",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
-    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_form_checks", "vhr_get_bvh_wide_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_packet_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
+    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_set_kernel_timing",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
@@ -117,6 +117,18 @@ RAYTRACING_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 COMPUTE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 _lib = None
+
+
+def option_table():
+    """vhr_option_info for every option of the library's table: {name: (default, min, max)}."""
+    L = load()
+    out = {}
+    for i in range(L.vhr_option_count()):
+        name, d, lo, hi = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        if L.vhr_option_info(i, C.byref(name), C.byref(d), C.byref(lo), C.byref(hi)) != 0:
+            raise VhrError(f"vhr_option_info({i})")
+        out[name.value.decode()] = (int(d.value), int(lo.value), int(hi.value))
+    return out
 
 
 def source_fingerprint():
@@ -216,7 +228,6 @@ def load():
     L.vhr_get_ray_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_form_checks.argtypes = [vp, C.POINTER(u64)]
-    L.vhr_get_bvh_wide_checks.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_current_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.vhr_get_bvh_builder.argtypes = [vp, C.POINTER(i32)]
     L.vhr_get_bvh_fingerprint.argtypes = [vp, C.POINTER(u64)]
@@ -224,9 +235,14 @@ def load():
     L.vhr_get_traversal_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_reflection_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_debug_wave_lifetimes.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.vhr_source_fingerprint.restype = C.c_char_p
     L.vhr_source_fingerprint.argtypes = []
-    L.vhr_get_packet_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_drain_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i32)]
+    L.vhr_option_count.restype = i32
+    L.vhr_option_count.argtypes = []
+    L.vhr_option_info.argtypes = [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.vhr_get_build_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.vhr_atrous_overlap.restype = u32
     L.vhr_atrous_overlap.argtypes = [u32]
@@ -552,6 +568,14 @@ class Context:
         d["active_lane_utilisation"] = (out[2] + out[4]) / (64.0 * out[5]) if out[5] else 0.0
         return d
 
+    def wave_lifetimes(self, capacity=1 << 20):
+        """Lifetimes (shader clock ticks) of the last ray-tracing launch's waves (what raygen_cost_order sorts by)."""
+        import numpy as np
+        out = np.zeros(capacity, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self.check(self.L.vhr_debug_wave_lifetimes(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), capacity, C.byref(n)), "wave_lifetimes")
+        return out[:n.value].copy()
+
     def traversal_cycles(self):
         out = (C.c_uint64 * 8)()
         self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
@@ -569,12 +593,6 @@ class Context:
         self.check(self.L.vhr_get_bvh_builder(self.handle, C.byref(out)), "get_bvh_builder")
         return int(out.value)
 
-    def bvh_wide_checks(self):
-        """Self-check of the four-wide tree ("bvh_wide"): (wide nodes, child boxes checked, boxes not containing the binary tree's, structural errors)."""
-        out = (C.c_uint64 * 4)()
-        self.check(self.L.vhr_get_bvh_wide_checks(self.handle, out), "bvh_wide_checks")
-        return tuple(int(v) for v in out)
-
     def bvh_fingerprint(self):
         out = C.c_uint64()
         self.check(self.L.vhr_get_bvh_fingerprint(self.handle, C.byref(out)), "bvh_fingerprint")
@@ -586,13 +604,15 @@ class Context:
         self.check(self.L.vhr_get_build_times(self.handle, out), "build_times")
         return float(out[0]), float(out[1])
 
-    def packet_statistics(self):
-        out = (C.c_uint64 * 9)()
-        self.check(self.L.vhr_get_packet_statistics(self.handle, out), "packet_statistics")
-        d = dict(packets=out[0], node_visits=out[1], triangle_tests=out[2], lane_tests=out[3], cycles=out[4], cut_entries=out[5],
-                 drain_trips_le4=out[6], drain_trips_le8=out[7], drain_trips_le16=out[8])
-        d["active_lane_utilisation"] = out[3] / (64.0 * (out[1] + out[2])) if out[1] + out[2] else 0.0
-        return d
+    def drain_statistics(self):
+        out = (C.c_uint64 * 4)()
+        self.check(self.L.vhr_get_drain_statistics(self.handle, out), "drain_statistics")
+        return dict(cut_entries=out[0], drain_trips_le4=out[1], drain_trips_le8=out[2], drain_trips_le16=out[3])
+
+    def get_option(self, key):
+        out = C.c_int32()
+        self.check(self.L.vhr_get_option(self.handle, key.encode(), C.byref(out)), f"get_option({key})")
+        return int(out.value)
 
     def bvh_statistics(self):
         out = (C.c_uint64 * 5)()
