@@ -450,17 +450,38 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     lap("tree");
     out.max_depth = b.max_depth;
 
-    // Triangle order: the leaves in the breadth-first order of the inner nodes that own them, left child first (the order the inner
-    // nodes are numbered in below): the leaves under one node are neighbours in `tris`
+    // Triangle order: by TREELETS.  Breadth first over groups of up to four subtrees -- an inner node with its two children, of which the
+    // inner one with the largest box is opened (replaced by its two children, in place) until there are four or only leaves are left --
+    // and the leaves of one group are neighbours in `tris`: the two to four leaves a ray reaches within two steps of each other share
+    // cache lines (against the plain breadth-first order of the binary tree's leaves, r4: equal on sponza_proc, the any-hit launch -3 % on
+    // bistro_proc).
     std::vector<uint32_t> leaf_pos(b.nodes.size(), 0u);
     if (b.nodes[0].left >= 0) {
         uint32_t pos = 0;
         std::vector<int32_t> queue{ 0 };
         for (size_t head = 0; head < queue.size(); ++head) {
-            const TmpNode &t = b.nodes[queue[head]];
-            for (const int32_t c : { t.left, t.right }) {
-                if (b.nodes[c].left >= 0) queue.push_back(c);
-                else { leaf_pos[c] = pos; pos += b.nodes[c].count; }
+            const int32_t id = queue[head];
+            int32_t child[4] = { b.nodes[id].left, b.nodes[id].right, -1, -1 };
+            int nc = 2;
+            while (nc < 4) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (int c = 0; c < nc; ++c) {
+                    const TmpNode &t = b.nodes[child[c]];
+                    if (t.left < 0) continue;
+                    const float area = t.box.half_area();
+                    if (area > best_area) { best_area = area; best = c; }
+                }
+                if (best < 0) break;
+                const TmpNode &t = b.nodes[child[best]];
+                for (int c = nc; c > best + 1; --c) child[c] = child[c - 1];
+                child[best] = t.left;
+                child[best + 1] = t.right;
+                ++nc;
+            }
+            for (int c = 0; c < nc; ++c) {
+                if (b.nodes[child[c]].left >= 0) queue.push_back(child[c]);
+                else { leaf_pos[child[c]] = pos; pos += b.nodes[child[c]].count; }
             }
         }
     }

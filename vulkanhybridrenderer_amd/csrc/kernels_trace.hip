@@ -665,27 +665,22 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
 // `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
-// `short_reach` (in: this lane's contribution; out: the wave's maximum, uniform): the same bound for the SHORT rays of a tile whose queue also holds
-// long ones (AO rays beside shadow rays).  Entries are not dropped for it; every entry carries the squared gap between its box and the bounds of
-// the origins in its last word, and a short ray skips the entries whose gap exceeds short_reach^2 without a box test.
 __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
-                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), float *short_reach = nullptr) {
+                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48))) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
         omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
         reach = fmaxf(reach, __shfl_xor(reach, off));
-        if (short_reach) *short_reach = fmaxf(*short_reach, __shfl_xor(*short_reach, off));
     }
     // wave-uniform from here on, and told so: the descent then runs on scalar registers and scalar branches
     auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
-    if (short_reach) *short_reach = uni(*short_reach);
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
     reach = uni(reach);
     const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
-    // The cut while it is being built: entry e lives in lane e (box, link, squared gap to the bounds of the origins).
-    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f, e_gap2 = 0.0f;
+    // The cut while it is being built: entry e lives in lane e (box, link).
+    float e_lx = 0.0f, e_hx = 0.0f, e_ly = 0.0f, e_hy = 0.0f, e_lz = 0.0f, e_hz = 0.0f;
     int e_link = 0;
     uint32_t cut_n = 0;
     auto gap2_of = [&](float lx, float hx, float ly, float hy, float lz, float hz) {
@@ -693,13 +688,13 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
                     gz = fmaxf(fmaxf(lz - omax.z, omin.z - hz), 0.0f);
         return (gx * gx + gy * gy) + gz * gz;
     };
-    auto put = [&](uint32_t slot, float lx, float hx, float ly, float hy, float lz, float hz, int link, float gap2) {
-        if (lane == slot) { e_lx = lx; e_hx = hx; e_ly = ly; e_hy = hy; e_lz = lz; e_hz = hz; e_link = link; e_gap2 = gap2; }
+    auto put = [&](uint32_t slot, float lx, float hx, float ly, float hy, float lz, float hz, int link) {
+        if (lane == slot) { e_lx = lx; e_hx = hx; e_ly = ly; e_hy = hy; e_lz = lz; e_hz = hz; e_link = link; }
     };
     auto add_entry = [&](float lx, float hx, float ly, float hy, float lz, float hz, int link) {
         const float g2 = gap2_of(lx, hx, ly, hy, lz, hz);
         if (g2 > reach2) return;                                                             // out of every ray's reach
-        put(cut_n, lx, hx, ly, hy, lz, hz, link, g2);
+        put(cut_n, lx, hx, ly, hy, lz, hz, link);
         ++cut_n;
     };
     int node = 0;
@@ -734,7 +729,7 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
     if (lane < cut_n) {
         s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
-        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), e_gap2);
+        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
     }
     wave_lds_sync();
     return cut_n;
@@ -811,7 +806,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
     __shared__ float s_ray_all[WAVES][5][kQueueBlock];    // per covered pixel: ray origin (3), the normal's half bits (2)
     __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
-    __shared__ float4 s_cut_all[WAVES][kCutMax][2];       // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, gap^2)
+    __shared__ float4 s_cut_all[WAVES][kCutMax][2];       // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
     // (the compiler cannot know that threadIdx.x >> 6 is the same in every lane of a wave: said explicitly, what derives
     // from it -- the LDS bases, the wave's tile -- stays in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
@@ -846,8 +841,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     s_vis[lane] = 0;
     const uint32_t first_kind = a.tp.shadow_enable ? 0u : 1u;
     const uint32_t last_kind = a.tp.ao_spp;           // kinds first_kind .. last_kind
-    // without shadow rays the queue holds AO rays only and the cut is pruned to their reach; with them it keeps every entry and an AO ray skips
-    // those beyond its reach (build_tile_cut)
+    // without shadow rays the queue holds AO rays only and the cut is pruned to their reach (with them in the queue, letting the AO rays skip
+    // the entries beyond their reach was measured: the test per entry costs sponza_proc what it saves bistro_proc, r4)
     const bool ao_only = first_kind != 0u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of the tile's ray origins
@@ -862,7 +857,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
         s_ray[0][lane] = origin.x; s_ray[1][lane] = origin.y; s_ray[2][lane] = origin.z;
         s_ray[3][lane] = __uint_as_float(nraw.x); s_ray[4][lane] = __uint_as_float(nraw.y);
-        ao_reach = a.tp.ao_tmax * onb_norm_bound(N);
+        if (ao_only) ao_reach = a.tp.ao_tmax * onb_norm_bound(N);      // (wave-uniform condition)
         omin = origin; omax = origin;
     }
     const unsigned long long cov_mask = __ballot(covered);
@@ -871,13 +866,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    if (total) {
-        float short_reach = ao_only ? 0.0f : ao_reach;
-        cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)),
-                               ao_only ? nullptr : &short_reach);
-        ao_reach = short_reach;                       // (uniform: the tile's maximum)
-    }
-    const float ao_reach2 = ao_only ? 3.0e38f : ao_reach * ao_reach;
+    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)));
     const uint32_t n_cut_entries = cut_n;
     uint32_t emask = 0;                               // cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
@@ -931,9 +920,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     // (the cut's boxes are absolute fp32 boxes whatever the node format)
                     const f3 noi_cut = COMPACT ? f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) } : noi;
                     for (uint32_t e = 0; e < cut_n; ++e) {
-                        const float4 b1 = s_cut[e][1];
-                        if (kind != 0u && b1.w > ao_reach2) continue;         // out of every AO ray's reach (a whole refill of AO rays skips the test)
-                        const float4 b0 = s_cut[e][0];
+                        const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
                         float tnu;
                         if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
                             if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
