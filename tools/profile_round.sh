@@ -2,8 +2,8 @@
 # Everything profiles/ holds for one round, taken on the GPU box in ONE gpurun call:   tools/profile_round.sh <tag>
 #   1. python bench.py (default flags)                           -> <tag>_bench_1gpu.json          (the line the driver measures)
 #   2. the same command under rocprofv3 --kernel-trace --stats   -> <tag>_kernel_stats_bench_1080p.csv, <tag>_bench_under_rocprof.json
-#   3. PMC passes, each a run of its own with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one
-#      pass; SQ counters in a third) + the FETCH_SIZE calibration  -> <tag>_traffic_pmc.json, <tag>_pmc_sq.txt, atrous_valu.json
+#   3. one SQ counter pass (--kernel-trace only) with the mirror ray on                     -> <tag>_pmc_sq.txt
+#      (traffic / instruction / address-unit counters per workload: tools/pmc_workload.sh -> profiles/pmc_<workload>.json)
 # The program itself follows `--` (python3 bench.py ...): no env / bash -c hop under the profiler.
 TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,25 +14,9 @@ B="--no-cpu-baseline --no-extras --min-seconds 0"
 echo "[1] bench"; python3 $R/bench.py > $OUT/${TAG}_bench_1gpu.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "[2] kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats_bench_1080p.csv
-echo "[3a] FETCH_SIZE calibration"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $R/tools/calibrate_fetch.py > $OUT/cal_fetch.log 2>&1 || { echo "calibration failed"; exit 1; }
-echo "[3b] FETCH_SIZE"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python3 $R/bench.py --steps 8 --warmup 2 $B > $OUT/bench_fetch.log 2>&1 || { echo "fetch pass failed"; exit 1; }
-echo "[3c] WRITE_SIZE"; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/bench_write -- python3 $R/bench.py --steps 8 --warmup 2 $B > $OUT/bench_write.log 2>&1 || { echo "write pass failed"; exit 1; }
-echo "[3d] SQ"; rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 8 --warmup 2 $B --reflections > $OUT/p1.log 2>&1 || { echo "SQ pass failed"; exit 1; }
-python3 $R/tools/summarize_traffic.py $OUT > $OUT/${TAG}_traffic_pmc.json
+echo "[3] SQ"; rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/p1 -- python3 $R/bench.py --steps 8 --warmup 2 $B --reflections > $OUT/p1.log 2>&1 || { echo "SQ pass failed"; exit 1; }
 python3 $R/tools/pmc_summary.py $OUT > $OUT/${TAG}_pmc_sq.txt
-python3 - <<PY
-import csv, glob, json, collections
-acc = collections.defaultdict(list)
-for f in glob.glob("$OUT/p1/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == "SQ_INSTS_VALU" and "svgf_atrous" in row["Kernel_Name"]:
-            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
-per = {k: sum(v) / len(v) for k, v in acc.items()}
-out = {"svgf_atrous_valu_insts_per_launch": round(sum(per.values()) / max(1, len(per))), "per_instantiation": per,
-       "source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU ... (tools/profile_round.sh $TAG), wave-level VALU instructions per dispatch, bench.py default workload"}
-json.dump(out, open("$OUT/atrous_valu.json", "w"), indent=1)
-print(json.dumps(out))
-PY
+# (the PMC files bench.py quotes -- traffic, a-trous instructions, address unit -- are tools/pmc_workload.sh's, one per workload, fingerprinted)
 tail -n 3 $OUT/${TAG}_bench_1gpu.json | cut -c1-600
 grep -E "svgf_atrous|raygen|temporal|copy_rows" $OUT/${TAG}_kernel_stats_bench_1080p.csv | cut -c1-200
 # [4] the same command with every dispatch in recorded order on the one stream (--option svgf_async_unread=0): the kernel summary then has
