@@ -795,7 +795,7 @@ __device__ __forceinline__ void order_blocks_by_cost(const uint32_t *__restrict_
 // live in scratch.  STATS: in-kernel counters and timers (vhr_set_ray_statistics).  Per covered pixel the wave keeps 5 words in LDS -- the ray
 // origin and the G-buffer normal as the halves it is -- and recomputes the pixel's seed and the ray's direction at refill with raygen.rgen's
 // exact arithmetic.
-template <int WAVES, bool COMPACT, bool SPILL, bool STATS>
+template <int WAVES, bool COMPACT, bool SPILL, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t tile_rows, const Stamps st) {
     vhr_stamp(st);
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // wave that has just finished a tile can run it for the tile: the visibility goes from LDS into the filter (rounded to the halves
     // the image holds, which is also what is stored), the normals are the ones the set-up loaded, and the gathers of 16 200 x 2 waves
     // spread over the launch instead of forming a kernel of their own that waits on memory.
-    if constexpr (!STATS) {
+    if constexpr (FUSE) {                             // (an instantiation of its own: the epilogue's registers and code stay out of the plain launch)
         if (a.fuse_temporal) {                                                               // (uniform)
             const TemporalArgs &t = a.temporal;
             if (in_range && x >= t.col_begin && x < t.limit_x && y >= t.row_begin && y < t.row_end && y < t.limit_y) {
@@ -1551,6 +1551,10 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
         auto by_flags = [&](auto waves_c) {
             constexpr int WV = decltype(waves_c)::value;
             const int sel = (compact ? 4 : 0) | (spill ? 2 : 0) | (a.stats ? 1 : 0);
+            if (a.fuse_temporal && compact && !a.stats) {       // "fuse_temporal": svgf.comp in the tiles' epilogues (the default node form only)
+                if (spill) go(raygen_queue_kernel<WV, true, true, false, true>); else go(raygen_queue_kernel<WV, true, false, false, true>);
+                return;
+            }
             switch (sel) {
                 case 0: go(raygen_queue_kernel<WV, false, false, false>); break;
                 case 1: go(raygen_queue_kernel<WV, false, false, true>); break;
@@ -1644,7 +1648,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
     // images, the queue kernel runs it in its tiles' epilogues (flush_deferred_raygen).  Only the default kernel has that epilogue, only
     // whole-image work on one stream qualifies, and only a pass nobody hooked an epilogue to (its owner expects the image when it runs).
     {
-        const bool default_kernel = ctx->options[kOptRaygenVariant] != 0;
+        // (the epilogue exists in the queue kernel on the 32-byte nodes only: issue_raygen)
+        const bool default_kernel = ctx->options[kOptRaygenVariant] != 0 && ctx->options[kOptCompactNodes] != 0 && ctx->nodes16_valid;
         const bool whole = a.row_begin == 0 && a.row_end == height && a.col_begin == 0 && a.col_end == width;
         const bool mirror = a.reflections && a.tp.reflections;
         if (ctx->options[kOptFuseTemporal] && ctx->may_defer_raygen && default_kernel && whole && !mirror && !a.stats && ctx->frames_in_flight == 1 &&
