@@ -10,7 +10,7 @@ for name in (sys.argv[1:] or ["sponza_proc", "bistro_proc"]):
     loop = HybridFrameLoop(scene, 1920, 1080, 12)
     ctx = loop.ctx
     ref = None
-    for builder in (0, 1, 1, 0):
+    for builder in (0, 2, 0, 2, 0, 2):
         ctx.set_option("bvh_builder", builder)
         ctx.upload_scene(scene)
         build_ms, upload_ms = ctx.build_times_ms()

@@ -161,6 +161,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
 // the device-side builder (csrc/kernels_bvh.hip, option "bvh_builder" 1): from ctx->d_vertices / d_indices / d_primitives into the
 // context's node and triangle arrays; VHR_ERROR_OUT_OF_SLOTS = fall back to the host builder (tree deeper than the walkers' stacks)
 int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris);
+int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris);     // "bvh_builder" 2
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
