@@ -313,9 +313,11 @@ def reflection_block(ctx, loop, frame_index, sync):
                     "(MI355X_MICROARCH.md: the tree is cache resident, HBM is not the level it is read from)"}
 
 
-def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
+def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400, slowest=None):
     """Blocks of exactly `steps` frames, each bracketed by barrier + synchronize, until `min_seconds` have been measured.
-    Returns (block seconds, next frame index)."""
+    `slowest(dt)`: with more than one rank, the MAX of the block's time over the ranks -- the stop decision is taken on that one number,
+    so every rank runs the same count of blocks (a rank that stopped on its own clock would leave the others in a barrier: r4, one
+    run in five at --min-seconds 0.05).  Returns (this rank's block seconds, next frame index)."""
     times, f, total = [], first_frame, 0.0
     while True:
         barrier()
@@ -325,7 +327,7 @@ def time_blocks(loop, barrier, first_frame, steps, min_seconds, max_blocks=400):
         barrier()
         dt = time.perf_counter() - t0
         times.append(dt)
-        total += dt
+        total += slowest(dt) if slowest is not None else dt
         f += steps
         if total >= min_seconds or len(times) >= max_blocks:
             return times, f
@@ -339,6 +341,9 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # not under torchrun: become the launcher (before anything touches the GPU)
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if os.environ.get("VHR_BENCH_WATCHDOG"):                      # debugging aid: every rank dumps its Python stacks and exits after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VHR_BENCH_WATCHDOG"]), exit=True)
     if args.dry_launch:
         print(json.dumps({"dry_launch": None, "n_gpus": args.gpus, "note": "nothing to launch: one rank, or already under torch.distributed.run"}), flush=True)
         return
@@ -404,6 +409,7 @@ def main():
         raise SystemExit(3)
     ctx = loop.ctx
     build_ms, upload_ms = ctx.build_times_ms()
+    k0_builder = "device (binned SAH)" if ctx.bvh_builder_used() == 1 else "host (binned SAH)"
     option_overrides = {}
     for kv in args.option:
         key, _, val = kv.partition("=")
@@ -457,7 +463,11 @@ def main():
     # ---- the timed region: blocks of exactly --steps frames, repeated until --min-seconds have been measured (a single 20-frame
     # block lasts 14 ms); every block is bracketed by barrier + synchronize, the MEDIAN block is reported ----
     first_timed = f
-    block_s, f = time_blocks(loop, barrier, f, args.steps, args.min_seconds)
+    def slowest_rank(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    block_s, f = time_blocks(loop, barrier, f, args.steps, args.min_seconds, slowest=slowest_rank if world > 1 else None)
     ctx.gather_performance_statistics()
     atrous_timed = ctx.kernel_time("svgf_atrous")
     ctx.set_option("kernel_timing_stride", 1)
@@ -536,16 +546,15 @@ def main():
     # always-on mirror ray, and the same workload with two frames in flight ----
     extras = {}
     if world == 1 and not args.no_extras:
-        def one(options=None, device_k0=None, refl_out=None, **kw):
+        def one(options=None, host_k0=None, refl_out=None, **kw):
             lp = HybridFrameLoop(scene, W, H, n_frames, **common, **kw)
             for key, val in {**option_overrides, **(options or {})}.items():
                 lp.ctx.set_option(key, val)
-            if device_k0 is not None:          # the same scene on the tree the DEVICE builds ("bvh_builder" 1, csrc/kernels_bvh.hip)
-                lp.ctx.set_option("bvh_builder", 1)
+            if host_k0 is not None:            # the same scene on the tree the HOST builds ("bvh_builder" 0, csrc/bvh_build.cpp)
+                lp.ctx.set_option("bvh_builder", 0)
                 lp.ctx.upload_scene(scene)
-                device_k0["k0_build_ms"], device_k0["k0_upload_ms"] = (round(v, 1) for v in lp.ctx.build_times_ms())
-                device_k0["builder_used"] = "device (PLOC along the Morton order)" if lp.ctx.bvh_builder_used() == 1 else "host (the device tree was refused: too deep)"
-                device_k0["bvh_max_depth"] = int(lp.ctx.bvh_statistics()["max_depth"])
+                host_k0["k0_build_ms"], host_k0["k0_upload_ms"] = (round(v, 1) for v in lp.ctx.build_times_ms())
+                host_k0["bvh_max_depth"] = int(lp.ctx.bvh_statistics()["max_depth"])
 
             def sync():
                 torch.cuda.synchronize()
@@ -581,12 +590,12 @@ def main():
         ms, mr = one(options={"fuse_temporal": 1}, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
         extras["ms_per_step_temporal_fused_into_ray_tracing"] = ms
         extras["value_temporal_fused_into_ray_tracing"] = mr
-        # K0 where the reference runs it (resource_manager.cpp:650,692,792 build BLAS / TLAS on the GPU): the device-built tree costs a
-        # fraction of the host's SAH build and a few node visits more per ray; the timed region above uses the host tree (the default)
-        dk = {}
-        ms, mr = one(device_k0=dk, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
-        dk["ms_per_step"], dk["value"] = ms, mr
-        extras["device_k0"] = dk
+        # K0: the timed region above runs on the tree built on the device, where the reference builds its BLAS / TLAS
+        # (resource_manager.cpp:650,692,792); this is the same binned-SAH algorithm on the host's cores ("bvh_builder" 0) and the frame on its tree
+        hk = {}
+        ms, mr = one(host_k0=hk, reflections=_bounces(args), frames_in_flight=args.frames_in_flight)
+        hk["ms_per_step"], hk["value"] = ms, mr
+        extras["host_k0"] = hk
         other = 2 if args.frames_in_flight == 1 else 1
         ms, mr = one(reflections=_bounces(args), frames_in_flight=other)
         extras[f"ms_per_step_frames_in_flight_{other}"] = ms
@@ -717,9 +726,9 @@ def main():
                 "address_unit": address_unit_block(pmc, raygen_ms),
                 "note": "counters cover the any-hit (shadow + AO) queue kernel; utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops)",
             },
-            # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); here a host
-            # binned-SAH build + upload, once per scene, outside the frame
-            "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1),
+            # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); so does this
+            # (binned SAH, csrc/kernels_bvh.hip), once per scene, outside the frame.  upload = scene arrays + the tree fetched back for the host's self-checks
+            "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1), "k0_builder": k0_builder,
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),
                            "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2) if kt["blit"][1] else None,      # None: all three blits are stores of a-trous launches

@@ -451,10 +451,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                        event pairs on the dispatch packets (16 us per frame; the only form with "frames_in_flight" > 1); 0 = off
  *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair (a timed dispatch
  *                        costs ~6 us that the next kernel waits for)
- *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 3); "bvh_builder" 0 = binned SAH on the
- *  host (default: the better tree), 1 = Morton sort + PLOC on the device like the reference's BLAS / TLAS (resource_manager.cpp:650,692,792;
- *  20-40x faster to build, a tree the walkers need more visits in; images bit-identical); "bvh_build_threads" 0 = up to 16 host threads
- *  (default), 1 = serial -- the tree is the same whatever the count. */
+ *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 3); "bvh_builder" 1 = binned SAH on the
+ *  device (default), where the reference builds its BLAS / TLAS (resource_manager.cpp:650,692,792), 0 = the same algorithm on the host
+ *  (csrc/bvh_build.cpp: 8 / 28x slower to build on the two test scenes, the same tree up to the order of leaves in memory; images
+ *  bit-identical; also what a host-only context and a device build deeper than the walkers' stacks fall back to); "bvh_build_threads"
+ *  (host builder) 0 = up to 16 host threads (default), 1 = serial -- the tree is the same whatever the count. */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);
 int32_t vhr_option_count(void);
@@ -507,8 +508,8 @@ int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_
 /* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792;
  * here the binned-SAH build runs on the host): out[0] = build, out[1] = upload of scene + tree, in milliseconds of host time. */
 int vhr_get_build_times(vhr_context *ctx, double out[2]);
-/* Which builder made the current tree: 0 = the host's binned SAH, 1 = the device's LBVH ("bvh_builder" 1; it falls back to the host
- * builder for a scene of a single leaf and for a tree deeper than the walkers' stacks) */
+/* Which builder made the current tree: 0 = the host's, 1 = the device's ("bvh_builder" 1, the default; it falls back to the host builder
+ * for a scene of a single leaf and for a tree deeper than the walkers' stacks) */
 int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,

@@ -60,3 +60,22 @@ def test_under_torchrun_a_rank_without_a_device_is_an_error_too():
 def test_one_rank_needs_no_launcher():
     rc, line, r = run(["--gpus", "1", "--dry-launch"])
     assert rc == 0 and line["dry_launch"] is None
+
+
+def test_ranks_stop_the_timed_region_together(tmp_path):
+    """bench.time_blocks with two gloo ranks: the stop decision is taken on the slowest rank's time of each block, so both ranks run
+    the same count of blocks whatever their own clocks say (r4: a rank that had measured --min-seconds on its own clock left the timed
+    region one block early and the other rank waited in a barrier for ever)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for attempt in range(3):                         # (the threshold sits at a block boundary: several tries, every one must agree)
+        out = tmp_path / f"counts{attempt}.txt"
+        port = 29871 + attempt
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "tests", "time_blocks_worker.py"), str(out), "1"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, b = out.read_text().split()
+        assert a == b and int(a) >= 1

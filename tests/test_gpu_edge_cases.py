@@ -235,19 +235,23 @@ def test_non_finite_geometry_is_rejected():
         c.close()
 
 
-def test_parallel_bvh_build_makes_the_same_tree():
-    """The host builder's thread pool ("bvh_build_threads"): same node / triangle counts and depth, and the same image bit for bit,
-    with 1, 3 and the default number of threads on a scene large enough to be split (sponza_proc, 257 k triangles)."""
+def test_every_builder_makes_the_same_tree():
+    """The host builder's thread pool ("bvh_builder" 0 with "bvh_build_threads" 1, 3 and the default) and the device's builder (the
+    default): the same algorithm, so the same node / triangle counts and depth, and the same image bit for bit, on a scene large enough
+    to be split among threads and to run the device builder's level passes (sponza_proc, 257 k triangles)."""
     scene = scenes.sponza_proc()
     W, H = 256, 144
     tp = abi.default_trace_params(reflections=False)
     pfd = camera.dolly_frames(scene, W, H, 2)[1]
     ref = None
-    for threads in (1, 3, 0):
+    for threads in (1, 3, 0, None):
         c = lib.Context(W, H)
         try:
-            c.set_option("bvh_build_threads", threads)
+            if threads is not None:
+                c.set_option("bvh_builder", 0)
+                c.set_option("bvh_build_threads", threads)
             c.upload_scene(scene)
+            assert c.bvh_builder_used() == (1 if threads is None else 0)
             c.set_trace_params(tp)
             path = lib.HybridRenderPath(c, 0, 0, 2, False, 5, lambda ctx: ctx.standin_gbuffer(0))
             path.build()

@@ -372,12 +372,11 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         // (a primitive without triangles shares its prefix with the next one: the search below picks the LAST primitive whose prefix is
         // <= t, which is the one that owns triangle t, because an empty primitive's successor starts at the same value)
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = ctx->bvh_builder == 2 ? device_build_bvh_sah(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris)
-                                             : device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris);
+        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == VHR_OK) {
             device_built = true;
-            ctx->bvh_builder_used = ctx->bvh_builder;
+            ctx->bvh_builder_used = 1;
             ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
             // the host-side self-checks want the result: fetched outside the build's time like the checks themselves
             bvh.nodes.resize(ctx->node_count); bvh.nodes_ch.resize(ctx->node_count); bvh.nodes48.resize(ctx->node_count); bvh.nodes16.resize(ctx->node_count);
@@ -568,7 +567,7 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         return VHR_OK;
     }
     if (!std::strcmp(key, "bvh_builder")) {                  // applies to the next vhr_update_geometry
-        if (value < 0 || value > 2) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (host binned SAH), 1 (device PLOC) or 2 (device binned SAH)");
+        if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (binned SAH on the host) or 1 (binned SAH on the device)");
         ctx->bvh_builder = value;
         return VHR_OK;
     }

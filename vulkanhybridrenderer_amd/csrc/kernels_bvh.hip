@@ -1,20 +1,33 @@
-// K0 on the device (option "bvh_builder" 1): the acceleration structure built where the reference builds it -- on the GPU
-// (ResourceManager::UpdateBLAS / UpdateTLAS, /root/reference/src/rendering_backend/resource_manager.cpp:593-801 record
-// vkCmdBuildAccelerationStructuresKHR; the BVH itself is the driver's).  Same semantics as csrc/bvh_build.cpp: one geometry per
-// Primitive with its transform baked in (:608-617), all opaque, two-sided, one identity instance => a world-space triangle soup.
+// K0 on the device (option "bvh_builder" 1, the default): the acceleration structure built where the reference builds it -- on the
+// GPU (ResourceManager::UpdateBLAS / UpdateTLAS, /root/reference/src/rendering_backend/resource_manager.cpp:593-801 record
+// vkCmdBuildAccelerationStructuresKHR with PREFER_FAST_TRACE; the BVH itself is the driver's).  Same semantics as csrc/bvh_build.cpp:
+// one geometry per Primitive with its transform baked in (:608-617), all opaque, two-sided, one identity instance => a world-space
+// triangle soup.
 //
-// Triangles in flat (primitive-major) order -> world-space Moeller-Trumbore records with the host builder's arithmetic (this file is
-// compiled without FMA contraction, so the records are bit-identical to the host's) -> 30-bit Morton codes of the box centres ->
-// radix sort (rocPRIM through hipCUB) -> agglomerative clustering along that order (PLOC: every round each cluster merges with the
-// neighbour that makes the smallest box, if the choice is mutual) -> subtrees of <= leaf_tris triangles collapsed into leaves, the
-// triangles in depth-first order -> the 64-byte (lo, hi) nodes -> the derived forms (centre / half extent, 48-byte, half precision)
-// with the host's formulas.  Root = node 0, parents before children.
+// The algorithm is the host builder's -- binned SAH, 16 bins per axis over the bounds of the triangles' box centres, cost =
+// area_left * n_left + area_right * n_right, split until one triangle is left (the layout stage then turns every subtree of
+// <= leaf_tris triangles into a leaf, which is where the host stops splitting) -- run level by level on the GPU:
+//   * triangles in flat (primitive-major) order -> world-space Moeller-Trumbore records with the host builder's arithmetic (this file
+//     is compiled without FMA contraction, so the records are bit-identical to the host's) + boxes + the bounds of the box centres;
+//   * nodes of more than kSmallNode triangles: one pass per level over all triangle positions.  Bin (every active node a workgroup's
+//     256 positions touch gets bins in LDS, flushed with one look-first atomic per touched word), one thread per node sweeps its bins
+//     and chooses the plane, a device-wide scan of the "goes left" flags gives every triangle its new position, a scatter moves it.
+//     A node's triangles stay a contiguous range of `order`, so the finished `order` is the tree's depth-first order;
+//   * subtrees of <= kSmallNode triangles: one wave each, its triangles in LDS, an explicit stack, bins in LDS, the sweep spread over
+//     the lanes;
+//   * layout: subtrees of <= leaf_tris triangles collapse into leaves, the inner nodes that remain are numbered breadth first like the
+//     host's (root = node 0, parents before children) -> the 64-byte (lo, hi) nodes -> the derived forms (centre / half extent,
+//     48-byte, half precision) with the host's formulas.
+// Node ids while building: leaf k = the triangle at position k of the final order, inner nodes n + creation rank (a small subtree
+// reserves the ids of all its inner nodes when it is made: one returning atomic per subtree, not per node -- 1.4 M of those on one
+// counter cost bistro_proc's build 42 ms).
 //
-// (A first version split the Morton order top-down (Karras 2012).  On sponza_proc its tree cost 39 node visits and 12 triangle tests
-// per ray against the host SAH tree's 8.3 and 0.85 -- the walls' big triangles sat deep inside subtrees of small ones -- and
-// bistro_proc's came out deeper than the walkers' stacks.  Clustering bottom-up by box surface keeps big triangles near the top.)
-// The tree differs from the host's; any-hit results do not depend on the tree and closest hits commit by (t, flat index), so images
-// are the same bit for bit with either builder (tests/test_gpu_fuzz.py).
+// On sponza_proc and bistro_proc the tree has the host tree's node count, depth and visits per ray; the triangle order inside the
+// leaves and the leaves' order in memory differ (depth-first here, by treelets on the host), which costs the any-hit launch <= 1 %.
+// Any-hit results do not depend on the tree and closest hits commit by (t, flat index), so images are the same bit for bit with either
+// builder (tests/test_gpu_fuzz.py).  r4, MI355X: 7 ms for sponza_proc's 258 k triangles, 22 ms for bistro_proc's 2.9 M (host: 50 /
+// 610 ms on the box's cores); a bottom-up clustering builder (PLOC) that stood here until r4 took 7 / 20 ms and its trees cost the
+// Raytrace Pass +10 / +22 % (profiles/r4_k0_device.txt).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -99,106 +112,9 @@ __global__ __launch_bounds__(256) void k0_triangles_kernel(const vhr_vertex *__r
     }
 }
 
-// ---- 2. Morton codes of the box centres: 10 bits per axis ----
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-__global__ __launch_bounds__(256) void k0_morton_kernel(const Box6 *__restrict__ boxes, const uint32_t *__restrict__ centre_bounds, uint32_t n,
-                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    uint32_t code = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float lo = unordered(centre_bounds[a]), hi = unordered(centre_bounds[3 + a]);
-        const float c = 0.5f * (boxes[t].lo[a] + boxes[t].hi[a]);
-        const float ext = hi - lo;
-        const float u = ext > 0.0f ? (c - lo) / ext : 0.0f;
-        const uint32_t q = uint32_t(fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f));
-        code |= spread10(q) << (2 - a);
-    }
-    keys[t] = code;
-    vals[t] = t;
-}
-
-// ---- 3. clustering: PLOC (parallel locally-ordered clustering, Meister & Bittner 2018).  The clusters start as the single triangles
-// in Morton order; every round each cluster looks kSearch neighbours up and down that order for the one whose union with it has the
-// smallest surface, mutual choices merge into a new node, the survivors are compacted (order kept), until one cluster is left.  A big
-// triangle is nobody's cheapest partner, so it stays single until the clusters around it have grown to its size: it ends up high in
-// the tree instead of bloating the boxes of a deep subtree -- the failure of a plain Morton-split tree on architectural scenes.
-// Node ids: leaves 0 .. n-1 (position in the sorted order), inner nodes n + creation rank (deterministic: ranks come from a scan).
-constexpr int kSearch = 16;
-
-__device__ __forceinline__ float union_half_area(const Box6 &a, const Box6 &b) {
-    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]),
-                dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
-    return dx * dy + dy * dz + dz * dx;
-}
-__global__ __launch_bounds__(256) void k0_init_clusters_kernel(const Box6 *__restrict__ boxes, const uint32_t *__restrict__ sorted_vals, uint32_t n, Box6 *__restrict__ cbox,
-                                                               uint32_t *__restrict__ cid, Box6 *__restrict__ node_box, uint32_t *__restrict__ node_size) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= n) return;
-    const Box6 b = boxes[sorted_vals[k]];
-    cbox[k] = b;
-    cid[k] = k;
-    node_box[k] = b;
-    node_size[k] = 1u;
-}
-__global__ __launch_bounds__(256) void k0_nearest_kernel(const Box6 *__restrict__ cbox, uint32_t count, uint32_t *__restrict__ nearest, uint32_t search) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    const Box6 mine = cbox[i];
-    const uint32_t j0 = i > search ? i - search : 0u, j1 = min(count - 1u, i + search);
-    float best = 3.0e38f;
-    uint32_t bestj = i;
-    for (uint32_t j = j0; j <= j1; ++j) {
-        if (j == i) continue;
-        const float a = union_half_area(mine, cbox[j]);
-        if (a < best) { best = a; bestj = j; }              // (ascending j: ties keep the lower index, on both sides of a pair)
-    }
-    nearest[i] = bestj;
-}
-// flags: keep[i] = the cluster survives the round (it does not merge, or it is the lower index of a merging pair); merge[i] = it is that lower index
-__global__ __launch_bounds__(256) void k0_mark_kernel(const uint32_t *__restrict__ nearest, uint32_t count, uint32_t *__restrict__ keep, uint32_t *__restrict__ merge) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t j = nearest[i];
-    const bool mutual = j != i && nearest[j] == i;
-    keep[i] = (!mutual || i < j) ? 1u : 0u;
-    merge[i] = (mutual && i < j) ? 1u : 0u;
-}
-__global__ __launch_bounds__(256) void k0_merge_kernel(const Box6 *__restrict__ cbox, const uint32_t *__restrict__ cid, const uint32_t *__restrict__ nearest,
-                                                       const uint32_t *__restrict__ keep, const uint32_t *__restrict__ keep_pos, const uint32_t *__restrict__ merge,
-                                                       const uint32_t *__restrict__ merge_pos, uint32_t count, uint32_t next_node, Box6 *__restrict__ cbox_out,
-                                                       uint32_t *__restrict__ cid_out, int2 *__restrict__ node_children, uint32_t *__restrict__ node_parent,
-                                                       Box6 *__restrict__ node_box, uint32_t *__restrict__ node_size) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count || !keep[i]) return;
-    Box6 b = cbox[i];
-    uint32_t id = cid[i];
-    if (merge[i]) {
-        const uint32_t j = nearest[i], node = next_node + merge_pos[i];
-        const Box6 o = cbox[j];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(b.lo[a], o.lo[a]); b.hi[a] = fmaxf(b.hi[a], o.hi[a]); }
-        node_children[node] = int2{ int(id), int(cid[j]) };
-        node_parent[id] = node;
-        node_parent[cid[j]] = node;
-        node_box[node] = b;
-        node_size[node] = node_size[id] + node_size[cid[j]];
-        id = node;
-    }
-    cbox_out[keep_pos[i]] = b;
-    cid_out[keep_pos[i]] = id;
-}
-
-// ---- 4. the finished tree -> the walkers' layout.  A subtree of at most `leaf_tris` triangles becomes a leaf (its triangles are
-// consecutive in the depth-first order of the tree, which is the order `tris` gets); the inner nodes that remain are numbered in
-// reverse creation order -- the root, made last, is node 0, and every parent precedes its children. ----
+// ---- 2. the finished tree -> the walkers' layout.  A subtree of at most `leaf_tris` triangles becomes a leaf (its triangles are
+// consecutive in the depth-first order of the tree, which is the order `tris` gets); the inner nodes that remain are numbered
+// breadth first (k0_bfs_keys_kernel below). ----
 // each triangle climbs to the root: its depth-first position = the sizes of the left siblings passed on the way; the depth of its leaf
 __global__ __launch_bounds__(256) void k0_positions_kernel(const int2 *__restrict__ node_children, const uint32_t *__restrict__ node_parent,
                                                            const uint32_t *__restrict__ node_size, uint32_t n, uint32_t root, uint32_t leaf_tris,
@@ -239,26 +155,26 @@ __device__ __forceinline__ void set_child(BvhNode &node, int which, const Box6 &
 }
 __global__ __launch_bounds__(256) void k0_emit_kernel(const int2 *__restrict__ node_children, const Box6 *__restrict__ node_box, const uint32_t *__restrict__ node_size,
                                                       const uint32_t *__restrict__ kept_rank, const uint32_t *__restrict__ position, uint32_t n, uint32_t total_nodes,
-                                                      uint32_t kept, uint32_t leaf_tris, BvhNode *__restrict__ nodes, uint32_t parents_first) {
+                                                      uint32_t leaf_tris, BvhNode *__restrict__ nodes) {
     const uint32_t node = n + blockIdx.x * 256u + threadIdx.x;
     if (node >= total_nodes || node_size[node] <= leaf_tris) return;
     const int2 ch = node_children[node];
     auto link_of = [&](uint32_t c) -> int32_t {
         const uint32_t size = node_size[c];
-        if (size > leaf_tris) return int32_t(parents_first ? kept_rank[c - n] : kept - 1u - kept_rank[c - n]);     // creation order top-down, reverse creation order bottom-up
+        if (size > leaf_tris) return int32_t(kept_rank[c - n]);
         return ~int32_t((first_triangle(node_children, position, n, c) << 2) | (size - 1u));
     };
     BvhNode out{};
     set_child(out, 0, node_box[uint32_t(ch.x)], link_of(uint32_t(ch.x)));
     set_child(out, 1, node_box[uint32_t(ch.y)], link_of(uint32_t(ch.y)));
-    nodes[parents_first ? kept_rank[node - n] : kept - 1u - kept_rank[node - n]] = out;
+    nodes[kept_rank[node - n]] = out;
 }
 __global__ __launch_bounds__(256) void k0_kept_flags_kernel(const uint32_t *__restrict__ node_size, uint32_t n, uint32_t total_nodes, uint32_t leaf_tris, uint32_t *__restrict__ flags) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (n + k < total_nodes) flags[k] = node_size[n + k] > leaf_tris ? 1u : 0u;
 }
 
-// ---- 6. the derived node forms, with the host's formulas (bvh_build.cpp finalize_ch / finalize16) ----
+// ---- 3. the derived node forms, with the host's formulas (bvh_build.cpp finalize_ch / finalize16) ----
 __device__ __forceinline__ uint32_t upper16(float h) {
     uint32_t bits = __float_as_uint(h);
     if (h > 0.0f && (bits & 0xffffu)) bits += 0x10000u;
@@ -344,18 +260,7 @@ __global__ __launch_bounds__(256) void k0_node_bounds_kernel(const BvhNode *__re
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// K0 on the device, top-down ("bvh_builder" 2): the host builder's algorithm -- binned SAH, 16 bins per axis over the bounds of the
-// triangles' box centres, cost = area_left * n_left + area_right * n_right, split until one triangle is left (the layout stage then
-// turns every subtree of <= leaf_tris triangles into a leaf, which is where the host stops splitting) -- level by level on the GPU.
-//   * nodes of more than kSmallNode triangles: one pass per level over all triangle positions.  Bin (a workgroup whose 256 positions
-//     lie in one node accumulates in LDS and flushes 48 bins once; else global atomics), one thread per node sweeps its bins and
-//     chooses the plane, a device-wide scan of the "goes left" flags gives every triangle its new position, a scatter moves it.  A node's
-//     triangles stay a contiguous range of `order`, so the finished `order` is the tree's depth-first order.
-//   * subtrees of <= kSmallNode triangles: one wave each, its triangles in LDS, an explicit stack, bins in LDS.
-// Node ids as for the clustering builder: leaf k = the triangle at position k of the final order, inner nodes n + creation rank --
-// here a parent is created before its children, so the layout stage numbers the inner nodes in creation order (root = node 0).
-// ---------------------------------------------------------------------------------------------
+// ---- 4. the tree: binned SAH, top-down ----
 constexpr uint32_t kSmallNode = 64;
 constexpr uint32_t kNoNode = 0xffffffffu;
 constexpr int kBinWords = 13;                 // per bin: count, triangle-box lo / hi (6), box-centre lo / hi (6) -- floats as ordered uints
@@ -389,12 +294,6 @@ __device__ __forceinline__ void bins_accumulate(uint32_t *bins, int axis, int b,
     for (int a = 0; a < 3; ++a) {
         atomicMin(&w[1 + a], ordered(box.lo[a])); atomicMax(&w[4 + a], ordered(box.hi[a]));
         atomicMin(&w[7 + a], ordered(c[a])); atomicMax(&w[10 + a], ordered(c[a]));
-    }
-}
-__device__ __forceinline__ void bins_clear(uint32_t *bins, uint32_t t, uint32_t stride) {
-    for (uint32_t k = t; k < 48u * kBinWords; k += stride) {
-        const uint32_t word = k % kBinWords;
-        bins[k] = word == 0 ? 0u : ((word >= 1 && word <= 3) || (word >= 7 && word <= 9) ? 0xffffffffu : 0u);
     }
 }
 __global__ __launch_bounds__(256) void k0_sah_clear_bins_kernel(uint32_t *__restrict__ bins, uint32_t nodes) {
@@ -773,7 +672,7 @@ __global__ __launch_bounds__(256) void k0_sah_leaves_kernel(const Box6 *__restri
     node_size[k] = 1u;
 }
 // breadth-first numbering of the kept inner nodes, the host's (bvh_build.cpp "breadth-first numbering"): by depth, then left to right
-__global__ __launch_bounds__(256) void k0_sah_bfs_keys_kernel(const uint32_t *__restrict__ node_size, const uint2 *__restrict__ node_place, uint32_t n, uint32_t total_nodes,
+__global__ __launch_bounds__(256) void k0_bfs_keys_kernel(const uint32_t *__restrict__ node_size, const uint2 *__restrict__ node_place, uint32_t n, uint32_t total_nodes,
                                                               uint32_t leaf_tris, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (n + k >= total_nodes) return;
@@ -781,17 +680,13 @@ __global__ __launch_bounds__(256) void k0_sah_bfs_keys_kernel(const uint32_t *__
     keys[k] = node_size[n + k] > leaf_tris ? (static_cast<unsigned long long>(place.x) << 32) | place.y : ~0ull;
     vals[k] = k;
 }
-__global__ __launch_bounds__(256) void k0_sah_bfs_rank_kernel(const uint32_t *__restrict__ sorted_vals, uint32_t kept, uint32_t *__restrict__ rank) {
+__global__ __launch_bounds__(256) void k0_bfs_rank_kernel(const uint32_t *__restrict__ sorted_vals, uint32_t kept, uint32_t *__restrict__ rank) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < kept) rank[sorted_vals[k]] = k;
 }
 __global__ __launch_bounds__(256) void k0_iota_kernel(uint32_t *__restrict__ order, uint32_t *__restrict__ pos_node, uint32_t n) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < n) { order[k] = k; pos_node[k] = 0u; }
-}
-__global__ __launch_bounds__(256) void k0_identity_positions_kernel(uint32_t *__restrict__ position, uint32_t n) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < n) position[k] = k;
 }
 
 struct Scratch {            // device allocations of one build, freed together
@@ -820,111 +715,6 @@ struct Scratch {            // device allocations of one build, freed together
 // stacks (kMaxBvhDepth) -- the caller then falls back to the host builder.  `tri_prefix`: first flat triangle of every primitive.
 int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in) {
     const uint32_t n = total_tris, leaf_tris = uint32_t(std::max(1, std::min(kMaxLeafTris, leaf_tris_in)));
-    if (n <= leaf_tris) return VHR_ERROR_OUT_OF_SLOTS;            // (a scene that fits one leaf: the host builder's special case)
-    hipStream_t s = ctx->stream;
-    Scratch tmp;
-    const uint32_t total_cap = 2u * n;                            // node ids: n leaves + at most n - 1 inner nodes
-    uint32_t *d_prefix, *d_bounds, *d_keys, *d_vals, *d_keys2, *d_vals2, *d_cid[2], *d_nearest, *d_keep, *d_keep_pos, *d_merge, *d_merge_pos, *d_parent, *d_size,
-             *d_position, *d_counts;
-    BvhTri *d_tris_flat;
-    Box6 *d_boxes, *d_cbox[2], *d_node_box;
-    int2 *d_children;
-    K0_TRY(tmp.alloc(&d_prefix, tri_prefix.size()));
-    K0_TRY(tmp.alloc(&d_bounds, 12));
-    K0_TRY(tmp.alloc(&d_counts, 4));
-    K0_TRY(tmp.alloc(&d_keys, n)); K0_TRY(tmp.alloc(&d_vals, n)); K0_TRY(tmp.alloc(&d_keys2, n)); K0_TRY(tmp.alloc(&d_vals2, n));
-    K0_TRY(tmp.alloc(&d_tris_flat, n)); K0_TRY(tmp.alloc(&d_boxes, n));
-    for (int k = 0; k < 2; ++k) { K0_TRY(tmp.alloc(&d_cbox[k], n)); K0_TRY(tmp.alloc(&d_cid[k], n)); }
-    K0_TRY(tmp.alloc(&d_nearest, n)); K0_TRY(tmp.alloc(&d_keep, n)); K0_TRY(tmp.alloc(&d_keep_pos, n)); K0_TRY(tmp.alloc(&d_merge, n)); K0_TRY(tmp.alloc(&d_merge_pos, n));
-    K0_TRY(tmp.alloc(&d_parent, total_cap)); K0_TRY(tmp.alloc(&d_size, total_cap)); K0_TRY(tmp.alloc(&d_node_box, total_cap)); K0_TRY(tmp.alloc(&d_children, total_cap));
-    K0_TRY(tmp.alloc(&d_position, n));
-    K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_tris), sizeof(BvhTri) * n));
-
-    K0_TRY(hipMemcpyAsync(d_prefix, tri_prefix.data(), tri_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    const uint32_t init_bounds[12] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    K0_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
-    K0_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), s));
-    const dim3 block(256);
-    auto grid = [](uint32_t count) { return dim3((count + 255u) / 256u); };
-    hipLaunchKernelGGL(k0_triangles_kernel, grid(n), block, 0, s, ctx->d_vertices, ctx->d_indices, ctx->d_primitives, d_prefix, uint32_t(tri_prefix.size()), n,
-                       d_tris_flat, d_boxes, d_bounds);
-    hipLaunchKernelGGL(k0_morton_kernel, grid(n), block, 0, s, d_boxes, d_bounds, n, d_keys, d_vals);
-    size_t sort_bytes = 0, scan_bytes = 0;
-    K0_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_keys, d_keys2, d_vals, d_vals2, int(n), 0, 30, s));
-    K0_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_keep, d_keep_pos, int(n), s));
-    char *d_work;
-    K0_TRY(tmp.alloc(&d_work, std::max(sort_bytes, scan_bytes)));
-    K0_TRY(hipcub::DeviceRadixSort::SortPairs(d_work, sort_bytes, d_keys, d_keys2, d_vals, d_vals2, int(n), 0, 30, s));
-    hipLaunchKernelGGL(k0_init_clusters_kernel, grid(n), block, 0, s, d_boxes, d_vals2, n, d_cbox[0], d_cid[0], d_node_box, d_size);
-    // ---- the clustering rounds (the cluster count comes back to the host once per round: two words) ----
-    uint32_t count = n, next_node = n;
-    int cur = 0;
-    const char *search_env = std::getenv("VHR_K0_SEARCH");          // (experiments: the search radius along the Morton order)
-    const uint32_t search = search_env ? uint32_t(std::max(1, std::atoi(search_env))) : uint32_t(kSearch);
-    for (int round = 0; count > 1 && round < 4096; ++round) {
-        hipLaunchKernelGGL(k0_nearest_kernel, grid(count), block, 0, s, d_cbox[cur], count, d_nearest, search);
-        hipLaunchKernelGGL(k0_mark_kernel, grid(count), block, 0, s, d_nearest, count, d_keep, d_merge);
-        K0_TRY(hipcub::DeviceScan::ExclusiveSum(d_work, scan_bytes, d_keep, d_keep_pos, int(count), s));
-        K0_TRY(hipcub::DeviceScan::ExclusiveSum(d_work, scan_bytes, d_merge, d_merge_pos, int(count), s));
-        hipLaunchKernelGGL(k0_merge_kernel, grid(count), block, 0, s, d_cbox[cur], d_cid[cur], d_nearest, d_keep, d_keep_pos, d_merge, d_merge_pos, count, next_node,
-                           d_cbox[cur ^ 1], d_cid[cur ^ 1], d_children, d_parent, d_node_box, d_size);
-        uint32_t last[2][2];            // (position, flag) of the last cluster, for keep and merge: total = position + flag
-        K0_TRY(hipMemcpyAsync(&last[0][0], d_keep_pos + count - 1, 4, hipMemcpyDeviceToHost, s));
-        K0_TRY(hipMemcpyAsync(&last[0][1], d_keep + count - 1, 4, hipMemcpyDeviceToHost, s));
-        K0_TRY(hipMemcpyAsync(&last[1][0], d_merge_pos + count - 1, 4, hipMemcpyDeviceToHost, s));
-        K0_TRY(hipMemcpyAsync(&last[1][1], d_merge + count - 1, 4, hipMemcpyDeviceToHost, s));
-        K0_TRY(hipStreamSynchronize(s));
-        const uint32_t kept = last[0][0] + last[0][1], merged = last[1][0] + last[1][1];
-        if (merged == 0 || kept + merged != count) return ctx->fail(VHR_ERROR_DEVICE, "device K0: a clustering round made no progress");
-        next_node += merged;
-        count = kept;
-        cur ^= 1;
-    }
-    if (count != 1 || next_node != 2u * n - 1u) return ctx->fail(VHR_ERROR_DEVICE, "device K0: the clustering did not end in one tree");
-    const uint32_t total_nodes = next_node, root = next_node - 1u;
-    // ---- layout ----
-    hipLaunchKernelGGL(k0_positions_kernel, grid(n), block, 0, s, d_children, d_parent, d_size, n, root, leaf_tris, d_position, d_counts);
-    hipLaunchKernelGGL(k0_place_triangles_kernel, grid(n), block, 0, s, d_tris_flat, d_vals2, d_position, n, ctx->d_tris);
-    const uint32_t n_inner_all = total_nodes - n;
-    uint32_t *d_kept = d_keep, *d_kept_rank = d_keep_pos;        // (the rounds are over: their flag / scan arrays, n entries >= n - 1)
-    hipLaunchKernelGGL(k0_kept_flags_kernel, grid(n_inner_all), block, 0, s, d_size, n, total_nodes, leaf_tris, d_kept);
-    K0_TRY(hipcub::DeviceScan::ExclusiveSum(d_work, scan_bytes, d_kept, d_kept_rank, int(n_inner_all), s));
-    uint32_t last_rank = 0, last_flag = 0, h_depth = 0;
-    K0_TRY(hipMemcpyAsync(&last_rank, d_kept_rank + n_inner_all - 1, 4, hipMemcpyDeviceToHost, s));
-    K0_TRY(hipMemcpyAsync(&last_flag, d_kept + n_inner_all - 1, 4, hipMemcpyDeviceToHost, s));
-    K0_TRY(hipMemcpyAsync(&h_depth, d_counts, 4, hipMemcpyDeviceToHost, s));
-    K0_TRY(hipStreamSynchronize(s));
-    const uint32_t n_inner = last_rank + last_flag;
-    if (n_inner == 0 || !last_flag) return VHR_ERROR_OUT_OF_SLOTS;           // (the whole scene collapsed into one leaf)
-    K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_nodes), sizeof(BvhNode) * n_inner));
-    K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_nodes_ch), sizeof(BvhNodeCH) * n_inner));
-    K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_nodes48), sizeof(BvhNode48) * n_inner));
-    K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_nodes16), sizeof(BvhNode16) * n_inner));
-    hipLaunchKernelGGL(k0_emit_kernel, grid(n_inner_all), block, 0, s, d_children, d_node_box, d_size, d_kept_rank, d_position, n, total_nodes, n_inner, leaf_tris, ctx->d_nodes, 0u);
-    hipLaunchKernelGGL(k0_node_bounds_kernel, grid(n_inner), block, 0, s, ctx->d_nodes, n_inner, d_bounds + 6);
-    uint32_t h_bounds[12];
-    K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
-    K0_TRY(hipStreamSynchronize(s));
-    K0_TRY(hipGetLastError());
-    for (int a = 0; a < 3; ++a) {
-        const float lo = unordered(h_bounds[6 + a]), hi = unordered(h_bounds[9 + a]);
-        ctx->bvh_centre[a] = lo <= hi ? 0.5f * (lo + hi) : 0.0f;
-    }
-    hipLaunchKernelGGL(k0_forms_kernel, grid(n_inner), block, 0, s, ctx->d_nodes, n_inner, ctx->bvh_centre[0], ctx->bvh_centre[1], ctx->bvh_centre[2], ctx->d_nodes_ch,
-                       ctx->d_nodes48, ctx->d_nodes16);
-    K0_TRY(hipStreamSynchronize(s));
-    K0_TRY(hipGetLastError());
-    ctx->node_count = n_inner;
-    ctx->tri_count = n;
-    ctx->bvh_depth = h_depth;                  // inner nodes on the longest root-to-leaf path
-    if (std::getenv("VHR_K0_TRACE")) std::fprintf(stderr, "K0 device: %u triangles, %u inner nodes, depth %u\n", n, n_inner, h_depth);
-    if (h_depth > uint32_t(kMaxBvhDepth)) return VHR_ERROR_OUT_OF_SLOTS;
-    return VHR_OK;
-}
-
-// "bvh_builder" 2: the top-down binned-SAH build (see k0_sah_* above).  Same contract as device_build_bvh.
-int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in) {
-    const uint32_t n = total_tris, leaf_tris = uint32_t(std::max(1, std::min(kMaxLeafTris, leaf_tris_in)));
     if (n <= leaf_tris || n < 2u) return VHR_ERROR_OUT_OF_SLOTS;
     hipStream_t s = ctx->stream;
     Scratch tmp;
@@ -934,7 +724,7 @@ int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_pref
         if (!trace) return;
         (void)hipStreamSynchronize(s);
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "K0 device (SAH) %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        std::fprintf(stderr, "K0 device %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
     const uint32_t total_cap = 2u * n;
@@ -1016,8 +806,8 @@ int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_pref
         K0_TRY(hipMemcpyAsync(&h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, s));
         K0_TRY(hipStreamSynchronize(s));
         if (h_counters.error) return VHR_ERROR_OUT_OF_SLOTS;
-        if (h_counters.next_active > max_active || h_counters.small_roots > max_small) return ctx->fail(VHR_ERROR_DEVICE, "device K0 (SAH): a node list overflowed");
-        if (trace) std::fprintf(stderr, "K0 device (SAH) level %d: %u nodes -> %u, %u small roots\n", level, n_active, h_counters.next_active, h_counters.small_roots);
+        if (h_counters.next_active > max_active || h_counters.small_roots > max_small) return ctx->fail(VHR_ERROR_DEVICE, "device K0: a node list overflowed");
+        if (trace) std::fprintf(stderr, "K0 device level %d: %u nodes -> %u, %u small roots\n", level, n_active, h_counters.next_active, h_counters.small_roots);
         n_active = h_counters.next_active;
         n_small = h_counters.small_roots;
         cur ^= 1;
@@ -1032,7 +822,7 @@ int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_pref
     K0_TRY(hipGetLastError());
     if (h_counters.error) return VHR_ERROR_OUT_OF_SLOTS;
     lap("small subtrees");
-    if (h_counters.inner != n - 1u) return ctx->fail(VHR_ERROR_DEVICE, "device K0 (SAH): the splits did not end in one binary tree");
+    if (h_counters.inner != n - 1u) return ctx->fail(VHR_ERROR_DEVICE, "device K0: the splits did not end in one binary tree");
     const uint32_t total_nodes = 2u * n - 1u, root_id = n;
     uint32_t h_size_root = n;
     K0_TRY(hipMemcpyAsync(d_size + root_id, &h_size_root, 4, hipMemcpyHostToDevice, s));
@@ -1058,11 +848,11 @@ int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_pref
         K0_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_keys[0], d_keys[1], d_vals[0], d_vals[1], int(n_inner_all), 0, 40, s));
         char *d_sort_work;
         K0_TRY(tmp.alloc(&d_sort_work, sort_bytes));
-        hipLaunchKernelGGL(k0_sah_bfs_keys_kernel, grid(n_inner_all), block, 0, s, d_size, d_place, n, total_nodes, leaf_tris, d_keys[0], d_vals[0]);
+        hipLaunchKernelGGL(k0_bfs_keys_kernel, grid(n_inner_all), block, 0, s, d_size, d_place, n, total_nodes, leaf_tris, d_keys[0], d_vals[0]);
         K0_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_work, sort_bytes, d_keys[0], d_keys[1], d_vals[0], d_vals[1], int(n_inner_all), 0, 40, s));
-        hipLaunchKernelGGL(k0_sah_bfs_rank_kernel, grid(n_inner), block, 0, s, d_vals[1], n_inner, d_kept_rank);
+        hipLaunchKernelGGL(k0_bfs_rank_kernel, grid(n_inner), block, 0, s, d_vals[1], n_inner, d_kept_rank);
     }
-    hipLaunchKernelGGL(k0_emit_kernel, grid(n_inner_all), block, 0, s, d_children, d_node_box, d_size, d_kept_rank, d_position, n, total_nodes, n_inner, leaf_tris, ctx->d_nodes, 1u);
+    hipLaunchKernelGGL(k0_emit_kernel, grid(n_inner_all), block, 0, s, d_children, d_node_box, d_size, d_kept_rank, d_position, n, total_nodes, leaf_tris, ctx->d_nodes);
     hipLaunchKernelGGL(k0_node_bounds_kernel, grid(n_inner), block, 0, s, ctx->d_nodes, n_inner, d_bounds + 6);
     K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
     K0_TRY(hipStreamSynchronize(s));
@@ -1079,7 +869,7 @@ int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_pref
     ctx->node_count = n_inner;
     ctx->tri_count = n;
     ctx->bvh_depth = h_depth;
-    if (std::getenv("VHR_K0_TRACE")) std::fprintf(stderr, "K0 device (SAH): %u triangles, %u inner nodes, depth %u\n", n, n_inner, h_depth);
+    if (std::getenv("VHR_K0_TRACE")) std::fprintf(stderr, "K0 device: %u triangles, %u inner nodes, depth %u\n", n, n_inner, h_depth);
     if (h_depth > uint32_t(kMaxBvhDepth)) return VHR_ERROR_OUT_OF_SLOTS;
     return VHR_OK;
 }

@@ -92,8 +92,8 @@ static_assert(sizeof(BvhTri) == 48, "BvhTri");
 
 constexpr int kMaxLeafTris = 4;      // encoding limit of a leaf link
 constexpr int kDefaultLeafTris = 3;  // r2, on the 48-byte-node kernel: 3 / 4 -> sponza_proc 351 / 372 us, bistro_proc 511 / 511 us (scratch/ab_leaf.py)
-// Depth bound of any tree the walkers are given == the capacity of their traversal stacks.  40 since r3: the device builder's trees
-// ("bvh_builder" 1) run deeper than the host's SAH trees (bistro_proc 36 against 28); the host builder stays far below either bound.
+// Depth bound of any tree the walkers are given == the capacity of their traversal stacks (sponza_proc 22, bistro_proc 28; a deeper
+// tree from the device builder sends the build to the host builder, whose forced median splits keep any scene below the bound).
 constexpr int kMaxBvhDepth = 40;
 constexpr int kTraceStack = 40;      // per-pixel kernels: the whole stack in LDS
 constexpr int kSpillStack = 64;      // queue kernels: the part of the stack beyond their LDS levels lives in scratch (a power of two: masked indices)
@@ -161,7 +161,6 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
 // the device-side builder (csrc/kernels_bvh.hip, option "bvh_builder" 1): from ctx->d_vertices / d_indices / d_primitives into the
 // context's node and triangle arrays; VHR_ERROR_OUT_OF_SLOTS = fall back to the host builder (tree deeper than the walkers' stacks)
 int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris);
-int device_build_bvh_sah(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris);     // "bvh_builder" 2
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
@@ -356,7 +355,7 @@ struct vhr_context {
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
     int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
-    int bvh_builder = 0;                         // "bvh_builder": 0 = host binned SAH (default), 1 = device LBVH (csrc/kernels_bvh.hip)
+    int bvh_builder = 1;                         // "bvh_builder": 1 = binned SAH on the device (csrc/kernels_bvh.hip, default), 0 = on the host (csrc/bvh_build.cpp)
     int bvh_builder_used = 0;                    // which one made the current tree (the device builder falls back for trees too deep / too small)
     double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
     double bvh_check_ms = 0.0;                                 // the self-checks of the node forms + the fingerprint (not part of K0)

@@ -588,7 +588,7 @@ class Context:
         return tuple(int(v) for v in out)
 
     def bvh_builder_used(self):
-        """0 = the host's binned SAH made the current tree, 1 = the device's LBVH (option "bvh_builder")."""
+        """Which builder made the current tree: 1 = the device's (option "bvh_builder" 1, the default), 0 = the host's."""
         out = C.c_int32()
         self.check(self.L.vhr_get_bvh_builder(self.handle, C.byref(out)), "get_bvh_builder")
         return int(out.value)
