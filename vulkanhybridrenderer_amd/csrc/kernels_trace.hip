@@ -797,13 +797,13 @@ __device__ __forceinline__ void order_blocks_by_cost(const uint32_t *__restrict_
 // exact arithmetic.
 template <int WAVES, bool COMPACT, bool SPILL, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
-                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t tile_rows, const Stamps st) {
+                                                                          const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t steal_threshold, const Stamps st) {
     vhr_stamp(st);
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
     extern __shared__ int s_dyn[];                    // per wave: (stack_levels + 3) x 64 ints
     const unsigned long long t_start = stats ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_setup = 0, t_refill = 0, t_nodes = 0, t_leaves = 0, n_refills = 0;
-    __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit 0: shadow ray occluded; bits 8..: AO rays that escaped
+    __shared__ uint32_t s_vis_all[WAVES][kQueueBlock];    // bit k: the pixel's ray of kind k (0 = shadow, 1.. = AO) found an occluder
     __shared__ float s_ray_all[WAVES][5][kQueueBlock];    // per covered pixel: ray origin (3), the normal's half bits (2)
     __shared__ uint8_t s_list_all[WAVES][kQueueBlock];    // compacted covered pixels
     __shared__ float4 s_cut_all[WAVES][kCutMax][2];       // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -)
@@ -892,6 +892,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = uint32_t(__popcll(idle));
         const unsigned long long t0 = stats ? __builtin_readcyclecounter() : 0ull;
+        const bool queue_dry = next >= total;         // (before this trip's refill: the steal below reads the idle ballot taken above)
         if (next < total && (n_idle >= refill_threshold || n_idle == 64u)) {     // wave-uniform condition
             __builtin_amdgcn_s_setprio(0);            // (see below)
             ++n_refills;
@@ -930,6 +931,41 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
                 }
                 has = true;
+            }
+        }
+        // ---- the queue is dry: idle lanes take pending subtrees off the busy lanes' stacks ----
+        // Any hit = OR over the subtrees a ray touches, in any order and by any lane: a lane with nothing left to fetch takes the top stack entry
+        // of a busy lane and walks it for the same ray (the ray's registers come over by ds_bpermute).  One entry per busy lane and trip: the
+        // walkers of a long ray double from trip to trip.  A lane whose ray another lane has meanwhile found blocked stops.
+        if (steal_threshold && queue_dry && n_idle >= steal_threshold && n_idle != 64u) {         // wave-uniform
+            if (has && ((s_vis[pix] >> kind) & 1u)) has = false;                                  // (the idle ballot above is one trip old for such a lane: it steals next trip)
+            const bool donor = has && sp >= 1 && uint32_t(sp) <= stack_levels;                    // top entry in LDS (deeper ones live in scratch)
+            const unsigned long long dmask = __ballot(donor);
+            if (dmask) {
+                if (donor) s_list[lane_rank(dmask)] = uint8_t(lane);                              // (the list of covered pixels is not needed any more: the queue is dry)
+                wave_lds_sync();
+                const uint32_t nd = uint32_t(__popcll(dmask));
+                const uint32_t r = lane_rank(idle);
+                const bool thief = ((idle >> lane) & 1ull) && r < nd;
+                const uint32_t d = thief ? uint32_t(s_list[r]) : lane;
+                const int dsp = __shfl(sp, int(d));
+                const int link = (stack - lane + d)[(thief ? uint32_t(dsp) : 0u) * kQueueBlock];
+                const float t_ox = __shfl(ro.x, int(d)), t_oy = __shfl(ro.y, int(d)), t_oz = __shfl(ro.z, int(d));
+                const float t_dx = __shfl(rd.x, int(d)), t_dy = __shfl(rd.y, int(d)), t_dz = __shfl(rd.z, int(d));
+                const float t_ix = __shfl(rinv.x, int(d)), t_iy = __shfl(rinv.y, int(d)), t_iz = __shfl(rinv.z, int(d));
+                const float t_nx = __shfl(noi.x, int(d)), t_ny = __shfl(noi.y, int(d)), t_nz = __shfl(noi.z, int(d));
+                const float t_ax = COMPACT ? 0.0f : __shfl(ainv.x, int(d)), t_ay = COMPACT ? 0.0f : __shfl(ainv.y, int(d)), t_az = COMPACT ? 0.0f : __shfl(ainv.z, int(d));
+                const float t_tmax = __shfl(tmax, int(d));
+                const uint32_t t_pk = uint32_t(__shfl(int(pix | (kind << 8)), int(d)));
+                if (donor && lane_rank(dmask) < n_idle) --sp;                                     // its top entry has a taker
+                if (thief) {
+                    ro = f3{ t_ox, t_oy, t_oz }; rd = f3{ t_dx, t_dy, t_dz }; rinv = f3{ t_ix, t_iy, t_iz }; noi = f3{ t_nx, t_ny, t_nz };
+                    if (!COMPACT) ainv = f3{ t_ax, t_ay, t_az };
+                    tmax = t_tmax; pix = t_pk & 0xffu; kind = t_pk >> 8;
+                    cur = link; sp = 0; emask = 0;
+                    has = true;
+                }
+                if (stats) ++n_refills;
             }
         }
         if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
@@ -1037,8 +1073,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const bool finished = found || cur == kStackSentinel;
         if (has && finished) {
             has = false;
-            if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }                         // miss.rmiss:7 leaves 1.0
-            else if (!found) atomicAdd(&s_vis[pix], 256u);
+            if (found) atomicOr(&s_vis[pix], 1u << kind);                                     // miss.rmiss:7 leaves 1.0 where nothing is found
         }
         if (stats) {       // wave-level trip counts of the two inner loops = the slowest lane's (for lane utilisation)
             const unsigned long long t3 = __builtin_readcyclecounter();
@@ -1060,7 +1095,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     if (covered) {
         const uint32_t vis = s_vis[lane];
         shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
-        if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (vis >> 8)) / float(a.tp.ao_spp);   // rgen:55
+        if (a.tp.ao_spp) ao_payload = float(a.tp.ao_spp - uint32_t(__popc(vis >> 1))) / float(a.tp.ao_spp);             // rgen:55: the AO rays that escaped
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
@@ -1547,7 +1582,8 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
             const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
             if (!a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, n_blocks, wv, key, a.co);
         }
-        auto go = [&](auto kernel) { launch(ctx, kernel, dim3(n_blocks), dim3(kQueueBlock * wv), stack_bytes * wv, a, levels, threshold, (tiles_x + wv - 1u) / wv, early_exit, tile_rows); };
+        const uint32_t steal = uint32_t(std::max(0, std::min(63, ctx->options[kOptRaygenSteal])));
+        auto go = [&](auto kernel) { launch(ctx, kernel, dim3(n_blocks), dim3(kQueueBlock * wv), stack_bytes * wv, a, levels, threshold, (tiles_x + wv - 1u) / wv, early_exit, tile_rows, steal); };
         auto by_flags = [&](auto waves_c) {
             constexpr int WV = decltype(waves_c)::value;
             const int sel = (compact ? 4 : 0) | (spill ? 2 : 0) | (a.stats ? 1 : 0);
