@@ -874,6 +874,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tmax = 0.0f;
     int cur = 0, sp = 0;
+    int sbase = 0;                                    // "raygen_steal": stack rows 1 .. sbase have been taken by other lanes (row sbase holds a sentinel)
     uint32_t pix = 0, kind = 0;
     bool has = false;
     uint32_t next = 0;                                // queue head: wave-uniform, lives in a register
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
-                cur = 0; sp = 0;
+                cur = 0; sp = 0; sbase = 0;
                 {   // the ray against the tile's cut: hit subtrees go on its stack
                     emask = 0;
                     // (the cut's boxes are absolute fp32 boxes whatever the node format)
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         // walkers of a long ray double from trip to trip.  A lane whose ray another lane has meanwhile found blocked stops.
         if (steal_threshold && queue_dry && n_idle >= steal_threshold && n_idle != 64u) {         // wave-uniform
             if (has && ((s_vis[pix] >> kind) & 1u)) has = false;                                  // (the idle ballot above is one trip old for such a lane: it steals next trip)
-            const bool donor = has && sp >= 1 && uint32_t(sp) <= stack_levels;                    // top entry in LDS (deeper ones live in scratch)
+            const bool donor = has && sp > sbase && uint32_t(sbase) < stack_levels;               // rows sbase + 1 .. sp are its own; row sbase + 1 is in LDS
             const unsigned long long dmask = __ballot(donor);
             if (dmask) {
                 if (donor) s_list[lane_rank(dmask)] = uint8_t(lane);                              // (the list of covered pixels is not needed any more: the queue is dry)
@@ -948,8 +949,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const uint32_t r = lane_rank(idle);
                 const bool thief = ((idle >> lane) & 1ull) && r < nd;
                 const uint32_t d = thief ? uint32_t(s_list[r]) : lane;
-                const int dsp = __shfl(sp, int(d));
-                const int link = (stack - lane + d)[(thief ? uint32_t(dsp) : 0u) * kQueueBlock];
+                const int drow = __shfl(sbase, int(d)) + 1;                                       // the donor's LOWEST entry: the far child pushed first, the largest subtree it holds
+                const int link = (stack - lane + d)[(thief ? uint32_t(drow) : 0u) * kQueueBlock];
                 const float t_ox = __shfl(ro.x, int(d)), t_oy = __shfl(ro.y, int(d)), t_oz = __shfl(ro.z, int(d));
                 const float t_dx = __shfl(rd.x, int(d)), t_dy = __shfl(rd.y, int(d)), t_dz = __shfl(rd.z, int(d));
                 const float t_ix = __shfl(rinv.x, int(d)), t_iy = __shfl(rinv.y, int(d)), t_iz = __shfl(rinv.z, int(d));
@@ -957,12 +958,16 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const float t_ax = COMPACT ? 0.0f : __shfl(ainv.x, int(d)), t_ay = COMPACT ? 0.0f : __shfl(ainv.y, int(d)), t_az = COMPACT ? 0.0f : __shfl(ainv.z, int(d));
                 const float t_tmax = __shfl(tmax, int(d));
                 const uint32_t t_pk = uint32_t(__shfl(int(pix | (kind << 8)), int(d)));
-                if (donor && lane_rank(dmask) < n_idle) --sp;                                     // its top entry has a taker
+                wave_lds_sync();
+                if (donor && lane_rank(dmask) < n_idle) {                                         // its lowest entry has a taker: a sentinel in its place ends the donor's walk there
+                    ++sbase;
+                    stack[uint32_t(sbase) * kQueueBlock] = kStackSentinel;
+                }
                 if (thief) {
                     ro = f3{ t_ox, t_oy, t_oz }; rd = f3{ t_dx, t_dy, t_dz }; rinv = f3{ t_ix, t_iy, t_iz }; noi = f3{ t_nx, t_ny, t_nz };
                     if (!COMPACT) ainv = f3{ t_ax, t_ay, t_az };
                     tmax = t_tmax; pix = t_pk & 0xffu; kind = t_pk >> 8;
-                    cur = link; sp = 0; emask = 0;
+                    cur = link; sp = 0; sbase = 0; emask = 0;
                     has = true;
                 }
                 if (stats) ++n_refills;
@@ -1069,6 +1074,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             emask &= emask - 1u;
             cur = __float_as_int(s_cut[e][1].z);
             sp = 0;                                   // the pop of the empty stack left it at -1
+            sbase = 0;                                // (every row is this lane's own again)
         }
         const bool finished = found || cur == kStackSentinel;
         if (has && finished) {

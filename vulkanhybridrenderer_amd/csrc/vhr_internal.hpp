@@ -269,7 +269,7 @@ struct RayStats {
     X(kOptEarlyExit, "raygen_early_exit", 4, 0, 15)             /* sixteenths of the walkers that entered below which the node loop is left */ \
     X(kOptRaygenTileRows, "raygen_tile_rows", 0, 0, 8)          /* rows of a wave's tile; 0 = auto (6 for launches that fill < 70 % of the wave slots) */ \
     X(kOptRaygenCostOrder, "raygen_cost_order", 1, 0, 2)        /* start the longest-lived tiles first: 1 = launches of >= 2 048 workgroups, 2 = any */ \
-    X(kOptRaygenSteal, "raygen_steal", 0, 0, 63)                /* queue dry and >= n lanes idle: idle lanes take pending subtrees off busy lanes' stacks; 0 = never */ \
+    X(kOptRaygenSteal, "raygen_steal", 8, 0, 63)                /* queue dry and >= n lanes idle: idle lanes take pending subtrees off busy lanes' stacks; 0 = never */ \
     /* the a-trous kernel */                                                                                                            \
     X(kOptAtrousSmallTiles, "atrous_small_tiles", -1, -1, 1)    /* 4-row tiles: -1 auto (below 32 8-row tiles per CU), 0 never, 1 always */ \
     /* the frame's schedule */                                                                                                          \
