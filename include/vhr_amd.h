@@ -509,8 +509,9 @@ int vhr_get_drain_statistics(vhr_context *ctx, uint64_t out[4]);
  * bytes-per-pixel bytes), used to calibrate rocprofv3's FETCH_SIZE for the SVGF kernels' access widths. */
 int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_t bytes_per_lane);
 
-/* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792;
- * here the binned-SAH build runs on the host): out[0] = build, out[1] = upload of scene + tree, in milliseconds of host time. */
+/* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792; so does
+ * "bvh_builder" 1, the default): out[0] = the build, out[1] = the upload of the scene arrays (+ the tree, built on the host; or the tree
+ * fetched back for the host's containment checks, built on the device), in milliseconds of host time. */
 int vhr_get_build_times(vhr_context *ctx, double out[2]);
 /* Which builder made the current tree: 0 = the host's, 1 = the device's ("bvh_builder" 1, the default; it falls back to the host builder
  * for a scene of a single leaf and for a tree deeper than the walkers' stacks) */
