@@ -106,3 +106,45 @@ def test_random_triangle_soup_mirror_ray(oracle, seed, n_tris, n_prims):
         assert (f16(frames[1]["reflections"])[..., 3] > 0).mean() > 0.2
     finally:
         g.close()
+
+
+def stacks(seed, copies, n_extra):
+    """`copies` coincident copies of one triangle (every box centre equal: no plane separates them, the builders halve the range by
+    count) stacked above a floor, next to `n_extra` random small triangles -- the device builder's by-position splits at the level
+    passes (more than 64 coincident triangles) and inside a wave's subtree (fewer)."""
+    rng = np.random.default_rng(seed)
+    b = scenes._Builder()
+    b.add(scenes.plane([-5, 0, 5], [10, 0, 0], [0, 0, -10], 2, 2), base_color=(0.7, 0.7, 0.7, 1))
+    one = np.array([[-0.8, 1.0, 0.0], [0.9, 1.1, 0.2], [0.0, 2.4, -0.3]], np.float32)
+    tri = np.repeat(one[None], copies, axis=0)
+    if n_extra:
+        centre = rng.uniform([-3, 0.2, -3], [3, 3, 3], size=(n_extra, 1, 3))
+        tri = np.concatenate([tri, (centre + rng.normal(size=(n_extra, 3, 3)) * 0.15).astype(np.float32)])
+    pos = tri.reshape(-1, 3)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    nrm = np.repeat(nrm / np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-20), 3, axis=0).astype(np.float32)
+    b.add((pos, nrm, rng.random((len(pos), 2)).astype(np.float32), np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)), base_color=scenes._palette(1))
+    camera = dict(position=(0.0, 1.8, 6.5), yaw=0.0, pitch=-0.1, yfov=0.9, znear=0.1, dolly=(0.02, 0.0, -0.04))
+    return b.finish(f"stacks{seed}", camera, directional_light((0.25, -0.9, 0.3)))
+
+
+@pytest.mark.parametrize("copies,n_extra", [(40, 0), (63, 2), (64, 1), (65, 0), (300, 500), (3, 57), (2, 0)])
+def test_device_builder_corner_cases(oracle, copies, n_extra):
+    """The device builder around its own seams: a scene that is one wave's subtree from the start (<= 64 triangles), one just above,
+    coincident triangles that no plane separates (halved by count at a level pass and inside a subtree), a scene of a few triangles.
+    Both builders' trees pass the containment check and give the oracle's visibility bit for bit."""
+    scene = stacks(7, copies, n_extra)
+    W, H = 96, 64
+    tp = abi.default_trace_params(reflections=False)
+    frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
+    try:
+        for builder in (1, 0):
+            g.ctx.set_option("bvh_builder", builder)
+            g.ctx.upload_scene(scene)
+            assert g.ctx.bvh_builder_used() == builder and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+            for i, fr in enumerate(frames):
+                g.frame(fr["pfd"], fr["gbuf"])
+                assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"builder {builder}, frame {i}"
+    finally:
+        g.close()
