@@ -40,12 +40,13 @@ out = {"fingerprint": lib.source_fingerprint(), "workload": "$KEY", "bench_argum
        "sq_per_kernel": sq,
        "source": "tools/pmc_workload.sh: rocprofv3 --kernel-trace --pmc, one pass per counter group (FETCH_SIZE with its calibration, WRITE_SIZE, SQ_*, TA_*); per-dispatch averages"}
 for k, c in ta.items():
-    if "raygen_queue_kernel" in k and ", false>" in k.replace("true>", "X") and "TA_TA_BUSY_sum" in c:      # the timed flavour (STATS = false is the last template argument)
+    targs = k.split("<", 1)[1].rsplit(">", 1)[0].split(", ") if "<" in k else []
+    if "raygen_queue_kernel" in k and len(targs) >= 4 and targs[3] == "false" and "TA_TA_BUSY_sum" in c:      # the timed flavour (<WAVES, COMPACT, SPILL, STATS, FUSE>: STATS = false)
         cycles = c["GRBM_GUI_ACTIVE"] / 8
         out["raygen_ta"] = {"kernel": k, "wave_level_load_instructions": round(c["TA_FLAT_READ_WAVEFRONTS_sum"]), "ta_busy_cycles_sum": round(c["TA_TA_BUSY_sum"]),
                             "kernel_cycles": round(cycles), "ta_busy_frac": round(c["TA_TA_BUSY_sum"] / (256 * cycles), 4),
                             "ta_cycles_per_load_instruction": round(c["TA_TA_BUSY_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"], 2)}
-    if "reflection_queue_kernel" in k and "TA_TA_BUSY_sum" in c and "reflection_ta" not in out:
+    if "reflection_queue_kernel" in k and len(targs) >= 3 and targs[2] == "false" and "TA_TA_BUSY_sum" in c and "reflection_ta" not in out:      # (<SPILL, BOUNCES, STATS>)
         cycles = c["GRBM_GUI_ACTIVE"] / 8
         out["reflection_ta"] = {"kernel": k, "wave_level_load_instructions": round(c["TA_FLAT_READ_WAVEFRONTS_sum"]), "ta_busy_cycles_sum": round(c["TA_TA_BUSY_sum"]),
                                 "kernel_cycles": round(cycles), "ta_busy_frac": round(c["TA_TA_BUSY_sum"] / (256 * cycles), 4)}
