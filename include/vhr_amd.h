@@ -458,7 +458,8 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 3); "bvh_builder" 1 = binned SAH on the
  *  device (default), where the reference builds its BLAS / TLAS (resource_manager.cpp:650,692,792), 0 = the same algorithm on the host
  *  (csrc/bvh_build.cpp: 8 / 28x slower to build on the two test scenes, the same tree up to the order of leaves in memory; images
- *  bit-identical; also what a host-only context and a device build deeper than the walkers' stacks fall back to); "bvh_build_threads"
+ *  bit-identical; also what a host-only context and a device build deeper than the walkers' stacks fall back to -- "bvh_device_max_depth"
+ *  1..40 (default 40 = those stacks) lowers the depth at which the device builder gives up, for tests of that hand-over); "bvh_build_threads"
  *  (host builder) 0 = up to 16 host threads (default), 1 = serial -- the tree is the same whatever the count. */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);

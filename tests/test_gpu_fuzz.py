@@ -148,3 +148,32 @@ def test_device_builder_corner_cases(oracle, copies, n_extra):
                 assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"builder {builder}, frame {i}"
     finally:
         g.close()
+
+
+def test_a_tree_deeper_than_the_device_builder_may_keep_goes_to_the_host_builder(oracle):
+    """The device builder measures its tree's depth in the layout stage and hands a tree deeper than the walkers' stacks (40) to the host
+    builder, whose forced median splits bound the depth.  Binned SAH does not get that deep on anything fp32 can hold (rows of triangles
+    20x apart from one to the next reach 32), so the hand-over is driven by "bvh_device_max_depth": with 8 the device build of a soup is
+    refused, the host's tree is used, and the image is the oracle's either way."""
+    scene = soup(5, 3000, 6)
+    W, H = 96, 64
+    tp = abi.default_trace_params(reflections=False)
+    frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
+    try:
+        assert g.ctx.bvh_builder_used() == 1
+        depth_device = g.ctx.bvh_statistics()["max_depth"]
+        g.ctx.set_option("bvh_device_max_depth", 8)
+        g.ctx.upload_scene(scene)
+        st = g.ctx.bvh_statistics()
+        assert g.ctx.bvh_builder_used() == 0 and st["max_depth"] == depth_device > 8 and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+        for i, fr in enumerate(frames):
+            g.frame(fr["pfd"], fr["gbuf"])
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"frame {i}"
+        g.ctx.set_option("bvh_device_max_depth", 40)
+        g.ctx.upload_scene(scene)
+        assert g.ctx.bvh_builder_used() == 1
+        with pytest.raises(lib.VhrError):
+            g.ctx.set_option("bvh_device_max_depth", 41)
+    finally:
+        g.close()

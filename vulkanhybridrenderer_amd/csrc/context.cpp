@@ -566,6 +566,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         ctx->bvh_leaf_tris = value;
         return VHR_OK;
     }
+    if (!std::strcmp(key, "bvh_device_max_depth")) {         // applies to the next vhr_update_geometry
+        if (value < 1 || value > kMaxBvhDepth) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_device_max_depth must be 1..40");
+        ctx->bvh_device_max_depth = value;
+        return VHR_OK;
+    }
     if (!std::strcmp(key, "bvh_builder")) {                  // applies to the next vhr_update_geometry
         if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (binned SAH on the host) or 1 (binned SAH on the device)");
         ctx->bvh_builder = value;

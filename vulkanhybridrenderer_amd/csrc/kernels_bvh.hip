@@ -870,7 +870,7 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
     ctx->tri_count = n;
     ctx->bvh_depth = h_depth;
     if (std::getenv("VHR_K0_TRACE")) std::fprintf(stderr, "K0 device: %u triangles, %u inner nodes, depth %u\n", n, n_inner, h_depth);
-    if (h_depth > uint32_t(kMaxBvhDepth)) return VHR_ERROR_OUT_OF_SLOTS;
+    if (h_depth > uint32_t(std::min(kMaxBvhDepth, ctx->bvh_device_max_depth))) return VHR_ERROR_OUT_OF_SLOTS;
     return VHR_OK;
 }
 

@@ -358,6 +358,7 @@ struct vhr_context {
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
     int bvh_builder = 1;                         // "bvh_builder": 1 = binned SAH on the device (csrc/kernels_bvh.hip, default), 0 = on the host (csrc/bvh_build.cpp)
     int bvh_builder_used = 0;                    // which one made the current tree (the device builder falls back for trees too deep / too small)
+    int bvh_device_max_depth = vhr::kMaxBvhDepth; // "bvh_device_max_depth": the device builder hands a deeper tree to the host builder (kMaxBvhDepth = the walkers' stacks; tests lower it)
     double bvh_build_ms = 0.0, geometry_upload_ms = 0.0;      // K0: host build / device upload of the last vhr_update_geometry
     double bvh_check_ms = 0.0;                                 // the self-checks of the node forms + the fingerprint (not part of K0)
 
