@@ -11,16 +11,21 @@
  * Threading and streams: like the reference (renderer.cpp:184-235) one host thread drives one context.  Everything a frame PUBLISHES is
  * issued in order on the context's stream (the one given at creation, or an internal one with VHR_CREATE_INTERNAL_STREAM): after
  * vhr_graph_execute returns, work the caller enqueues on that stream sees every image the graph's passes declare as outputs.  Two things
- * leave that stream, both owned and joined by the library:
+ * leave that stream, all owned and joined by the library:
  *   - "svgf_async_unread" (default 1): a compute pass's a-trous dispatch whose output nothing reads (the reference's fifth iteration,
  *     hybrid_render_path.cpp:299-328) runs on a library-owned SIDE stream beside whatever the context's stream does next; the context's
  *     stream waits for it before the next compute pass, before storage-image uploads / downloads / vhr_get_storage_image and in
  *     vhr_synchronize.  A caller that reads that dispatch's storage image itself on the context's stream must call vhr_synchronize first
  *     or set the option to 0 (every dispatch in recorded order on the one stream).
+ *   - "reflection_async" (default 1): the mirror ray's launch runs on a second library-owned stream behind the shadow / AO launch, beside the
+ *     SVGF pass; the context's stream waits for it before a pass epilogue, before the frame's next external pass, at the end of
+ *     vhr_graph_execute (so the sentence above holds for the Reflections image too), before image uploads / downloads / vhr_get_*_image and
+ *     in vhr_synchronize.
  *   - "frames_in_flight" 2 / 3 (opt-in): the front of a frame (up to its last ray-tracing pass) runs on a second stream; vhr_get_current_stream
  *     tells an external pass which stream to enqueue on.
  * Pass time stamps ("pass_timestamps", vhr_graph_gather_performance_statistics) cover what the CONTEXT'S stream executes between a pass's
- * first kernel and the next kernel behind it: with the side stream on, "SVGF Denoise Pass" covers 1 temporal + 4 a-trous dispatches + the
+ * first kernel and the next kernel behind it: "Raytrace Pass" covers the shadow / AO launch (+ the mirror ray's with "reflection_async" 0);
+ * with the side stream on, "SVGF Denoise Pass" covers 1 temporal + 4 a-trous dispatches + the
  * blits where the reference's vkCmdWriteTimestamp pair covers five a-trous dispatches (render_graph.cpp:167-182); with "svgf_async_unread" 0
  * it covers all five.  In mode 1 the END of a pass is stored by the next LIBRARY kernel on the stream, so GPU work an external (graphics)
  * pass's callback enqueues on the stream right behind a library pass is charged to that pass; mode 2 closes the pass in front of every such
@@ -427,6 +432,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "atrous_small_tiles" -1 (default) = 4-row instead of 8-row tiles when the launch has < 32 8-row tiles per CU (a 1080p frame and every screen
  *                        tile use 4-row tiles, a 4K frame 8-row ones), 0 = never, 1 = always
  *  The frame's schedule:
+ *   "reflection_async"   1 (default) = the mirror ray's launch (raygen.rgen:59-65; its image is not denoised, nothing of the SVGF pass reads it) runs
+ *                        on a stream of the library's own behind the shadow / AO launch, beside the SVGF pass; the context's stream waits for it
+ *                        before the frame's next external pass, at the end of vhr_graph_execute and wherever the library waits or hands an
+ *                        image out.  Frame with the mirror ray -2 % (sponza_proc) / -6 % (bistro_proc); "Raytrace Pass" then times the
+ *                        shadow / AO launch alone and the SVGF pass's time includes what it shares with the mirror ray.  0 = in the pass, in order
  *   "fuse_blits"         1 (default) = a compute pass records its dispatches and blits and issues them when its callback returns; a same-extent
  *                        blit whose source is the output (or the normals input) of a recorded a-trous dispatch becomes a second store of that
  *                        launch instead of a copy kernel (all three blits of hybrid_render_path.cpp:310-325); 0 = every blit is a copy

@@ -364,3 +364,35 @@ def test_svgf_comp_fused_into_the_ray_tracing_tiles_changes_no_image():
     for s, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with svgf.comp fused into the ray-tracing kernel"
+
+
+def test_mirror_ray_on_its_own_stream_changes_no_image():
+    """Option "reflection_async" (default 1): the mirror ray's launch runs on a stream of the library's own behind the shadow / AO launch,
+    beside the SVGF pass.  The G-buffer of every frame is written in place by the stand-in kernel on the context's stream with no
+    synchronisation between frames (the mirror ray reads it: the frame must end with its mirror ray), and after 3 and after 8 frames the
+    Reflections image, the raw visibility and the denoised image equal the in-order schedule's bit for bit."""
+    W, H = 480, 270
+    scene = scenes.sponza_proc()
+    pfds = camera.dolly_frames(scene, W, H, 8)
+    outs = {}
+    for mode in (0, 1):
+        c = lib.Context(W, H, device=0)
+        try:
+            c.upload_scene(scene)
+            c.set_option("reflection_async", mode)
+            path = lib.HybridRenderPath(c, 0, 0, 0, True, 5, lambda cc: cc.standin_gbuffer(0))
+            path.build()
+            snaps = []
+            for i, pfd in enumerate(pfds):
+                c.update_per_frame_ubo(0, pfd)
+                c.execute(0, 0)
+                if i in (2, 7):
+                    snaps.append([c.download(lib.REFLECTIONS), c.download(lib.RAYTRACED), c.download(lib.DENOISED)])
+            outs[mode] = snaps
+            path.destroy()
+        finally:
+            c.close()
+    assert outs[0][1][0][..., 3].any()                            # (something was hit)
+    for s, (a, b) in enumerate(zip(outs[0], outs[1])):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with the mirror ray on its own stream"

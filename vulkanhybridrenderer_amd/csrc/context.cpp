@@ -116,6 +116,8 @@ int vhr_context::sync_streams() {
     if (front_stream && hipStreamSynchronize(front_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(front stream) failed");
     if (side_stream && hipStreamSynchronize(side_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(side stream) failed");
     side_pending = false;
+    if (refl_stream && hipStreamSynchronize(refl_stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize(mirror-ray stream) failed");
+    refl_pending = false;
     if (hipStreamSynchronize(stream) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamSynchronize failed");     // (a null handle is the default stream)
     return VHR_OK;
 }
@@ -124,6 +126,13 @@ int vhr_context::join_side() {
     if (!side_pending) return VHR_OK;
     side_pending = false;
     if (hipStreamWaitEvent(stream, side_done, 0) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamWaitEvent(side stream) failed");
+    return VHR_OK;
+}
+
+int vhr_context::join_refl() {
+    if (!refl_pending) return VHR_OK;
+    refl_pending = false;
+    if (hipStreamWaitEvent(stream, refl_done, 0) != hipSuccess) return fail(VHR_ERROR_DEVICE, "hipStreamWaitEvent(mirror-ray stream) failed");
     return VHR_OK;
 }
 
@@ -256,6 +265,9 @@ void vhr_destroy(vhr_context *ctx) {
     ctx->sync_streams();
     vhr_graph_destroy_resources(ctx);
     if (ctx->front_stream) hipStreamDestroy(ctx->front_stream);
+    if (ctx->refl_stream) hipStreamDestroy(ctx->refl_stream);
+    if (ctx->refl_ready) hipEventDestroy(ctx->refl_ready);
+    if (ctx->refl_done) hipEventDestroy(ctx->refl_done);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->side_ready) hipEventDestroy(ctx->side_ready);
     if (ctx->side_done) hipEventDestroy(ctx->side_done);
@@ -726,12 +738,14 @@ int vhr_get_transient_image(vhr_context *ctx, const char *name, vhr_image_info *
     if (!ctx || !name || !out) return VHR_ERROR_INVALID_ARGUMENT;
     auto it = ctx->images.find(name);
     if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + name + "'");
+    if (!ctx->host_only) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }      // the caller is about to use the pointer on the context's stream
     return image_info(ctx, it->second, out);
 }
 
 int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out) {
     if (!ctx || !out || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->host_only) { const int jr2 = ctx->join_refl(); if (jr2 != VHR_OK) return jr2; }
     if (!ctx->host_only) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // the caller is about to use the pointer on the context's stream
     return image_info(ctx, ctx->storage_images[id], out);
 }
@@ -742,6 +756,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
     if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
+    { const int jr2 = ctx->join_refl(); if (jr2 != VHR_OK) return jr2; }
     if (storage || to_device) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // (a side-stream dispatch reads storage images and the pass's published copies)
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -1717,6 +1717,27 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         m.row_end = owned_end;
         m.col_begin = owned_col_begin & ~15u;
         m.col_end = owned_col_end;
+        // "reflection_async": on a stream of its own, behind the shadow / AO launch and beside whatever the caller's stream does next (the SVGF
+        // pass, which reads nothing of it).  One stream and event pair per context; the caller's stream joins at the next external pass, at the
+        // end of the frame, and wherever the library waits or hands images out.
+        hipStream_t const main_stream = ctx->stream;
+        PassDescription *const main_pass = ctx->cur_pass;
+        bool on_own_stream = false;
+        if (ctx->options[kOptReflectionAsync] && ctx->frames_in_flight == 1 && !m.stats) {
+            bool ok = true;
+            if (!ctx->refl_stream)
+                ok = hipStreamCreateWithFlags(&ctx->refl_stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->refl_ready, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->refl_done, hipEventDisableTiming) == hipSuccess;
+            if (ok && ctx->refl_pending) ok = ctx->join_refl() == VHR_OK;                    // (one launch at a time on that stream)
+            ok = ok && hipEventRecord(ctx->refl_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->refl_stream, ctx->refl_ready, 0) == hipSuccess;
+            if (ok) {
+                on_own_stream = true;
+                ctx->stream = ctx->refl_stream;
+                ctx->cur_pass = nullptr;             // the pass's time stamps stay on the caller's stream
+                ctx->no_stamps = true;
+            }
+        }
         ctx->time_begin(kKernelReflection);
         if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
@@ -1739,6 +1760,14 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m);
         }
         ctx->time_end(kKernelReflection);
+        if (on_own_stream) {
+            ctx->no_stamps = false;
+            ctx->cur_pass = main_pass;
+            const bool rec = hipEventRecord(ctx->refl_done, ctx->refl_stream) == hipSuccess;
+            ctx->stream = main_stream;
+            ctx->refl_pending = true;
+            if (!rec) return ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(mirror-ray stream) failed");
+        }
     }
     if (hipGetLastError() != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "raygen kernel launch failed");
     if (a.stats) {

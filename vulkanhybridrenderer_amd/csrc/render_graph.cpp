@@ -356,6 +356,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         p.begin_stamped = p.end_on_last_dispatch = p.stamped_in_kernel = false;
         ctx->cur_pass = stamps ? &p : nullptr;
         if (p.kind == PassKind::Graphics) {
+            { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }               // its owner may read the Reflections image (or rewrite the G-buffer the mirror ray reads)
             if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // its owner enqueues on the stream
             // An in-kernel END stamp still pending belongs to the library pass in front of this one; whatever the owner's callback enqueues
             // on the stream would be charged to that pass (the stamp is stored by the NEXT library kernel).  "pass_timestamps" 2 closes the
@@ -390,6 +391,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         // vhr_get_current_stream tells the callback.
         ctx->stream = (split && pi + 1 < ctx->front_passes) ? ctx->front_stream : back;
         if (p.epilogue_cb && ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
+        if (p.epilogue_cb) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }      // its owner expects the pass's images, the mirror ray's among them
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
         ctx->stream = back;
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it
@@ -403,6 +405,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
     // kernel every call that waits for the stream issues first (vhr_synchronize, GatherPerformanceStatistics, image downloads).
     // "pass_timestamps" 2 issues that kernel here instead, for hosts that neither run ahead nor wait (+6 us per frame).
     if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // no pass took it: issued as it is
+    { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }        // "reflection_async": the frame ends with its mirror ray (the next frame's producer rewrites what it reads)
     if (ctx->pending_end && ctx->options[vhr::kOptPassTimestamps] == 2) vhr::launch_stamp(ctx);
     return VHR_OK;
 }

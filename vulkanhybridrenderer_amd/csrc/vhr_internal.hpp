@@ -276,6 +276,7 @@ struct RayStats {
     X(kOptFuseBlits, "fuse_blits", 1, 0, 1)                     /* a pass's blits as stores of its a-trous launches */                   \
     X(kOptSvgfElideUnread, "svgf_elide_unread", 0, 0, 1)        /* do not launch an a-trous dispatch nothing reads (the reference's fifth) */ \
     X(kOptSvgfAsyncUnread, "svgf_async_unread", 1, 0, 2)        /* ... or issue it on the side stream: 1 = where it pays, 2 = always */  \
+    X(kOptReflectionAsync, "reflection_async", 1, 0, 1)         /* the mirror ray's launch on a stream of its own, beside the SVGF pass */  \
     X(kOptFuseTemporal, "fuse_temporal", 0, 0, 1)               /* svgf.comp in the ray-tracing kernel's tile epilogues */              \
     X(kOptFramesInFlight, "frames_in_flight", 1, 1, 3)          /* read by vhr_graph_build */                                            \
     /* screen tiles / row strips (one process per GPU) */                                                                               \
@@ -399,6 +400,13 @@ struct vhr_context {
     const void *side_reads[2] = { nullptr, nullptr }, *side_writes = nullptr;      // the images the pending dispatch reads / writes (hazard checks)
     bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
     int join_side();                   // the current stream waits for the side stream's pending dispatch (no-op without one)
+    // "reflection_async": the mirror ray's launch (not denoised: nothing of the SVGF pass reads it) runs on `refl_stream` beside the SVGF pass;
+    // the caller's stream waits for it (join_refl) before the frame's next external pass, at the end of vhr_graph_execute, and wherever the
+    // library waits for or hands out the context's images.
+    hipStream_t refl_stream = nullptr;
+    hipEvent_t refl_ready = nullptr, refl_done = nullptr;
+    bool refl_pending = false;
+    int join_refl();
 
     // statistics
     bool ray_stats_enabled = false;
