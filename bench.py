@@ -688,6 +688,11 @@ def main():
                                   "profiles/*kernel_stats* hold rocprofv3's average over all launches, one row per step size"),
                 # the reference's dead fifth dispatch (step 16; nothing reads its output): issued on the side stream, where it fills what the next
                 # frame's ray-tracing kernel leaves free -- its launch lasts as long as it shares the chip, which says nothing about the kernel
+                # with the mirror ray on, its launch runs beside the SVGF pass (option reflection_async, default): the a-trous launches then share the
+                # chip with a kernel of another pass and `achieved` says what they get of it, not what the kernel does alone (the run without
+                # --reflections is the kernel's own number)
+                "shares_the_chip_with": ("reflection_queue_kernel (the mirror ray's launch on its own stream, reflection_async)"
+                                         if _bounces(args) and world == 1 and option_overrides.get("reflection_async", 1) and args.frames_in_flight == 1 else None),
                 "side_stream_launch": None if not async_dead else {
                     "what": "svgf_atrous_filter.comp step 16, the dispatch hybrid_render_path.cpp:299-328 never reads (option svgf_async_unread): same kernel, "
                             "same bytes, beside raygen_queue_kernel of the next frame; not on the frame's critical path and not part of `achieved`",
