@@ -469,7 +469,9 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *  device (default), where the reference builds its BLAS / TLAS (resource_manager.cpp:650,692,792), 0 = the same algorithm on the host
  *  (csrc/bvh_build.cpp: 8 / 28x slower to build on the two test scenes, the same tree up to the order of leaves in memory; images
  *  bit-identical; also what a host-only context and a device build deeper than the walkers' stacks fall back to -- "bvh_device_max_depth"
- *  1..40 (default 40 = those stacks) lowers the depth at which the device builder gives up, for tests of that hand-over); "bvh_build_threads"
+ *  1..40 (default 40 = those stacks) lowers the depth at which the device builder gives up, for tests of that hand-over); "bvh_host_checks" 1 =
+ *  a device-built tree is fetched and the host's containment checks repeated on it (default 0: they run on the device; vhr_get_bvh_form_checks
+ *  reports either); "bvh_build_threads"
  *  (host builder) 0 = up to 16 host threads (default), 1 = serial -- the tree is the same whatever the count. */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);
@@ -521,8 +523,8 @@ int vhr_get_drain_statistics(vhr_context *ctx, uint64_t out[4]);
 int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_t bytes_per_lane);
 
 /* K0 cost of the last vhr_update_geometry (the reference builds its BLAS / TLAS on the device, resource_manager.cpp:650,692,792; so does
- * "bvh_builder" 1, the default): out[0] = the build, out[1] = the upload of the scene arrays (+ the tree, built on the host; or the tree
- * fetched back for the host's containment checks, built on the device), in milliseconds of host time. */
+ * "bvh_builder" 1, the default): out[0] = the build, out[1] = the upload of the scene arrays (+ the tree, where the host built it), in
+ * milliseconds of host time.  The containment checks of the node forms run where the tree is and are not part of either. */
 int vhr_get_build_times(vhr_context *ctx, double out[2]);
 /* Which builder made the current tree: 0 = the host's, 1 = the device's ("bvh_builder" 1, the default; it falls back to the host builder
  * for a scene of a single leaf and for a tree deeper than the walkers' stacks) */

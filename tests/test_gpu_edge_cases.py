@@ -282,10 +282,20 @@ def test_every_node_form_contains_its_box():
     for scene in (tiny, scenes.sponza_proc(0.5), scenes.bistro_proc(0.25, n_primitives=400, n_textures=4, texture_size=16), far):
         c = lib.Context(64, 64)
         try:
-            c.upload_scene(scene)
-            boxes, ch_bad, n48_bad, n16_bad = c.bvh_form_checks()
-            assert boxes == 2 * c.bvh_statistics()["nodes"] and boxes > 0
-            assert (ch_bad, n48_bad, n16_bad) == (0, 0, 0), (scene.name, ch_bad, n48_bad, n16_bad)
+            # the device-built tree is checked where it is (k0_check_forms_kernel); "bvh_host_checks" 1 fetches it and repeats the checks with
+            # the host's code: the same counts, and the same fingerprint whether it is taken right away or when first asked for;
+            # then the host builder's tree
+            seen = []
+            for builder, host_checks in ((1, 0), (1, 1), (0, 0)):
+                c.set_option("bvh_builder", builder)
+                c.set_option("bvh_host_checks", host_checks)
+                c.upload_scene(scene)
+                assert c.bvh_builder_used() == builder
+                boxes, ch_bad, n48_bad, n16_bad = c.bvh_form_checks()
+                assert boxes == 2 * c.bvh_statistics()["nodes"] and boxes > 0
+                assert (ch_bad, n48_bad, n16_bad) == (0, 0, 0), (scene.name, builder, host_checks, ch_bad, n48_bad, n16_bad)
+                seen.append((boxes, c.bvh_fingerprint()))
+            assert seen[0] == seen[1]
         finally:
             c.close()
 

@@ -320,6 +320,21 @@ static void normal_matrix3(const float *m, float out[9]) {
     out[2] = float(c20 * id); out[5] = float(c21 * id); out[8] = float(c22 * id);
 }
 
+// the device-built tree on the host (for "bvh_host_checks" and the fingerprint)
+static int fetch_device_tree(vhr_context *ctx, HostBvh &bvh) {
+    bvh.nodes.resize(ctx->node_count); bvh.nodes_ch.resize(ctx->node_count); bvh.nodes48.resize(ctx->node_count); bvh.nodes16.resize(ctx->node_count);
+    bvh.tris.resize(ctx->tri_count);
+    HIP_TRY(ctx, hipMemcpy(bvh.nodes.data(), ctx->d_nodes, sizeof(BvhNode) * ctx->node_count, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bvh.nodes_ch.data(), ctx->d_nodes_ch, sizeof(BvhNodeCH) * ctx->node_count, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bvh.nodes48.data(), ctx->d_nodes48, sizeof(BvhNode48) * ctx->node_count, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bvh.nodes16.data(), ctx->d_nodes16, sizeof(BvhNode16) * ctx->node_count, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bvh.tris.data(), ctx->d_tris, sizeof(BvhTri) * ctx->tri_count, hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; ++a) bvh.centre[a] = ctx->bvh_centre[a];
+    bvh.nodes16_valid = nodes16_in_range(bvh);
+    bvh.max_depth = ctx->bvh_depth;
+    return VHR_OK;
+}
+
 int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t vertex_count, const uint32_t *indices,
                         uint32_t index_count, const vhr_primitive *primitives, uint32_t primitive_count) {
     if (!ctx || (!vertices && vertex_count) || (!indices && index_count) || (!primitives && primitive_count))
@@ -390,17 +405,13 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
             device_built = true;
             ctx->bvh_builder_used = 1;
             ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-            // the host-side self-checks want the result: fetched outside the build's time like the checks themselves
-            bvh.nodes.resize(ctx->node_count); bvh.nodes_ch.resize(ctx->node_count); bvh.nodes48.resize(ctx->node_count); bvh.nodes16.resize(ctx->node_count);
-            bvh.tris.resize(ctx->tri_count);
-            HIP_TRY(ctx, hipMemcpy(bvh.nodes.data(), ctx->d_nodes, sizeof(BvhNode) * ctx->node_count, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bvh.nodes_ch.data(), ctx->d_nodes_ch, sizeof(BvhNodeCH) * ctx->node_count, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bvh.nodes48.data(), ctx->d_nodes48, sizeof(BvhNode48) * ctx->node_count, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bvh.nodes16.data(), ctx->d_nodes16, sizeof(BvhNode16) * ctx->node_count, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bvh.tris.data(), ctx->d_tris, sizeof(BvhTri) * ctx->tri_count, hipMemcpyDeviceToHost));
-            for (int a = 0; a < 3; ++a) bvh.centre[a] = ctx->bvh_centre[a];
-            bvh.nodes16_valid = nodes16_in_range(bvh);
-            bvh.max_depth = ctx->bvh_depth;
+            // its self-checks ran on the device (k0_check_forms_kernel); "bvh_host_checks" 1 fetches the tree and repeats them with the host's
+            // code (tests hold the two equal).  The fingerprint is computed when somebody asks for it (vhr_get_bvh_fingerprint).
+            ctx->bvh_fingerprint_valid = false;
+            if (ctx->bvh_host_checks) {
+                const int frc = fetch_device_tree(ctx, bvh);
+                if (frc != VHR_OK) return frc;
+            }
         } else {
             hipFree(ctx->d_nodes); hipFree(ctx->d_nodes16); hipFree(ctx->d_nodes_ch); hipFree(ctx->d_nodes48); hipFree(ctx->d_tris);
             ctx->d_nodes = nullptr; ctx->d_nodes16 = nullptr; ctx->d_nodes_ch = nullptr; ctx->d_nodes48 = nullptr; ctx->d_tris = nullptr;
@@ -413,12 +424,15 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
         ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     }
-    if (uint64_t(bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
+    if (uint64_t(device_built ? ctx->node_count : bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
     const auto t_build1 = std::chrono::steady_clock::now();       // K0 proper ends here; the self-checks below are timed apart
-    check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
-    ctx->nodes16_valid = bvh.nodes16_valid && ctx->bvh_form_checks[3] == 0;      // else the walkers stay on the 48-byte nodes
-    ctx->bvh_fingerprint = bvh_fingerprint(bvh);
+    if (!device_built || ctx->bvh_host_checks) {
+        check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
+        ctx->nodes16_valid = bvh.nodes16_valid && ctx->bvh_form_checks[3] == 0;      // else the walkers stay on the 48-byte nodes
+        ctx->bvh_fingerprint = bvh_fingerprint(bvh);
+        ctx->bvh_fingerprint_valid = true;
+    }
     ctx->bvh_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
     if (ctx->host_only) {
         ctx->node_count = uint32_t(bvh.nodes.size());
@@ -578,6 +592,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
         ctx->bvh_leaf_tris = value;
         return VHR_OK;
     }
+    if (!std::strcmp(key, "bvh_host_checks")) {              // applies to the next vhr_update_geometry
+        if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_host_checks must be 0 or 1");
+        ctx->bvh_host_checks = value;
+        return VHR_OK;
+    }
     if (!std::strcmp(key, "bvh_device_max_depth")) {         // applies to the next vhr_update_geometry
         if (value < 1 || value > kMaxBvhDepth) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_device_max_depth must be 1..40");
         ctx->bvh_device_max_depth = value;
@@ -710,6 +729,13 @@ int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity,
 
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!ctx->bvh_fingerprint_valid && !ctx->host_only && ctx->d_nodes && ctx->node_count) {      // a device-built tree: fetched now, hashed like the host's
+        HostBvh bvh;
+        const int frc = fetch_device_tree(ctx, bvh);
+        if (frc != VHR_OK) return frc;
+        ctx->bvh_fingerprint = bvh_fingerprint(bvh);
+        ctx->bvh_fingerprint_valid = true;
+    }
     *out = ctx->bvh_fingerprint;
     return VHR_OK;
 }

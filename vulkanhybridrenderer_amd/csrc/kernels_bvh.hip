@@ -240,6 +240,68 @@ __global__ __launch_bounds__(256) void k0_forms_kernel(const BvhNode *__restrict
     nodes48[k] = n48;
 }
 
+// The host's self-checks of the derived node forms (bvh_build.cpp check_node_forms + nodes16_in_range), on the device: every form must CONTAIN
+// the (lo, hi) boxes in exact arithmetic (doubles hold every value involved exactly).  out[0] boxes checked, out[1] centre / half-extent boxes
+// that do not contain theirs, out[2] 48-byte boxes that do not contain the centre / half-extent box (or links that differ), out[3] 32-byte
+// boxes that do not contain theirs (or links that differ), out[4] halves of the 32-byte form outside the range its walker reads (inf / NaN /
+// subnormal): the caller keeps out[3] only if out[4] == 0, like the host, which checks the 32-byte form only where it is in use.
+__device__ __forceinline__ double half_value_d(uint32_t h) {
+    const int e = int((h >> 10) & 31u), m = int(h & 1023u);
+    const double v = e == 0 ? ldexp(double(m), -24) : (e == 31 ? (m ? __builtin_nan("") : __builtin_inf()) : ldexp(double(1024 + m), e - 25));
+    return (h & 0x8000u) ? -v : v;
+}
+__global__ __launch_bounds__(256) void k0_check_forms_kernel(const BvhNode *__restrict__ nodes, const BvhNodeCH *__restrict__ nodes_ch, const BvhNode48 *__restrict__ nodes48,
+                                                             const BvhNode16 *__restrict__ nodes16, uint32_t count, float cx, float cy, float cz,
+                                                             unsigned long long *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    uint32_t bad[5] = { 0u, 0u, 0u, 0u, 0u };
+    if (k < count) {
+        const BvhNode nd = nodes[k];
+        const BvhNodeCH ch = nodes_ch[k];
+        const BvhNode48 n48 = nodes48[k];
+        const BvhNode16 n16 = nodes16[k];
+        const double centre[3] = { double(cx), double(cy), double(cz) };
+        auto upper = [](uint32_t w16) { return double(__uint_as_float(w16 << 16)); };
+        const double h48[6] = { upper(n48.hp[0] >> 16), upper(n48.hp[0] & 0xffffu), upper(n48.hp[1] >> 16), upper(n48.hp[1] & 0xffffu), upper(n48.hp[2] >> 16), upper(n48.hp[2] & 0xffffu) };
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t ec = (n16.c[i] >> 10) & 31u, eh = (n16.h[i] >> 10) & 31u;
+            if (ec == 31u || (ec == 0u && n16.c[i] != 0) || eh == 31u || eh == 0u) ++bad[4];
+        }
+        for (int which = 0; which < 2; ++which) {
+            const float *box = which == 0 ? nd.box0 : nd.box1;
+            const float *hh = which == 0 ? ch.h0 : ch.h1;
+            ++bad[0];
+            for (int a = 0; a < 3; ++a) {
+                const double lo = box[2 * a], hi = box[2 * a + 1];
+                const double c = (a == 0 ? ch.cx : a == 1 ? ch.cy : ch.cz)[which], h = hh[a];
+                const double c48 = (a == 0 ? n48.cx : a == 1 ? n48.cy : n48.cz)[which], hw = h48[3 * which + a];
+                const uint32_t cb = n16.c[2 * a + which], hb = n16.h[2 * a + which];
+                const double c16 = centre[a] + half_value_d(cb), h16 = half_value_d(hb);
+                const bool normal16 = (cb == 0u || (((cb >> 10) & 31u) != 0u && ((cb >> 10) & 31u) != 31u)) && ((hb >> 10) & 31u) != 0u && ((hb >> 10) & 31u) != 31u;
+                if (!(lo <= hi)) {                           // an absent child: never entered in any form
+                    if (!(h < 0.0)) ++bad[1];
+                    if (!(hw < 0.0)) ++bad[2];
+                    if (!(h16 < 0.0)) ++bad[3];
+                    continue;
+                }
+                if (c - h > lo || c + h < hi) ++bad[1];
+                if (c48 != c || hw < h) ++bad[2];
+                if (!normal16 || !(c16 - h16 <= lo) || !(c16 + h16 >= hi)) ++bad[3];
+            }
+        }
+        auto as48 = [](int32_t link) { return link >= 0 ? link * int32_t(sizeof(BvhNode48)) : link; };
+        if (n48.child0 != as48(nd.child0) || n48.child1 != as48(nd.child1) || ch.child0 != nd.child0 || ch.child1 != nd.child1) ++bad[2];
+        auto as16 = [](int32_t link) { return link >= 0 ? link * int32_t(sizeof(BvhNode16)) : link; };
+        if (n16.child0 != as16(nd.child0) || n16.child1 != as16(nd.child1)) ++bad[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        uint32_t v = bad[i];
+        for (int off = 32; off > 0; off >>= 1) v += uint32_t(__shfl_xor(int(v), off));
+        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&out[i], (unsigned long long)v);
+    }
+}
+
 // bounds of all child boxes (the scene centre of the half-precision form): one reduction over the nodes
 __global__ __launch_bounds__(256) void k0_node_bounds_kernel(const BvhNode *__restrict__ nodes, uint32_t count, uint32_t *__restrict__ bounds) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
@@ -863,9 +925,23 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
     }
     hipLaunchKernelGGL(k0_forms_kernel, grid(n_inner), block, 0, s, ctx->d_nodes, n_inner, ctx->bvh_centre[0], ctx->bvh_centre[1], ctx->bvh_centre[2], ctx->d_nodes_ch,
                        ctx->d_nodes48, ctx->d_nodes16);
+    {   // the self-checks of the node forms, where the nodes are (the host builder's tree is checked on the host)
+        unsigned long long *d_checks;
+        K0_TRY(tmp.alloc(&d_checks, 5));
+        K0_TRY(hipMemsetAsync(d_checks, 0, 5 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k0_check_forms_kernel, grid(n_inner), block, 0, s, ctx->d_nodes, ctx->d_nodes_ch, ctx->d_nodes48, ctx->d_nodes16, n_inner,
+                           ctx->bvh_centre[0], ctx->bvh_centre[1], ctx->bvh_centre[2], d_checks);
+        unsigned long long h_checks[5];
+        K0_TRY(hipMemcpyAsync(h_checks, d_checks, sizeof(h_checks), hipMemcpyDeviceToHost, s));
+        K0_TRY(hipStreamSynchronize(s));
+        const bool in_range = h_checks[4] == 0ull && size_t(n_inner) * sizeof(BvhNode16) < (size_t(1) << 31);
+        for (int i = 0; i < 3; ++i) ctx->bvh_form_checks[i] = h_checks[i];
+        ctx->bvh_form_checks[3] = in_range ? h_checks[3] : 0ull;
+        ctx->nodes16_valid = in_range && h_checks[3] == 0ull;      // else the walkers stay on the 48-byte nodes
+    }
     K0_TRY(hipStreamSynchronize(s));
     K0_TRY(hipGetLastError());
-    lap("layout + node forms");
+    lap("layout + node forms + self-checks");
     ctx->node_count = n_inner;
     ctx->tri_count = n;
     ctx->bvh_depth = h_depth;

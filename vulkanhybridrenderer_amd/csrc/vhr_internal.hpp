@@ -350,6 +350,8 @@ struct vhr_context {
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
     vhr::BvhNode48 *d_nodes48 = nullptr;
     uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
+    bool bvh_fingerprint_valid = false;             // a device-built tree is hashed when somebody asks (it would have to be fetched first)
+    int bvh_host_checks = 0;                        // "bvh_host_checks" 1: a device-built tree is fetched and the host's self-checks repeated on it
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
     float bvh_centre[3] = { 0, 0, 0 };
     bool nodes16_valid = false;      // the 32-byte half-precision nodes exist for this tree (extent within the half range) and passed the containment check
