@@ -79,3 +79,45 @@ def test_ranks_stop_the_timed_region_together(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         a, b = out.read_text().split()
         assert a == b and int(a) >= 1
+
+
+def test_counter_files_are_quoted_only_for_the_library_and_workload_they_were_collected_on(tmp_path, monkeypatch):
+    """bench.load_pmc: profiles/pmc_<workload>.json is quoted when its fingerprint equals the loaded library's and its
+    workload is the one being measured at N = 1; a stale fingerprint, another workload or N > 1 give (None, the reason)."""
+    import argparse
+    import bench
+    args = argparse.Namespace(gpus=1, gltf=None, scene="sponza_proc", width=1920, height=1080, ao_spp=2, reflections=False, refl_bounces=0)
+    key = bench.workload_key(args)
+    assert key == "sponza_proc_1920x1080_ao2_refl0"
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / f"pmc_{key}.json").write_text(json.dumps({"fingerprint": "abc", "workload": key, "svgf_atrous_mean_traffic_bytes_per_launch": 1.0}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    d, why = bench.load_pmc(args, "abc")
+    assert d is not None and why is None and d["workload"] == key
+    d, why = bench.load_pmc(args, "def")
+    assert d is None and "stale" in why and "abc" in why and "def" in why
+    args.ao_spp = 4
+    d, why = bench.load_pmc(args, "abc")
+    assert d is None and "no profiles/pmc_sponza_proc_1920x1080_ao4_refl0.json" in why
+    args.ao_spp, args.gpus = 2, 2
+    d, why = bench.load_pmc(args, "abc")
+    assert d is None and "N > 1" in why
+
+
+def test_committed_counter_files_name_their_workload_and_one_library():
+    """The counter files under profiles/ (one per BASELINE configuration measured on one GPU) carry their workload key in the file name
+    and inside, the fields bench.py reads, and ONE library fingerprint between them (they are collected together, on the round's
+    final library; bench.py refuses them on any other)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "pmc_*.json")))
+    assert len(files) >= 4
+    prints = set()
+    for f in files:
+        d = json.load(open(f))
+        assert os.path.basename(f) == f"pmc_{d['workload']}.json"
+        assert d["svgf_atrous_mean_traffic_bytes_per_launch"] > 0 and d["svgf_atrous_valu_insts_per_launch"] > 0
+        ta = d["raygen_ta"]
+        assert "raygen_queue_kernel" in ta["kernel"] and 0.0 < ta["ta_busy_frac"] < 1.0 and 10.0 < ta["ta_cycles_per_load_instruction"] < 64.0
+        prints.add(d["fingerprint"])
+    assert len(prints) == 1
