@@ -217,22 +217,28 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
         loop.finish_pending_exchange()
         torch.cuda.synchronize()
         x0, x1, y0, y1 = loop.owned_rect()
-        mine = alias_tensor(loop.ctx.transient_info(lib.DENOISED))[y0:y1, x0:x1].contiguous().view(torch.int16)
-        mine = mine.cpu() if cpu else mine
+        def tile_of(ctx_, image):
+            t = alias_tensor(ctx_.transient_info(image)).view(torch.int16)
+            return t.cpu() if cpu else t
+        mine = tile_of(loop.ctx, lib.DENOISED)[y0:y1, x0:x1].contiguous()
+        mine_refl = tile_of(loop.ctx, lib.REFLECTIONS)[y0:y1, x0:x1].contiguous() if _bounces(args) else None      # (not denoised: the mirror ray's own launch)
+        if mine_refl is not None:
+            mine = torch.cat([mine, mine_refl], dim=-1).contiguous()           # one message per rank: denoised | reflections
         sizes = [None] * world
         dist.all_gather_object(sizes, (x0, x1, y0, y1))
         if rank == 0:
             ref.frame(i)
             torch.cuda.synchronize()
-            full = alias_tensor(ref.ctx.transient_info(lib.DENOISED)).view(torch.int16)
-            full = full.cpu() if cpu else full
+            full = tile_of(ref.ctx, lib.DENOISED)
+            if mine_refl is not None:
+                full = torch.cat([full, tile_of(ref.ctx, lib.REFLECTIONS)], dim=-1)
             ok &= bool(torch.equal(mine, full[y0:y1, x0:x1]))
             gathered = loop.gathered_frame()                              # C2: the frame assembled on rank 0 (tiling.StripGather / vhr_comm_*)
             if gathered is not None:
-                ok &= bool(torch.equal(gathered.view(torch.int16).cpu(), full.cpu()))
+                ok &= bool(torch.equal(gathered.view(torch.int16).cpu(), full[..., :4].cpu()))
             for r in range(1, world):
                 a0, a1, b0, b1 = sizes[r]
-                buf = torch.empty((b1 - b0, a1 - a0, 4), dtype=torch.int16, device=mine.device)
+                buf = torch.empty((b1 - b0, a1 - a0, full.shape[-1]), dtype=torch.int16, device=mine.device)
                 dist.recv(buf, src=r)
                 ok &= bool(torch.equal(buf, full[b0:b1, a0:a1]))
         else:

@@ -18,9 +18,9 @@
  *     vhr_synchronize.  A caller that reads that dispatch's storage image itself on the context's stream must call vhr_synchronize first
  *     or set the option to 0 (every dispatch in recorded order on the one stream).
  *   - "reflection_async" (default 1): the mirror ray's launch runs on a second library-owned stream behind the shadow / AO launch, beside the
- *     SVGF pass; the context's stream waits for it before a pass epilogue, before the frame's next external pass, at the end of
- *     vhr_graph_execute (so the sentence above holds for the Reflections image too), before image uploads / downloads / vhr_get_*_image and
- *     in vhr_synchronize.
+ *     SVGF pass; the context's stream waits for it before a pass epilogue (not with value 2), before the frame's next external pass, at the
+ *     end of vhr_graph_execute (so the sentence above holds for the Reflections image too), before image uploads, before downloads of and
+ *     vhr_get_transient_image on the Reflections image, and in vhr_synchronize.
  *   - "frames_in_flight" 2 / 3 (opt-in): the front of a frame (up to its last ray-tracing pass) runs on a second stream; vhr_get_current_stream
  *     tells an external pass which stream to enqueue on.
  * Pass time stamps ("pass_timestamps", vhr_graph_gather_performance_statistics) cover what the CONTEXT'S stream executes between a pass's
@@ -436,7 +436,9 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                        on a stream of the library's own behind the shadow / AO launch, beside the SVGF pass; the context's stream waits for it
  *                        before the frame's next external pass, at the end of vhr_graph_execute and wherever the library waits or hands an
  *                        image out.  Frame with the mirror ray -2 % (sponza_proc) / -6 % (bistro_proc); "Raytrace Pass" then times the
- *                        shadow / AO launch alone and the SVGF pass's time includes what it shares with the mirror ray.  0 = in the pass, in order
+ *                        shadow / AO launch alone and the SVGF pass's time includes what it shares with the mirror ray.  0 = in the pass, in order;
+ *                        2 = as 1, and pass epilogues (vhr_graph_set_pass_epilogue) do not wait for it: for owners whose hooks touch neither the
+ *                        Reflections image nor the G-buffer (the multi-GPU harness: its hooks exchange visibility and SVGF history)
  *   "fuse_blits"         1 (default) = a compute pass records its dispatches and blits and issues them when its callback returns; a same-extent
  *                        blit whose source is the output (or the normals input) of a recorded a-trous dispatch becomes a second store of that
  *                        launch instead of a copy kernel (all three blits of hybrid_render_path.cpp:310-325); 0 = every blit is a copy

@@ -181,7 +181,9 @@ def test_bench_launches_its_own_ranks_and_labels_a_shared_device_truthfully():
     if torch.cuda.device_count() < 2:
         r, line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
         assert r.returncode == 2 and "error" in line and line["n_gpus"] == 2 and line["value"] is None
-    r, line = _bench(["--gpus", "2", "--share-device", "--width", "640", "--height", "360", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
+    # (with the mirror ray: its launch runs beside the SVGF pass and the harness's pass epilogues do not wait for it, "reflection_async" 2;
+    # the verification compares the Reflections tiles too)
+    r, line = _bench(["--gpus", "2", "--share-device", "--reflections", "--width", "640", "--height", "360", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
                       "--no-cpu-baseline", "--verify-frames", "2"])
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert line["n_gpus"] == 1 and line["ranks"] == 2

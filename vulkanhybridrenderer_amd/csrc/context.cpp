@@ -764,14 +764,14 @@ int vhr_get_transient_image(vhr_context *ctx, const char *name, vhr_image_info *
     if (!ctx || !name || !out) return VHR_ERROR_INVALID_ARGUMENT;
     auto it = ctx->images.find(name);
     if (it == ctx->images.end()) return ctx->fail(VHR_ERROR_NOT_FOUND, std::string("no transient image named '") + name + "'");
-    if (!ctx->host_only) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }      // the caller is about to use the pointer on the context's stream
+    // (the caller is about to use the pointer on the context's stream: the mirror ray's pending launch writes this image)
+    if (!ctx->host_only && it->second.ptr == ctx->refl_writes) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }
     return image_info(ctx, it->second, out);
 }
 
 int vhr_get_storage_image(vhr_context *ctx, int32_t id, vhr_image_info *out) {
     if (!ctx || !out || id < 0 || uint32_t(id) >= vhr_context::kMaxGlobalResources || !ctx->storage_images[id].used)
         return ctx ? ctx->fail(VHR_ERROR_NOT_FOUND, "no such storage image") : VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->host_only) { const int jr2 = ctx->join_refl(); if (jr2 != VHR_OK) return jr2; }
     if (!ctx->host_only) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // the caller is about to use the pointer on the context's stream
     return image_info(ctx, ctx->storage_images[id], out);
 }
@@ -782,7 +782,7 @@ static int copy_image(vhr_context *ctx, const Image &im, void *host, uint64_t by
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->recorded.empty()) { const int rc = vhr::flush_recorded(ctx); if (rc != VHR_OK) return rc; }    // called from inside a compute pass
     if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
-    { const int jr2 = ctx->join_refl(); if (jr2 != VHR_OK) return jr2; }
+    if (to_device || im.ptr == ctx->refl_writes) { const int jr2 = ctx->join_refl(); if (jr2 != VHR_OK) return jr2; }      // (an upload may rewrite what the mirror ray reads)
     if (storage || to_device) { const int jrc = ctx->join_side(); if (jrc != VHR_OK) return jrc; }      // (a side-stream dispatch reads storage images and the pass's published copies)
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(im.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, im.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));

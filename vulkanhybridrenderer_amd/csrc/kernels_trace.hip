@@ -1766,6 +1766,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const bool rec = hipEventRecord(ctx->refl_done, ctx->refl_stream) == hipSuccess;
             ctx->stream = main_stream;
             ctx->refl_pending = true;
+            ctx->refl_writes = m.reflections;
             if (!rec) return ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(mirror-ray stream) failed");
         }
     }

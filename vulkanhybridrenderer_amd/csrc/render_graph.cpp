@@ -391,7 +391,9 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
         // vhr_get_current_stream tells the callback.
         ctx->stream = (split && pi + 1 < ctx->front_passes) ? ctx->front_stream : back;
         if (p.epilogue_cb && ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
-        if (p.epilogue_cb) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }      // its owner expects the pass's images, the mirror ray's among them
+        // its owner expects the pass's images, the mirror ray's among them ("reflection_async" 2: the owners of epilogues promise not to touch
+        // the Reflections image or the G-buffer -- the multi-GPU harness, whose hooks exchange visibility and SVGF history only)
+        if (p.epilogue_cb && ctx->options[vhr::kOptReflectionAsync] != 2) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }
         if (p.epilogue_cb) p.epilogue_cb(p.epilogue_user, ctx);
         ctx->stream = back;
         if (!ctx->error.empty()) return VHR_ERROR_GRAPH;                       // a callback's call failed: surface it

@@ -276,7 +276,7 @@ struct RayStats {
     X(kOptFuseBlits, "fuse_blits", 1, 0, 1)                     /* a pass's blits as stores of its a-trous launches */                   \
     X(kOptSvgfElideUnread, "svgf_elide_unread", 0, 0, 1)        /* do not launch an a-trous dispatch nothing reads (the reference's fifth) */ \
     X(kOptSvgfAsyncUnread, "svgf_async_unread", 1, 0, 2)        /* ... or issue it on the side stream: 1 = where it pays, 2 = always */  \
-    X(kOptReflectionAsync, "reflection_async", 1, 0, 1)         /* the mirror ray's launch on a stream of its own, beside the SVGF pass */  \
+    X(kOptReflectionAsync, "reflection_async", 1, 0, 2)         /* the mirror ray's launch on a stream of its own, beside the SVGF pass */  \
     X(kOptFuseTemporal, "fuse_temporal", 0, 0, 1)               /* svgf.comp in the ray-tracing kernel's tile epilogues */              \
     X(kOptFramesInFlight, "frames_in_flight", 1, 1, 3)          /* read by vhr_graph_build */                                            \
     /* screen tiles / row strips (one process per GPU) */                                                                               \
@@ -408,6 +408,7 @@ struct vhr_context {
     hipStream_t refl_stream = nullptr;
     hipEvent_t refl_ready = nullptr, refl_done = nullptr;
     bool refl_pending = false;
+    const void *refl_writes = nullptr; // the image the pending launch writes (the one whose readers must wait)
     int join_refl();
 
     // statistics

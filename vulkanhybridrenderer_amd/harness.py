@@ -86,6 +86,8 @@ class HybridFrameLoop:
             self.ctx.set_option("trace_overlap", 1 if self.trace_overlap else 0)
             # the path's own host driver runs the doubling a-trous schedule, so later iterations may compute fewer overlap rows
             self.ctx.set_option("strip_shrink_overlap", 1)
+            # the pass epilogues below exchange visibility and SVGF history only: the mirror ray's launch need not be waited for there
+            self.ctx.set_option("reflection_async", 2)
             if self.comm is None:
                 self.exchanges = tiling.StripExchanges(dist, self.plan, trace_overlap=self.trace_overlap, denoise=denoise, gather=self._gather_requested,
                                                        allow_degraded=self._allow_degraded)
