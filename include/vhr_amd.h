@@ -543,6 +543,11 @@ int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]);
 /* A 64-bit hash of the last build's nodes and leaf triangles in their final order: two builds of the same input must agree whatever
  * "bvh_build_threads" was. */
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out);
+/* A 64-bit hash of the TREE rather than of its arrays: per inner node the bits of its two child boxes and its children's hashes, per leaf
+ * the flat ids of its triangles in ascending order -- independent of the numbering of the nodes, of the order of the leaves in memory and
+ * of the order of the triangles inside a leaf.  The host's and the device's build of a scene agree on it ("bvh_builder" 0 / 1: the same
+ * algorithm, the same tree; the reference's BLAS / TLAS are the driver's, resource_manager.cpp:593-801). */
+int vhr_get_bvh_tree_fingerprint(vhr_context *ctx, uint64_t *out);
 
 #ifdef __cplusplus
 }

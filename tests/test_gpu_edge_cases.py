@@ -237,8 +237,11 @@ def test_non_finite_geometry_is_rejected():
 
 def test_every_builder_makes_the_same_tree():
     """The host builder's thread pool ("bvh_builder" 0 with "bvh_build_threads" 1, 3 and the default) and the device's builder (the
-    default): the same algorithm, so the same node / triangle counts and depth, and the same image bit for bit, on a scene large enough
-    to be split among threads and to run the device builder's level passes (sponza_proc, 257 k triangles)."""
+    default): the same algorithm, so the same TREE -- vhr_get_bvh_tree_fingerprint hashes every inner node's child boxes (their bits) and
+    every leaf's set of triangles, whatever the order of nodes, leaves and triangles in memory --, the same counts and depth, and the same
+    image bit for bit, on a scene large enough to be split among threads and to run the device builder's level passes (sponza_proc, 257 k
+    triangles).  The array hash (vhr_get_bvh_fingerprint) is equal among the host's thread counts and differs for the device's tree: its
+    leaves lie in depth-first order, the host's by treelets."""
     scene = scenes.sponza_proc()
     W, H = 256, 144
     tp = abi.default_trace_params(reflections=False)
@@ -258,13 +261,30 @@ def test_every_builder_makes_the_same_tree():
             c.update_per_frame_ubo(0, pfd)
             c.execute(0, 0)
             c.synchronize()
-            got = (c.bvh_statistics(), c.download(lib.RAYTRACED))
+            got = (c.bvh_statistics(), c.download(lib.RAYTRACED), c.bvh_tree_fingerprint(), c.bvh_fingerprint())
             path.destroy()
         finally:
             c.close()
         if ref is None:
             ref = got
-        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), threads
+        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[2] == ref[2] and got[2] != 0, threads
+        assert (got[3] == ref[3]) == (threads is not None), threads
+
+
+def test_host_and_device_builders_make_the_same_tree_of_the_large_scene():
+    """bistro_proc at half its size (0.7 M triangles, 21 levels of the device builder's level passes): one tree fingerprint from both builders."""
+    scene = scenes.bistro_proc(0.5)
+    prints = []
+    c = lib.Context(64, 64)
+    try:
+        for builder in (1, 0):
+            c.set_option("bvh_builder", builder)
+            c.upload_scene(scene)
+            assert c.bvh_builder_used() == builder
+            prints.append((c.bvh_tree_fingerprint(), c.bvh_statistics()["nodes"], c.bvh_statistics()["max_depth"]))
+    finally:
+        c.close()
+    assert prints[0] == prints[1] and prints[0][0] != 0
 
 
 def test_every_node_form_contains_its_box():

@@ -644,6 +644,34 @@ uint64_t bvh_fingerprint(const HostBvh &bvh) {
     return h;
 }
 
+// A hash of the TREE rather than of its arrays: per inner node the bits of its two child boxes and its children's hashes (left, right),
+// per leaf the flat ids of its triangles in ascending order -- whatever the numbering of the nodes, the order of the leaves in memory and
+// the order of the triangles inside a leaf.  Two builders that make the same tree agree on it (the host's and the device's: tests).
+// Needs parents before children in `nodes` (both builders number breadth first).
+uint64_t bvh_tree_fingerprint(const HostBvh &bvh) {
+    auto mix = [](uint64_t h, uint64_t w) { h = (h ^ w) * 1099511628211ull; return h ^ (h >> 29); };
+    auto leaf_hash = [&](int32_t link) {
+        const uint32_t v = ~uint32_t(link), first = v >> 2, count = (v & 3u) + 1u;
+        uint32_t ids[4] = { 0, 0, 0, 0 };
+        for (uint32_t i = 0; i < count; ++i) ids[i] = bvh.tris[first + i].flat;
+        std::sort(ids, ids + count);
+        uint64_t h = mix(14695981039346656037ull, count);
+        for (uint32_t i = 0; i < count; ++i) h = mix(h, ids[i]);
+        return h;
+    };
+    std::vector<uint64_t> sig(bvh.nodes.size(), 0);
+    for (size_t k = bvh.nodes.size(); k-- > 0;) {
+        const BvhNode &nd = bvh.nodes[k];
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < 6; ++i) { uint32_t b0, b1; std::memcpy(&b0, &nd.box0[i], 4); std::memcpy(&b1, &nd.box1[i], 4); h = mix(h, (uint64_t(b0) << 32) | b1); }
+        const bool absent1 = !(nd.box1[0] <= nd.box1[1]);                   // (a one-leaf scene: child 1 is a copy of child 0 behind an empty box)
+        h = mix(h, nd.child0 >= 0 ? sig[size_t(nd.child0)] : leaf_hash(nd.child0));
+        h = mix(h, absent1 ? 0ull : (nd.child1 >= 0 ? sig[size_t(nd.child1)] : leaf_hash(nd.child1)));
+        sig[k] = h;
+    }
+    return sig.empty() ? 0ull : sig[0];
+}
+
 // Every derived node form must CONTAIN the (lo, hi) boxes of `nodes` in exact arithmetic -- that is all the walkers' bit-identity
 // rests on (boxes only cull).  out: boxes checked, centre / half-extent boxes that do not contain theirs, 48-byte boxes that do not
 // contain the centre / half-extent box, half-precision 32-byte (compact) boxes that do not contain theirs.  (vhr_get_bvh_form_checks)

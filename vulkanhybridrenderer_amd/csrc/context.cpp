@@ -431,6 +431,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         check_node_forms(bvh, ctx->bvh_form_checks, ctx->bvh_build_threads);
         ctx->nodes16_valid = bvh.nodes16_valid && ctx->bvh_form_checks[3] == 0;      // else the walkers stay on the 48-byte nodes
         ctx->bvh_fingerprint = bvh_fingerprint(bvh);
+        ctx->bvh_tree_fingerprint = bvh_tree_fingerprint(bvh);
         ctx->bvh_fingerprint_valid = true;
     }
     ctx->bvh_check_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build1).count();
@@ -727,16 +728,30 @@ int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity,
     return VHR_OK;
 }
 
+static int fingerprints_of_device_tree(vhr_context *ctx) {      // a device-built tree: fetched when somebody asks, hashed like the host's
+    if (ctx->bvh_fingerprint_valid || ctx->host_only || !ctx->d_nodes || !ctx->node_count) return VHR_OK;
+    HostBvh bvh;
+    const int frc = fetch_device_tree(ctx, bvh);
+    if (frc != VHR_OK) return frc;
+    ctx->bvh_fingerprint = bvh_fingerprint(bvh);
+    ctx->bvh_tree_fingerprint = bvh_tree_fingerprint(bvh);
+    ctx->bvh_fingerprint_valid = true;
+    return VHR_OK;
+}
+
 int vhr_get_bvh_fingerprint(vhr_context *ctx, uint64_t *out) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
-    if (!ctx->bvh_fingerprint_valid && !ctx->host_only && ctx->d_nodes && ctx->node_count) {      // a device-built tree: fetched now, hashed like the host's
-        HostBvh bvh;
-        const int frc = fetch_device_tree(ctx, bvh);
-        if (frc != VHR_OK) return frc;
-        ctx->bvh_fingerprint = bvh_fingerprint(bvh);
-        ctx->bvh_fingerprint_valid = true;
-    }
+    const int rc = fingerprints_of_device_tree(ctx);
+    if (rc != VHR_OK) return rc;
     *out = ctx->bvh_fingerprint;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_tree_fingerprint(vhr_context *ctx, uint64_t *out) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    const int rc = fingerprints_of_device_tree(ctx);
+    if (rc != VHR_OK) return rc;
+    *out = ctx->bvh_tree_fingerprint;
     return VHR_OK;
 }
 

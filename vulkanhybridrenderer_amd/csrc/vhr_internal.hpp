@@ -156,6 +156,7 @@ struct HostBvh {
 void check_node_forms(const HostBvh &bvh, uint64_t out[4], int threads = 0);
 bool nodes16_in_range(const HostBvh &bvh);      // no inf / NaN / subnormal half in the 32-byte form (a device-built tree: the host decides)
 uint64_t bvh_fingerprint(const HostBvh &bvh);
+uint64_t bvh_tree_fingerprint(const HostBvh &bvh);      // of the tree, not of its arrays: equal for the host's and the device's build of a scene
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
                uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
 // the device-side builder (csrc/kernels_bvh.hip, option "bvh_builder" 1): from ctx->d_vertices / d_indices / d_primitives into the
@@ -350,6 +351,7 @@ struct vhr_context {
     vhr::BvhNodeCH *d_nodes_ch = nullptr;
     vhr::BvhNode48 *d_nodes48 = nullptr;
     uint64_t bvh_fingerprint = 0;                   // bvh_fingerprint() of the last build (vhr_get_bvh_fingerprint)
+    uint64_t bvh_tree_fingerprint = 0;              // bvh_tree_fingerprint() of the last build (vhr_get_bvh_tree_fingerprint)
     bool bvh_fingerprint_valid = false;             // a device-built tree is hashed when somebody asks (it would have to be fetched first)
     int bvh_host_checks = 0;                        // "bvh_host_checks" 1: a device-built tree is fetched and the host's self-checks repeated on it
     uint64_t bvh_form_checks[4] = { 0, 0, 0, 0 };   // check_node_forms of the last build (vhr_get_bvh_form_checks)
