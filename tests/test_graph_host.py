@@ -182,7 +182,8 @@ def test_host_side_bvh_build_forms_and_thread_independence(vhr):
                 st = c.bvh_statistics()
                 assert boxes == 2 * st["nodes"] and (ch_bad, n48_bad, n16_bad) == (0, 0, 0), (scene.name, threads)
                 assert st["triangles"] == scene.triangle_count
-                stats.append((st["nodes"], st["triangles"], st["max_depth"], c.bvh_fingerprint()))
+                stats.append((st["nodes"], st["triangles"], st["max_depth"], c.bvh_fingerprint(), c.bvh_tree_fingerprint()))
+                assert stats[-1][4] not in (0, stats[-1][3])          # (a hash of the tree, not of its arrays)
             finally:
                 c.close()
         assert all(st == stats[0] for st in stats), (scene.name, stats)
