@@ -70,9 +70,11 @@ def test_random_triangle_soup_matches_oracle_bvh_and_brute_force(oracle, seed, n
         # the host's builder ("bvh_builder" 0; the frames above ran on the device-built tree, the default): the same triangles, the same
         # images; both pass the host's containment check of the node forms
         assert g.ctx.bvh_builder_used() == 1
+        tree_device = g.ctx.bvh_tree_fingerprint()
         g.ctx.set_option("bvh_builder", 0)
         g.ctx.upload_scene(scene)
         assert g.ctx.bvh_builder_used() == 0 and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+        assert g.ctx.bvh_tree_fingerprint() == tree_device != 0, "the host's and the device's builder made different trees"
         for i, fr in enumerate(frames):
             g.frame(fr["pfd"], fr["gbuf"])
             assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"frame {i}: visibility differs on the host-built tree"
@@ -139,13 +141,16 @@ def test_device_builder_corner_cases(oracle, copies, n_extra):
     frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
     g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp)
     try:
+        trees = []
         for builder in (1, 0):
             g.ctx.set_option("bvh_builder", builder)
             g.ctx.upload_scene(scene)
             assert g.ctx.bvh_builder_used() == builder and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+            trees.append(g.ctx.bvh_tree_fingerprint())
             for i, fr in enumerate(frames):
                 g.frame(fr["pfd"], fr["gbuf"])
                 assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"builder {builder}, frame {i}"
+        assert trees[0] == trees[1] != 0                   # (coincident triangles too: both builders halve them by count, in flat order)
     finally:
         g.close()
 
