@@ -467,7 +467,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *                        event pairs on the dispatch packets (16 us per frame; the only form with "frames_in_flight" > 1); 0 = off
  *   "kernel_timing_stride" n >= 1: with vhr_set_kernel_timing on, only every n-th launch of a kind carries its event pair (a timed dispatch
  *                        costs ~6 us that the next kernel waits for)
- *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 3); "bvh_builder" 1 = binned SAH on the
+ *  Not in the table (they configure the next vhr_update_geometry): "bvh_leaf_triangles" 1..4 (default 2); "bvh_builder" 1 = binned SAH on the
  *  device (default), where the reference builds its BLAS / TLAS (resource_manager.cpp:650,692,792), 0 = the same algorithm on the host
  *  (csrc/bvh_build.cpp: 8 / 28x slower to build on the two test scenes, the same tree up to the order of leaves in memory; images
  *  bit-identical; also what a host-only context and a device build deeper than the walkers' stacks fall back to -- "bvh_device_max_depth"

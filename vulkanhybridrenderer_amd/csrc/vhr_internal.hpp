@@ -91,7 +91,8 @@ struct BvhTri {
 static_assert(sizeof(BvhTri) == 48, "BvhTri");
 
 constexpr int kMaxLeafTris = 4;      // encoding limit of a leaf link
-constexpr int kDefaultLeafTris = 3;  // r2, on the 48-byte-node kernel: 3 / 4 -> sponza_proc 351 / 372 us, bistro_proc 511 / 511 us (scratch/ab_leaf.py)
+constexpr int kDefaultLeafTris = 2;  // r4 (scratch/ab_leaf.py, any-hit launch with 1 / 2 / 3 / 4): sponza_proc 359 / 322 / 325 / 341 us, bistro_proc 467 / 420 / 429 / 448;
+                                     // the mirror-ray launch is indifferent between 2 and 3 (244 / 242, 429 / 433); 5.5 % more nodes than with 3
 // Depth bound of any tree the walkers are given == the capacity of their traversal stacks (sponza_proc 22, bistro_proc 28; a deeper
 // tree from the device builder sends the build to the host builder, whose forced median splits keep any scene below the bound).
 constexpr int kMaxBvhDepth = 40;
