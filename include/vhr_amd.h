@@ -412,6 +412,7 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *   "lds_stack_levels"   traversal-stack entries per lane kept in LDS, deeper entries spill to scratch (default 8)
  *   "raygen_early_exit"  n/16: the inner-node loop is left once the walking lanes have dropped to that fraction of those that entered it
  *                        (0 = only when all are done; default 6 -- with "raygen_steal" filling the lanes, leaving a little earlier pays: r4)
+ *   "reflection_early_exit" the same fraction for the mirror ray's (closest-hit) walk (default 8)
  *   "raygen_waves_per_block" 1, 2 or 4 tiles (= waves) per workgroup (default 2)
  *   "compact_nodes"      1 (default) = the any-hit queue kernel walks 32-byte nodes: both child boxes as centre and half extent in IEEE halves
  *                        relative to the scene centre, widened until they contain the fp32 boxes in exact arithmetic (vhr_get_bvh_form_checks),

@@ -269,6 +269,7 @@ struct RayStats {
     X(kOptWavesPerBlock, "raygen_waves_per_block", 2, 1, 4)     /* tiles (= waves) per workgroup of raygen_queue_kernel: 1, 2 or 4 */    \
     X(kOptCompactNodes, "compact_nodes", 1, 0, 1)               /* the 32-byte half-precision nodes where the tree has them */          \
     X(kOptEarlyExit, "raygen_early_exit", 6, 0, 15)             /* sixteenths of the walkers that entered below which the node loop is left */ \
+    X(kOptReflectionEarlyExit, "reflection_early_exit", 8, 0, 15) /* the same for the mirror ray's walk (r4: 6 -> 8 = bistro_proc's launch -4 %, sponza_proc's equal) */ \
     X(kOptRaygenTileRows, "raygen_tile_rows", 0, 0, 8)          /* rows of a wave's tile; 0 = auto (6 for launches that fill < 70 % of the wave slots) */ \
     X(kOptRaygenCostOrder, "raygen_cost_order", 1, 0, 2)        /* start the longest-lived tiles first: 1 = launches of >= 2 048 workgroups, 2 = any */ \
     X(kOptRaygenSteal, "raygen_steal", 8, 0, 63)                /* queue dry and >= n lanes idle: idle lanes take pending subtrees off busy lanes' stacks; 0 = never */ \
