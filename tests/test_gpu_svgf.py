@@ -396,3 +396,42 @@ def test_mirror_ray_on_its_own_stream_changes_no_image():
     for s, (a, b) in enumerate(zip(outs[0], outs[1])):
         for k, (x, y) in enumerate(zip(a, b)):
             assert np.array_equal(x, y), f"snapshot {s}: image {k} differs with the mirror ray on its own stream"
+
+
+def test_a_compute_pass_that_reads_the_mirror_rays_image_waits_for_its_launch():
+    """"reflection_async": the mirror ray's launch is still running on its own stream when the next pass is issued.  A compute pass that
+    blits the Reflections image into a storage image (a command of the caller's, not of the SVGF schedule) must wait for it: the copy equals
+    the image, frame after frame, as with every launch in order."""
+    W, H = 480, 270
+    scene = scenes.sponza_proc()
+    pfds = camera.dolly_frames(scene, W, H, 4)
+    F4, F2, D = abi.FORMAT_R16G16B16A16_SFLOAT, abi.FORMAT_R16G16_SFLOAT, abi.FORMAT_D32_SFLOAT
+    copies = {}
+    for mode in (0, 1):
+        c = lib.Context(W, H, device=0)
+        try:
+            c.upload_scene(scene)
+            c.set_option("reflection_async", mode)
+            c.set_trace_params(abi.default_trace_params(reflections=True))
+            store = {}
+            c.add_graphics_pass("G-Buffer Pass", [], [lib.transient(lib.NORMALS, F4, 1, lib.ATTACHMENT_IMAGE), lib.transient(lib.MOTION, F4, 2, lib.ATTACHMENT_IMAGE),
+                                                      lib.transient(lib.DEPTH, D, 3, lib.ATTACHMENT_IMAGE)], lambda cc: cc.standin_gbuffer(0))
+            c.add_raytracing_pass("Raytrace Pass", [lib.transient(lib.NORMALS, F4, 0), lib.transient(lib.DEPTH, D, 1, lib.SAMPLED_IMAGE)],
+                                  [lib.transient(lib.RAYTRACED, F2, 2), lib.transient(lib.REFLECTIONS, F4, 3)], lambda ec: ec.trace_rays(W, H))
+            c.add_compute_pass("Copy Pass", [lib.transient(lib.REFLECTIONS, F4, 0)], [lib.transient(lib.DENOISED, F4, 1)], [lib.ATROUS_SHADER], 24,
+                               lambda ec: ec.blit_image_transient_to_storage(lib.REFLECTIONS, store["id"]))
+            c.add_graphics_pass("Sink", [lib.transient(lib.DENOISED, F4, 0, lib.SAMPLED_IMAGE)], [lib.render_output(0)], None)
+            c.build()
+            store["id"] = c.upload_new_storage_image(W, H, F4)
+            out = []
+            for pfd in pfds:
+                c.update_per_frame_ubo(0, pfd)
+                c.execute(0, 0)
+                out.append((c.download(store["id"]), c.download(lib.REFLECTIONS)))
+            copies[mode] = out
+        finally:
+            c.close()
+    assert copies[0][-1][1][..., 3].any()
+    for f, ((copy0, img0), (copy1, img1)) in enumerate(zip(copies[0], copies[1])):
+        assert np.array_equal(copy1, img1) and np.array_equal(copy0, img0), f"frame {f}: the copy is not the image"
+        assert np.array_equal(img0, img1), f"frame {f}: the image differs with the mirror ray on its own stream"

@@ -821,6 +821,27 @@ int flush_recorded(vhr_context *ctx) {
     const bool async = ctx->options[kOptSvgfAsyncUnread] != 0 && ctx->frames_in_flight == 1;
     size_t deferred = size_t(-1);
     const void *normals_copy = nullptr, *input_copy = nullptr;
+    // "reflection_async": a recorded command that reads or writes the image the mirror ray's pending launch writes, or writes one it reads,
+    // waits for that launch (the SVGF pass's own commands do neither: they run beside it)
+    if (ctx->refl_pending) {
+        auto reads = [&](const void *p) { return p && p == ctx->refl_writes; };
+        auto writes = [&](const void *p) { return p && (p == ctx->refl_writes || p == ctx->refl_reads[0] || p == ctx->refl_reads[1]); };
+        bool touches = false;
+        for (const SvgfCmd &c : ctx->recorded) {
+            switch (c.kind) {
+                case SvgfCmd::Temporal:
+                    touches |= reads(c.t.normals) || reads(c.t.motion) || reads(c.t.prev_normals) || reads(c.t.history) || reads(c.t.raytraced) || reads(c.t.moments_in) ||
+                               writes(c.t.integrated_out) || writes(c.t.moments_out);
+                    break;
+                case SvgfCmd::Atrous:
+                    touches |= reads(c.a.normals) || reads(c.a.in) || writes(c.a.out) || writes(c.a.out2) || writes(c.a.normals_out);
+                    break;
+                default:
+                    touches |= reads(c.src_base) || writes(c.dst_base);
+            }
+        }
+        if (touches) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) { ctx->recorded.clear(); return jrc; } }
+    }
     // does command c touch what the side stream's pending dispatch reads (`side_reads`) or writes (`side_writes`)?
     auto conflicts = [&](const SvgfCmd &c) {
         auto reads = [&](const void *p) { return p && p == ctx->side_writes; };

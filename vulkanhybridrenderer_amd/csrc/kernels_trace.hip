@@ -1767,6 +1767,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             ctx->stream = main_stream;
             ctx->refl_pending = true;
             ctx->refl_writes = m.reflections;
+            ctx->refl_reads[0] = m.normals; ctx->refl_reads[1] = m.depth;
             if (!rec) return ctx->fail(VHR_ERROR_DEVICE, "hipEventRecord(mirror-ray stream) failed");
         }
     }

@@ -413,6 +413,7 @@ struct vhr_context {
     hipEvent_t refl_ready = nullptr, refl_done = nullptr;
     bool refl_pending = false;
     const void *refl_writes = nullptr; // the image the pending launch writes (the one whose readers must wait)
+    const void *refl_reads[2] = { nullptr, nullptr };      // ... and the G-buffer images it reads (whose writers must wait)
     int join_refl();
 
     // statistics
