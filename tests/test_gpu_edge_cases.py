@@ -86,7 +86,7 @@ def test_axis_parallel_light_and_rays(oracle):
     assert 0.01 < (f16(frames[1]["shadow_ao"])[..., 0] == 0).mean() < 0.95
 
 
-@pytest.mark.parametrize("ao_spp", [0, 1, 4, 16, 20])
+@pytest.mark.parametrize("ao_spp", [0, 1, 4, 16, 20, 31, 32, 64])       # (up to 31: one blocked bit per ray in the pixel's word; beyond: a count)
 def test_ao_sample_counts(oracle, ao_spp):
     """BASELINE.json configs 3 and 5 use 4 and 16 AO samples."""
     tp = abi.default_trace_params(ao_spp=ao_spp, reflections=False)

@@ -844,6 +844,10 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // without shadow rays the queue holds AO rays only and the cut is pruned to their reach (with them in the queue, letting the AO rays skip
     // the entries beyond their reach was measured: the test per entry costs sponza_proc what it saves bistro_proc, r4)
     const bool ao_only = first_kind != 0u;
+    // A pixel's visibility word holds one "blocked" bit per ray kind (what lets several lanes share a ray: "raygen_steal") while the kinds fit a
+    // word; with more than 31 AO samples it holds bit 0 for the shadow ray and, from bit 8 up, the COUNT of AO rays that escaped, and a ray is
+    // walked by the one lane that fetched it.
+    const bool kind_bits = last_kind <= 31u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of the tile's ray origins
     float ao_reach = 0.0f;                                                                   // bound of tmax * |d| over this pixel's AO rays
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         // Any hit = OR over the subtrees a ray touches, in any order and by any lane: a lane with nothing left to fetch takes the top stack entry
         // of a busy lane and walks it for the same ray (the ray's registers come over by ds_bpermute).  One entry per busy lane and trip: the
         // walkers of a long ray double from trip to trip.  A lane whose ray another lane has meanwhile found blocked stops.
-        if (steal_threshold && queue_dry && n_idle >= steal_threshold && n_idle != 64u) {         // wave-uniform
+        if (steal_threshold && kind_bits && queue_dry && n_idle >= steal_threshold && n_idle != 64u) {         // wave-uniform
             if (has && ((s_vis[pix] >> kind) & 1u)) has = false;                                  // (the idle ballot above is one trip old for such a lane: it steals next trip)
             const bool donor = has && sp > sbase && uint32_t(sbase) < stack_levels;               // rows sbase + 1 .. sp are its own; row sbase + 1 is in LDS
             const unsigned long long dmask = __ballot(donor);
@@ -1079,7 +1083,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         const bool finished = found || cur == kStackSentinel;
         if (has && finished) {
             has = false;
-            if (found) atomicOr(&s_vis[pix], 1u << kind);                                     // miss.rmiss:7 leaves 1.0 where nothing is found
+            if (kind_bits) { if (found) atomicOr(&s_vis[pix], 1u << kind); }                  // miss.rmiss:7 leaves 1.0 where nothing is found
+            else if (kind == 0) { if (found) atomicOr(&s_vis[pix], 1u); }
+            else if (!found) atomicAdd(&s_vis[pix], 256u);
         }
         if (stats) {       // wave-level trip counts of the two inner loops = the slowest lane's (for lane utilisation)
             const unsigned long long t3 = __builtin_readcyclecounter();
@@ -1101,7 +1107,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     if (covered) {
         const uint32_t vis = s_vis[lane];
         shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
-        if (a.tp.ao_spp) ao_payload = float(a.tp.ao_spp - uint32_t(__popc(vis >> 1))) / float(a.tp.ao_spp);             // rgen:55: the AO rays that escaped
+        if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (kind_bits ? a.tp.ao_spp - uint32_t(__popc(vis >> 1)) : (vis >> 8))) / float(a.tp.ao_spp);   // rgen:55: the AO rays that escaped
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
