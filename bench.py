@@ -289,7 +289,11 @@ def address_unit_block(pmc, raygen_ms):
 
 def reflection_block(ctx, loop, frame_index, sync):
     """`traversal_reflection`: the mirror-ray launch's own counters and time (reflection_queue_kernel: raygen.rgen:59-65 + reflection_hit.rchit).
-    One untimed frame with the in-kernel statistics on, eight more with an event pair on the launch."""
+    Eight frames with an event pair on the launch and "reflection_async" 0 -- the launch alone on the chip, which is what avg_launch_ms,
+    mrays_per_s, effective_traversal_gbs and l2_frac describe --, then one untimed frame with the in-kernel statistics on (the library runs a
+    statistics frame in order too).  With "reflection_async" on, the same launch's duration beside the SVGF pass is reported next to it."""
+    async_mode = ctx.get_option("reflection_async")
+    ctx.set_option("reflection_async", 0)
     ctx.set_kernel_timing(["reflection"])
     ctx.kernel_time("reflection", reset=True)
     for i in range(frame_index, frame_index + 8):
@@ -297,6 +301,7 @@ def reflection_block(ctx, loop, frame_index, sync):
     sync()
     ms, n = ctx.kernel_time("reflection")
     ctx.set_kernel_timing(False)
+    ctx.set_option("reflection_async", async_mode)
     ctx.set_ray_statistics(True)
     loop.frame(frame_index + 8)
     sync()
@@ -315,6 +320,7 @@ def reflection_block(ctx, loop, frame_index, sync):
             "refills_per_wave": round(st["refills"] / max(1, st["waves"]), 2),
             "walk_share_of_wave_lifetime": round(st["cycles_walk"] / max(1, st["cycles_total"]), 3),
             "effective_traversal_gbs": round(gbs, 1), "l2_frac": round(gbs / L2_PEAK_GBS, 4),
+            "shares_the_chip_with": None, "timed_with": "reflection_async 0 (the launch alone on the chip; the frame itself runs it beside the SVGF pass when the option is on)",
             "note": "utilisation = (node visits + triangle tests) / (64 x wave-level trips of those loops); l2_frac = effective_traversal_gbs / the L2's 34.5 TB/s "
                     "(MI355X_MICROARCH.md: the tree is cache resident, HBM is not the level it is read from)"}
 

@@ -20,7 +20,10 @@
  *   - "reflection_async" (default 1): the mirror ray's launch runs on a second library-owned stream behind the shadow / AO launch, beside the
  *     SVGF pass; the context's stream waits for it before a pass epilogue (not with value 2), before the frame's next external pass, at the
  *     end of vhr_graph_execute (so the sentence above holds for the Reflections image too), before image uploads, before downloads of and
- *     vhr_get_transient_image on the Reflections image, and in vhr_synchronize.
+ *     vhr_get_transient_image on the Reflections image, in vhr_get_current_stream (not with value 2: a caller who asks for the stream is
+ *     about to enqueue kernels of its own, which may read Reflections or rewrite the G-buffer the launch reads) and in vhr_synchronize.
+ *     With value 2 (the multi-GPU harness) a caller's own kernels that touch Reflections or the G-buffer inside a frame must call
+ *     vhr_get_transient_image on Reflections (or vhr_synchronize) first.
  *   - "frames_in_flight" 2 / 3 (opt-in): the front of a frame (up to its last ray-tracing pass) runs on a second stream; vhr_get_current_stream
  *     tells an external pass which stream to enqueue on.
  * Pass time stamps ("pass_timestamps", vhr_graph_gather_performance_statistics) cover what the CONTEXT'S stream executes between a pass's
@@ -85,7 +88,9 @@ int  vhr_synchronize(vhr_context *ctx);               /* hipStreamSynchronize on
  * vhr_create.  Inside a pass or epilogue callback it is the stream that pass is ordered on: with "frames_in_flight" > 1 the passes up to
  * the last ray-tracing pass run on a second, library-owned stream, and an external graphics pass (the G-buffer producer) MUST enqueue its
  * work there -- or make that stream wait for its own -- for the Raytrace Pass to see a complete G-buffer (render_graph.cpp:722-796 orders
- * the same hand-over with image barriers). */
+ * the same hand-over with image barriers).  The call also makes the stream wait for a held-back ray-tracing launch ("fuse_temporal") and for
+ * the mirror ray's pending launch ("reflection_async" 1): whatever the caller enqueues behind it sees the frame's images as the single-stream
+ * schedule would leave them. */
 int  vhr_get_current_stream(vhr_context *ctx, void **stream);
 const char *vhr_version(void);
 int  vhr_abi_struct_sizes(uint32_t out[8]);            /* vertex, material, primitive, light, per-frame, push constants, trace params, 0 */

@@ -5,7 +5,8 @@
 #   3. tools/other_configs.sh -> profiles/<tag>_other_configs_1gpu.json
 # Run it after the LAST change under csrc/ or include/: the counter files carry the library's source fingerprint and bench.py quotes them
 # only on that library.  On the GPU box the results land in gpurun_out/; copy them into profiles/ afterwards with `tools/finalize_round.sh <tag> collect`.
-TAG=${1:-r4}
+set -o pipefail      # a failed counter pass must stop the round: `... | tail -1` alone reports tail's status
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ "$2" = "collect" ]; then
     cp $R/gpurun_out/pmc/pmc_*.json $R/profiles/ || exit 1

@@ -9,6 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 KEY=$(python3 $R/bench.py --print-workload-key "$@") || exit 1
 OUT=$R/gpurun_out/pmc/$KEY
 rm -rf $OUT; mkdir -p $OUT
+rm -f $R/gpurun_out/pmc/pmc_$KEY.json      # a failed pass must not leave an earlier run's file for `cp gpurun_out/pmc/pmc_*.json profiles/`
 cd /tmp && export TMPDIR=/tmp
 B="--steps 8 --warmup 2 --no-cpu-baseline --no-extras --min-seconds 0 $*"
 echo "[$KEY] FETCH_SIZE calibration"; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $R/tools/calibrate_fetch.py > $OUT/cal_fetch.log 2>&1 || { echo "calibration failed"; tail -3 $OUT/cal_fetch.log; exit 1; }

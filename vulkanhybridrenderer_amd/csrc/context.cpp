@@ -295,6 +295,9 @@ const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_s
 int vhr_get_current_stream(vhr_context *ctx, void **stream) {
     if (!ctx || !stream) return VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }      // the caller is about to enqueue behind it
+    // ... and its own kernels may read the Reflections image or rewrite the G-buffer the mirror ray's pending launch reads: the stream waits for
+    // that launch here ("reflection_async" 2 = the multi-GPU hooks, which only touch SVGF images and join where they must, keep the overlap)
+    if (!ctx->host_only && ctx->options[vhr::kOptReflectionAsync] != 2) { const int jrc = ctx->join_refl(); if (jrc != VHR_OK) return jrc; }
     *stream = static_cast<void *>(ctx->stream);       // inside a pass callback of vhr_graph_execute: the stream that pass is ordered on
     return VHR_OK;
 }
@@ -722,7 +725,8 @@ int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity,
     if (!ctx || !out || !count) return VHR_ERROR_INVALID_ARGUMENT;
     const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_;
     const vhr_context::CostOrder &co = ctx->cost_order_raygen;
-    const uint32_t n = std::min<uint32_t>(capacity, co.cost_blocks[co.slot] * uint32_t(std::max(1, std::min(4, ctx->options[vhr::kOptWavesPerBlock]))));
+    // (the words the launch wrote: its blocks x the waves per block it ran with -- "raygen_waves_per_block" 3 runs as 2 -- and never more than the buffer holds)
+    const uint32_t n = std::min<uint32_t>(capacity, co.cost_blocks[co.slot] ? std::min(co.cost_waves[co.slot], co.capacity) : 0u);
     *count = n;
     if (n && hipMemcpy(out, co.cost[co.slot], size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "wave lifetimes: copy failed");
     return VHR_OK;

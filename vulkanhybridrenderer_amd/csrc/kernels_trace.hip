@@ -1558,6 +1558,7 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
         co.order_blocks[prev] = 0;
     }
     co.cost_blocks[slot] = n_blocks; co.cost_key[slot] = key;
+    co.cost_waves[slot] = n_waves;
 }
 
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {

@@ -437,6 +437,7 @@ struct vhr_context {
         uint32_t slot = 0;                         // the slot the last launch wrote its lifetimes to
         hipStream_t stream = nullptr;              // ... and the stream it was issued on (an order only connects launches of one stream)
         uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape cost[slot] was written by (0 blocks = nothing)
+        uint32_t cost_waves[2] = { 0, 0 };                                 // ... and the words it wrote there (blocks x the waves per block the launch ran with)
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
     };
     CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
