@@ -235,6 +235,19 @@ int  vhr_hybrid_build(vhr_hybrid_render_path *path);        /* RenderPath::Build
 int  vhr_hybrid_rebuild(vhr_hybrid_render_path *path, const vhr_hybrid_settings *settings); /* Rebuild (:22-27) */
 int  vhr_hybrid_get_push_constants(vhr_hybrid_render_path *path, vhr_svgf_push_constants *out);
 const char *vhr_hybrid_last_error(vhr_hybrid_render_path *path);
+/* Checkpoint / resume of the path's cross-frame state (the reference has none; its only state that survives a frame is
+ * the five persistent SVGF storage images of hybrid_render_path.cpp:247-262, the previous frame's view / projection matrices and
+ * frame_index, renderer.cpp:187-190,202).  The blob is host memory: a header (extent, formats, byte counts), the PerFrameData the last
+ * vhr_graph_execute ran with -- a restored renderer continues with view_prev / proj_prev = its view / proj and frame_index + 1, which is
+ * what Renderer::Render's function-static carries --, then the images in the order integrated[0], integrated[1], previous normals, history,
+ * moments history, each as the path's NEXT frame will see it (the moments double buffer's current side; the ping-pong pair in its
+ * frame-start order), so a blob loads into any path of the same extent whatever pool indices that path was given.  A context restored
+ * from a blob continues bit-identically (tests/test_gpu_svgf.py).  `last_frame` may be NULL. */
+int  vhr_hybrid_state_size(vhr_hybrid_render_path *path, uint64_t *bytes);
+int  vhr_hybrid_save_state(vhr_hybrid_render_path *path, void *blob, uint64_t bytes);
+int  vhr_hybrid_load_state(vhr_hybrid_render_path *path, const void *blob, uint64_t bytes, vhr_per_frame_data *last_frame);
+/* The PerFrameData the last vhr_graph_execute of the context ran with (zeros before the first). */
+int  vhr_get_last_per_frame_ubo(vhr_context *ctx, vhr_per_frame_data *out);
 
 /* ---------------------------------------------------------------------------------------------
  * RaytracedRenderPath (src/render_paths/raytraced_render_path.{h,cpp}) re-hosted on

@@ -435,3 +435,69 @@ def test_a_compute_pass_that_reads_the_mirror_rays_image_waits_for_its_launch():
     for f, ((copy0, img0), (copy1, img1)) in enumerate(zip(copies[0], copies[1])):
         assert np.array_equal(copy1, img1) and np.array_equal(copy0, img0), f"frame {f}: the copy is not the image"
         assert np.array_equal(img0, img1), f"frame {f}: the image differs with the mirror ray on its own stream"
+
+
+@pytest.mark.parametrize("reflections,frames_in_flight", [(False, 1), (True, 1), (False, 2)])
+def test_checkpoint_resume_continues_bit_identically(reflections, frames_in_flight):
+    """SURVEY.md section 5 (checkpoint / resume): the path's cross-frame state is the five persistent SVGF images (hybrid_render_path.cpp:
+    247-262) + the previous frame's matrices and frame_index (renderer.cpp:187-190,202).  Six frames in one context == three frames, a
+    vhr_hybrid_save_state, a FRESH context, vhr_hybrid_load_state, three more frames: Denoised, Raytraced and all five storage images
+    bit-identical after every resumed frame -- with the library's default schedule (dead iteration on the side stream, the mirror ray on
+    its own stream) and with two frames in flight."""
+    from vulkanhybridrenderer_amd.harness import HybridFrameLoop
+    W, H = 480, 270
+    scene = scenes.sponza_proc()
+    keys = ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")
+
+    def snapshot(loop):
+        c = loop.ctx
+        c.synchronize()
+        pc = loop.path.push_constants()
+        out = [c.download(lib.DENOISED), c.download(lib.RAYTRACED)] + [c.download(int(pc[k])) for k in keys]
+        out += [c.download(int(pc["integrated_shadow_and_ao"][j])) for j in (0, 1)]
+        if reflections:
+            out.append(c.download(lib.REFLECTIONS))
+        return out
+
+    whole = HybridFrameLoop(scene, W, H, 6, reflections=reflections, frames_in_flight=frames_in_flight)
+    try:
+        want = []
+        for i in range(6):
+            whole.frame(i)
+            want.append(snapshot(whole))
+    finally:
+        whole.close()
+    first = HybridFrameLoop(scene, W, H, 6, reflections=reflections, frames_in_flight=frames_in_flight)
+    try:
+        for i in range(3):
+            first.frame(i)
+        state = first.save_state()
+        pfd2 = first.pfds[2].tobytes()
+    finally:
+        first.close()
+    assert state["next_frame"] == 3
+    second = HybridFrameLoop(scene, W, H, 6, reflections=reflections, frames_in_flight=frames_in_flight)
+    try:
+        # the blob carries the caller's half of the state: the last PerFrameData, from which the next frame's previous matrices follow
+        last = second.path.load_state(state["svgf"])
+        assert last.tobytes() == pfd2
+        assert np.array_equal(second.pfds[3]["camera_view_prev_frame"], last["camera_view"]) and int(second.pfds[3]["frame_index"]) == int(last["frame_index"]) + 1
+        nxt = second.load_state(state)
+        assert nxt == 3
+        for i in range(nxt, 6):
+            second.frame(i)
+            got = snapshot(second)
+            for k, (a, b) in enumerate(zip(got, want[i])):
+                assert np.array_equal(a, b), f"frame {i}: image {k} of the resumed context differs"
+        # a blob of another extent is refused, with a message
+        other = lib.Context(64, 48)
+        try:
+            p = lib.HybridRenderPath(other, denoise=True)
+            p.build()
+            with pytest.raises(lib.VhrError, match="another extent"):
+                p.load_state(state["svgf"])
+            p.destroy()
+        finally:
+            other.close()
+    finally:
+        second.close()

@@ -207,3 +207,23 @@ def test_current_stream_of_a_host_only_context():
         assert c.current_stream() == 0
     finally:
         c.close()
+
+
+def test_svgf_state_blob_size_and_refusals(ctx):
+    """vhr_hybrid_state_size / _save_state / _load_state (checkpoint / resume) on a host-only context: the size is a
+    header (with the 584-byte PerFrameData) + the five images; a path without SVGF images has no state; saving needs a device."""
+    p = lib.HybridRenderPath(ctx, shadow_mode=0, ambient_occlusion_mode=0, reflection_mode=2, denoise=True)
+    p.build()
+    import ctypes as C
+    n = C.c_uint64()
+    assert ctx.L.vhr_hybrid_state_size(p.handle, C.byref(n)) == 0
+    images = 1920 * 1080 * (4 * 8 + 4)
+    assert 584 <= n.value - images <= 1024
+    with pytest.raises(lib.VhrError, match="host-only"):
+        p.save_state()
+    with pytest.raises(lib.VhrError, match="shorter than its header|host-only"):
+        p.load_state(np.zeros(16, np.uint8))
+    p.rebuild(denoise_shadow_and_ao=0)
+    with pytest.raises(lib.VhrError, match="no SVGF images"):
+        p.save_state()
+    p.destroy()

@@ -562,6 +562,12 @@ int vhr_update_per_frame_ubo(vhr_context *ctx, uint32_t resource_idx, const vhr_
     return VHR_OK;
 }
 
+int vhr_get_last_per_frame_ubo(vhr_context *ctx, vhr_per_frame_data *out) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    std::memcpy(out, &ctx->per_frame[ctx->last_resource_idx], sizeof *out);
+    return VHR_OK;
+}
+
 int vhr_set_trace_params(vhr_context *ctx, const vhr_trace_params *p) {
     if (!ctx || !p) return VHR_ERROR_INVALID_ARGUMENT;
     if (p->ao_spp > 64) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "trace params: ao_spp > 64");

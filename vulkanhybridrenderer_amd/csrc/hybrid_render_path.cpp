@@ -7,6 +7,8 @@
 // the reference would compile after swapping the Vulkan render graph for this one.
 #include "render_paths.hpp"
 
+#include <cstring>
+#include <string>
 #include <utility>
 
 namespace vhr {
@@ -276,5 +278,100 @@ int vhr_hybrid_get_push_constants(vhr_hybrid_render_path *p, vhr_svgf_push_const
 }
 
 const char *vhr_hybrid_last_error(vhr_hybrid_render_path *p) { return p ? p->error.c_str() : ""; }
+
+// ---- checkpoint / resume of the SVGF state (vhr_amd.h; through the public C ABI only, like the rest of this file) ----
+namespace {
+struct SvgfStateHeader {
+    char magic[8];                  // "VHRSVGF1"
+    uint32_t version, width, height, image_count;
+    int32_t format[5];
+    uint64_t image_bytes[5];
+    uint64_t total_bytes;
+    vhr_per_frame_data last_frame;
+};
+constexpr char kStateMagic[8] = { 'V', 'H', 'R', 'S', 'V', 'G', 'F', '1' };
+
+// the five images in blob order, as the NEXT frame addresses them (the frame-start order of the ping-pong pair, :328)
+int svgf_state_images(vhr_hybrid_render_path *p, int32_t ids[5], vhr_image_info info[5]) {
+    if (!p->path.svgf_textures_created) { p->error = "SVGF state: the path has no SVGF images (denoise off, or not built)"; return VHR_ERROR_GRAPH; }
+    const vhr::SVGFPushConstants &pc = p->path.svgf_push_constants;
+    ids[0] = pc.integrated_shadow_and_ao[0]; ids[1] = pc.integrated_shadow_and_ao[1]; ids[2] = pc.prev_frame_normals_and_object_ids;
+    ids[3] = pc.shadow_and_ao_history; ids[4] = pc.shadow_and_ao_moments_history;
+    for (int i = 0; i < 5; ++i) {
+        const int rc = vhr_get_storage_image(p->context.handle, ids[i], &info[i]);
+        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+    }
+    return VHR_OK;
+}
+}  // namespace
+
+int vhr_hybrid_state_size(vhr_hybrid_render_path *p, uint64_t *bytes) {
+    if (!p || !bytes) return VHR_ERROR_INVALID_ARGUMENT;
+    int32_t ids[5]; vhr_image_info info[5];
+    const int rc = svgf_state_images(p, ids, info);
+    if (rc < 0) return rc;
+    uint64_t total = sizeof(SvgfStateHeader);
+    for (int i = 0; i < 5; ++i) total += uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel;
+    *bytes = total;
+    return VHR_OK;
+}
+
+int vhr_hybrid_save_state(vhr_hybrid_render_path *p, void *blob, uint64_t bytes) {
+    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+    int32_t ids[5]; vhr_image_info info[5];
+    int rc = svgf_state_images(p, ids, info);
+    if (rc < 0) return rc;
+    SvgfStateHeader h{};
+    std::memcpy(h.magic, kStateMagic, 8);
+    h.version = 1; h.width = info[0].width; h.height = info[0].height; h.image_count = 5;
+    h.total_bytes = sizeof h;
+    for (int i = 0; i < 5; ++i) {
+        h.format[i] = info[i].format;
+        h.image_bytes[i] = uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel;
+        h.total_bytes += h.image_bytes[i];
+    }
+    if (bytes != h.total_bytes) { p->error = "SVGF state: the blob must hold exactly vhr_hybrid_state_size bytes"; return VHR_ERROR_INVALID_ARGUMENT; }
+    rc = vhr_get_last_per_frame_ubo(p->context.handle, &h.last_frame);
+    if (rc < 0) return rc;
+    char *out = static_cast<char *>(blob);
+    std::memcpy(out, &h, sizeof h);
+    out += sizeof h;
+    for (int i = 0; i < 5; ++i) {          // (a download waits for every stream of the context, the side stream's dead iteration included)
+        rc = vhr_download_storage_image(p->context.handle, ids[i], out, h.image_bytes[i]);
+        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+        out += h.image_bytes[i];
+    }
+    return VHR_OK;
+}
+
+int vhr_hybrid_load_state(vhr_hybrid_render_path *p, const void *blob, uint64_t bytes, vhr_per_frame_data *last_frame) {
+    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+    int32_t ids[5]; vhr_image_info info[5];
+    int rc = svgf_state_images(p, ids, info);
+    if (rc < 0) return rc;
+    SvgfStateHeader h;
+    if (bytes < sizeof h) { p->error = "SVGF state: blob shorter than its header"; return VHR_ERROR_INVALID_ARGUMENT; }
+    std::memcpy(&h, blob, sizeof h);
+    if (std::memcmp(h.magic, kStateMagic, 8) != 0 || h.version != 1 || h.image_count != 5) { p->error = "SVGF state: not a version-1 state blob"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (h.total_bytes != bytes) { p->error = "SVGF state: byte count differs from the header's"; return VHR_ERROR_INVALID_ARGUMENT; }
+    uint64_t total = sizeof h;
+    for (int i = 0; i < 5; ++i) {
+        if (h.width != info[i].width || h.height != info[i].height || h.format[i] != info[i].format ||
+            h.image_bytes[i] != uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel) {
+            p->error = "SVGF state: the blob was saved from a path of another extent or image format";
+            return VHR_ERROR_INVALID_ARGUMENT;
+        }
+        total += h.image_bytes[i];
+    }
+    if (total != bytes) { p->error = "SVGF state: image byte counts do not add up to the blob"; return VHR_ERROR_INVALID_ARGUMENT; }
+    const char *in = static_cast<const char *>(blob) + sizeof h;
+    for (int i = 0; i < 5; ++i) {
+        rc = vhr_upload_storage_image(p->context.handle, ids[i], in, h.image_bytes[i]);
+        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+        in += h.image_bytes[i];
+    }
+    if (last_frame) *last_frame = h.last_frame;
+    return VHR_OK;
+}
 
 }  // extern "C"

@@ -337,6 +337,7 @@ int vhr_graph_execute(vhr_context *ctx, uint32_t resource_idx, uint32_t image_id
     if (resource_idx >= 3) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "resource_idx >= MAX_FRAMES_IN_FLIGHT");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->error.clear();
+    ctx->last_resource_idx = resource_idx;
     const bool split = ctx->frames_in_flight > 1 && ctx->front_passes != 0;
     const uint32_t slot = ctx->frames_in_flight > 1 ? resource_idx % uint32_t(ctx->frames_in_flight) : 0u;
     hipStream_t const back = ctx->stream;

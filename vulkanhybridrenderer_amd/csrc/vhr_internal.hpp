@@ -341,6 +341,7 @@ struct vhr_context {
     vhr::DeviceTexture *d_textures = nullptr;
     bool textures_dirty = false;
     vhr_per_frame_data per_frame[3] = {};
+    uint32_t last_resource_idx = 0;    // the slot the last vhr_graph_execute ran with (vhr_get_last_per_frame_ubo)
     vhr_trace_params trace_params = {};
 
     // scene

@@ -241,6 +241,24 @@ class HybridFrameLoop:
         self.ctx.update_per_frame_ubo(idx, self.pfds[self.frame_slot(i)])
         self.ctx.execute(idx, 0)
 
+    # ---- checkpoint / resume (the path's only cross-frame state) ----
+    def save_state(self):
+        """The SVGF state behind the last frame run (vhr_hybrid_save_state) + the index of the next frame: what a fresh loop over the same
+        camera path needs to continue bit-identically (the caller's half of the state -- previous view / projection, frame_index,
+        renderer.cpp:187-190,202 -- is a function of the frame index here and travels inside the blob as the last PerFrameData)."""
+        self.finish_pending_exchange()
+        return {"svgf": self.path.save_state(), "next_frame": self.current + 1}
+
+    def load_state(self, state):
+        """Restore a save_state(); returns the index of the frame to run next.  The blob's last PerFrameData must be the one this loop's
+        camera path has for that frame (else the histories belong to another sequence)."""
+        last = self.path.load_state(state["svgf"])
+        nxt = int(state["next_frame"])
+        if nxt >= 1 and last.tobytes() != self.pfds[self.frame_slot(nxt - 1)].tobytes():
+            raise ValueError("load_state: the checkpoint was taken on another camera path / frame sequence")
+        self.current = nxt - 1
+        return nxt
+
     def owned_rows(self):
         return self.plan.row_begin, self.plan.row_end
 

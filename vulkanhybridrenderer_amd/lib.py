@@ -27,7 +27,8 @@ EXPORTS = [
     "vhr_graph_set_pass_epilogue", "vhr_graph_bind_external_image", "vhr_trace_rays", "vhr_compute_get_display_size",
     "vhr_compute_dispatch", "vhr_compute_blit_image_storage_to_transient", "vhr_compute_blit_image_transient_to_storage",
     "vhr_compute_blit_image_storage_to_storage", "vhr_hybrid_create", "vhr_hybrid_destroy", "vhr_hybrid_build",
-    "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_get_display_size",
+    "vhr_hybrid_rebuild", "vhr_hybrid_get_push_constants", "vhr_hybrid_last_error", "vhr_hybrid_state_size", "vhr_hybrid_save_state",
+    "vhr_hybrid_load_state", "vhr_get_last_per_frame_ubo", "vhr_get_display_size",
     "vhr_get_transient_image", "vhr_get_storage_image", "vhr_upload_transient_image", "vhr_download_transient_image",
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip", "vhr_set_tile",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
@@ -203,6 +204,10 @@ def load():
     L.vhr_hybrid_get_push_constants.argtypes = [vp, vp]
     L.vhr_hybrid_last_error.argtypes = [vp]
     L.vhr_hybrid_last_error.restype = C.c_char_p
+    L.vhr_hybrid_state_size.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_hybrid_save_state.argtypes = [vp, vp, u64]
+    L.vhr_hybrid_load_state.argtypes = [vp, vp, u64, vp]
+    L.vhr_get_last_per_frame_ubo.argtypes = [vp, vp]
     L.vhr_get_display_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.vhr_get_transient_image.argtypes = [vp, C.c_char_p, C.POINTER(ImageInfo)]
     L.vhr_get_storage_image.argtypes = [vp, i32, C.POINTER(ImageInfo)]
@@ -725,6 +730,21 @@ class HybridRenderPath:
         pc = np.zeros((), abi.svgf_push_constants_dtype)
         self.ctx.check(self.ctx.L.vhr_hybrid_get_push_constants(self.handle, _p(pc)), "get_push_constants")
         return pc
+
+    def save_state(self):
+        """vhr_hybrid_save_state: the path's cross-frame state (five SVGF images + the last frame's PerFrameData) as a uint8 array."""
+        n = C.c_uint64()
+        self._check(self.ctx.L.vhr_hybrid_state_size(self.handle, C.byref(n)), "vhr_hybrid_state_size")
+        blob = np.empty(int(n.value), np.uint8)
+        self._check(self.ctx.L.vhr_hybrid_save_state(self.handle, _p(blob), n.value), "vhr_hybrid_save_state")
+        return blob
+
+    def load_state(self, blob):
+        """vhr_hybrid_load_state; returns the PerFrameData of the frame the blob was saved behind."""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        last = np.zeros((), abi.per_frame_dtype)
+        self._check(self.ctx.L.vhr_hybrid_load_state(self.handle, _p(blob), blob.size, _p(last)), "vhr_hybrid_load_state")
+        return last
 
     def destroy(self):
         if self.handle:
