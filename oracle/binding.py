@@ -27,7 +27,9 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libvhr_oracle.so")
-        if not os.path.exists(so):
+        if os.environ.get("VHR_ORACLE_LIB"):          # tests/test_sanitizers.py: the AddressSanitizer build (make -C oracle asan)
+            so = os.path.abspath(os.environ["VHR_ORACLE_LIB"])
+        elif not os.path.exists(so):
             build()
         L = C.CDLL(so)
         u32, f32, vp, i32 = C.c_uint32, C.c_float, C.c_void_p, C.c_int

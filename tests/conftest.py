@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("VHR_TEST_LIB"):       # tests/test_sanitizers.py: the host-only tests on the AddressSanitizer build of the library
+        from vulkanhybridrenderer_amd import lib
+        lib.LIB_PATH = os.path.abspath(os.environ["VHR_TEST_LIB"])
 
 
 @pytest.fixture(scope="session")
