@@ -401,11 +401,16 @@ def main():
     # library's own RCCL calls (--comm c_abi) need one GPU per rank (RCCL refuses two ranks on one device) and have not met a second
     # device yet, so they are never chosen silently: the launcher gives them a separate, time-bounded run (launch_ranks: c_abi_route).
     comm_mode = args.comm if args.comm != "auto" else "torch"
-    if comm_mode == "c_abi" and world > 1 and (args.share_device or args.backend != "nccl"):
+    # (VHR_RCCL_LIBRARY: the library csrc/comm.cpp loads in RCCL's place.  With tests/rccl_shim's stand-in named there, vhr_comm_* runs
+    # N ranks on one GPU -- a functional run of the library's own exchange code, which the line then says)
+    rccl_override = os.environ.get("VHR_RCCL_LIBRARY") or None
+    if comm_mode == "c_abi" and world > 1 and (args.share_device or args.backend != "nccl") and not rccl_override:
         if rank == 0:
             _error_line("--comm c_abi needs one GPU per rank and the nccl backend", args)
         raise SystemExit(2)
     comm_note = None
+    if comm_mode == "c_abi" and rccl_override:
+        comm_note = f"vhr_comm_* over VHR_RCCL_LIBRARY={os.path.basename(rccl_override)} in RCCL's place: a functional run of the library's exchange code, not a measurement"
 
     def make_loop(mode):
         return HybridFrameLoop(scene, W, H, n_frames, reflections=_bounces(args), rank=rank, world=world, dist=dist if world > 1 else None,

@@ -347,8 +347,11 @@ int vhr_set_tile(vhr_context *ctx, uint32_t col_begin, uint32_t col_end, uint32_
  * The reference is single-GPU (one queue, renderer.cpp:135); these calls exist for an integrator that shards the framebuffer by
  * row strips.  The row arithmetic follows the reference's SVGF schedule (hybrid_render_path.cpp:288-329:
  * the published image is the output of a-trous iteration n-2, iteration i reads +-2*2^i rows) and is the one
- * vulkanhybridrenderer_amd/tiling.py uses (tests/test_comm_plan.py compares the two).  RCCL is loaded on first use.
- * N > 1 has not run on hardware yet (rounds 1-3 had one GPU): world size 1 is smoke-tested, the planner is tested on the CPU.
+ * vulkanhybridrenderer_amd/tiling.py uses (tests/test_comm_plan.py compares the two).  RCCL is loaded on first use: the copy the process
+ * already holds (a PyTorch process), else the ROCm installation's; the environment variable VHR_RCCL_LIBRARY=<path> names the library to
+ * load instead (a site's own build).  N > 1 has not run on two DEVICES yet (rounds 1-5 had one GPU per box); world 2 and 4 run on one GPU
+ * through tests/rccl_shim (a stand-in for the eight RCCL entry points this file uses, named through that variable), bit-identical to the
+ * torch.distributed route and to the single context, with one injected failure per error path (tests/test_comm_shim.py).
  * Error handling: a failure inside a grouped batch closes the group, marks the communicator unusable and is reported; what was
  * enqueued before it is drained by vhr_comm_finish_frame_exchanges. */
 typedef struct vhr_strip_plan {

@@ -171,6 +171,58 @@ def test_every_tuning_option_is_result_neutral(oracle, option, values):
         assert all(float(np.sqrt(np.mean((f16(o) - f16(frames[-1]["denoised"])) ** 2))) <= 1e-4 for o in outs)
 
 
+_TRACE_OPTIONS = ("raygen_variant", "reflection_variant", "refill_threshold", "lds_stack_levels", "raygen_waves_per_block", "compact_nodes", "raygen_early_exit",
+                  "reflection_early_exit", "raygen_tile_rows", "raygen_cost_order", "raygen_steal", "reflection_async", "fuse_temporal", "svgf_async_unread")
+
+
+@pytest.mark.parametrize("shadow,ao_spp,bounces", [(True, 0, 0), (True, 16, 0), (True, 33, 1), (False, 2, 1), (True, 2, 2), (False, 64, 0)])
+def test_tuning_options_crossed_with_trace_parameters(oracle, shadow, ao_spp, bounces):
+    """The neutrality test above sweeps every option at the default trace parameters; a bug of round 4 (raygen_steal's one blocked bit per
+    ray with more than 31 AO samples) lived in the cross.  Here every option that touches the ray-tracing launches or their place in the
+    frame takes its smallest, largest and a middle value under: no AO rays, 16 and 33 and 64 AO samples (the visibility word's two
+    encodings), shadows off, one and two mirror bounces.  Per setting, two frames: the visibility image bit-exact against the oracle,
+    Reflections and Denoised bit-identical to the same context's run with every option at its default (frame 0 carries NaN motion
+    vectors, so it restarts the SVGF history: frame 1 is comparable between runs)."""
+    scene = scenes.tiny_scene()
+    W, H = 72, 56
+    tp = abi.default_trace_params(shadow=shadow, ao_spp=ao_spp, reflections=bounces)
+    frames, _, _ = oracle_frames(oracle, scene, W, H, 2, tp)
+    table = lib.option_table()
+    g = GpuHybrid(scene, W, H, shadow=shadow, ao=bool(ao_spp), reflections=bool(bounces), trace_params=tp)
+    try:
+        def run(tag):
+            out = None
+            for fr in frames:
+                g.frame(fr["pfd"], fr["gbuf"])
+                got = g.ctx.download(lib.RAYTRACED)
+                assert np.array_equal(got, fr["shadow_ao"]), (tag, int((got != fr["shadow_ao"]).any(-1).sum()))
+                out = (g.ctx.download(lib.DENOISED), g.ctx.download(lib.REFLECTIONS) if bounces else None)
+            return out
+        base = run("defaults")
+        if bounces:
+            _refl_equal(base[1], frames[-1]["reflections"])
+        for name in _TRACE_OPTIONS:
+            default, lo, hi = table[name]
+            for v in sorted({lo, hi, (lo + hi) // 2} - {default}):
+                g.ctx.set_option(name, v)
+                got = run((name, v))
+                g.ctx.set_option(name, default)
+                assert np.array_equal(got[0], base[0]), (name, v, "Denoised differs from the default options' run")
+                if bounces and name != "reflection_variant":
+                    assert np.array_equal(got[1], base[1]), (name, v, "Reflections differ from the default options' run")
+                elif bounces:
+                    _refl_equal(got[1], frames[-1]["reflections"])
+    finally:
+        g.close()
+
+
+def _refl_equal(got_bits, want_bits):
+    """mirror-ray payloads against the oracle on the tiny scene: same hit mask, colour within 3 fp16 steps everywhere"""
+    a, b = f16(got_bits), f16(want_bits)
+    assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0)
+    assert (np.abs(a - b) <= 3 * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)).all()
+
+
 def test_sky_only_frame(oracle):
     scene = scenes.tiny_scene()
     scene.camera = dict(scene.camera, pitch=1.45)        # look straight up: nothing but sky

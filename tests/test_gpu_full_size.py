@@ -110,6 +110,37 @@ def test_1080p_eight_virtual_screen_tiles_equal_single_context():
     _check_against_reference(plans, results, ref)
 
 
+@pytest.mark.parametrize("bounces,options", [(1, (("reflection_async", 1), ("svgf_async_unread", 1))), (1, (("reflection_async", 2), ("svgf_async_unread", 2))),
+                                             (2, (("reflection_async", 0), ("svgf_async_unread", 2)))])
+def test_config4_bistro_1080p_eight_screen_tiles_full_hybrid(bounces, options):
+    """BASELINE config 4 AS DEFINED: bistro_proc 1920x1080, shadows + 2 AO rays + the mirror ray (raygen.rgen:59-65) + SVGF on 2 x 4 screen
+    tiles -- then two bounces.  Eight contexts on one GPU: every rank's Raytraced, Reflections and Denoised rectangle equals the single
+    context's over three dolly frames, bit for bit -- object ids above 2048 (fp16 aliasing, gbuf.frag:43) at tile borders, the mirror
+    ray's launch beside the SVGF pass with and without the epilogues waiting for it, the dead a-trous dispatch on the side stream."""
+    W, H = 1920, 1080
+    sc = scenes.bistro_proc()
+    tp = abi.default_trace_params(ao_spp=2, reflections=bounces)
+    pfds = camera.dolly_frames(sc, W, H, 3)
+    ref, mv_rows, mv_cols = _single_context_reference(sc, W, H, pfds, tp)
+    plans, results = _run_strips(sc, W, H, 8, pfds, mv_rows, trace_overlap=True, shrink=True, grid=None, max_motion_cols=mv_cols, options=options, tp=tp)
+    assert (plans[0].grid_rows, plans[0].grid_cols) == (2, 4)
+    _check_against_reference(plans, results, ref)
+
+
+def test_config5_bistro_4k_eight_screen_tiles_16spp_two_bounces():
+    """BASELINE config 5 AS DEFINED: bistro_proc 3840x2160, 16 AO samples, two mirror bounces, SVGF, 2 x 4 screen tiles of 960 x 1080 with the
+    history halo exchange: two frames, every rank's three rectangles bit-identical to the single context's."""
+    W, H = 3840, 2160
+    sc = scenes.bistro_proc()
+    tp = abi.default_trace_params(ao_spp=16, reflections=2)
+    pfds = camera.dolly_frames(sc, W, H, 2)
+    ref, mv_rows, mv_cols = _single_context_reference(sc, W, H, pfds, tp)
+    plans, results = _run_strips(sc, W, H, 8, pfds, mv_rows, trace_overlap=True, shrink=True, grid=None, max_motion_cols=mv_cols, tp=tp)
+    assert (plans[0].grid_rows, plans[0].grid_cols) == (2, 4)
+    assert [(p.col_end - p.col_begin, p.row_end - p.row_begin) for p in plans] == [(960, 1080)] * 8
+    _check_against_reference(plans, results, ref)
+
+
 def _denoised_close(out_bits, den_bits, what):
     """BASELINE.json's float tolerance on the denoised image: RMSE <= 1e-4, every channel within 4e-3, finite, in [0, 1]."""
     out, den = f16(out_bits), f16(den_bits)

@@ -14,13 +14,17 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None, tp=None):
     """`world` contexts on one GPU, one thread each, each computing its strip (grid "strips") or screen tile (grid (rows, cols) or None =
     the planner's choice) with host-side copies standing in for the RCCL exchanges.  Returns (plans, per-rank per-frame (raytraced,
-    denoised) cut to the owned rectangle)."""
-    tp = abi.default_trace_params(reflections=False)
+    denoised, reflections or None) cut to the owned rectangle).  `tp`: the trace parameters (default: shadows + 2 AO rays, no mirror ray);
+    with a mirror ray the Raytraced Reflections image of a tile is part of the result (raygen.rgen:59-65: per-pixel independent, nothing
+    of it is exchanged)."""
+    if tp is None:
+        tp = abi.default_trace_params(reflections=False)
+    refl = bool(tp["reflections"])
     plans = [tiling.make_tile_plan(W, H, world, r, max_motion_rows, max_motion_cols, grid=grid) for r in range(world)]
-    ranks = [GpuHybrid(scene, W, H, reflections=False, trace_params=tp, gbuffer="standin") for _ in range(world)]
+    ranks = [GpuHybrid(scene, W, H, shadow=bool(tp["shadow_enable"]), ao=bool(tp["ao_spp"]), reflections=refl, trace_params=tp, gbuffer="standin") for _ in range(world)]
     barrier = threading.Barrier(world)
     results = [[] for _ in range(world)]
     errors = []
@@ -63,7 +67,8 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
                 rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], (plan.halo_rows, plan.halo_cols)))
             for pfd in pfds:
                 g.frame(pfd)
-                results[rank].append((cut(g.ctx.download(lib.RAYTRACED), plan.rect).copy(), cut(g.ctx.download(lib.DENOISED), plan.rect).copy()))
+                results[rank].append((cut(g.ctx.download(lib.RAYTRACED), plan.rect).copy(), cut(g.ctx.download(lib.DENOISED), plan.rect).copy(),
+                                      cut(g.ctx.download(lib.REFLECTIONS), plan.rect).copy() if refl else None))
                 barrier.wait()
             if counts is not None:
                 counts[rank] = (g.ctx.kernel_time("svgf_atrous")[1], g.ctx.kernel_time("svgf_atrous_async")[1])
@@ -83,14 +88,17 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
     return plans, results
 
 
-def _single_context_reference(scene, W, H, pfds):
-    """Every frame's (raytraced, denoised) of one whole-image context, and the largest motion in rows and columns."""
-    single = GpuHybrid(scene, W, H, reflections=False, trace_params=abi.default_trace_params(reflections=False), gbuffer="standin")
+def _single_context_reference(scene, W, H, pfds, tp=None):
+    """Every frame's (raytraced, denoised, reflections or None) of one whole-image context, and the largest motion in rows and columns."""
+    if tp is None:
+        tp = abi.default_trace_params(reflections=False)
+    refl = bool(tp["reflections"])
+    single = GpuHybrid(scene, W, H, shadow=bool(tp["shadow_enable"]), ao=bool(tp["ao_spp"]), reflections=refl, trace_params=tp, gbuffer="standin")
     ref, mv_rows, mv_cols = [], 0.0, 0.0
     try:
         for pfd in pfds:
             single.frame(pfd)
-            ref.append((single.ctx.download(lib.RAYTRACED), single.ctx.download(lib.DENOISED)))
+            ref.append((single.ctx.download(lib.RAYTRACED), single.ctx.download(lib.DENOISED), single.ctx.download(lib.REFLECTIONS) if refl else None))
             mv = f16(single.ctx.download(lib.MOTION))
             d = single.ctx.download(lib.DEPTH)
             if (d != 0).any():
@@ -104,9 +112,12 @@ def _single_context_reference(scene, W, H, pfds):
 def _check_against_reference(plans, results, ref):
     for r, plan in enumerate(plans):
         x0, x1, y0, y1 = plan.rect
-        for f, (rt, den) in enumerate(results[r]):
+        for f, (rt, den, refl) in enumerate(results[r]):
             assert np.array_equal(rt, ref[f][0][y0:y1, x0:x1]), f"rank {r} frame {f}: raytraced rectangle differs"
             assert np.array_equal(den, ref[f][1][y0:y1, x0:x1]), f"rank {r} frame {f}: denoised rectangle differs"
+            assert (refl is None) == (ref[f][2] is None)
+            if refl is not None:
+                assert np.array_equal(refl, ref[f][2][y0:y1, x0:x1]), f"rank {r} frame {f}: reflections rectangle differs"
 
 
 @pytest.mark.parametrize("world,grid,trace_overlap,shrink", [(4, (2, 2), True, True), (4, (2, 2), False, False), (6, (2, 3), True, True), (6, (3, 2), True, False),
@@ -122,6 +133,23 @@ def test_virtual_screen_tiles_bit_identical(world, grid, trace_overlap, shrink):
     plans, results = _run_strips(scene, W, H, world, pfds, mv_rows, trace_overlap, shrink, grid=grid, max_motion_cols=mv_cols)
     if grid:
         assert (plans[0].grid_rows, plans[0].grid_cols) == grid
+    _check_against_reference(plans, results, ref)
+
+
+@pytest.mark.parametrize("bounces,ao_spp,refl_async,side", [(1, 2, 0, 0), (1, 2, 1, 2), (1, 2, 2, 2), (2, 2, 1, 1), (2, 5, 2, 2)])
+def test_virtual_tiles_with_the_mirror_ray(bounces, ao_spp, refl_async, side):
+    """The configurations BASELINE.json DEFINES as tiled (configs 4 and 5) trace the mirror ray (raygen.rgen:59-65), config 5 two bounces:
+    on 2 x 2 tiles the Raytraced, Denoised AND Reflections rectangles of every rank equal the single context's bit for bit, with the
+    mirror ray's launch in stream order ("reflection_async" 0), beside the SVGF pass (1) and with the epilogues not waiting for it (2, what
+    the multi-GPU harness sets) while the exchanges' uploads and downloads run, and with the dead a-trous dispatch on the side stream."""
+    scene = scenes.bistro_proc(detail=0.02, n_primitives=2200, n_textures=8, texture_size=64)      # textured, ids above 2048 (fp16 aliasing across tile borders)
+    W, H = 144, 132
+    tp = abi.default_trace_params(ao_spp=ao_spp, reflections=bounces)
+    pfds = camera.dolly_frames(scene, W, H, 4)
+    ref, mv_rows, mv_cols = _single_context_reference(scene, W, H, pfds, tp)
+    assert (f16(ref[1][2])[..., 3] > 0).mean() > 0.2                   # the mirror ray does hit things
+    plans, results = _run_strips(scene, W, H, 4, pfds, mv_rows, True, True, grid=(2, 2), max_motion_cols=mv_cols,
+                                 options=(("reflection_async", refl_async), ("svgf_async_unread", side)), tp=tp)
     _check_against_reference(plans, results, ref)
 
 

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -56,7 +57,14 @@ Rccl &rccl() {
         // A copy the process already holds first (the loader knows libraries by soname, librccl.so.1: a PyTorch process has its
         // own build loaded), else the ROCm installation's -- with local scope, so that this library's choice never rebinds
         // anybody else's ncclXxx references.
+        // VHR_RCCL_LIBRARY=<path>: that library and no other (a site's own RCCL build; tests/rccl_shim's stand-in, which lets the exchanges of
+        // N ranks run on ONE GPU, where RCCL itself refuses two ranks per device).  A path that does not load is an error, not a fall-through.
+        if (const char *forced = std::getenv("VHR_RCCL_LIBRARY"); forced && *forced) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) { const char *e = dlerror(); r.error = std::string("VHR_RCCL_LIBRARY: ") + (e ? e : forced); return; }
+        }
         for (int flags : { RTLD_NOW | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL }) {
+            if (r.handle) break;
             for (const char *name : { "librccl.so.1", "librccl.so" }) {
                 r.handle = dlopen(name, flags);
                 if (r.handle) break;
