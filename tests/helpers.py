@@ -18,6 +18,17 @@ def bits_equal_nan_aware(a, b):
     return (a == b) | (nan_a & nan_b)
 
 
+def assert_reflections_identical(got_bits, want_bits, what="reflections"):
+    """Mirror-ray payloads (raygen.rgen:59-65 + reflection_hit.rchit) against the oracle: BIT-IDENTICAL.  From G-buffer texel to the fp16
+    store the GPU evaluates the oracle's individually rounded fp32 operations in the oracle's order (no contraction, IEEE division and
+    square root, sRGB through the same 256-entry table, closest hit by (t, flat triangle index)) -- measured in round 5 on whole 1080p
+    frames and 4K bands of both stand-in scenes, one and two bounces: 0 payloads differ.  (Rounds 1-4 allowed 2-3 fp16 steps on 99.8 % of the
+    pixels and nothing on the rest; the allowance dated from a hardware-reciprocal shading path that no longer exists.)"""
+    got, want = np.asarray(got_bits, np.uint16), np.asarray(want_bits, np.uint16)
+    same = bits_equal_nan_aware(got, want)
+    assert same.all(), f"{what}: {int((~same).any(-1).sum())} payloads differ from the oracle, first at {np.argwhere(~same)[:4].tolist()}"
+
+
 class GpuHybrid:
     """Hybrid render path on the GPU with host-supplied G-buffers (the untouched raster stage)."""
 

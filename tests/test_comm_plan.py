@@ -194,6 +194,22 @@ def test_bench_launches_its_own_ranks_and_labels_a_shared_device_truthfully():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bench_refuses_more_gpus_than_the_box_has(n):
+    """`python bench.py --gpus N` on a box with fewer than N devices (what the driver's scaling run would meet on a one-GPU box): ONE error
+    line in the contract's JSON shape (value null, n_gpus N), exit code 2, within seconds -- no rank is started, nothing hangs."""
+    import time
+    import torch
+    if torch.cuda.device_count() >= n:
+        pytest.skip(f"the box has {torch.cuda.device_count()} devices")
+    t0 = time.time()
+    r, line = _bench(["--gpus", str(n), "--steps", "2", "--warmup", "1"], timeout=120)
+    assert time.time() - t0 < 60
+    assert r.returncode == 2 and line is not None and "error" in line and line["n_gpus"] == n and line["value"] is None, (r.stdout[-1000:], r.stderr[-1000:])
+    assert line["metric"].startswith("Mrays/s") and line["devices_visible"] == torch.cuda.device_count()
+
+
+@pytest.mark.gpu
 def test_bench_through_the_c_abi_at_world_two(tmp_path):
     """bench.py --gpus 2 WITHOUT torchrun (the launcher starts the ranks): the measured route is torch.distributed over RCCL, and the
     launcher's second, time-bounded run reports the library's own RCCL calls (vhr_comm_*) as `c_abi_route`.  Then --comm c_abi as the

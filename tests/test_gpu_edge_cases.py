@@ -4,13 +4,13 @@ the tile sizes, axis-parallel rays (zero direction components), the BASELINE ao_
 import numpy as np
 import pytest
 
-from tests.helpers import GpuHybrid, f16, oracle_frames
+from tests.helpers import GpuHybrid, assert_reflections_identical, f16, oracle_frames
 from vulkanhybridrenderer_amd import abi, camera, lib, scenes
 
 pytestmark = pytest.mark.gpu
 
 
-def _check(oracle, scene, W, H, n_frames, tp, denoise=True, refl_steps=2):
+def _check(oracle, scene, W, H, n_frames, tp, denoise=True):
     frames, osc, _ = oracle_frames(oracle, scene, W, H, n_frames, tp, denoise=denoise)
     g = GpuHybrid(scene, W, H, denoise=denoise, trace_params=tp)
     try:
@@ -18,10 +18,7 @@ def _check(oracle, scene, W, H, n_frames, tp, denoise=True, refl_steps=2):
             g.frame(fr["pfd"], fr["gbuf"])
             assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), f"frame {i}: visibility"
             if tp["reflections"]:
-                a, b = f16(g.ctx.download(lib.REFLECTIONS)), f16(fr["reflections"])
-                assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0), f"frame {i}: reflection hit mask"
-                tol = refl_steps * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)
-                assert (np.abs(a - b) <= tol).all(), f"frame {i}: reflection colour off by {np.abs(a - b).max()}"
+                assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], f"frame {i}: reflections")
             if denoise:
                 den, ref = f16(g.ctx.download(lib.DENOISED)), f16(fr["denoised"])
                 assert float(np.sqrt(np.mean((den - ref) ** 2))) <= 1e-4, f"frame {i}: denoised RMSE"
@@ -34,7 +31,7 @@ def test_textured_scene_with_id_aliasing(oracle):
     """bistro_proc in miniature: 2200 primitives (ids above 2048 alias in fp16, gbuf.frag:43), sRGB base-colour
     textures with REPEAT/LINEAR samplers sampled by the closest-hit shader (reflection_hit.rchit:27-39)."""
     scene = scenes.bistro_proc(detail=0.02, n_primitives=2200, n_textures=8, texture_size=64)
-    frames = _check(oracle, scene, 160, 90, 3, abi.default_trace_params(), refl_steps=3)
+    frames = _check(oracle, scene, 160, 90, 3, abi.default_trace_params())
     ids = f16(frames[1]["gbuf"][0])[..., 3]
     assert ids.max() > 2048 and (ids[ids > 2048] % 2 == 0).all()          # odd ids above 2048 are not representable
     assert (f16(frames[1]["reflections"])[..., 3] > 0).mean() > 0.5
@@ -217,10 +214,8 @@ def test_tuning_options_crossed_with_trace_parameters(oracle, shadow, ao_spp, bo
 
 
 def _refl_equal(got_bits, want_bits):
-    """mirror-ray payloads against the oracle on the tiny scene: same hit mask, colour within 3 fp16 steps everywhere"""
-    a, b = f16(got_bits), f16(want_bits)
-    assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0)
-    assert (np.abs(a - b) <= 3 * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)).all()
+    """mirror-ray payloads against the oracle: bit-identical"""
+    assert_reflections_identical(got_bits, want_bits)
 
 
 def test_sky_only_frame(oracle):

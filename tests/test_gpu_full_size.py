@@ -5,7 +5,7 @@ eight virtual row strips reproduce the single-context 1080p frame bit for bit.""
 import numpy as np
 import pytest
 
-from tests.helpers import GpuHybrid, f16
+from tests.helpers import GpuHybrid, assert_reflections_identical, f16
 from tests.test_gpu_strips import _check_against_reference, _run_strips, _single_context_reference
 from vulkanhybridrenderer_amd import abi, camera, lib, scenes
 
@@ -150,19 +150,16 @@ def _denoised_close(out_bits, den_bits, what):
     assert out[..., :2].min() >= 0.0 and out[..., :2].max() <= 1.0 + 2.0 ** -10, what
 
 
-def _reflections_close(got_bits, want_bits, rows, min_fraction):
-    """Mirror-ray payloads: identical hit mask, colour within 3 fp16 steps on at least `min_fraction` of the pixels."""
-    a, b = f16(got_bits)[rows[0]:rows[1]], f16(want_bits)[rows[0]:rows[1]]
-    assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0)
-    close = (np.abs(a - b) <= 3 * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)).all(-1)
-    assert close.mean() > min_fraction, close.mean()
-    return b
+def _reflections_identical(got_bits, want_bits, rows):
+    """Mirror-ray payloads of the rows: bit-identical to the oracle's (tests/helpers.assert_reflections_identical); returns the oracle's values."""
+    assert_reflections_identical(got_bits[rows[0]:rows[1]], want_bits[rows[0]:rows[1]])
+    return f16(want_bits)[rows[0]:rows[1]]
 
 
 def test_config4_bistro_1080p_full_hybrid_whole_frame(oracle):
     """BASELINE config 4's per-GPU-independent content: bistro_proc (2.9 M triangles, 3000 primitives -> fp16 id aliasing,
     64 textures) at 1080p with shadows + AO + the mirror ray + SVGF, three frames of the dolly.  Whole frames against the
-    oracle: visibility bit-exact and reflections within 3 fp16 steps on the middle frame (raygen.rgen:32-65), the denoised image
+    oracle: visibility AND the mirror ray's payloads bit-exact on the middle frame (raygen.rgen:32-65), the denoised image
     of EVERY frame against the oracle's SVGF (RMSE <= 1e-4, max <= 4e-3) -- object ids above 2048 (rounded by the fp16 G-buffer
     channel, gbuf.frag:43) reach svgf.comp's and svgf_atrous_filter.comp:40-42's id tests here; then the second bounce
     (config 5's extension) on the last frame."""
@@ -181,7 +178,7 @@ def test_config4_bistro_1080p_full_hybrid_whole_frame(oracle):
             if i == 1:
                 sa, refl, mask, _ = osc.raygen(pfd, tp, n, d)
                 assert np.array_equal(rt, sa), f"{(rt != sa).any(-1).sum()} pixels differ"
-                b = _reflections_close(g.ctx.download(lib.REFLECTIONS), refl, (0, H), 0.9999)
+                b = _reflections_identical(g.ctx.download(lib.REFLECTIONS), refl, (0, H))
                 assert (b[..., 3] > 0).mean() > 0.3
             # SVGF on identical inputs (the GPU's visibility image, equal to the oracle's on the frame checked above)
             _denoised_close(g.ctx.download(lib.DENOISED), svgf.frame(pfd, n, m, rt), f"frame {i}")
@@ -193,7 +190,7 @@ def test_config4_bistro_1080p_full_hybrid_whole_frame(oracle):
         n, m, d = _gbuffer(g)
         sa, refl, mask, _ = osc.raygen(frames[2], tp2, n, d)
         assert np.array_equal(g.ctx.download(lib.RAYTRACED), sa)
-        _reflections_close(g.ctx.download(lib.REFLECTIONS), refl, (0, H), 0.998)
+        _reflections_identical(g.ctx.download(lib.REFLECTIONS), refl, (0, H))
     finally:
         g.close()
 
@@ -201,7 +198,7 @@ def test_config4_bistro_1080p_full_hybrid_whole_frame(oracle):
 def test_config5_bistro_4k_16spp_two_bounces(oracle):
     """BASELINE config 5's frame on one GPU: bistro_proc at 3840x2160, 16 AO samples (raygen.rgen:44-55 with the sample count
     as a parameter), two-bounce mirror reflections, SVGF.  One frame after a warm-up frame: a 96-row band across the middle
-    of the image against the oracle (visibility image bit-exact, reflections within 3 fp16 steps on >= 99.8 %), AO values in
+    of the image against the oracle (visibility image and mirror-ray payloads bit-exact), AO values in
     {k / 16}, sky pixels (1, 1), and both frames' denoised images whole against the oracle's SVGF run on the same visibility
     image (ids above 2048 in the edge-stopping functions, svgf_atrous_filter.comp:40-42, at the full size)."""
     W, H = 3840, 2160
@@ -222,7 +219,7 @@ def test_config5_bistro_4k_16spp_two_bounces(oracle):
             sa, refl, mask, rays = osc.raygen(pfd, tp, n, d, rows=band)
             assert np.array_equal(rt[band[0]:band[1]], sa[band[0]:band[1]]), \
                 f"{(rt[band[0]:band[1]] != sa[band[0]:band[1]]).any(-1).sum()} pixels of the band differ"
-            b = _reflections_close(g.ctx.download(lib.REFLECTIONS), refl, band, 0.998)
+            b = _reflections_identical(g.ctx.download(lib.REFLECTIONS), refl, band)
             assert (b[..., 3] > 0).mean() > 0.3
             covered = d != 0
             assert covered[band[0]:band[1]].mean() > 0.5

@@ -5,7 +5,7 @@ import pytest
 
 from vulkanhybridrenderer_amd import abi, lib, scenes
 from vulkanhybridrenderer_amd.camera import directional_light
-from tests.helpers import GpuHybrid, f16, oracle_frames
+from tests.helpers import GpuHybrid, assert_reflections_identical, f16, oracle_frames
 
 pytestmark = pytest.mark.gpu
 
@@ -100,10 +100,7 @@ def test_random_triangle_soup_mirror_ray(oracle, seed, n_tris, n_prims):
                 g.ctx.set_option("reflection_variant", variant)
                 g.ctx.execute(0, 0)
                 g.ctx.synchronize()
-                a, b = f16(g.ctx.download(lib.REFLECTIONS)), f16(fr["reflections"])
-                assert np.array_equal(a[..., 3] > 0, b[..., 3] > 0), f"frame {i} variant {variant}: reflection hit mask"
-                tol = 2 * 2.0 ** -10 * np.maximum(np.abs(b), 2.0 ** -14)
-                assert (np.abs(a - b) <= tol).all(), f"frame {i} variant {variant}: reflection colour off by {np.abs(a - b).max()}"
+                assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], f"frame {i} variant {variant}: reflections")
             g.ctx.set_option("reflection_variant", 1)
         assert (f16(frames[1]["reflections"])[..., 3] > 0).mean() > 0.2
     finally:

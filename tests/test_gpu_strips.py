@@ -218,7 +218,6 @@ def test_golden_fixtures_on_gpu():
     try:
         gh.frame(pfd, (t["normals"], t["motion"], t["depth"]))
         assert np.array_equal(gh.ctx.download(lib.RAYTRACED), t["shadow_ao"])       # visibility: bit-exact vs the committed vector
-        a, b = f16(gh.ctx.download(lib.REFLECTIONS)), f16(t["reflections"])
-        assert (np.abs(a - b) <= 2.0 ** -9 * np.maximum(np.abs(b), 2.0 ** -14)).all()
+        assert np.array_equal(gh.ctx.download(lib.REFLECTIONS), t["reflections"])      # ... and so are the mirror ray's payloads
     finally:
         gh.close()

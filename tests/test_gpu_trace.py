@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from vulkanhybridrenderer_amd import abi, camera, lib, scenes
-from tests.helpers import GpuHybrid, f16, oracle_frames
+from tests.helpers import GpuHybrid, assert_reflections_identical, f16, oracle_frames
 
 pytestmark = pytest.mark.gpu
 
@@ -21,12 +21,7 @@ def _compare_trace(ob, scene, W, H, n_frames, tp):
             sa = g.ctx.download(lib.RAYTRACED)
             assert np.array_equal(sa, fr["shadow_ao"]), \
                 f"frame {i}: visibility differs at {np.argwhere(sa != fr['shadow_ao'])[:8]} ({(sa != fr['shadow_ao']).any(-1).sum()} px)"
-            refl = g.ctx.download(lib.REFLECTIONS)
-            a, b = f16(refl), f16(fr["reflections"])
-            hit_gpu, hit_cpu = a[..., 3] > 0, b[..., 3] > 0
-            assert np.array_equal(hit_gpu, hit_cpu), f"frame {i}: reflection hit masks differ"
-            tol = 2.0 ** -9 * np.maximum(np.abs(b), 2.0 ** -14)      # 2 fp16 ulps
-            assert (np.abs(a - b) <= tol).all(), f"frame {i}: reflection colour off by {np.abs(a - b).max()}"
+            assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], f"frame {i}: reflections")
     finally:
         g.close()
 
