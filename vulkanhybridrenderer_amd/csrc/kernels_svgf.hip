@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
     // (a plain 16-byte vector type: the tap's texel is then ONE ds_read_b128; as HIP's uint4 struct the compiler fetched it as
     // ds_read2_b64 = two 8-byte reads at a 16-byte lane stride, each a two-way bank conflict)
     typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
-    __shared__ lds_u4 s_a[TH][TW];                   // shadow, ao (fp32), (var_s, var_a) halves, (nx, ny) halves
-    __shared__ uint32_t s_ni[TH][TW];                // nz (high half) | truncated id as a half (low half)
+    typedef uint32_t lds_u2 __attribute__((ext_vector_type(2)));
+    __shared__ lds_u4 s_a[TH][TW];                   // shadow, ao, var_s, var_a: fp32 (all four enter the sums through packed fp32 instructions)
+    __shared__ lds_u2 s_n[TH][TW];                   // (nx, ny) halves | nz (high half), truncated id as a half (low half)
     const int W = int(a.width), H = int(a.height);
     const int max_x = min(W, int(ceilf(a.display_w))), max_y = min(H, int(ceilf(a.display_h)));
     const int tid = int(threadIdx.x);
@@ -312,20 +313,21 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
     }
 
     // ---- the 3x3 variance pre-filter (:17-38): vertical taps in-lane, horizontal via DPP ----
+    // (the weights are powers of two, so every product is exact and each sum below rounds exactly where the shader's += rounds; written as
+    // FMAs on the half operands -- v_fma_mix_f32 widens them inside the instruction -- 3 instructions per column and channel for the
+    // 3 conversions + 3 products + 2 sums of the literal form)
     f2v var_p[NK];
 #pragma unroll
     for (int kq = 0; kq < NK; ++kq) {
-        f2v own = f2v{ 0.0f, 0.0f }, edge = f2v{ 0.0f, 0.0f };
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float w = j == 1 ? 0.5f : 0.25f;
-            const float2 qo = unpack_rg16f(pv_own[kq][j]), qe = unpack_rg16f(pv_edge[kq][j]);
-            own += f2v{ w * qo.x, w * qo.y };
-            edge += f2v{ w * qe.x, w * qe.y };
-        }
+        auto column = [](const uint32_t (&v)[3]) {
+            const half2_t h0 = as_half2(v[0]), h1 = as_half2(v[1]), h2 = as_half2(v[2]);
+            return f2v{ fmaf(0.25f, float(h2.x), fmaf(0.5f, float(h1.x), 0.25f * float(h0.x))),
+                        fmaf(0.25f, float(h2.y), fmaf(0.5f, float(h1.y), 0.25f * float(h0.y))) };
+        };
+        const f2v own = column(pv_own[kq]), edge = column(pv_edge[kq]);
         const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
         const f2v right = f2v{ wave_shl1(edge.x, own.x), wave_shl1(edge.y, own.y) };
-        var_p[kq] = 0.25f * left + 0.5f * own + 0.25f * right;
+        var_p[kq] = f2v{ fmaf(0.25f, right.x, fmaf(0.5f, own.x, 0.25f * left.x)), fmaf(0.25f, right.y, fmaf(0.5f, own.y, 0.25f * left.y)) };
     }
     // ---- registers -> LDS (converted once per texel) ----
     if (stager) {
@@ -335,11 +337,12 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                 const int kk = p * PASS + r0;
                 if (kk < TH) {
                     uint4 va = make_uint4(0u, 0u, 0u, 0u);
-                    uint32_t ni = kInvalidId;
+                    uint32_t nxy = 0u, ni = kInvalidId;
                     if (all_loaded || (pf_ok & (1u << p))) {
                         const uint2 vin = pf_in[p], n = pf_nm[p];
-                        const float2 xy = unpack_rg16f(vin.x);
-                        va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), vin.y, n.x);
+                        const float2 xy = unpack_rg16f(vin.x), zw = unpack_rg16f(vin.y);
+                        va = make_uint4(__float_as_uint(xy.x), __float_as_uint(xy.y), __float_as_uint(zw.x), __float_as_uint(zw.y));
+                        nxy = n.x;
                         // int(w) as a half (:57, :83).  The taps compare ids as HALVES (v_cmp_eq_f16): -0 == +0 like int(-0.x) == 0, and a
                         // NaN id becomes 0 here, which is what int(NaN) is in the oracle (decision viii)
                         _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                         ni = (n.y << 16) | uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
                     }
                     s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
-                    s_ni[kk][c] = ni;
+                    s_n[kk][c] = lds_u2{ nxy, ni };
                 }
             }
         };
@@ -363,21 +366,27 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
         if (k >= R || uint32_t(cx) >= a.limit_x || uint32_t(cy) >= a.row_end || uint32_t(cy) >= a.limit_y) continue;
         const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
         const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
-        const float2 p_zw = unpack_rg16f(pa.z);
-        const half2_t np_xy = as_half2(pa.w);
-        const uint32_t nip = s_ni[k + 2][tx + 2 * STEP];
-        const float np_z = float(as_half2(nip).y);
-        const _Float16 idp = as_half2(nip).x;
+        const lds_u2 pn = s_n[k + 2][tx + 2 * STEP];
+        const half2_t np_xy = as_half2(pn.x);
+        const float np_z = float(as_half2(pn.y).y);
+        const _Float16 idp = as_half2(pn.y).x;
         // 1 / (4 sqrt(var) + 1e-6) (:48-50), times log2(e): the luminance weight is an exp2
         const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
                              __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].y) + 1e-6f) * 1.44269504088896341f };
         f2v sw = f2v{ 1.0f, 1.0f };                                                     // :70-71
         f2v s01 = p_xy;
-        float s2 = p_zw.x, s3 = p_zw.y;
+        f2v s23 = f2v{ u2f(pa.z), u2f(pa.w) };
+        // (kept in a vector register on purpose: a packed instruction takes ONE scalar operand, and that slot is better spent on the per-pair
+        // constants log2 k below, which would otherwise be moved into vector registers pair by pair)
+        float k128 = 128.0f;
+        asm volatile("" : "+v"(k128));
 #pragma unroll
         for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
             lds_u4 qa[4];
             float L[4];
+            float lg[4];
+            bool same[4];
+            f2v kc[2];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const int tp = 4 * g + h, idx = tp < 12 ? tp : tp + 1;                  // skip the centre (:77)
@@ -387,13 +396,21 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                 // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
                 const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
                 const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
-                const uint32_t niq = s_ni[row][col];
+                kc[h >> 1][h & 1] = lx + ly;
+                const lds_u2 qn = s_n[row][col];
                 float dd;                                                               // :44-46: nz nz' (the half widened by the instruction) ...
-                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(niq), "v"(np_z));
-                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qa[h].w), dd, false);      // ... + nx nx' + ny ny'
-                const float lg = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));               // log2; -inf at 0
-                L[h] = as_half2(niq).x == idp ? fmaf(lg, 128.0f, lx + ly) : -__builtin_inff();    // :40-42, :87 (out of the image: a NaN id)
+                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(qn.y), "v"(np_z));
+                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qn.x), dd, false);         // ... + nx nx' + ny ny'
+                lg[h] = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));                        // log2; -inf at 0
+                same[h] = as_half2(qn.y).x == idp;                                      // :40-42 (out of the image: a NaN id)
             }
+            // 128 log2(n.n') + log2 k for two taps per instruction (a packed fp32 FMA occupies the SIMD like a plain one)
+            const f2v L01 = __builtin_elementwise_fma(f2v{ lg[0], lg[1] }, f2v{ k128, k128 }, kc[0]);
+            const f2v L23 = __builtin_elementwise_fma(f2v{ lg[2], lg[3] }, f2v{ k128, k128 }, kc[1]);
+            L[0] = same[0] ? L01.x : -__builtin_inff();                                 // :87 in the exponent
+            L[1] = same[1] ? L01.y : -__builtin_inff();
+            L[2] = same[2] ? L23.x : -__builtin_inff();
+            L[3] = same[3] ? L23.y : -__builtin_inff();
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const f2v q_xy = f2v{ u2f(qa[h].x), u2f(qa[h].y) };
@@ -402,12 +419,10 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                                     __builtin_amdgcn_exp2f(fmaf(-fabsf(dl.y), inv.y, L[h])) };          // :88-89 with :87 in the exponent
                 sw += w2;                                                               // :91
                 s01 = __builtin_elementwise_fma(w2, q_xy, s01);                         // :92
-                const f2v wq = w2 * w2;
-                const half2_t q_zw = as_half2(qa[h].z);
-                s2 = fmaf(wq.x, float(q_zw.x), s2);
-                s3 = fmaf(wq.y, float(q_zw.y), s3);
+                s23 = __builtin_elementwise_fma(w2 * w2, f2v{ u2f(qa[h].z), u2f(qa[h].w) }, s23);
             }
         }
+        const float s2 = s23.x, s3 = s23.y;
         const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
         const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
         const uint32_t out_off = texel_offset(cy, cx);
