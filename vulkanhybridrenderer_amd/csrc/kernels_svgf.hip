@@ -255,6 +255,17 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
     uint32_t pf_ok = 0;
     uint32_t pv_own[NK][3], pv_edge[NK][3];
     const bool interior = x0 - 2 * STEP >= 0 && x0 + kTileX + 2 * STEP <= max_x && y0 - 2 * STEP >= 0 && y0 + (TH - 3) * STEP < max_y;
+#if defined(VHR_ATROUS_KO) && (VHR_ATROUS_KO & 1)
+    if (true) {
+        pf_ok = (1u << NP) - 1u;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { pf_in[p] = make_uint2(0x38003800u + uint32_t(tid), 0x2c002c00u); pf_nm[p] = make_uint2(0x38003800u, 0x3c003800u + uint32_t(p)); }
+#pragma unroll
+        for (int kq = 0; kq < NK; ++kq)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { pv_own[kq][j] = 0x2c002c00u + uint32_t(tx); pv_edge[kq][j] = 0x2c002c00u; }
+    } else
+#endif
     if (interior) {
         pf_ok = (1u << NP) - 1u;
         if (stager) {
@@ -426,6 +437,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
         const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
         const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
         const uint32_t out_off = texel_offset(cy, cx);
+#if defined(VHR_ATROUS_KO) && (VHR_ATROUS_KO & 2)
+        if (texel.x == 0x12345678u && texel.y == 0x9abcdef0u)       // (practically never: the arithmetic stays alive, nothing is stored)
+#endif
         *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
         if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
         if (a.normals_out) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.normals_out) + out_off) = *reinterpret_cast<const uint2 *>(nm_base + out_off);
