@@ -3,6 +3,8 @@ usage: python scratch/refl_counters.py [scene ...] [option=value ...]"""
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from vulkanhybridrenderer_amd import lib as _lib
+if os.environ.get("VHR_LIB_VARIANT"): _lib.LIB_PATH = os.path.abspath(os.environ["VHR_LIB_VARIANT"])
 import bench
 from vulkanhybridrenderer_amd import scenes
 from vulkanhybridrenderer_amd.harness import HybridFrameLoop

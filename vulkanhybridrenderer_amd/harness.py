@@ -28,6 +28,22 @@ def alias_tensor(info):
     return torch.as_tensor(_DeviceArray(info), device="cuda")
 
 
+# Options by tile size for world > 1 (tools/tile_ceilings.py --sweep, profiles/r5_tile_ceilings.txt): the defaults are tuned on whole 1080p / 4K
+# frames; a rank's rectangle of an 8-GPU run is a launch of a few hundred workgroups that does not fill the chip for one round.
+# [(computed pixels up to, {option: value})], first match.
+TILE_TUNING = []
+
+
+def tuned_tile_options(computed_pixels, world):
+    """The option overrides HybridFrameLoop applies for a rank that computes `computed_pixels` (its rectangle grown by the overlap)."""
+    if world <= 1:
+        return {}
+    for limit, options in TILE_TUNING:
+        if computed_pixels <= limit:
+            return dict(options)
+    return {}
+
+
 class CommBringUpError(RuntimeError):
     """The library's own RCCL route (vhr_comm_*) did not come up.  Raised on EVERY rank of the job or on none, so the ranks stay in step
     and may all take another route (or all stop)."""

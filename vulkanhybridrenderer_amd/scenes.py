@@ -289,6 +289,62 @@ def sponza_proc(detail=1.0):
     return b.finish("sponza_proc", camera, directional_light(REFERENCE_LIGHT_DIRECTION))
 
 
+def sponza_hard(detail=1.0):
+    """sponza_proc's atrium with the triangle budget spent the way a modelled building spends it (the uniform tessellation of
+    sponza_proc is kind to a BVH): floor, walls and gallery slabs are TWO triangles each (boxes 40 m long), the 48 columns are 24-gons of two
+    segments (slivers 9 cm x 2.6 m), and what that frees goes into dense drapery -- six curtains in the nave, six banners hung flush against
+    the long walls (inside the walls' huge boxes), two layers of overlapping folds each -- and finer urns.  ~254 k triangles in 103
+    primitives, same camera, light and dolly as sponza_proc.  An extra beside the headline, not a BASELINE configuration."""
+    d = lambda n: max(2, int(round(n * detail)))   # noqa: E731
+    b = _Builder()
+    L, Wd, Ht = 20.0, 8.0, 14.0
+    k = 0
+    b.add(plane([-L, 0, Wd], [2 * L, 0, 0], [0, 0, -2 * Wd], 1, 1), base_color=(0.62, 0.58, 0.52, 1), roughness=0.9); k += 1
+    b.add(plane([-L, 0, -Wd], [2 * L, 0, 0], [0, Ht, 0], 1, 1), base_color=(0.75, 0.7, 0.62, 1)); k += 1
+    b.add(plane([L, 0, Wd], [-2 * L, 0, 0], [0, Ht, 0], 1, 1), base_color=(0.75, 0.7, 0.62, 1)); k += 1
+    b.add(plane([-L, 0, Wd], [0, 0, -2 * Wd], [0, Ht, 0], 1, 1), base_color=(0.7, 0.66, 0.6, 1)); k += 1
+    b.add(plane([L, 0, -Wd], [0, 0, 2 * Wd], [0, Ht, 0], 1, 1), base_color=(0.7, 0.66, 0.6, 1)); k += 1
+    gz = 4.5
+    for sgn in (-1.0, 1.0):
+        z0, z1 = (sgn * Wd, sgn * gz)
+        b.add(plane([-L, 6.0, max(z0, z1)], [2 * L, 0, 0], [0, 0, -(Wd - gz)], 1, 1), base_color=(0.66, 0.62, 0.55, 1)); k += 1
+        b.add(plane([-L, 5.7, min(z0, z1)], [2 * L, 0, 0], [0, 0, (Wd - gz)], 1, 1), base_color=(0.6, 0.56, 0.5, 1)); k += 1
+    xs = np.linspace(-17.5, 17.5, 12)
+    col_lo = cylinder(0.35, 5.2, 24, 2)
+    col_hi = cylinder(0.28, 5.0, 24, 2)
+    for sgn in (-1.0, 1.0):
+        for x in xs:
+            b.add(col_lo, trs((x, 0.0, sgn * gz)), base_color=_palette(k), roughness=0.7); k += 1
+        for x in xs:
+            b.add(col_hi, trs((x, 6.0, sgn * gz)), base_color=_palette(k), roughness=0.7); k += 1
+    spacing = xs[1] - xs[0]
+    arch = half_torus(spacing * 0.5, 0.3, d(32), d(48))
+    for sgn in (-1.0, 1.0):
+        for a, c in zip(xs[:-1], xs[1:]):
+            b.add(arch, trs(((a + c) * 0.5, 5.2, sgn * gz), scale=(1.0, 0.55, 1.0)), base_color=_palette(k), roughness=0.6); k += 1
+    # drapery: each primitive is two layers of folds 4 cm apart (overlapping boxes all the way down the tree)
+    layer_a = curtain(2.6, 4.2, d(51), d(51), 3.0, 0.18)
+    layer_b = curtain(2.6, 4.2, d(51), d(51), 3.5, 0.15)
+    pb = layer_b[0].copy(); pb[:, 2] += 0.04
+    drape = merge([layer_a, (pb, layer_b[1], layer_b[2], layer_b[3])])
+    for j in range(6):             # in the nave
+        x = -16.0 + j * (32.0 / 5.0)
+        z = (-1.0 if j % 2 else 1.0) * (1.2 + 0.35 * (j % 3))
+        b.add(drape, trs((x, 11.5 - 0.4 * (j % 4), z), rot_y=0.35 * ((j % 5) - 2)), base_color=_palette(k), roughness=0.95); k += 1
+    for j in range(6):             # banners flush against the long walls
+        x = -15.0 + j * 6.0
+        sgn = -1.0 if j % 2 else 1.0
+        b.add(drape, trs((x, 10.5, sgn * (Wd - 0.25)), scale=(1.6, 1.6, 1.0)), base_color=_palette(k), roughness=0.95); k += 1
+    urn = sphere(0.55, d(48), d(48))
+    for j in range(12):
+        x = -15.0 + j * (30.0 / 11.0)
+        z = (1.0 if j % 2 else -1.0) * 2.6
+        b.add(urn, trs((x, 0.88, z), scale=(1.0, 1.6, 1.0)), base_color=_palette(k), metallic=0.6, roughness=0.35); k += 1
+    camera = dict(position=(-17.0, 2.0, 0.4), yaw=-np.pi / 2, pitch=0.06, yfov=0.9, znear=0.1, aspect=16.0 / 9.0,
+                  dolly=(0.05, 0.0, 0.0))
+    return b.finish("sponza_hard", camera, directional_light(REFERENCE_LIGHT_DIRECTION))
+
+
 def _procedural_texture(k, size=512):
     """Deterministic RGBA8 texture (checker + stripes + hash noise), sRGB base-colour content."""
     y, x = np.mgrid[0:size, 0:size].astype(np.uint32)
