@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--reflections", action="store_true", help="also trace the mirror ray raygen.rgen always issues")
     p.add_argument("--refl-bounces", type=int, default=None, choices=[0, 1, 2],
                    help="mirror bounces (1 = --reflections = the reference; 2 = BASELINE config 5's extension; second-bounce rays are NOT counted in value)")
-    p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "tiny"])
+    p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "sponza_hard", "tiny"])
     p.add_argument("--gltf", default=None, help="load this .gltf / .glb instead of a procedural scene (vulkanhybridrenderer_amd/gltf.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=16, help="frames of the same workload the CPU oracle is timed on (~1.3 s each on the GPU box's 128 threads)")
@@ -392,7 +392,7 @@ def main():
         from vulkanhybridrenderer_amd import gltf
         scene = gltf.load(args.gltf)
     else:
-        scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "tiny": scenes.tiny_scene}[args.scene]()
+        scene = {"sponza_proc": scenes.sponza_proc, "bistro_proc": scenes.bistro_proc, "sponza_hard": scenes.sponza_hard, "tiny": scenes.tiny_scene}[args.scene]()
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup + (args.verify_frames if world > 1 else 0), args.max_gbuffers)
     common = dict(shadow=True, ao_spp=args.ao_spp, denoise=True, device=local_rank)
