@@ -332,8 +332,11 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
     for (int kq = 0; kq < NK; ++kq) {
         auto column = [](const uint32_t (&v)[3]) {
             const half2_t h0 = as_half2(v[0]), h1 = as_half2(v[1]), h2 = as_half2(v[2]);
-            return f2v{ fmaf(0.25f, float(h2.x), fmaf(0.5f, float(h1.x), 0.25f * float(h0.x))),
-                        fmaf(0.25f, float(h2.y), fmaf(0.5f, float(h1.y), 0.25f * float(h0.y))) };
+            float a0, a1;                          // 0.25 h0 (exact), the half widened by the instruction
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(v[0]), "v"(0.25f));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(v[0]), "v"(0.25f));
+            (void)h0;
+            return f2v{ fmaf(0.25f, float(h2.x), fmaf(0.5f, float(h1.x), a0)), fmaf(0.25f, float(h2.y), fmaf(0.5f, float(h1.y), a1)) };
         };
         const f2v own = column(pv_own[kq]), edge = column(pv_edge[kq]);
         const f2v left = f2v{ wave_shr1(edge.x, own.x), wave_shr1(edge.y, own.y) };
@@ -378,8 +381,10 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
         const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
         const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
         const lds_u2 pn = s_n[k + 2][tx + 2 * STEP];
-        const half2_t np_xy = as_half2(pn.x);
-        const float np_z = float(as_half2(pn.y).y);
+        // The centre's normal at HALF length (exact: a power of two): n.n' then arrives as dd / 2 <= 0.501, and the dot product's own output
+        // clamp to [0, 1] (v_fma_mix_f32's) IS the shader's max(0, .) (:46) -- no v_max per tap; the factor comes back as +128 in the tap's constant below.
+        const half2_t np_xy = as_half2(pn.x) * half2_t{ _Float16(0.5f), _Float16(0.5f) };
+        const float np_z = 0.5f * float(as_half2(pn.y).y);
         const _Float16 idp = as_half2(pn.y).x;
         // 1 / (4 sqrt(var) + 1e-6) (:48-50), times log2(e): the luminance weight is an exp2
         const f2v inv = f2v{ __builtin_amdgcn_rcpf(4.0f * __builtin_amdgcn_sqrtf(var_p[kq].x) + 1e-6f) * 1.44269504088896341f,
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
 #pragma unroll
         for (int g = 0; g < 6; ++g) {                                                   // :72-94, four taps per trip
             lds_u4 qa[4];
+            lds_u2 qn[4];
             float L[4];
             float lg[4];
             bool same[4];
@@ -403,18 +409,34 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                 const int tp = 4 * g + h, idx = tp < 12 ? tp : tp + 1;                  // skip the centre (:77)
                 const int y = idx / 5 - 2, x = idx % 5 - 2;
                 const int row = k + 2 + y, col = tx + 2 * STEP + x * STEP;
+#if defined(VHR_ATROUS_KO) && (VHR_ATROUS_KO & 4)
+                // (knock-out: no LDS read in the taps -- values the compiler cannot fold, derived from the centre texel and the tap index)
+                qa[h] = lds_u4{ pa.x + uint32_t(tp) * 8192u, pa.y ^ (uint32_t(tp) << 12), pa.z + uint32_t(tp), pa.w };
+                qn[h] = lds_u2{ pn.x ^ (uint32_t(tp) << 3), pn.y ^ (uint32_t(tp) << 19) };
+                (void)row; (void)col;
+#else
                 qa[h] = s_a[row][col];
+                qn[h] = s_n[row][col];
+#endif
                 // log2 of the B3 spline factors (:62-68): 3/8, 1/4, 1/16
                 const float lx = (x == 0) ? -1.41503749927884381f : ((x == 1 || x == -1) ? -2.0f : -4.0f);
                 const float ly = (y == 0) ? -1.41503749927884381f : ((y == 1 || y == -1) ? -2.0f : -4.0f);
-                kc[h >> 1][h & 1] = lx + ly;
-                const lds_u2 qn = s_n[row][col];
-                float dd;                                                               // :44-46: nz nz' (the half widened by the instruction) ...
-                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(qn.y), "v"(np_z));
-                dd = __builtin_amdgcn_fdot2(np_xy, as_half2(qn.x), dd, false);         // ... + nx nx' + ny ny'
-                lg[h] = __builtin_amdgcn_logf(fmaxf(dd, 0.0f));                        // log2; -inf at 0
-                same[h] = as_half2(qn.y).x == idp;                                      // :40-42 (out of the image: a NaN id)
+                kc[h >> 1][h & 1] = lx + ly + 128.0f;                                   // (+128 = -128 log2(1/2): the half-length normal)
+                same[h] = as_half2(qn[h].y).x == idp;                                   // :40-42 (out of the image: a NaN id)
             }
+            // :44-46 for the four taps: (nx nx' + ny ny') + nz nz' -- the shader's order --, the second instruction widening the half nz' itself and
+            // clamping to [0, 1]: max(0, .) for free (v_dot2_f32_f16's own clamp bit does not act on gfx950: scratch/clamp_probe.hip).  ONE asm
+            // statement: a dot product's result needs three wait states before a vector instruction may read it -- the compiler inserts them
+            // (s_nop) for its own instructions and cannot for an asm statement's operands (the clamped FMA as a statement of its own read garbage)
+            // -- and here the other three taps' instructions ARE the wait states.  The VOP3P dot takes its addend 0 inline (the compiler's own
+            // choice, v_dot2c, needs a v_mov per tap to zero its accumulator).
+            asm("v_dot2_f32_f16 %0, %4, %5, 0\n\tv_dot2_f32_f16 %1, %4, %6, 0\n\tv_dot2_f32_f16 %2, %4, %7, 0\n\tv_dot2_f32_f16 %3, %4, %8, 0\n\t"
+                "v_fma_mix_f32 %0, %9, %13, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\tv_fma_mix_f32 %1, %10, %13, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\t"
+                "v_fma_mix_f32 %2, %11, %13, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\tv_fma_mix_f32 %3, %12, %13, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp"
+                : "=&v"(lg[0]), "=&v"(lg[1]), "=&v"(lg[2]), "=&v"(lg[3])
+                : "v"(np_xy), "v"(qn[0].x), "v"(qn[1].x), "v"(qn[2].x), "v"(qn[3].x), "v"(qn[0].y), "v"(qn[1].y), "v"(qn[2].y), "v"(qn[3].y), "v"(np_z));
+#pragma unroll
+            for (int h = 0; h < 4; ++h) lg[h] = __builtin_amdgcn_logf(lg[h]);              // log2; -inf at 0
             // 128 log2(n.n') + log2 k for two taps per instruction (a packed fp32 FMA occupies the SIMD like a plain one)
             const f2v L01 = __builtin_elementwise_fma(f2v{ lg[0], lg[1] }, f2v{ k128, k128 }, kc[0]);
             const f2v L23 = __builtin_elementwise_fma(f2v{ lg[2], lg[3] }, f2v{ k128, k128 }, kc[1]);
