@@ -43,6 +43,7 @@ def test_c_abi_exchanges_on_one_gpu_equal_the_single_context_and_the_torch_route
     r, line2 = _bench(args + ["--comm", "torch"], timeout=600)
     assert r.returncode == 0 and line2["config"]["strips_vs_single_context"] == "bit-identical", (r.stdout[-2000:], r.stderr[-3000:])
     assert line2["config"]["parallelism"] == line["config"]["parallelism"]
+    _sweep_shim_directories()
 
 
 def _run_ranks(shim, world, frames, fail, fail_rank, mode="", timeout_s=8):
@@ -64,7 +65,17 @@ def _run_ranks(shim, world, frames, fail, fail_rank, mode="", timeout_s=8):
             out, _ = p.communicate()
         outs.append(out)
         codes.append(p.returncode)
+    _sweep_shim_directories()
     return codes, outs, hung
+
+
+def _sweep_shim_directories():
+    """A run that ends in an injected failure leaves its message directory behind (the shim removes it when the last rank destroys its
+    communicator): /dev/shm is memory, so the test cleans up what the shim of THIS test module created."""
+    import glob
+    import shutil
+    for d in glob.glob("/dev/shm/vhr_rccl_shim_*"):
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def test_shim_ranks_without_a_launcher_run_clean(shim):
