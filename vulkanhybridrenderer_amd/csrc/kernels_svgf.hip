@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                         // NaN id becomes 0 here, which is what int(NaN) is in the oracle (decision viii)
                         _Float16 idh = __builtin_truncf16(as_half2(n.y).y);
                         idh = idh == idh ? idh : _Float16(0.0f);
-                        ni = (n.y << 16) | uint32_t(*reinterpret_cast<const uint16_t *>(&idh));
+                        // nz (the low half of n.y) into the high half, the id's bits into the low half: one byte permute
+                        ni = __builtin_amdgcn_perm(uint32_t(*reinterpret_cast<const uint16_t *>(&idh)), n.y, 0x01000504u);
                     }
                     s_a[kk][c] = lds_u4{ va.x, va.y, va.z, va.w };
                     s_n[kk][c] = lds_u2{ nxy, ni };
@@ -455,9 +456,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
                 s23 = __builtin_elementwise_fma(w2 * w2, f2v{ u2f(qa[h].z), u2f(qa[h].w) }, s23);
             }
         }
-        const float s2 = s23.x, s3 = s23.y;
-        const float rs = __builtin_amdgcn_rcpf(sw.x), ra = __builtin_amdgcn_rcpf(sw.y);
-        const uint2 texel = pack_rgba16f(s01.x * rs, s01.y * ra, s2 * (rs * rs), s3 * (ra * ra));      // :97-101
+        const f2v r = f2v{ __builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y) };
+        const f2v o01 = s01 * r, o23 = s23 * (r * r);                                     // :97-101 (three packed products)
+        const uint2 texel = pack_rgba16f(o01.x, o01.y, o23.x, o23.y);
         const uint32_t out_off = texel_offset(cy, cx);
 #if defined(VHR_ATROUS_KO) && (VHR_ATROUS_KO & 2)
         if (texel.x == 0x12345678u && texel.y == 0x9abcdef0u)       // (practically never: the arithmetic stays alive, nothing is stored)
