@@ -464,8 +464,17 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
         if (texel.x == 0x12345678u && texel.y == 0x9abcdef0u)       // (practically never: the arithmetic stays alive, nothing is stored)
 #endif
         *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out) + out_off) = texel;
-        if (a.out2) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.out2) + out_off) = texel;
-        if (a.normals_out) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(a.normals_out) + out_off) = *reinterpret_cast<const uint2 *>(nm_base + out_off);
+        // The fused blits' stores (and the one load) with the image base in scalar registers and the 32-bit texel offset in a vector register, spelled
+        // out: for these nullable pointers the compiler builds a 64-bit vector address per access (a v_lshl_add_u64 each) where the main store
+        // above gets the scalar-base form.  Last instructions of the thread: nothing behind them depends on the counters the compiler tracks.
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        const u2v tv = u2v{ texel.x, texel.y };
+        if (a.out2) asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(out_off), "v"(tv), "s"(a.out2) : "memory");
+        if (a.normals_out) {
+            u2v nv;
+            asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(nv) : "v"(out_off), "s"(a.normals) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(out_off), "v"(nv), "s"(a.normals_out) : "memory");
+        }
     }
 }
 
