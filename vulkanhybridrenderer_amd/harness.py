@@ -104,6 +104,11 @@ class HybridFrameLoop:
             self.ctx.set_option("strip_shrink_overlap", 1)
             # the pass epilogues below exchange visibility and SVGF history only: the mirror ray's launch need not be waited for there
             self.ctx.set_option("reflection_async", 2)
+            # options by tile size (TILE_TUNING above: the r5 sweep found none worth setting, the hook stays)
+            cx0, cx1, cy0, cy1 = p.computed_rect()
+            self.tile_options = tuned_tile_options((cx1 - cx0) * (cy1 - cy0), world)
+            for key, value in self.tile_options.items():
+                self.ctx.set_option(key, value)
             if self.comm is None:
                 self.exchanges = tiling.StripExchanges(dist, self.plan, trace_overlap=self.trace_overlap, denoise=denoise, gather=self._gather_requested,
                                                        allow_degraded=self._allow_degraded)
