@@ -5,11 +5,12 @@
 // (:187-205, zero previous matrices on frame 0, frame_index++), UpdatePerFrameUBO, RenderGraph::Execute.
 // The two raster stages that stay with the integrator (G-buffer, composition) are fed by the library's stand-ins.
 //
-// Build: make -C vulkanhybridrenderer_amd/csrc examples      Run (MI355X): examples/hybrid_frames [frames] [out.ppm]
+// Build: make -C vulkanhybridrenderer_amd/csrc examples      Run (MI355X): examples/hybrid_frames [frames] [out.ppm] [straight]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "render_paths.hpp"     // vhr::HybridRenderPath on the facade of include/vhr_render_graph.hpp
@@ -80,6 +81,7 @@ float half_to_float(uint16_t h) {
 int main(int argc, char **argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 8;
     const char *ppm = argc > 2 ? argv[2] : nullptr;
+    const bool checkpoint = !(argc > 3 && std::strcmp(argv[3], "straight") == 0);      // "straight": no save / restore half way
     const uint32_t W = 640, H = 360;
     try {
         vhr::DeviceContext context(0, W, H);
@@ -174,6 +176,19 @@ int main(int argc, char **argv) {
             resource_manager.UpdatePerFrameUBO(0, pfd);
             render_graph.Execute(0, 0);
             prev_view = view; prev_proj = proj;
+            if (checkpoint && f == frames / 2) {
+                // Checkpoint / resume (the reference has none): the path's cross-frame state out to host memory, the SVGF images thrown away
+                // (Rebuild allocates fresh, zeroed ones), the state back in -- the frames that follow are the uninterrupted run's, bit for bit
+                // (tests/test_cpp_example.py compares the two runs' checksums).  The blob also carries the caller's half of the state: the last
+                // PerFrameData, from which prev_view / prev_proj / frame_index of the next frame follow (renderer.cpp:187-190,202).
+                const std::vector<uint8_t> state = path.SaveState();
+                path.Rebuild();
+                const vhr::PerFrameData last = path.LoadState(state);
+                if (std::memcmp(&last, &pfd, sizeof pfd) != 0) throw std::runtime_error("checkpoint: the blob's PerFrameData is not the last frame's");
+                std::memcpy(prev_view.m, last.camera_view, 64); std::memcpy(prev_proj.m, last.camera_proj, 64);
+                frame_index = last.frame_index + 1;
+                std::printf("checkpoint after frame %d: %zu bytes saved and restored\n", f, state.size());
+            }
         }
         render_graph.GatherPerformanceStatistics();
         vhr::check(context.handle, vhr_synchronize(context.handle), "vkDeviceWaitIdle");
@@ -184,6 +199,9 @@ int main(int argc, char **argv) {
                                                                 denoised.data(), denoised.size() * 2), "download");
         std::vector<float> depth(size_t(W) * H);
         vhr::check(context.handle, vhr_download_transient_image(context.handle, "Depth", depth.data(), depth.size() * 4), "download");
+        unsigned long long checksum = 1469598103934665603ull;                      // FNV-1a over the denoised image's bits
+        for (uint16_t w : denoised) { checksum ^= w; checksum *= 1099511628211ull; }
+        std::printf("denoised checksum %016llx\n", checksum);
         double shadow = 0.0, ao = 0.0, covered = 0.0;
         for (size_t i = 0; i < depth.size(); ++i)
             if (depth[i] != 0.0f) { shadow += half_to_float(denoised[4 * i]); ao += half_to_float(denoised[4 * i + 1]); covered += 1.0; }

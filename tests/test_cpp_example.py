@@ -30,3 +30,11 @@ def test_example_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
     assert out.stat().st_size > 640 * 360 * 3
+    # the run above saved the path's state half way (HybridRenderPath::SaveState), rebuilt the path and restored it (LoadState): its last frame is the
+    # uninterrupted run's, bit for bit
+    assert "checkpoint after frame 4" in r.stdout
+    straight = subprocess.run([EXE, "8", str(tmp_path / "straight.ppm"), "straight"], capture_output=True, text=True, timeout=300)
+    assert straight.returncode == 0 and "checkpoint" not in straight.stdout.replace("denoised checksum", ""), straight.stdout + straight.stderr
+    pick = lambda text: [l for l in text.splitlines() if l.startswith("denoised checksum")]
+    assert pick(r.stdout) and pick(r.stdout) == pick(straight.stdout), (pick(r.stdout), pick(straight.stdout))
+    assert (tmp_path / "straight.ppm").read_bytes() == out.read_bytes()

@@ -279,6 +279,8 @@ int vhr_hybrid_get_push_constants(vhr_hybrid_render_path *p, vhr_svgf_push_const
 
 const char *vhr_hybrid_last_error(vhr_hybrid_render_path *p) { return p ? p->error.c_str() : ""; }
 
+}  // extern "C"
+
 // ---- checkpoint / resume of the SVGF state (vhr_amd.h; through the public C ABI only, like the rest of this file) ----
 namespace {
 struct SvgfStateHeader {
@@ -292,23 +294,21 @@ struct SvgfStateHeader {
 constexpr char kStateMagic[8] = { 'V', 'H', 'R', 'S', 'V', 'G', 'F', '1' };
 
 // the five images in blob order, as the NEXT frame addresses them (the frame-start order of the ping-pong pair, :328)
-int svgf_state_images(vhr_hybrid_render_path *p, int32_t ids[5], vhr_image_info info[5]) {
-    if (!p->path.svgf_textures_created) { p->error = "SVGF state: the path has no SVGF images (denoise off, or not built)"; return VHR_ERROR_GRAPH; }
-    const vhr::SVGFPushConstants &pc = p->path.svgf_push_constants;
+int svgf_state_images(vhr_context *ctx, const vhr::HybridRenderPath &path, int32_t ids[5], vhr_image_info info[5], std::string &error) {
+    if (!path.svgf_textures_created) { error = "SVGF state: the path has no SVGF images (denoise off, or not built)"; return VHR_ERROR_GRAPH; }
+    const vhr::SVGFPushConstants &pc = path.svgf_push_constants;
     ids[0] = pc.integrated_shadow_and_ao[0]; ids[1] = pc.integrated_shadow_and_ao[1]; ids[2] = pc.prev_frame_normals_and_object_ids;
     ids[3] = pc.shadow_and_ao_history; ids[4] = pc.shadow_and_ao_moments_history;
     for (int i = 0; i < 5; ++i) {
-        const int rc = vhr_get_storage_image(p->context.handle, ids[i], &info[i]);
-        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+        const int rc = vhr_get_storage_image(ctx, ids[i], &info[i]);
+        if (rc < 0) { error = std::string("SVGF state: ") + vhr_last_error(ctx); return rc; }
     }
     return VHR_OK;
 }
-}  // namespace
 
-int vhr_hybrid_state_size(vhr_hybrid_render_path *p, uint64_t *bytes) {
-    if (!p || !bytes) return VHR_ERROR_INVALID_ARGUMENT;
+int svgf_state_size(vhr_context *ctx, const vhr::HybridRenderPath &path, uint64_t *bytes, std::string &error) {
     int32_t ids[5]; vhr_image_info info[5];
-    const int rc = svgf_state_images(p, ids, info);
+    const int rc = svgf_state_images(ctx, path, ids, info, error);
     if (rc < 0) return rc;
     uint64_t total = sizeof(SvgfStateHeader);
     for (int i = 0; i < 5; ++i) total += uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel;
@@ -316,10 +316,9 @@ int vhr_hybrid_state_size(vhr_hybrid_render_path *p, uint64_t *bytes) {
     return VHR_OK;
 }
 
-int vhr_hybrid_save_state(vhr_hybrid_render_path *p, void *blob, uint64_t bytes) {
-    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+int svgf_state_save(vhr_context *ctx, const vhr::HybridRenderPath &path, void *blob, uint64_t bytes, std::string &error) {
     int32_t ids[5]; vhr_image_info info[5];
-    int rc = svgf_state_images(p, ids, info);
+    int rc = svgf_state_images(ctx, path, ids, info, error);
     if (rc < 0) return rc;
     SvgfStateHeader h{};
     std::memcpy(h.magic, kStateMagic, 8);
@@ -330,48 +329,77 @@ int vhr_hybrid_save_state(vhr_hybrid_render_path *p, void *blob, uint64_t bytes)
         h.image_bytes[i] = uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel;
         h.total_bytes += h.image_bytes[i];
     }
-    if (bytes != h.total_bytes) { p->error = "SVGF state: the blob must hold exactly vhr_hybrid_state_size bytes"; return VHR_ERROR_INVALID_ARGUMENT; }
-    rc = vhr_get_last_per_frame_ubo(p->context.handle, &h.last_frame);
+    if (bytes != h.total_bytes) { error = "SVGF state: the blob must hold exactly vhr_hybrid_state_size bytes"; return VHR_ERROR_INVALID_ARGUMENT; }
+    rc = vhr_get_last_per_frame_ubo(ctx, &h.last_frame);
     if (rc < 0) return rc;
     char *out = static_cast<char *>(blob);
     std::memcpy(out, &h, sizeof h);
     out += sizeof h;
     for (int i = 0; i < 5; ++i) {          // (a download waits for every stream of the context, the side stream's dead iteration included)
-        rc = vhr_download_storage_image(p->context.handle, ids[i], out, h.image_bytes[i]);
-        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+        rc = vhr_download_storage_image(ctx, ids[i], out, h.image_bytes[i]);
+        if (rc < 0) { error = std::string("SVGF state: ") + vhr_last_error(ctx); return rc; }
         out += h.image_bytes[i];
     }
     return VHR_OK;
 }
 
-int vhr_hybrid_load_state(vhr_hybrid_render_path *p, const void *blob, uint64_t bytes, vhr_per_frame_data *last_frame) {
-    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+int svgf_state_load(vhr_context *ctx, const vhr::HybridRenderPath &path, const void *blob, uint64_t bytes, vhr_per_frame_data *last_frame, std::string &error) {
     int32_t ids[5]; vhr_image_info info[5];
-    int rc = svgf_state_images(p, ids, info);
+    int rc = svgf_state_images(ctx, path, ids, info, error);
     if (rc < 0) return rc;
     SvgfStateHeader h;
-    if (bytes < sizeof h) { p->error = "SVGF state: blob shorter than its header"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (bytes < sizeof h) { error = "SVGF state: blob shorter than its header"; return VHR_ERROR_INVALID_ARGUMENT; }
     std::memcpy(&h, blob, sizeof h);
-    if (std::memcmp(h.magic, kStateMagic, 8) != 0 || h.version != 1 || h.image_count != 5) { p->error = "SVGF state: not a version-1 state blob"; return VHR_ERROR_INVALID_ARGUMENT; }
-    if (h.total_bytes != bytes) { p->error = "SVGF state: byte count differs from the header's"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (std::memcmp(h.magic, kStateMagic, 8) != 0 || h.version != 1 || h.image_count != 5) { error = "SVGF state: not a version-1 state blob"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (h.total_bytes != bytes) { error = "SVGF state: byte count differs from the header's"; return VHR_ERROR_INVALID_ARGUMENT; }
     uint64_t total = sizeof h;
     for (int i = 0; i < 5; ++i) {
         if (h.width != info[i].width || h.height != info[i].height || h.format[i] != info[i].format ||
             h.image_bytes[i] != uint64_t(info[i].width) * info[i].height * info[i].bytes_per_pixel) {
-            p->error = "SVGF state: the blob was saved from a path of another extent or image format";
+            error = "SVGF state: the blob was saved from a path of another extent or image format";
             return VHR_ERROR_INVALID_ARGUMENT;
         }
         total += h.image_bytes[i];
     }
-    if (total != bytes) { p->error = "SVGF state: image byte counts do not add up to the blob"; return VHR_ERROR_INVALID_ARGUMENT; }
+    if (total != bytes) { error = "SVGF state: image byte counts do not add up to the blob"; return VHR_ERROR_INVALID_ARGUMENT; }
     const char *in = static_cast<const char *>(blob) + sizeof h;
     for (int i = 0; i < 5; ++i) {
-        rc = vhr_upload_storage_image(p->context.handle, ids[i], in, h.image_bytes[i]);
-        if (rc < 0) { p->error = std::string("SVGF state: ") + vhr_last_error(p->context.handle); return rc; }
+        rc = vhr_upload_storage_image(ctx, ids[i], in, h.image_bytes[i]);
+        if (rc < 0) { error = std::string("SVGF state: ") + vhr_last_error(ctx); return rc; }
         in += h.image_bytes[i];
     }
     if (last_frame) *last_frame = h.last_frame;
     return VHR_OK;
 }
+}  // namespace
 
+// the facade's methods (csrc/render_paths.hpp): errors throw like every other call of the facade
+std::vector<uint8_t> vhr::HybridRenderPath::SaveState() {
+    std::string error;
+    uint64_t n = 0;
+    if (svgf_state_size(context.handle, *this, &n, error) < 0) throw std::runtime_error(error);
+    std::vector<uint8_t> blob(n);
+    if (svgf_state_save(context.handle, *this, blob.data(), n, error) < 0) throw std::runtime_error(error);
+    return blob;
+}
+vhr::PerFrameData vhr::HybridRenderPath::LoadState(const std::vector<uint8_t> &blob) {
+    std::string error;
+    vhr::PerFrameData last{};
+    if (svgf_state_load(context.handle, *this, blob.data(), blob.size(), &last, error) < 0) throw std::runtime_error(error);
+    return last;
+}
+
+extern "C" {
+int vhr_hybrid_state_size(vhr_hybrid_render_path *p, uint64_t *bytes) {
+    if (!p || !bytes) return VHR_ERROR_INVALID_ARGUMENT;
+    return svgf_state_size(p->context.handle, p->path, bytes, p->error);
+}
+int vhr_hybrid_save_state(vhr_hybrid_render_path *p, void *blob, uint64_t bytes) {
+    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+    return svgf_state_save(p->context.handle, p->path, blob, bytes, p->error);
+}
+int vhr_hybrid_load_state(vhr_hybrid_render_path *p, const void *blob, uint64_t bytes, vhr_per_frame_data *last_frame) {
+    if (!p || !blob) return VHR_ERROR_INVALID_ARGUMENT;
+    return svgf_state_load(p->context.handle, p->path, blob, bytes, last_frame, p->error);
+}
 }  // extern "C"

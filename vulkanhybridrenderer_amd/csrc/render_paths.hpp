@@ -4,6 +4,9 @@
 // Settings the reference changes through ImGui radio buttons (then Rebuild()) are plain public members here.
 #pragma once
 
+#include <cstdint>
+#include <vector>
+
 #include "vhr_render_graph.hpp"
 
 namespace vhr {
@@ -38,6 +41,12 @@ public:
     // the five persistent SVGF images (pool indices) travel in the push constants, hybrid_render_path.cpp:247-262
     SVGFPushConstants svgf_push_constants{};
     bool svgf_textures_created = false;
+
+    // Checkpoint / resume of the path's cross-frame state (no reference counterpart; vhr_amd.h: vhr_hybrid_save_state).  SaveState returns the blob
+    // (header + the last PerFrameData + the five SVGF images as the next frame addresses them); LoadState restores it into this path (same extent) and
+    // returns that PerFrameData: the caller continues with view_prev / proj_prev = its view / proj and frame_index + 1 (renderer.cpp:187-190,202).
+    std::vector<uint8_t> SaveState();
+    PerFrameData LoadState(const std::vector<uint8_t> &blob);
 };
 
 class RaytracedRenderPath : public RenderPath {
