@@ -168,7 +168,7 @@ def test_every_tuning_option_is_result_neutral(oracle, option, values):
         assert all(float(np.sqrt(np.mean((f16(o) - f16(frames[-1]["denoised"])) ** 2))) <= 1e-4 for o in outs)
 
 
-_TRACE_OPTIONS = ("raygen_variant", "reflection_variant", "refill_threshold", "lds_stack_levels", "raygen_waves_per_block", "compact_nodes", "raygen_early_exit",
+_TRACE_OPTIONS = ("raygen_variant", "reflection_variant", "refill_threshold", "lds_stack_levels", "reflection_lds_stack_levels", "raygen_waves_per_block", "compact_nodes", "raygen_early_exit",
                   "reflection_early_exit", "raygen_tile_rows", "raygen_cost_order", "raygen_steal", "reflection_async", "fuse_temporal", "svgf_async_unread")
 
 

@@ -115,6 +115,7 @@ def test_mirror_ray_kernels_bit_identical(oracle, scene_name, W, H):
                 for variant, levels in ((0, 8), (1, 8), (1, 32), (1, 2)):
                     g.ctx.set_option("reflection_variant", variant)
                     g.ctx.set_option("lds_stack_levels", levels)
+                    g.ctx.set_option("reflection_lds_stack_levels", levels)       # the mirror ray's walk has its own count (r5)
                     g.frame(pfd)
                     out[(variant, levels)] = g.ctx.download(lib.REFLECTIONS)
                     st = g.ctx.ray_statistics()
@@ -126,4 +127,5 @@ def test_mirror_ray_kernels_bit_identical(oracle, scene_name, W, H):
             assert (f16(out[(0, 8)])[..., 3] > 0).mean() > 0.1
     finally:
         g.ctx.set_option("lds_stack_levels", 8)
+        g.ctx.set_option("reflection_lds_stack_levels", lib.option_table()["reflection_lds_stack_levels"][0])
         g.close()

@@ -20,6 +20,9 @@ CONFIGS = {"config2": ("sponza_proc", 1920, 1080, 2, 0), "config3": ("sponza_pro
 SWEEP = [("fuse_temporal", 1), ("atrous_small_tiles", 0), ("atrous_small_tiles", 1), ("raygen_waves_per_block", 1), ("raygen_waves_per_block", 4),
          ("raygen_cost_order", 0), ("raygen_cost_order", 2), ("svgf_async_unread", 0), ("svgf_async_unread", 2), ("raygen_tile_rows", 6), ("raygen_tile_rows", 8),
          ("reflection_async", 0)]
+if os.environ.get("VHR_SWEEP"):                     # another list of arms: VHR_SWEEP="raygen_tile_rows=4,refill_threshold=8"
+    SWEEP = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in os.environ["VHR_SWEEP"].split(",")]
+ONLY_N = [int(v) for v in os.environ["VHR_ONLY_N"].split(",")] if os.environ.get("VHR_ONLY_N") else None
 XGMI_GBS, GROUP_LATENCY_US = 153.0, 20.0          # one direct link between two GPUs of the node; one grouped RCCL batch (MI355X_MICROARCH.md)
 args = [a for a in sys.argv[1:] if "=" not in a and not a.startswith("--")]
 flags = [a for a in sys.argv[1:] if a.startswith("--")]
@@ -92,7 +95,7 @@ for n in (1, 2, 4, 8):
                               "ms_exposed": round(ms + comm_ms, 4), "ms_overlapped": round(max(ms, comm_ms), 4),
                               "share_of_linear_exposed_pct": round(100.0 * base / (n * (ms + comm_ms)), 1), "share_of_linear_overlapped_pct": round(100.0 * base / (n * max(ms, comm_ms)), 1)}
     print(json.dumps(line), flush=True)
-    if "--sweep" in flags and n > 1:
+    if "--sweep" in flags and n > 1 and (ONLY_N is None or n in ONLY_N):
         gains = []
         for k, v in SWEEP:
             if (k == "reflection_async" and not refl) or loop.ctx.get_option(k) == v:

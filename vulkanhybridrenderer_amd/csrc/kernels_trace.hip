@@ -1747,7 +1747,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
         }
         ctx->time_begin(kKernelReflection);
         if (m.tp.reflections <= 2 && ctx->options[kOptReflectionVariant] != 0) {
-            const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptLdsStackLevels]))));
+            const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptReflectionLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptReflectionEarlyExit])));
             const uint32_t tiles_x = (m.col_end - m.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);

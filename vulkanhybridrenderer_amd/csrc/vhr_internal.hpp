@@ -266,6 +266,7 @@ struct RayStats {
     /* the queue kernels */                                                                                                             \
     X(kOptRefillThreshold, "refill_threshold", 16, 1, 64)       /* idle lanes that trigger a refill from the tile's ray queue */        \
     X(kOptLdsStackLevels, "lds_stack_levels", 8, 1, 32)         /* traversal stack entries kept in LDS (deeper ones live in scratch) */ \
+    X(kOptReflectionLdsStackLevels, "reflection_lds_stack_levels", 10, 1, 32) /* the same for the mirror ray's walk (r5: 8 -> 10 = bistro_proc's launch -4 %, sponza_proc's equal; the any-hit launch loses 2-3 % at 10) */ \
     X(kOptWavesPerBlock, "raygen_waves_per_block", 2, 1, 4)     /* tiles (= waves) per workgroup of raygen_queue_kernel: 1, 2 or 4 */    \
     X(kOptCompactNodes, "compact_nodes", 1, 0, 1)               /* the 32-byte half-precision nodes where the tree has them */          \
     X(kOptEarlyExit, "raygen_early_exit", 6, 0, 15)             /* sixteenths of the walkers that entered below which the node loop is left */ \
