@@ -227,3 +227,33 @@ def test_svgf_state_blob_size_and_refusals(ctx):
     with pytest.raises(lib.VhrError, match="no SVGF images"):
         p.save_state()
     p.destroy()
+
+
+def test_svgf_state_blob_header_is_validated_before_anything_is_touched(ctx):
+    """vhr_hybrid_load_state on blobs that are not what vhr_hybrid_save_state writes: wrong magic, version, image count, byte counts, extent --
+    each refused with its message before any image is uploaded (also run under AddressSanitizer by tests/test_sanitizers.py: no read past
+    a short blob)."""
+    import ctypes as C
+    import struct
+    p = lib.HybridRenderPath(ctx, shadow_mode=0, ambient_occlusion_mode=0, reflection_mode=2, denoise=True)
+    p.build()
+    n = C.c_uint64()
+    assert ctx.L.vhr_hybrid_state_size(p.handle, C.byref(n)) == 0
+    W, H = 1920, 1080
+    sizes = [W * H * 8] * 4 + [W * H * 4]
+    fmts = [F4] * 4 + [F2]
+
+    def header(magic=b"VHRSVGF1", version=1, w=W, h=H, count=5, formats=fmts, image_bytes=sizes, total=None):
+        total = n.value if total is None else total
+        return struct.pack("<8s4I5i4x5QQ", magic, version, w, h, count, *formats, *image_bytes, total) + bytes(584)
+
+    good = header()
+    assert len(good) == n.value - sum(sizes)                                         # the layout this test assumes is the library's
+    cases = [(b"", "shorter than its header"), (good[:100], "shorter than its header"), (header(magic=b"NOTSTATE"), "not a version-1"),
+             (header(version=2), "not a version-1"), (header(count=4), "not a version-1"), (good, "byte count differs"),
+             (header(total=len(good)), "another extent|do not add up"), (header(w=64, total=len(good)), "another extent"),
+             (header(formats=[F4] * 5, total=len(good)), "another extent"), (header(image_bytes=[8] * 5, total=len(good)), "another extent")]
+    for blob, message in cases:
+        with pytest.raises(lib.VhrError, match=message):
+            p.load_state(np.frombuffer(blob, np.uint8) if blob else np.zeros(0, np.uint8))
+    p.destroy()
