@@ -679,7 +679,7 @@ def main():
                 "multi_gpu_on_hardware": None if world == 1 else bool(not args.share_device and args.backend == "nccl"),
                 "multi_gpu_note": None if world == 1 else (f"{world} ranks on ONE GPU over gloo through host memory: a functional check of the tile path, not a scaling measurement"
                                                            if args.share_device else ("one GPU per rank" + ("" if args.backend == "nccl" else ", exchanges over gloo through host memory"))),
-                "final_gather": (f"denoised tiles -> rank 0 every frame (point-to-point over {transport}, overlapped with the next frame's ray tracing, "
+                "final_gather": (f"denoised tiles -> rank 0 every frame (point-to-point over {'vhr_comm_start_frame_exchanges (the same grouped batch as the halos)' if comm_mode == 'c_abi' else transport}, overlapped with the next frame's ray tracing, "
                                  "finished inside the timed region)" if gather_on else ("off" + (f" (disabled at run time: {gather_error})" if gather_error else ""))) if world > 1 else None,
                 "degraded": degraded or None,
                 "note": "Sponza/lavapipe unavailable (no assets, no Vulkan): procedural stand-in scene; "
