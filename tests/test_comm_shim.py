@@ -27,7 +27,8 @@ def shim():
     return SHIM
 
 
-@pytest.mark.parametrize("world,extra", [(2, ["--grid", "strips"]), (2, ["--grid", "1x2", "--exchange-raytraced"]), (4, ["--grid", "2x2"]), (4, ["--grid", "auto", "--refl-bounces", "2"])])
+@pytest.mark.parametrize("world,extra", [(2, ["--grid", "strips"]), (2, ["--grid", "1x2", "--exchange-raytraced"]), (3, ["--grid", "1x3"]), (3, ["--grid", "strips", "--exchange-raytraced"]),
+                                         (4, ["--grid", "2x2"]), (4, ["--grid", "auto", "--refl-bounces", "2"])])
 def test_c_abi_exchanges_on_one_gpu_equal_the_single_context_and_the_torch_route(shim, world, extra, monkeypatch):
     args = ["--gpus", str(world), "--share-device", "--scene", "tiny", "--width", "320", "--height", "200", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
             "--no-cpu-baseline", "--no-extras", "--verify-frames", "3", "--reflections"] + extra
