@@ -87,10 +87,12 @@ class FrameDriver:
         self._prev_view = np.zeros((4, 4))   # zero matrices on frame 0 (function-static zero init)
         self._prev_proj = np.zeros((4, 4))
 
-    def next(self, position, yaw=0.0, pitch=0.0, roll=0.0):
+    def next(self, position, yaw=0.0, pitch=0.0, roll=0.0, world=None):
         t = np.eye(4)
         t[:3, 3] = position
         transform = t @ yaw_pitch_roll(yaw, pitch, roll)
+        if world is not None:                 # a scene that was rotated as a whole (scenes.rotated): the camera rides along
+            transform = np.asarray(world, dtype=np.float64) @ transform
         view = np.linalg.inv(transform)
         pfd = np.zeros((), abi.per_frame_dtype)
         pfd["camera_view"] = abi.mat_to_glm(view)
@@ -120,5 +122,5 @@ def dolly_frames(scene, width, height, n_frames, start_frame_index=0):
     step = np.asarray(scene.camera["dolly"], dtype=np.float64)
     out = []
     for i in range(n_frames):
-        out.append(drv.next(pos + step * i, scene.camera["yaw"], scene.camera["pitch"], scene.camera.get("roll", 0.0)))
+        out.append(drv.next(pos + step * i, scene.camera["yaw"], scene.camera["pitch"], scene.camera.get("roll", 0.0), scene.camera.get("world")))
     return out

@@ -345,6 +345,25 @@ def sponza_hard(detail=1.0):
     return b.finish("sponza_hard", camera, directional_light(REFERENCE_LIGHT_DIRECTION))
 
 
+def rotated(scene, rot_y=0.6, rot_x=0.25, name=None):
+    """The same scene turned as a whole -- geometry, camera and light -- about y, then x: every image is the unrotated scene's up to rounding, but
+    no wall, floor or column is axis-aligned any more, so every large triangle's BOX holds far more than the triangle (what a model that was not
+    built along the world axes does to a BVH).  An extra beside the headline (profiles/r5_sponza_hard.txt)."""
+    import copy
+    R = trs(rot_y=rot_y, rot_x=rot_x)
+    out = copy.copy(scene)
+    out.name = name or (scene.name + "_rot")
+    out.primitives = scene.primitives.copy()
+    for i in range(len(out.primitives)):
+        m = abi.glm_to_mat(out.primitives["transform"][i]) if hasattr(abi, "glm_to_mat") else np.asarray(out.primitives["transform"][i], np.float64).reshape(4, 4).T
+        out.primitives["transform"][i] = abi.mat_to_glm(R @ m)
+    out.camera = dict(scene.camera, world=R)
+    light = scene.light.copy()
+    d = np.asarray(light["direction"][:3], np.float64)
+    out.light = directional_light(tuple((R[:3, :3] @ d).tolist()), color=tuple(light["color"][:3].tolist()), intensity=float(light["intensity"][0]))
+    return out
+
+
 def _procedural_texture(k, size=512):
     """Deterministic RGBA8 texture (checker + stripes + hash noise), sRGB base-colour content."""
     y, x = np.mgrid[0:size, 0:size].astype(np.uint32)
@@ -425,3 +444,15 @@ def bistro_proc(detail=1.0, n_primitives=3000, n_textures=64, texture_size=512):
     camera = dict(position=(-50.0, 1.7, 0.6), yaw=-np.pi / 2, pitch=0.04, yfov=0.9, znear=0.1, aspect=16.0 / 9.0,
                   dolly=(0.05, 0.0, 0.0))
     return b.finish("bistro_proc", camera, directional_light(REFERENCE_LIGHT_DIRECTION), textures)
+
+
+def sponza_proc_rot():
+    return rotated(sponza_proc())
+
+
+def sponza_hard_rot():
+    return rotated(sponza_hard())
+
+
+def bistro_proc_rot():
+    return rotated(bistro_proc())
