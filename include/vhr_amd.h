@@ -496,7 +496,11 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *  1..40 (default 40 = those stacks) lowers the depth at which the device builder gives up, for tests of that hand-over); "bvh_host_checks" 1 =
  *  a device-built tree is fetched and the host's containment checks repeated on it (default 0: they run on the device; vhr_get_bvh_form_checks
  *  reports either); "bvh_build_threads"
- *  (host builder) 0 = up to 16 host threads (default), 1 = serial -- the tree is the same whatever the count. */
+ *  (host builder) 0 = up to 16 host threads (default), 1 = serial -- the tree is the same whatever the count; "bvh_presplit" 0 (default) =
+ *  one reference per triangle, n = 1..400: triangles whose box wastes more than 1 % of the scene box's half area enter the build once per
+ *  grid cell they pass through, with at most about n % more references than triangles (csrc/presplit.hpp, both builders, the same tree;
+ *  images bit-identical, vhr_get_bvh_statistics then counts references; on a scene with such triangles the any-hit launch gains and the
+ *  mirror ray's closest-hit launch loses, profiles/r5_sponza_hard.txt; vhr_get_bvh_presplit_level tells what the last build did). */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);
 int32_t vhr_option_count(void);
@@ -553,6 +557,9 @@ int vhr_get_build_times(vhr_context *ctx, double out[2]);
 /* Which builder made the current tree: 0 = the host's, 1 = the device's ("bvh_builder" 1, the default; it falls back to the host builder
  * for a scene of a single leaf and for a tree deeper than the walkers' stacks) */
 int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used);
+/* "bvh_presplit": the grid level (cell edge = longest scene edge / 2^level) the current tree's references were split on, -1 = every
+ * triangle is one reference (the option is off, no triangle qualified, or the budget allowed no level) */
+int vhr_get_bvh_presplit_level(vhr_context *ctx, int32_t *level);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

@@ -15,15 +15,19 @@ if "--parity" in names:
     sc = scenes.rotated(scenes.tiny_scene())
     tp = abi.default_trace_params()
     frames, _, _ = oracle_frames(ob, sc, 96, 64, 3, tp)
-    g = GpuHybrid(sc, 96, 64, trace_params=tp)
-    for fr in frames:
-        g.frame(fr["pfd"], fr["gbuf"])
-        assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), "tiny_rot: visibility differs from the oracle"
-        assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"])
-    g.close()
+    for gopts in ({}, {"bvh_presplit": 400}, {"bvh_presplit": 400, "bvh_builder": 0}):
+        g = GpuHybrid(sc, 96, 64, trace_params=tp, geometry_options=gopts)
+        print("tiny_rot", gopts, g.ctx.bvh_statistics(), "builder", g.ctx.bvh_builder_used() if hasattr(g.ctx, "bvh_builder_used") else "?", flush=True)
+        for fr in frames:
+            g.frame(fr["pfd"], fr["gbuf"])
+            assert np.array_equal(g.ctx.download(lib.RAYTRACED), fr["shadow_ao"]), "tiny_rot: visibility differs from the oracle"
+            assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"])
+        g.close()
     print("tiny_rot: visibility and mirror-ray payloads bit-exact against the oracle over 3 frames", flush=True)
 for name in (names or DEFAULT):
-    loop = HybridFrameLoop(getattr(scenes, name)(), 1920, 1080, 24, reflections=1)
+    name, _, opts = name.partition(":")                 # scene:key=value,key=value  (options read by UpdateGeometry)
+    gopts = {k: int(v) for k, v in (kv.split("=") for kv in opts.split(",") if kv)}
+    loop = HybridFrameLoop(getattr(scenes, name)(), 1920, 1080, 24, reflections=1, geometry_options=gopts)
     ctx = loop.ctx
     def sync():
         torch.cuda.synchronize(); ctx.synchronize()
@@ -44,7 +48,7 @@ for name in (names or DEFAULT):
     rs, ts, bv = ctx.ray_statistics(), ctx.traversal_statistics(), ctx.bvh_statistics()
     ctx.set_ray_statistics(False)
     rays = max(1, rs["unique_rays"] - (blk["rays"] if blk else 0))
-    print(json.dumps({"scene": name, "covered": round(loop.covered_pixels[5] / (1920 * 1080), 3), "any_hit_us": round(ms / n * 1e3, 1), "frame_ms_with_mirror_ray": round(best, 4),
+    print(json.dumps({"scene": name, "options": gopts, "refs": bv["triangles"], "k0_ms": round(ctx.bvh_build_ms(), 1) if hasattr(ctx, "bvh_build_ms") else None, "covered": round(loop.covered_pixels[5] / (1920 * 1080), 3), "any_hit_us": round(ms / n * 1e3, 1), "frame_ms_with_mirror_ray": round(best, 4),
                       "nodes": bv["nodes"], "depth": bv["max_depth"], "mirror_ms_alone": blk and blk["avg_launch_ms"], "mirror_visits_per_ray": blk and blk["node_visits_per_ray"],
                       "mirror_lanes": blk and blk["active_lane_utilisation"]}), flush=True)
     loop.close()

@@ -33,8 +33,10 @@ class GpuHybrid:
     """Hybrid render path on the GPU with host-supplied G-buffers (the untouched raster stage)."""
 
     def __init__(self, scene, width, height, shadow=True, ao=True, reflections=True, denoise=True, trace_params=None,
-                 gbuffer="host", atrous_steps=5):
+                 gbuffer="host", atrous_steps=5, geometry_options=None):
         self.ctx = lib.Context(width, height)
+        for key, value in (geometry_options or {}).items():          # options UpdateGeometry reads
+            self.ctx.set_option(key, value)
         self.ctx.upload_scene(scene)
         if trace_params is not None:
             self.ctx.set_trace_params(trace_params)

@@ -107,6 +107,53 @@ def test_random_triangle_soup_mirror_ray(oracle, seed, n_tris, n_prims):
         g.close()
 
 
+@pytest.mark.parametrize("seed,n_tris,n_prims,percent", [(21, 300, 3, 400), (22, 1500, 6, 100), (23, 6000, 9, 50)])
+def test_presplit_references_same_tree_same_bits(oracle, seed, n_tris, n_prims, percent):
+    """Option "bvh_presplit" (csrc/presplit.hpp): a soup turned off the world axes (its floor's triangles then waste a good share of the
+    scene box) built with split references -- by the device's builder and by the host's: more references than triangles, the same tree
+    from both, node forms that pass the containment check, and the oracle's visibility words and mirror-ray payloads bit for bit (a
+    reference is the whole triangle behind a smaller box: what a ray hits, at which t and with which tie break, cannot change).  Against
+    the oracle's brute force as well where that is affordable."""
+    scene = scenes.rotated(soup(seed, n_tris, n_prims), rot_y=0.6, rot_x=0.25)
+    W, H = 96, 64
+    tp = abi.default_trace_params()
+    frames, osc, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, geometry_options={"bvh_presplit": percent})
+    try:
+        trees = []
+        for builder in (1, 0):
+            if builder == 0:
+                g.ctx.set_option("bvh_builder", 0)
+                g.ctx.upload_scene(scene)
+            assert g.ctx.bvh_builder_used() == builder and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+            refs, level = g.ctx.bvh_statistics()["triangles"], g.ctx.bvh_presplit_level()
+            assert level >= 0 and scene.triangle_count < refs <= scene.triangle_count * (100 + 2 * percent) // 100, (builder, refs, level)
+            trees.append((g.ctx.bvh_tree_fingerprint(), refs, level))
+            for i, fr in enumerate(frames):
+                g.frame(fr["pfd"], fr["gbuf"])
+                got = g.ctx.download(lib.RAYTRACED)
+                assert np.array_equal(got, fr["shadow_ao"]), f"builder {builder}, frame {i}: visibility differs from the oracle's"
+                if n_tris <= 1500 and builder == 1:
+                    brute = osc.raygen(fr["pfd"], tp, fr["gbuf"][0], fr["gbuf"][2], use_bvh=False, want_reflections=False)[0]
+                    assert np.array_equal(got, brute), f"frame {i}: visibility differs from the oracle's brute force"
+                for variant in (1, 0):
+                    g.ctx.set_option("reflection_variant", variant)
+                    g.ctx.execute(0, 0)
+                    g.ctx.synchronize()
+                    assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], f"builder {builder}, frame {i}, variant {variant}")
+                g.ctx.set_option("reflection_variant", 1)
+        assert trees[0] == trees[1] and trees[0][0] != 0, f"the host's and the device's builder made different trees: {trees}"
+        # ... and without the option the same context builds the one-reference-per-triangle tree again
+        g.ctx.set_option("bvh_presplit", 0)
+        g.ctx.set_option("bvh_builder", 1)
+        g.ctx.upload_scene(scene)
+        assert g.ctx.bvh_presplit_level() == -1 and g.ctx.bvh_statistics()["triangles"] == scene.triangle_count
+        g.frame(frames[1]["pfd"], frames[1]["gbuf"])
+        assert np.array_equal(g.ctx.download(lib.RAYTRACED), frames[1]["shadow_ao"])
+    finally:
+        g.close()
+
+
 def stacks(seed, copies, n_extra):
     """`copies` coincident copies of one triangle (every box centre equal: no plane separates them, the builders halve the range by
     count) stacked above a floor, next to `n_extra` random small triangles -- the device builder's by-position splits at the level

@@ -26,6 +26,7 @@
 #include <system_error>
 
 #include "vhr_internal.hpp"
+#include "presplit.hpp"
 
 namespace vhr {
 namespace {
@@ -384,7 +385,7 @@ inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((firs
 }  // namespace
 
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads) {
+               uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads, int presplit_percent) {
     const bool k0trace = std::getenv("VHR_K0_TRACE") != nullptr; auto k0t = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (k0trace) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "K0 %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - k0t).count()); k0t = t; } };
     Builder b;
@@ -416,7 +417,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
             b.tris.push_back(tri);
         }
     }
-    const uint32_t n = uint32_t(b.tris.size());
+    uint32_t n = uint32_t(b.tris.size());
     out.nodes.clear();
     out.nodes16.clear();
     out.nodes_ch.clear();
@@ -445,6 +446,66 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     }
     });
     lap("triangles + boxes");
+    out.presplit_level = -1;
+    if (presplit_percent > 0 && n >= 2u) {
+        // fat triangles entered once per grid cell they pass through (presplit.hpp; the device builder's k0_presplit_* kernels do the same)
+        float clo[3] = { b.centroid[0], b.centroid[1], b.centroid[2] }, chi[3] = { b.centroid[0], b.centroid[1], b.centroid[2] };
+        for (size_t i = 1; i < n; ++i)
+            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], b.centroid[i * 3 + a]); chi[a] = std::max(chi[a], b.centroid[i * 3 + a]); }
+        uint64_t estimates[presplit::kLevels] = {};
+        for (int k = 0; k < presplit::kLevels; ++k) {
+            const presplit::Grid g = presplit::make_grid(clo, chi, k);
+            std::mutex m;
+            parallel_for(n, hw, [&](size_t i0, size_t i1) {
+                uint64_t sum = 0;
+                for (size_t i = i0; i < i1; ++i) sum += presplit::estimate(g, b.tris[i], b.tri_box[i].lo, b.tri_box[i].hi);
+                std::lock_guard<std::mutex> lock(m);
+                estimates[k] += sum;
+            });
+        }
+        int level = presplit::choose_level(estimates, n, uint32_t(presplit_percent), clo, chi);
+        const uint64_t hard_limit = uint64_t(n) + 2ull * uint64_t(n) * uint64_t(presplit_percent) / 100ull;
+        std::vector<uint32_t> refs(n);
+        uint64_t total = n;
+        for (; level >= 0; --level) {                 // the exact count; an estimate that was too low by more than 2x goes one level up
+            const presplit::Grid g = presplit::make_grid(clo, chi, level);
+            parallel_for(n, hw, [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; ++i) refs[i] = presplit::references(g, b.tris[i], b.tri_box[i].lo, b.tri_box[i].hi, [](const float *, const float *) {});
+            });
+            total = 0;
+            for (uint32_t r : refs) total += r;
+            if (total <= hard_limit && total < (1ull << 31)) break;
+        }
+        if (level >= 0 && total > n) {
+            const presplit::Grid g = presplit::make_grid(clo, chi, level);
+            std::vector<uint64_t> start(size_t(n) + 1, 0);
+            for (size_t i = 0; i < n; ++i) start[i + 1] = start[i] + refs[i];
+            std::vector<BvhTri> tris2(total);
+            std::vector<Box> box2(total);
+            parallel_for(n, hw, [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; ++i) {
+                    uint64_t at = start[i];
+                    presplit::references(g, b.tris[i], b.tri_box[i].lo, b.tri_box[i].hi, [&](const float *lo, const float *hi) {
+                        tris2[at] = b.tris[i];
+                        for (int a = 0; a < 3; ++a) { box2[at].lo[a] = lo[a]; box2[at].hi[a] = hi[a]; }
+                        ++at;
+                    });
+                }
+            });
+            b.tris.swap(tris2);
+            b.tri_box.swap(box2);
+            n = uint32_t(total);
+            b.centroid.resize(size_t(n) * 3);
+            b.order.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                for (int a = 0; a < 3; ++a) b.centroid[i * 3 + a] = 0.5f * (b.tri_box[i].lo[a] + b.tri_box[i].hi[a]);
+                b.order[i] = uint32_t(i);
+            }
+            out.presplit_level = level;
+        }
+        if (k0trace) std::fprintf(stderr, "K0 presplit: level %d, %zu triangles -> %u references\n", level, refs.size(), n);
+        lap("presplit");
+    }
     b.nodes.reserve(size_t(n));
     b.build_parallel(n, threads);
     lap("tree");

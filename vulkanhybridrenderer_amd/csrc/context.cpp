@@ -402,7 +402,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         // (a primitive without triangles shares its prefix with the next one: the search below picks the LAST primitive whose prefix is
         // <= t, which is the one that owns triangle t, because an empty primitive's successor starts at the same value)
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris);
+        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris, ctx->bvh_presplit);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == VHR_OK) {
             device_built = true;
@@ -424,8 +424,9 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     }
     const auto t_build0 = std::chrono::steady_clock::now();
     if (!device_built) {
-        build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads);          // UpdateBLAS + UpdateTLAS
+        build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads, ctx->bvh_presplit);          // UpdateBLAS + UpdateTLAS
         ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+        ctx->bvh_presplit_level = bvh.presplit_level;
     }
     if (uint64_t(device_built ? ctx->node_count : bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
@@ -468,6 +469,12 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
 int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used) {
     if (!ctx || !used) return VHR_ERROR_INVALID_ARGUMENT;
     *used = ctx->bvh_builder_used;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_presplit_level(vhr_context *ctx, int32_t *level) {
+    if (!ctx || !level) return VHR_ERROR_INVALID_ARGUMENT;
+    *level = ctx->bvh_presplit_level;
     return VHR_OK;
 }
 
@@ -615,6 +622,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!std::strcmp(key, "bvh_builder")) {                  // applies to the next vhr_update_geometry
         if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (binned SAH on the host) or 1 (binned SAH on the device)");
         ctx->bvh_builder = value;
+        return VHR_OK;
+    }
+    if (!std::strcmp(key, "bvh_presplit")) {                 // applies to the next vhr_update_geometry
+        if (value < 0 || value > 400) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_presplit must be 0 (off) or the budget of extra triangle references in percent (1..400)");
+        ctx->bvh_presplit = value;
         return VHR_OK;
     }
     if (!std::strcmp(key, "bvh_build_threads")) {            // applies to the next vhr_update_geometry; the tree does not depend on it

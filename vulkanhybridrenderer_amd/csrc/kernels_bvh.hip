@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "vhr_internal.hpp"
+#include "presplit.hpp"
 
 namespace vhr {
 namespace {
@@ -746,6 +747,65 @@ __global__ __launch_bounds__(256) void k0_bfs_rank_kernel(const uint32_t *__rest
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < kept) rank[sorted_vals[k]] = k;
 }
+// ---- "bvh_presplit": the references of very fat triangles, one per grid cell they pass through (presplit.hpp, shared with the host builder) ----
+struct PresplitGrids { presplit::Grid g[presplit::kLevels]; };
+
+// per level: the estimated number of references, summed (64 bit) over the triangles
+__global__ __launch_bounds__(256) void k0_presplit_estimate_kernel(const BvhTri *__restrict__ tris, const Box6 *__restrict__ boxes, uint32_t n, PresplitGrids grids,
+                                                                   unsigned long long *__restrict__ estimates) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    BvhTri tri{};
+    Box6 b{};
+    if (t < n) { tri = tris[t]; b = boxes[t]; }
+    for (int k = 0; k < presplit::kLevels; ++k) {
+        unsigned long long e = t < n ? presplit::estimate(grids.g[k], tri, b.lo, b.hi) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        if ((threadIdx.x & 63u) == 0u && e) atomicAdd(&estimates[k], e);
+    }
+}
+// the exact number of references of every triangle on one grid
+__global__ __launch_bounds__(256) void k0_presplit_count_kernel(const BvhTri *__restrict__ tris, const Box6 *__restrict__ boxes, uint32_t n, presplit::Grid grid,
+                                                                uint32_t *__restrict__ refs, unsigned long long *__restrict__ total) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long count = 0ull;
+    if (t < n) {
+        const BvhTri tri = tris[t];
+        const Box6 b = boxes[t];
+        count = refs[t] = presplit::references(grid, tri, b.lo, b.hi, [](const float *, const float *) {});
+    }
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+    if ((threadIdx.x & 63u) == 0u && count) atomicAdd(total, count);
+}
+// ... and the references themselves, triangle t's from start[t] on; the bounds of their box centres like k0_triangles_kernel's
+__global__ __launch_bounds__(256) void k0_presplit_emit_kernel(const BvhTri *__restrict__ tris, const Box6 *__restrict__ boxes, uint32_t n, presplit::Grid grid,
+                                                               const uint32_t *__restrict__ start, BvhTri *__restrict__ out_tris, Box6 *__restrict__ out_boxes,
+                                                               uint32_t *__restrict__ centre_bounds) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, mx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    if (t < n) {
+        const BvhTri tri = tris[t];
+        const Box6 b = boxes[t];
+        uint32_t at = start[t];
+        presplit::references(grid, tri, b.lo, b.hi, [&](const float *lo, const float *hi) {
+            Box6 r;
+            for (int a = 0; a < 3; ++a) {
+                r.lo[a] = lo[a]; r.hi[a] = hi[a];
+                const float c = 0.5f * (lo[a] + hi[a]);
+                mn[a] = fminf(mn[a], c); mx[a] = fmaxf(mx[a], c);
+            }
+            out_tris[at] = tri;
+            out_boxes[at] = r;
+            ++at;
+        });
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = mn[a], hi = mx[a];
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+        if ((threadIdx.x & 63u) == 0u && lo <= hi) { atomic_min_checked(&centre_bounds[a], ordered(lo)); atomic_max_checked(&centre_bounds[3 + a], ordered(hi)); }
+    }
+}
+
 __global__ __launch_bounds__(256) void k0_iota_kernel(uint32_t *__restrict__ order, uint32_t *__restrict__ pos_node, uint32_t n) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < n) { order[k] = k; pos_node[k] = 0u; }
@@ -775,8 +835,9 @@ struct Scratch {            // device allocations of one build, freed together
 // Builds the tree from the scene arrays already on the device (ctx->d_vertices / d_indices / d_primitives) into ctx->d_nodes,
 // d_nodes_ch, d_nodes48, d_nodes16, d_tris.  Returns VHR_OK, or VHR_ERROR_OUT_OF_SLOTS when the tree is deeper than the walkers'
 // stacks (kMaxBvhDepth) -- the caller then falls back to the host builder.  `tri_prefix`: first flat triangle of every primitive.
-int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in) {
-    const uint32_t n = total_tris, leaf_tris = uint32_t(std::max(1, std::min(kMaxLeafTris, leaf_tris_in)));
+int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in, int presplit_percent) {
+    uint32_t n = total_tris;
+    const uint32_t leaf_tris = uint32_t(std::max(1, std::min(kMaxLeafTris, leaf_tris_in)));
     if (n <= leaf_tris || n < 2u) return VHR_ERROR_OUT_OF_SLOTS;
     hipStream_t s = ctx->stream;
     Scratch tmp;
@@ -789,21 +850,88 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
         std::fprintf(stderr, "K0 device %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    const dim3 block(256);
+    auto grid = [](uint32_t count) { return dim3((count + 255u) / 256u); };
+    // ---- the triangles (world space, their boxes, the bounds of the box centres), then -- "bvh_presplit" -- their references ----
+    uint32_t *d_prefix, *d_bounds, *d_counts;
+    BvhTri *d_tris_flat;
+    Box6 *d_boxes;
+    K0_TRY(tmp.alloc(&d_prefix, tri_prefix.size()));
+    K0_TRY(tmp.alloc(&d_bounds, 12));
+    K0_TRY(tmp.alloc(&d_counts, 4));
+    K0_TRY(tmp.alloc(&d_tris_flat, n)); K0_TRY(tmp.alloc(&d_boxes, n));
+    K0_TRY(hipMemcpyAsync(d_prefix, tri_prefix.data(), tri_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    const uint32_t init_bounds[12] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    K0_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+    K0_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k0_triangles_kernel, grid(n), block, 0, s, ctx->d_vertices, ctx->d_indices, ctx->d_primitives, d_prefix, uint32_t(tri_prefix.size()), n,
+                       d_tris_flat, d_boxes, d_bounds);
+    uint32_t h_bounds[12];
+    K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
+    K0_TRY(hipStreamSynchronize(s));
+    ctx->bvh_presplit_level = -1;
+    if (presplit_percent > 0) {
+        float clo[3], chi[3];
+        for (int a = 0; a < 3; ++a) { clo[a] = unordered(h_bounds[a]); chi[a] = unordered(h_bounds[3 + a]); }
+        PresplitGrids grids;
+        for (int k = 0; k < presplit::kLevels; ++k) grids.g[k] = presplit::make_grid(clo, chi, k);
+        unsigned long long *d_estimates;
+        uint32_t *d_refs, *d_start;
+        K0_TRY(tmp.alloc(&d_estimates, size_t(presplit::kLevels)));
+        K0_TRY(tmp.alloc(&d_refs, n)); K0_TRY(tmp.alloc(&d_start, n));
+        K0_TRY(hipMemsetAsync(d_estimates, 0, sizeof(unsigned long long) * presplit::kLevels, s));
+        hipLaunchKernelGGL(k0_presplit_estimate_kernel, grid(n), block, 0, s, d_tris_flat, d_boxes, n, grids, d_estimates);
+        uint64_t estimates[presplit::kLevels];
+        static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "64-bit sums");
+        K0_TRY(hipMemcpyAsync(estimates, d_estimates, sizeof(estimates), hipMemcpyDeviceToHost, s));
+        K0_TRY(hipStreamSynchronize(s));
+        int level = presplit::choose_level(estimates, n, uint32_t(presplit_percent), clo, chi);
+        const uint64_t hard_limit = uint64_t(n) + 2ull * uint64_t(n) * uint64_t(presplit_percent) / 100ull;
+        size_t ps_bytes = 0;
+        K0_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, ps_bytes, d_refs, d_start, int(n), s));
+        char *d_ps_work;
+        K0_TRY(tmp.alloc(&d_ps_work, ps_bytes));
+        uint64_t total = n;
+        unsigned long long *d_total;
+        K0_TRY(tmp.alloc(&d_total, size_t(1)));
+        for (; level >= 0; --level) {                 // the exact count; an estimate that was too low by more than 2x goes one level up
+            // (the total in 64 bits beside the counts: every count is below 2^30, but a 32-bit sum that wrapped could look small)
+            K0_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k0_presplit_count_kernel, grid(n), block, 0, s, d_tris_flat, d_boxes, n, grids.g[level], d_refs, d_total);
+            unsigned long long h_total = 0;
+            K0_TRY(hipMemcpyAsync(&h_total, d_total, sizeof(h_total), hipMemcpyDeviceToHost, s));
+            K0_TRY(hipStreamSynchronize(s));
+            total = h_total;
+            if (total <= hard_limit && total < (1ull << 31)) break;
+        }
+        if (level >= 0 && total > n) {
+            K0_TRY(hipcub::DeviceScan::ExclusiveSum(d_ps_work, ps_bytes, d_refs, d_start, int(n), s));
+            BvhTri *d_tris_refs;
+            Box6 *d_boxes_refs;
+            K0_TRY(tmp.alloc(&d_tris_refs, size_t(total))); K0_TRY(tmp.alloc(&d_boxes_refs, size_t(total)));
+            K0_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k0_presplit_emit_kernel, grid(n), block, 0, s, d_tris_flat, d_boxes, n, grids.g[level], d_start, d_tris_refs, d_boxes_refs, d_bounds);
+            K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
+            K0_TRY(hipStreamSynchronize(s));
+            K0_TRY(hipGetLastError());
+            if (trace) std::fprintf(stderr, "K0 device presplit: level %d, %u triangles -> %llu references\n", level, n, (unsigned long long)total);
+            d_tris_flat = d_tris_refs;
+            d_boxes = d_boxes_refs;
+            n = uint32_t(total);
+            ctx->bvh_presplit_level = level;
+        }
+        lap("presplit");
+    }
     const uint32_t total_cap = 2u * n;
     const uint32_t max_active = n / kSmallNode + 2u, max_small = n / 2u + 2u;
-    uint32_t *d_prefix, *d_bounds, *d_counts, *d_order[2], *d_pos_node[2], *d_flags, *d_scan, *d_bins, *d_parent, *d_size, *d_position, *d_kept, *d_kept_rank;
-    BvhTri *d_tris_flat;
-    Box6 *d_boxes, *d_node_box;
+    uint32_t *d_order[2], *d_pos_node[2], *d_flags, *d_scan, *d_bins, *d_parent, *d_size, *d_position, *d_kept, *d_kept_rank;
+    Box6 *d_node_box;
     int2 *d_children;
     SahNode *d_active[2];
     SahSplit *d_splits;
     SmallRoot *d_small;
     SahCounters *d_counters;
-    K0_TRY(tmp.alloc(&d_prefix, tri_prefix.size()));
-    K0_TRY(tmp.alloc(&d_bounds, 12));
-    K0_TRY(tmp.alloc(&d_counts, 4));
     K0_TRY(tmp.alloc(&d_counters, 1));
-    K0_TRY(tmp.alloc(&d_tris_flat, n)); K0_TRY(tmp.alloc(&d_boxes, n));
     for (int k = 0; k < 2; ++k) { K0_TRY(tmp.alloc(&d_order[k], n)); K0_TRY(tmp.alloc(&d_pos_node[k], n)); K0_TRY(tmp.alloc(&d_active[k], max_active)); }
     K0_TRY(tmp.alloc(&d_flags, n)); K0_TRY(tmp.alloc(&d_scan, n));
     K0_TRY(tmp.alloc(&d_bins, size_t(max_active) * 48u * kBinWords));
@@ -817,18 +945,7 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
     for (int k = 0; k < 2; ++k) { K0_TRY(tmp.alloc(&d_keys[k], n)); K0_TRY(tmp.alloc(&d_vals[k], n)); }
     K0_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_tris), sizeof(BvhTri) * n));
     K0_TRY(hipMemsetAsync(d_place + n, 0, sizeof(uint2), s));                 // the root: depth 0, first 0
-
-    K0_TRY(hipMemcpyAsync(d_prefix, tri_prefix.data(), tri_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    const uint32_t init_bounds[12] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    K0_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
-    K0_TRY(hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), s));
-    const dim3 block(256);
-    auto grid = [](uint32_t count) { return dim3((count + 255u) / 256u); };
-    hipLaunchKernelGGL(k0_triangles_kernel, grid(n), block, 0, s, ctx->d_vertices, ctx->d_indices, ctx->d_primitives, d_prefix, uint32_t(tri_prefix.size()), n,
-                       d_tris_flat, d_boxes, d_bounds);
     hipLaunchKernelGGL(k0_iota_kernel, grid(n), block, 0, s, d_order[0], d_pos_node[0], n);
-    uint32_t h_bounds[12];
-    K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
     K0_TRY(hipStreamSynchronize(s));
     lap("allocations + triangles");
     size_t scan_bytes = 0;

@@ -149,8 +149,9 @@ struct HostBvh {
     std::vector<BvhNode48> nodes48;
     float centre[3] = { 0, 0, 0 };
     bool nodes16_valid = false;        // false: some box does not fit the half range around `centre` (the walkers then stay on nodes48)
-    std::vector<BvhTri> tris;
+    std::vector<BvhTri> tris;          // one per REFERENCE ("bvh_presplit": a fat triangle is in several leaves)
     uint32_t max_depth = 0;
+    int presplit_level = -1;           // the grid level the references were split on, -1 = none were
 };
 
 // builds the BVH2 (csrc/bvh_build.cpp)
@@ -159,10 +160,10 @@ bool nodes16_in_range(const HostBvh &bvh);      // no inf / NaN / subnormal half
 uint64_t bvh_fingerprint(const HostBvh &bvh);
 uint64_t bvh_tree_fingerprint(const HostBvh &bvh);      // of the tree, not of its arrays: equal for the host's and the device's build of a scene
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0);
+               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0, int presplit_percent = 0);
 // the device-side builder (csrc/kernels_bvh.hip, option "bvh_builder" 1): from ctx->d_vertices / d_indices / d_primitives into the
 // context's node and triangle arrays; VHR_ERROR_OUT_OF_SLOTS = fall back to the host builder (tree deeper than the walkers' stacks)
-int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris);
+int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris, int presplit_percent);
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
@@ -365,6 +366,8 @@ struct vhr_context {
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
     int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
+    int bvh_presplit = 0;                        // "bvh_presplit": budget of extra triangle references in percent (csrc/presplit.hpp), 0 = off
+    int bvh_presplit_level = -1;                 // the grid level the current tree's references were split on (-1: none)
     int bvh_builder = 1;                         // "bvh_builder": 1 = binned SAH on the device (csrc/kernels_bvh.hip, default), 0 = on the host (csrc/bvh_build.cpp)
     int bvh_builder_used = 0;                    // which one made the current tree (the device builder falls back for trees too deep / too small)
     int bvh_device_max_depth = vhr::kMaxBvhDepth; // "bvh_device_max_depth": the device builder hands a deeper tree to the host builder (kMaxBvhDepth = the walkers' stacks; tests lower it)

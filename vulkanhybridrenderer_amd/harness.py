@@ -52,7 +52,7 @@ class CommBringUpError(RuntimeError):
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
                  atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True,
-                 frames_in_flight=1, allow_degraded=False, grid=None, comm="torch"):
+                 frames_in_flight=1, allow_degraded=False, grid=None, comm="torch", geometry_options=None):
         """grid: the screen decomposition for world > 1 -- None = the planner's choice (tiling.choose_grid), "strips" = row strips,
         or (grid_rows, grid_cols).  comm: "torch" = the exchanges through torch.distributed (tiling.StripExchanges), "c_abi" = through
         the library's own RCCL calls (vhr_comm_*, csrc/comm.cpp; the unique id travels over torch.distributed's store)."""
@@ -63,6 +63,8 @@ class HybridFrameLoop:
         torch.cuda.set_device(device)
         self.stream = torch.cuda.current_stream()
         self.ctx = lib.Context(width, height, device=device, stream=self.stream.cuda_stream)
+        for key, value in (geometry_options or {}).items():          # options UpdateGeometry reads ("bvh_presplit", "bvh_builder", ...)
+            self.ctx.set_option(key, value)
         self.ctx.upload_scene(scene)
         # frames in flight (vulkan_common.h:9, renderer.cpp:103-146): frame i uses resource index i mod n; the library then
         # issues the front of a frame (G-buffer, Raytrace Pass) on a second stream beside the previous frame's SVGF pass

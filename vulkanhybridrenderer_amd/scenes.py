@@ -456,3 +456,7 @@ def sponza_hard_rot():
 
 def bistro_proc_rot():
     return rotated(bistro_proc())
+
+
+def tiny_rot():
+    return rotated(tiny_scene())
