@@ -492,6 +492,13 @@ __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_
 __device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
+// A comparison as the 64-bit lane mask it is, and a select on such a mask.  Spelled out because a ballot of a bool the compiler holds as a
+// lane mask comes back through a vector register when it is handed to an asm statement (v_cndmask 0 / 1 + v_cmp_ne: two instructions per
+// mask, four per node visit, r5); masks combine on the scalar unit.  (Lanes that are switched off read 0.)
+__device__ __forceinline__ unsigned long long cmp_le_mask(float a, float b) { unsigned long long m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ unsigned long long cmp_gt_i32_mask_s(int uniform_a, int b) { unsigned long long m; asm("v_cmp_gt_i32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_a), "v"(b)); return m; }
+__device__ __forceinline__ int select_mask(int if_clear, int if_set, unsigned long long m) { int d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(m)); return d; }
+
 __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 noi, float tmin, float tlimit, float &tnear) {
     const f2v tx = __builtin_elementwise_fma(bx, f2v{ inv.x, inv.x }, f2v{ noi.x, noi.x });
     const f2v ty = __builtin_elementwise_fma(by, f2v{ inv.y, inv.y }, f2v{ noi.y, noi.y });
@@ -502,12 +509,52 @@ __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 n
     return tn <= tf;
 }
 
+constexpr int kQueueBlock = 64;
+constexpr int kStackSentinel = int(0x80000000u);   // not a node (>= 0) and not a leaf code the builder can emit
+
+// One box in centre / half-extent form (a cut entry, build_tile_cut) against one ray: `ainv` = |1/d|.  The three centre terms are one packed
+// FMA + one plain one, an axis's (near, far) pair is ONE packed FMA (-h and +h through neg_lo on the same register) that needs no min / max:
+// 5 FMAs + 4 min / max + the compare instead of box_test_pk's 3 + 10 + 1.  Culling only: the box is the (lo, hi) box grown by a few ulp.
+__device__ __forceinline__ unsigned long long box_test_ch1(float cx, float cy, float cz, float hx, float hy, float hz, f3 inv, f3 ainv, f3 noi, float tmin, float tlimit) {
+    const f2v cxy = __builtin_elementwise_fma(f2v{ cx, cy }, f2v{ inv.x, inv.y }, f2v{ noi.x, noi.y });
+    const float ciz = __builtin_fmaf(cz, inv.z, noi.z);
+    const f2v x = __builtin_elementwise_fma(f2v{ -hx, hx }, f2v{ ainv.x, ainv.x }, f2v{ cxy.x, cxy.x });
+    const f2v y = __builtin_elementwise_fma(f2v{ -hy, hy }, f2v{ ainv.y, ainv.y }, f2v{ cxy.y, cxy.y });
+    const f2v z = __builtin_elementwise_fma(f2v{ -hz, hz }, f2v{ ainv.z, ainv.z }, f2v{ ciz, ciz });
+    const float tn = hw_max3(x.x, y.x, hw_max(z.x, tmin));
+    const float tf = hw_min3(x.y, y.y, hw_min(z.y, tlimit));
+    return cmp_le_mask(tn, tf);
+}
+
+// A refilled ray against the tile's cut (build_tile_cut): the subtrees it hits go on its (empty) stack, the deepest -- the one closest to the
+// origins -- on top; those that do not fit the LDS levels are remembered in `emask`.  Written without branches like the node step: the link is
+// stored above the top whatever the test says (a slot above the top may hold anything) and the test's mask is the carry that moves the top.
+// 13 vector instructions per entry (r5; 19 with box_test_pk and a predicated push); the masks are lane masks in scalar registers (cmp_le_mask).  Ends with the top entry popped into `cur`.
+__device__ __forceinline__ void cut_to_stack(const float4 (*cut)[2], const uint32_t cut_n, int *stack, const uint32_t stack_levels, f3 inv, f3 noi, float tmin_v, float tlimit,
+                                             int &cur, int &sp, uint32_t &emask) {
+    const f3 ainv = f3{ fabsf(inv.x), fabsf(inv.y), fabsf(inv.z) };
+    emask = 0;
+    sp = 0;
+    for (uint32_t e = 0; e < cut_n; ++e) {
+        const float4 b0 = cut[e][0], b1 = cut[e][1];              // (cx, cy, cz, hx), (hy, hz, link, -): LDS broadcasts
+        const unsigned long long hit = box_test_ch1(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, inv, ainv, noi, tmin_v, tlimit);
+        const unsigned long long fits = cmp_gt_i32_mask_s(int(stack_levels) - 2, sp);          // sp + 2 < stack_levels (so sp + 1 <= stack_levels - 1: the store below stays inside the lane's rows)
+        stack[(uint32_t(sp) + 1u) * kQueueBlock] = __float_as_int(b1.z);
+        {
+            unsigned long long carry_out;
+            asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(sp), "s"(hit & fits));
+        }
+        if (hit & ~fits) emask = uint32_t(select_mask(int(emask), int(emask | (1u << e)), hit & ~fits));      // (wave-uniform and rare: a ray that hits more entries than the LDS levels hold)
+    }
+    if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
+}
+
 // Both child boxes of a centre / half-extent node (BvhNodeCH) against one ray: `ainv` = |1/d|.  The centre terms of the two boxes
 // share one packed FMA per axis; a box's (near, far) pair of an axis is ONE packed FMA (-h and +h through neg_lo on the same
 // register), so no per-axis min / max is needed: 9 FMAs + 8 min / max per node instead of 6 + 20.  Culling only (see BvhNodeCH).
 template <typename V4>
 __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q2, f3 inv, f3 ainv, f3 noi, float tmin, float tlimit,
-                                            bool &h0, bool &h1, float &tn0, float &tn1) {
+                                            float &tn0, float &tn1, float &tf0, float &tf1) {
     const f2v cix = __builtin_elementwise_fma(f2v{ q0.x, q0.y }, f2v{ inv.x, inv.x }, f2v{ noi.x, noi.x });
     const f2v ciy = __builtin_elementwise_fma(f2v{ q0.z, q0.w }, f2v{ inv.y, inv.y }, f2v{ noi.y, noi.y });
     const f2v ciz = __builtin_elementwise_fma(f2v{ q1.x, q1.y }, f2v{ inv.z, inv.z }, f2v{ noi.z, noi.z });
@@ -519,8 +566,14 @@ __device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q
     const f2v z1 = __builtin_elementwise_fma(f2v{ -q2.w, q2.w }, f2v{ ainv.z, ainv.z }, f2v{ ciz.y, ciz.y });
     tn0 = hw_max3(x0.x, y0.x, hw_max(z0.x, tmin));
     tn1 = hw_max3(x1.x, y1.x, hw_max(z1.x, tmin));
-    const float tf0 = hw_min3(x0.y, y0.y, hw_min(z0.y, tlimit));
-    const float tf1 = hw_min3(x1.y, y1.y, hw_min(z1.y, tlimit));
+    tf0 = hw_min3(x0.y, y0.y, hw_min(z0.y, tlimit));
+    tf1 = hw_min3(x1.y, y1.y, hw_min(z1.y, tlimit));
+}
+template <typename V4>
+__device__ __forceinline__ void box_pair_ch(const V4 q0, const V4 q1, const V4 q2, f3 inv, f3 ainv, f3 noi, float tmin, float tlimit,
+                                            bool &h0, bool &h1, float &tn0, float &tn1) {
+    float tf0, tf1;
+    box_pair_ch(q0, q1, q2, inv, ainv, noi, tmin, tlimit, tn0, tn1, tf0, tf1);
     h0 = tn0 <= tf0;
     h1 = tn1 <= tf1;
 }
@@ -545,14 +598,19 @@ VHR_MIX(mix_hi_neg_abs, "-", "|", "|", "1")
 #undef VHR_MIX
 
 __device__ __forceinline__ void box_pair_ch16(const uint32_t cx, const uint32_t cy, const uint32_t cz, const uint32_t hx, const uint32_t hy, const uint32_t hz,
-                                              f3 inv, f3 noi, float tmin, float tlimit, bool &h0, bool &h1, float &tn0, float &tn1) {
+                                              f3 inv, f3 noi, float tmin, float tlimit, float &tn0, float &tn1, float &tf0, float &tf1) {
     const float cx0 = mix_lo(cx, inv.x, noi.x), cx1 = mix_hi(cx, inv.x, noi.x);
     const float cy0 = mix_lo(cy, inv.y, noi.y), cy1 = mix_hi(cy, inv.y, noi.y);
     const float cz0 = mix_lo(cz, inv.z, noi.z), cz1 = mix_hi(cz, inv.z, noi.z);
     tn0 = hw_max3(mix_lo_neg_abs(hx, inv.x, cx0), mix_lo_neg_abs(hy, inv.y, cy0), hw_max(mix_lo_neg_abs(hz, inv.z, cz0), tmin));
     tn1 = hw_max3(mix_hi_neg_abs(hx, inv.x, cx1), mix_hi_neg_abs(hy, inv.y, cy1), hw_max(mix_hi_neg_abs(hz, inv.z, cz1), tmin));
-    const float tf0 = hw_min3(mix_lo_abs(hx, inv.x, cx0), mix_lo_abs(hy, inv.y, cy0), hw_min(mix_lo_abs(hz, inv.z, cz0), tlimit));
-    const float tf1 = hw_min3(mix_hi_abs(hx, inv.x, cx1), mix_hi_abs(hy, inv.y, cy1), hw_min(mix_hi_abs(hz, inv.z, cz1), tlimit));
+    tf0 = hw_min3(mix_lo_abs(hx, inv.x, cx0), mix_lo_abs(hy, inv.y, cy0), hw_min(mix_lo_abs(hz, inv.z, cz0), tlimit));
+    tf1 = hw_min3(mix_hi_abs(hx, inv.x, cx1), mix_hi_abs(hy, inv.y, cy1), hw_min(mix_hi_abs(hz, inv.z, cz1), tlimit));
+}
+__device__ __forceinline__ void box_pair_ch16(const uint32_t cx, const uint32_t cy, const uint32_t cz, const uint32_t hx, const uint32_t hy, const uint32_t hz,
+                                              f3 inv, f3 noi, float tmin, float tlimit, bool &h0, bool &h1, float &tn0, float &tn1) {
+    float tf0, tf1;
+    box_pair_ch16(cx, cy, cz, hx, hy, hz, inv, noi, tmin, tlimit, tn0, tn1, tf0, tf1);
     h0 = tn0 <= tf0;
     h1 = tn1 <= tf1;
 }
@@ -589,8 +647,6 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
 }
 
-constexpr int kQueueBlock = 64;
-constexpr int kStackSentinel = int(0x80000000u);   // not a node (>= 0) and not a leaf code the builder can emit
 
 // raygen.rgen:32-53 for one (pixel, kind): the ray direction, exact arithmetic
 __device__ __forceinline__ f3 ray_direction(const vhr_trace_params &tp, uint32_t seed, uint32_t kind, f3 L, f3 N) {
@@ -660,13 +716,13 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 
 // The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
 // origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -) --
-// and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
+// (as built; stored as centre / half extent, see the end of the function) and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
 // `reach` (this lane's contribution, 0 for lanes without rays; +inf = no pruning): an upper bound of how far any of the tile's
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
 // `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
 __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
-                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48))) {
+                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), const f3 centre = f3{ 0.0f, 0.0f, 0.0f }) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -728,8 +784,19 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     }
     if (open) add_entry(fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], node);                  // the budget ran out: the subtree itself
     if (lane < cut_n) {
-        s_cut[lane][0] = make_float4(e_lx, e_hx, e_ly, e_hy);
-        s_cut[lane][1] = make_float4(e_lz, e_hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
+        // centre / half extent (box_test_ch1), the centre relative to `centre` (the walkers of the half-precision nodes keep their ray origins
+        // relative to the scene's centre): c +- h contains [lo, hi] -- h carries 4 ulp of the magnitudes involved, the roundings of c, of
+        // hi - c and of the shift are below one each.  The root's "everything" box (+-3e38) stays finite: c = 0, h = 3e38 (1 + 2.4e-7).
+        auto ch = [](float lo, float hi, float shift, float &c, float &h) {
+            const float mid = 0.5f * lo + 0.5f * hi;
+            c = mid - shift;
+            h = fmaxf(hi - mid, mid - lo);
+            h += (fabsf(mid) + fabsf(shift) + h) * 2.4e-7f;
+        };
+        float cx, cy, cz, hx, hy, hz;
+        ch(e_lx, e_hx, centre.x, cx, hx); ch(e_ly, e_hy, centre.y, cy, hy); ch(e_lz, e_hz, centre.z, cz, hz);
+        s_cut[lane][0] = make_float4(cx, cy, cz, hx);
+        s_cut[lane][1] = make_float4(hy, hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
     }
     wave_lds_sync();
     return cut_n;
@@ -870,7 +937,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)));
+    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)),
+                                      COMPACT ? f3{ a.scene.centre[0], a.scene.centre[1], a.scene.centre[2] } : f3{ 0.0f, 0.0f, 0.0f });
     const uint32_t n_cut_entries = cut_n;
     uint32_t emask = 0;                               // cut entries this lane's ray hits that did not fit its LDS stack
     if (stats) t_setup = __builtin_readcyclecounter() - t_start;
@@ -920,21 +988,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
-                cur = 0; sp = 0; sbase = 0;
-                {   // the ray against the tile's cut: hit subtrees go on its stack
-                    emask = 0;
-                    // (the cut's boxes are absolute fp32 boxes whatever the node format)
-                    const f3 noi_cut = COMPACT ? f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) } : noi;
-                    for (uint32_t e = 0; e < cut_n; ++e) {
-                        const float4 b0 = s_cut[e][0], b1 = s_cut[e][1];
-                        float tnu;
-                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi_cut, tmin_v, tmax, tnu)) {
-                            if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
-                            else emask |= 1u << e;
-                        }
-                    }
-                    if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
-                }
+                sbase = 0;
+                cut_to_stack(s_cut, cut_n, stack, stack_levels, rinv, noi, tmin_v, tmax, cur, sp, emask);      // (its boxes are relative to the centre `noi` is)
                 has = true;
             }
         }
@@ -978,6 +1033,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             }
         }
         if (!__any(has)) break;                       // nothing in flight and (since all lanes were idle) nothing left to fetch
+#ifdef VHR_K1_COUNT_TRIPS
+        if (stats) ++n_drain_trips;                   // (scratch builds: the statistics' drain counter counts the outer loop's trips instead)
+#endif
         // The walk is a chain of dependent round trips, the refill a block of arithmetic that nothing waits for: a wave in the walk goes first when
         // both want the SIMD (r3c: -1.4 % on sponza_proc, nothing on bistro_proc)
         __builtin_amdgcn_s_setprio(3);
@@ -996,26 +1054,26 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
         while (has && cur >= 0) {
             if (uint32_t(__popcll(__ballot(true))) * 16u <= walkers_in * early_exit) break;   // ballot(true) = the walkers left; early_exit in 0..15 sixteenths, so the first trip always runs
             ++n_nodes;
-            float tn0, tn1;
-            bool h0, h1;
+            float tn0, tn1, tf0, tf1;
             int2 links;
             if (COMPACT) {
                 // `cur` is the node's BYTE offset (index * 32); two 16-byte loads per visit
                 const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.scene.nodes16) + uint32_t(cur));
                 const uint4 c0 = np[0], c1 = np[1];
-                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
+                box_pair_ch16(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rinv, noi, tmin_v, tmax, tn0, tn1, tf0, tf1);
                 links = int2{ int(c1.z), int(c1.w) };
             } else {
                 const Node48Words nw = load_node48(a.scene.nodes48, cur);
                 links = nw.links;
-                box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tmax, h0, h1, tn0, tn1);
+                box_pair_ch(nw.q0, nw.q1, nw.q2, rinv, ainv, noi, tmin_v, tmax, tn0, tn1, tf0, tf1);
             }
-            const bool both = h0 && h1, none = !(h0 || h1);
+            // The hit tests as lane masks in scalar registers (cmp_le_mask): what combines them is scalar work, what uses them takes them as they are.
+            const unsigned long long h0 = cmp_le_mask(tn0, tf0), h1 = cmp_le_mask(tn1, tf1);
             // Child 0 is entered if it is hit and child 1 is not, or is not nearer; the child NOT entered goes to the stack slot (a
             // meaningful entry only when both are hit).  Three selects and two carries per visit (r3; the (near, far) form took ten
             // vector instructions: masks are scalar work, selects are not).
-            const bool enter0 = bool(int(h0) & (int(!h1) | int(tn0 <= tn1)));         // (bitwise: && and || would become exec-mask regions)
-            const int nearc = enter0 ? links.x : links.y, farc = enter0 ? links.y : links.x;
+            const unsigned long long enter0 = h0 & (~h1 | cmp_le_mask(tn0, tn1));
+            const int nearc = select_mask(links.y, links.x, enter0), farc = select_mask(links.x, links.y, enter0);
             // One address serves both accesses: row min(sp, L+1) holds the top entry (sp - 1; the sentinel when the stack
             // is empty), the row after it is where entry sp goes.  The write is harmless when !both (above the top).
             int *const row = stack + min(uint32_t(sp), stack_levels + 1u) * kQueueBlock;
@@ -1027,15 +1085,15 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 if (SPILL && uint32_t(sp) > stack_levels) top = spill[(uint32_t(sp) - 1u - stack_levels) & uint32_t(kSpillStack - 1)];
                 if (uint32_t(sp) >= stack_levels) {
                     if (SPILL && uint32_t(sp) - stack_levels < uint32_t(kSpillStack)) spill[uint32_t(sp) - stack_levels] = farc;
-                    else overflow |= both ? 1u : 0u;                              // cannot happen (builder depth bound); counted
+                    else overflow |= uint32_t((h0 & h1) >> lane) & 1u;            // cannot happen (builder depth bound); counted
                 }
             }
-            cur = none ? top : nearc;                                             // popping the empty stack yields the sentinel
+            cur = select_mask(top, nearc, h0 | h1);                               // no child hit: popping the empty stack yields the sentinel
             {   // sp += h0 + h1 - 1: +1 both, 0 one, -1 none (with the sentinel) -- two add-with-carry, the hit masks as the carries
                 int t;
                 unsigned long long carry_out;
-                asm("v_addc_co_u32_e64 %0, %1, %2, -1, %3" : "=v"(t), "=s"(carry_out) : "v"(sp), "s"(__ballot(h0)));
-                asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(t), "s"(__ballot(h1)));
+                asm("v_addc_co_u32_e64 %0, %1, %2, -1, %3" : "=v"(t), "=s"(carry_out) : "v"(sp), "s"(h0));
+                asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(t), "s"(h1));
             }
         }
         const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
@@ -1094,7 +1152,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             for (int off = 32; off > 0; off >>= 1) { tn = max(tn, uint32_t(__shfl_xor(int(tn), off))); tt = max(tt, uint32_t(__shfl_xor(int(tt), off))); }
             n_wave_trips += tn + tt;
             if (next >= total) {
+#ifndef VHR_K1_COUNT_TRIPS
                 n_drain_trips += tn + tt;    // trips made after the tile's queue ran dry (nothing left to refill with)
+#endif
                 const uint32_t live = uint32_t(__popcll(__ballot(has)));   // rays still in flight after this round of trips
                 if (live <= 4u) n_drain_le4 += tn + tt;
                 if (live <= 8u) n_drain_le8 += tn + tt;
@@ -1234,21 +1294,8 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
-                if (cut_n) {
-                    // the ray against the tile's cut (build_tile_cut): the subtrees it hits go on its stack, the deepest -- the
-                    // one closest to the origin -- on top; the (t, flat index) order of the commit makes the result independent
-                    // of the order the subtrees are walked in
-                    emask = 0;
-                    for (uint32_t e = 0; e < cut_n; ++e) {
-                        const float4 b0 = cut[e][0], b1 = cut[e][1];
-                        float tnu;
-                        if (box_test_pk(f2v{ b0.x, b0.y }, f2v{ b0.z, b0.w }, f2v{ b1.x, b1.y }, rinv, noi, tmin_v, tmax, tnu)) {
-                            if (uint32_t(sp) + 2u < stack_levels) { ++sp; stack[uint32_t(sp) * kQueueBlock] = __float_as_int(b1.z); }
-                            else emask |= 1u << e;
-                        }
-                    }
-                    if (sp > 0) { cur = stack[uint32_t(sp) * kQueueBlock]; --sp; } else cur = kStackSentinel;
-                }
+                // the ray against the tile's cut: the (t, flat index) order of the commit makes the result independent of the order the subtrees are walked in
+                if (cut_n) cut_to_stack(cut, cut_n, stack, stack_levels, rinv, noi, tmin_v, tmax, cur, sp, emask);
                 has = true;
             }
         }
