@@ -714,14 +714,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) v4f *uniform_f4_ptr;         // constant address space + uniform address = SMEM loads
 typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 
-// The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
-// origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, link, -) --
-// (as built; stored as centre / half extent, see the end of the function) and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
-// `reach` (this lane's contribution, 0 for lanes without rays; +inf = no pruning): an upper bound of how far any of the tile's
-// rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
-// hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
-// `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
-__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
+// The same descent written on wave-uniform values (rounds 2-4): every comparison and every move of a box is a vector instruction for the whole
+// wave, ~100 per level.  Kept for the closest-hit walks and the raytraced path, whose launches are not bound by vector issue (and whose kernels
+// the lane-parallel form below does not compile for: the backend's verifier rejects a private-to-flat cast next to it).
+__device__ __forceinline__ uint32_t build_tile_cut_uniform(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
                                                    const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), const f3 centre = f3{ 0.0f, 0.0f, 0.0f }) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
@@ -798,6 +794,112 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
         s_cut[lane][0] = make_float4(cx, cy, cz, hx);
         s_cut[lane][1] = make_float4(hy, hz, __int_as_float(e_link >= 0 ? e_link * link_bytes : e_link), 0.0f);
     }
+    wave_lds_sync();
+    return cut_n;
+}
+
+
+// One entry of a tile's cut (build_tile_cut): what a lane knows about itself, and the store of a child's box in centre / half-extent form.
+struct CutLane {
+    f3 omin, omax;
+    float reach2, shift;
+    uint32_t axis;
+    bool lo_lane;
+    uint32_t my_child, lane;
+    int link_bytes;
+};
+__device__ __forceinline__ void cut_add_entry(const CutLane cl, float4 (*s_cut)[2], uint32_t &cut_n, const float word, const int child, const int link) {
+    if (cl.reach2 < 3.0e38f) {                                                               // (uniform; launches without shadow rays only)
+        const int b0 = 6 * child;
+        auto lane_word = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        const float lx = lane_word(word, b0), hx = lane_word(word, b0 + 1), ly = lane_word(word, b0 + 2), hy = lane_word(word, b0 + 3), lz = lane_word(word, b0 + 4),
+                    hz = lane_word(word, b0 + 5);
+        const float gx = fmaxf(fmaxf(lx - cl.omax.x, cl.omin.x - hx), 0.0f), gy = fmaxf(fmaxf(ly - cl.omax.y, cl.omin.y - hy), 0.0f),
+                    gz = fmaxf(fmaxf(lz - cl.omax.z, cl.omin.z - hz), 0.0f);
+        if ((gx * gx + gy * gy) + gz * gz > cl.reach2) return;                                // out of every ray's reach
+    }
+    // centre / half extent (box_test_ch1), the centre relative to `centre` (the walkers of the half-precision nodes keep their ray origins
+    // relative to the scene's centre): c +- h contains [lo, hi] -- h carries 4 ulp of the magnitudes involved, the roundings of c, of
+    // hi - c and of the shift are below one each.  The root's "everything" box (+-3e38) stays finite: c = 0, h = 3e38 (1 + 2.4e-7).
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(word), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]: the pair's other word
+    const float mid = 0.5f * word + 0.5f * other;                                          // (lo lanes: word = lo, other = hi)
+    const float c = mid - cl.shift;
+    float h = fmaxf(other - mid, mid - word);
+    h += (fabsf(mid) + fabsf(cl.shift) + h) * 2.4e-7f;
+    // (the cut is an LDS array at every call site; said so, so that the stores are ds_write and not flat stores behind an address-space test)
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float *const entry = (lds_float *)(&s_cut[0][0]) + cut_n * 8u;                       // (cx, cy, cz, hx), (hy, hz, link, -)
+    if (cl.lo_lane && cl.my_child == uint32_t(child)) { entry[cl.axis] = c; entry[3u + cl.axis] = h; }
+    if (cl.lane == 0u) entry[6] = __int_as_float(link >= 0 ? link * cl.link_bytes : link);
+    ++cut_n;
+}
+
+// The shared descent of a tile (see CUT above): `omin` / `omax` are this lane's contribution to the bounds of the tile's ray
+// origins (+-3e38 for lanes without one).  Leaves the cut in s_cut[0 .. n) -- centre / half extent: (cx, cy, cz, hx), (hy, hz, link, -) --
+// and returns n, wave-uniform.  Entries are in path order: the deeper an entry, the closer its box to the origins.
+// `reach` (this lane's contribution, 0 for lanes without rays; +inf = no pruning): an upper bound of how far any of the tile's
+// rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
+// hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
+// `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
+__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
+                                                   const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), const f3 centre = f3{ 0.0f, 0.0f, 0.0f }) {
+    // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        omin.x = fminf(omin.x, __shfl_xor(omin.x, off)); omin.y = fminf(omin.y, __shfl_xor(omin.y, off)); omin.z = fminf(omin.z, __shfl_xor(omin.z, off));
+        omax.x = fmaxf(omax.x, __shfl_xor(omax.x, off)); omax.y = fmaxf(omax.y, __shfl_xor(omax.y, off)); omax.z = fmaxf(omax.z, __shfl_xor(omax.z, off));
+        reach = fmaxf(reach, __shfl_xor(reach, off));
+    }
+    auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
+    omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    reach = uni(reach);
+    const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
+    // The descent is wave-uniform, but this chip's scalar unit has no float arithmetic: written on uniform values, every comparison, every
+    // min / max and every move of a box is a vector instruction for the whole wave -- about a hundred per level, 800 per tile, a seventh of the
+    // any-hit launch's instructions (r5).  So the lanes take a WORD of the 64-byte node each: lane w (of every sixteen) loads word w -- child 0's
+    // box in words 0-5 as (lo, hi) pairs per axis, child 1's in 6-11, the links in 12 and 13 -- and tests it against its own bound of the
+    // origins; the answers come back as a lane mask, the links by v_readlane, and everything that steers the descent is scalar.  An entry's
+    // centre / half-extent form is computed by the three even lanes that hold its lo words (the hi word comes from the neighbour by DPP) and
+    // stored straight to the cut in LDS.  ~20 vector instructions per level.
+    const uint32_t w = lane & 15u;
+    const bool is_hi = (w & 1u) != 0u;
+    const uint32_t axis = (w % 6u) >> 1;
+    const bool lo_lane = lane < 12u && !is_hi;          // the lanes that hold a box's lo words (one sixteen of the wave writes)
+    const uint32_t my_child = w >= 6u ? 1u : 0u;
+    // a lo word passes iff word <= omin[axis], a hi word iff omax[axis] <= word, i.e. -word <= -omax[axis]: one comparison with the sign flipped
+    const uint32_t flip = is_hi ? 0x80000000u : 0u;
+    const float ref = is_hi ? -(axis == 0u ? omax.x : axis == 1u ? omax.y : omax.z) : (axis == 0u ? omin.x : axis == 1u ? omin.y : omin.z);
+    const float shift = axis == 0u ? centre.x : axis == 1u ? centre.y : centre.z;
+    const uint32_t word_offset = w * 4u;
+    uint32_t cut_n = 0;
+    const CutLane cl{ omin, omax, reach2, shift, axis, lo_lane, my_child, lane, link_bytes };
+    // `word`: a node's words, one per lane; `child`'s box joins the cut with `link`
+#define add_entry(word, child, link) cut_add_entry(cl, s_cut, cut_n, word, child, link)
+    int node = 0;
+    float pword = is_hi ? 3.0e38f : -3.0e38f;                                              // the words `node`'s own box came in: for the root, "everything" as child 0
+    int pchild = 0;
+    bool open = true;                                                                      // `node` still waits for its entry
+    const char *const base = reinterpret_cast<const char *>(nodes);
+    for (int it = 0; it < max_entries - 2; ++it) {
+        const float word = *reinterpret_cast<const float *>(base + (uint32_t(node) * uint32_t(sizeof(BvhNode)) + word_offset));
+        const uint32_t inside = uint32_t(cmp_le_mask(__uint_as_float(__float_as_uint(word) ^ flip), ref));      // bit w: word w keeps the origins inside
+        const bool in0 = (inside & 0x3fu) == 0x3fu, in1 = (inside & 0xfc0u) == 0xfc0u;
+        const int link0 = __builtin_amdgcn_readlane(__float_as_int(word), 12), link1 = __builtin_amdgcn_readlane(__float_as_int(word), 13);
+        const bool follow0 = link0 >= 0 && in0, follow1 = !follow0 && link1 >= 0 && in1;
+        if (!(follow0 || follow1)) {                                                      // the descent ends here: both children join the cut
+            add_entry(word, 0, link0);
+            add_entry(word, 1, link1);
+            open = false;
+            break;
+        }
+        if (follow0) { add_entry(word, 1, link1); pchild = 0; node = link0; }
+        else { add_entry(word, 0, link0); pchild = 1; node = link1; }
+        pword = word;
+    }
+    if (open) {                                                                            // the budget ran out: the subtree itself
+        if (pchild == 0) add_entry(pword, 0, node); else add_entry(pword, 1, node);
+    }
+#undef add_entry
     wave_lds_sync();
     return cut_n;
 }
@@ -1467,7 +1569,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
     // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
-    const uint32_t cut_n = total && bounce == 0 ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    const uint32_t cut_n = total && bounce == 0 ? build_tile_cut_uniform(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     const unsigned long long tw0 = STATS ? __builtin_readcyclecounter() : 0ull;
     wave_queue_walk<SPILL, false, STATS>(
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
@@ -2006,7 +2108,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     uint32_t overflow = 0;
     // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
     // (one origin for every ray: the shared descent follows the boxes around the camera)
-    uint32_t cut_n = traced && total ? build_tile_cut(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
+    uint32_t cut_n = traced && total ? build_tile_cut_uniform(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
@@ -2042,7 +2144,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
     wave_lds_sync();
     // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
-    cut_n = nhit ? build_tile_cut(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    cut_n = nhit ? build_tile_cut_uniform(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
