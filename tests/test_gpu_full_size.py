@@ -110,6 +110,33 @@ def test_1080p_eight_virtual_screen_tiles_equal_single_context():
     _check_against_reference(plans, results, ref)
 
 
+def test_presplit_references_leave_the_1080p_frame_unchanged():
+    """Option "bvh_presplit" at full size on the scene built for it (sponza_hard turned off the world axes: two-triangle walls whose boxes fill the
+    atrium): the tree with split references -- 6 % more of them -- gives the Raytraced, Reflections and Denoised images of the tree without,
+    bit for bit, over three dolly frames (what a ray hits cannot depend on which boxes lead to the triangle)."""
+    W, H = 1920, 1080
+    sc = scenes.sponza_hard_rot()
+    tp = abi.default_trace_params()
+    pfds = camera.dolly_frames(sc, W, H, 3)
+    images = []
+    for presplit in (0, 25):
+        g = GpuHybrid(sc, W, H, trace_params=tp, gbuffer="standin", geometry_options={"bvh_presplit": presplit})
+        try:
+            refs, level = g.ctx.bvh_statistics()["triangles"], g.ctx.bvh_presplit_level()
+            assert (level, refs) == (-1, sc.triangle_count) if presplit == 0 else (level >= 0 and sc.triangle_count < refs <= sc.triangle_count * 3 // 2)
+            frames = []
+            for pfd in pfds:
+                g.frame(pfd)
+                frames.append(tuple(g.ctx.download(k).copy() for k in (lib.RAYTRACED, lib.REFLECTIONS, lib.DENOISED)))
+            images.append(frames)
+        finally:
+            g.close()
+    for i, (a, b) in enumerate(zip(*images)):
+        for name, x, y in zip(("Raytraced", "Reflections", "Denoised"), a, b):
+            assert np.array_equal(x, y), f"frame {i}: {name} differs with split references"
+    assert (f16(images[0][1][0])[..., 0] == 0).mean() > 0.05            # (shadowed pixels exist)
+
+
 @pytest.mark.parametrize("bounces,options", [(1, (("reflection_async", 1), ("svgf_async_unread", 1))), (1, (("reflection_async", 2), ("svgf_async_unread", 2))),
                                              (2, (("reflection_async", 0), ("svgf_async_unread", 2)))])
 def test_config4_bistro_1080p_eight_screen_tiles_full_hybrid(bounces, options):
