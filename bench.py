@@ -48,6 +48,7 @@ def parse():
                    help="mirror bounces (1 = --reflections = the reference; 2 = BASELINE config 5's extension; second-bounce rays are NOT counted in value)")
     p.add_argument("--scene", default="sponza_proc", choices=["sponza_proc", "bistro_proc", "sponza_hard", "tiny", "sponza_proc_rot", "sponza_hard_rot", "bistro_proc_rot"],
                    help="*_rot: the same scene with the whole world (geometry, light, camera path) turned off the world axes (scenes.rotated)")
+    p.add_argument("--bvh-frame", type=int, default=None, choices=[0, 1], help="option \"bvh_frame\": 1 (the library's default) = the boxes in the frame the builder finds for the scene (csrc/bvh_frame.hpp), 0 = along the world axes")
     p.add_argument("--bvh-presplit", type=int, default=0, help="option \"bvh_presplit\": budget of extra triangle references in percent (csrc/presplit.hpp), 0 = off")
     p.add_argument("--gltf", default=None, help="load this .gltf / .glb instead of a procedural scene (vulkanhybridrenderer_amd/gltf.py)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -399,8 +400,8 @@ def main():
     W, H = args.width, args.height
     n_frames = min(args.steps + args.warmup + (args.verify_frames if world > 1 else 0), args.max_gbuffers)
     common = dict(shadow=True, ao_spp=args.ao_spp, denoise=True, device=local_rank)
-    if args.bvh_presplit:
-        common["geometry_options"] = {"bvh_presplit": args.bvh_presplit}
+    if args.bvh_presplit or args.bvh_frame is not None:
+        common["geometry_options"] = {**({"bvh_presplit": args.bvh_presplit} if args.bvh_presplit else {}), **({"bvh_frame": args.bvh_frame} if args.bvh_frame is not None else {})}
     grid = None if args.grid == "auto" else ("strips" if args.grid == "strips" else tuple(int(v) for v in args.grid.lower().split("x")))
     # who moves the halos.  auto = torch.distributed (backend nccl IS RCCL): the route every N > 1 measurement so far has used.  The
     # library's own RCCL calls (--comm c_abi) need one GPU per rank (RCCL refuses two ranks on one device) and have not met a second
@@ -433,6 +434,8 @@ def main():
     build_ms, upload_ms = ctx.build_times_ms()
     k0_builder = "device (binned SAH)" if ctx.bvh_builder_used() == 1 else "host (binned SAH)"
     presplit_level = ctx.bvh_presplit_level()
+    _frame = ctx.bvh_frame()
+    bvh_frame = "world axes" if np.array_equal(_frame, np.eye(3, dtype=np.float32)) else [[round(float(v), 5) for v in row] for row in _frame]
     option_overrides = {}
     for kv in args.option:
         key, _, val = kv.partition("=")
@@ -756,7 +759,7 @@ def main():
             },
             # K0: the reference builds its BLAS / TLAS on the device once per scene (resource_manager.cpp:650,692,792); so does this
             # (binned SAH, csrc/kernels_bvh.hip), once per scene, outside the frame.  upload = scene arrays + the tree fetched back for the host's self-checks
-            "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1), "k0_builder": k0_builder, "bvh_presplit": {"percent": args.bvh_presplit, "level": presplit_level} if args.bvh_presplit else None,
+            "k0_build_ms": round(build_ms, 1), "k0_upload_ms": round(upload_ms, 1), "k0_builder": k0_builder, "bvh_frame": bvh_frame, "bvh_presplit": {"percent": args.bvh_presplit, "level": presplit_level} if args.bvh_presplit else None,
             "kernels_us": {"svgf_temporal": round(kt["svgf_temporal"][0] / max(1, kt["svgf_temporal"][1]) * 1e3, 2),
                            "svgf_atrous": round(atrous_us, 2),
                            "blit": round(kt["blit"][0] / max(1, kt["blit"][1]) * 1e3, 2) if kt["blit"][1] else None,      # None: all three blits are stores of a-trous launches

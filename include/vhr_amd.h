@@ -500,7 +500,12 @@ int vhr_get_ray_statistics(vhr_context *ctx, uint64_t out[4]);
  *  one reference per triangle, n = 1..400: triangles whose box wastes more than 1 % of the scene box's half area enter the build once per
  *  grid cell they pass through, with at most about n % more references than triangles (csrc/presplit.hpp, both builders, the same tree;
  *  images bit-identical, vhr_get_bvh_statistics then counts references; on a scene with such triangles the any-hit launch gains and the
- *  mirror ray's closest-hit launch loses, profiles/r5_sponza_hard.txt; vhr_get_bvh_presplit_level tells what the last build did). */
+ *  mirror ray's closest-hit launch loses, profiles/r5_sponza_hard.txt; vhr_get_bvh_presplit_level tells what the last build did);
+ *  "bvh_frame" 1 (default) = the boxes along the frame (a rotation, found by the builder: csrc/bvh_frame.hpp) that minimises the summed area
+ *  of the triangles' boxes, if that beats the world axes by 5 % -- a scene whose dominant orientation is not the world's walks up to twice as
+ *  fast for it, a scene along the world axes keeps them and its tree, bit for bit (the search costs such a scene ~1.5 ms of K0) --, 0 = the world
+ *  axes whatever the scene; the walkers rotate a ray once for the box tests and intersect triangles in world space as ever: images
+ *  bit-identical, both builders, the same tree (vhr_get_bvh_frame tells which frame the current tree uses; "bvh_presplit" is not combined with a rotated frame). */
 int vhr_set_option(vhr_context *ctx, const char *key, int32_t value);
 int vhr_get_option(vhr_context *ctx, const char *key, int32_t *value);
 int32_t vhr_option_count(void);
@@ -560,6 +565,8 @@ int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used);
 /* "bvh_presplit": the grid level (cell edge = longest scene edge / 2^level) the current tree's references were split on, -1 = every
  * triangle is one reference (the option is off, no triangle qualified, or the budget allowed no level) */
 int vhr_get_bvh_presplit_level(vhr_context *ctx, int32_t *level);
+/* "bvh_frame": the frame the current tree's boxes are in, row-major, row i = axis i in world coordinates (the identity: the world axes) */
+int vhr_get_bvh_frame(vhr_context *ctx, float out[9]);
 
 /* BVH facts for reporting: out[0] = node count, out[1] = triangle count, out[2] = max depth,
  * out[3] = node bytes, out[4] = triangle bytes */

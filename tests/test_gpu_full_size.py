@@ -120,7 +120,7 @@ def test_presplit_references_leave_the_1080p_frame_unchanged():
     pfds = camera.dolly_frames(sc, W, H, 3)
     images = []
     for presplit in (0, 25):
-        g = GpuHybrid(sc, W, H, trace_params=tp, gbuffer="standin", geometry_options={"bvh_presplit": presplit})
+        g = GpuHybrid(sc, W, H, trace_params=tp, gbuffer="standin", geometry_options={"bvh_presplit": presplit, "bvh_frame": 0})
         try:
             refs, level = g.ctx.bvh_statistics()["triangles"], g.ctx.bvh_presplit_level()
             assert (level, refs) == (-1, sc.triangle_count) if presplit == 0 else (level >= 0 and sc.triangle_count < refs <= sc.triangle_count * 3 // 2)

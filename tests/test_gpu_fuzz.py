@@ -118,7 +118,7 @@ def test_presplit_references_same_tree_same_bits(oracle, seed, n_tris, n_prims, 
     W, H = 96, 64
     tp = abi.default_trace_params()
     frames, osc, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
-    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, geometry_options={"bvh_presplit": percent})
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, geometry_options={"bvh_presplit": percent, "bvh_frame": 0})
     try:
         trees = []
         for builder in (1, 0):
@@ -148,6 +148,53 @@ def test_presplit_references_same_tree_same_bits(oracle, seed, n_tris, n_prims, 
         g.ctx.set_option("bvh_builder", 1)
         g.ctx.upload_scene(scene)
         assert g.ctx.bvh_presplit_level() == -1 and g.ctx.bvh_statistics()["triangles"] == scene.triangle_count
+        g.frame(frames[1]["pfd"], frames[1]["gbuf"])
+        assert np.array_equal(g.ctx.download(lib.RAYTRACED), frames[1]["shadow_ao"])
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("seed,n_tris,n_prims", [(31, 300, 3), (32, 2000, 6), (0, 0, 0)])
+def test_bvh_frame_same_tree_same_bits(oracle, seed, n_tris, n_prims):
+    """Option "bvh_frame" (csrc/bvh_frame.hpp): a soup turned off the world axes built with the boxes in the frame the builder finds -- by the
+    device's builder and by the host's: the same (non-identity) frame and the same tree from both, node forms that pass the containment check,
+    and the oracle's visibility words and mirror-ray payloads bit for bit from every walker (the queue kernels and the per-pixel ones, the
+    half-precision and the 48-byte nodes): only the boxes moved, the triangles are intersected in world space.  (Soups whose floor outweighs
+    their random triangles -- a soup of thousands has no orientation to find and keeps the world axes -- and a small Sponza-like scene.)"""
+    scene = scenes.rotated(soup(seed, n_tris, n_prims) if n_tris else scenes.sponza_proc(0.12), rot_y=0.6, rot_x=0.25)
+    W, H = 96, 64
+    tp = abi.default_trace_params()
+    frames, osc, _ = oracle_frames(oracle, scene, W, H, 2, tp, denoise=False)
+    g = GpuHybrid(scene, W, H, denoise=False, trace_params=tp, geometry_options={"bvh_frame": 1})
+    try:
+        trees = []
+        for builder in (1, 0):
+            if builder == 0:
+                g.ctx.set_option("bvh_builder", 0)
+                g.ctx.upload_scene(scene)
+            assert g.ctx.bvh_builder_used() == builder and g.ctx.bvh_form_checks()[1:] == (0, 0, 0)
+            frame = g.ctx.bvh_frame()
+            assert not np.array_equal(frame, np.eye(3, dtype=np.float32)) and np.allclose(frame @ frame.T, np.eye(3), atol=1e-5)
+            trees.append((g.ctx.bvh_tree_fingerprint(), frame.tobytes()))
+            for i, fr in enumerate(frames):
+                g.frame(fr["pfd"], fr["gbuf"])
+                got = g.ctx.download(lib.RAYTRACED)
+                assert np.array_equal(got, fr["shadow_ao"]), f"builder {builder}, frame {i}: visibility differs from the oracle's"
+                assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], f"builder {builder}, frame {i}")
+                if builder == 1 and i == 1:
+                    for key, val, back in (("raygen_variant", 0, 1), ("compact_nodes", 0, 1), ("reflection_variant", 0, 1), ("lds_stack_levels", 2, 8), ("raygen_steal", 0, 8)):
+                        g.ctx.set_option(key, val)
+                        g.ctx.execute(0, 0)
+                        g.ctx.synchronize()
+                        assert np.array_equal(g.ctx.download(lib.RAYTRACED), got), key
+                        assert_reflections_identical(g.ctx.download(lib.REFLECTIONS), fr["reflections"], key)
+                        g.ctx.set_option(key, back)
+        assert trees[0] == trees[1] and trees[0][0] != 0, "the host's and the device's builder chose different frames or made different trees"
+        # ... and without the option the same context builds along the world axes again
+        g.ctx.set_option("bvh_frame", 0)
+        g.ctx.set_option("bvh_builder", 1)
+        g.ctx.upload_scene(scene)
+        assert np.array_equal(g.ctx.bvh_frame(), np.eye(3, dtype=np.float32))
         g.frame(frames[1]["pfd"], frames[1]["gbuf"])
         assert np.array_equal(g.ctx.download(lib.RAYTRACED), frames[1]["shadow_ao"])
     finally:

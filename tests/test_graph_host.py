@@ -210,6 +210,7 @@ def test_presplit_references_on_the_host_builder():
         c = lib.Context(64, 64, host_only=True)
         try:
             c.set_option("bvh_presplit", presplit)
+            c.set_option("bvh_frame", 0)                 # (split references are for boxes along the world axes: a rotated frame takes their place)
             c.set_option("bvh_build_threads", threads)
             c.upload_scene(scene)
             assert c.bvh_form_checks()[1:] == (0, 0, 0)
@@ -232,6 +233,44 @@ def test_presplit_references_on_the_host_builder():
         for bad in (-1, 401):
             with pytest.raises(lib.VhrError):
                 c.set_option("bvh_presplit", bad)
+    finally:
+        c.close()
+
+
+def test_bvh_frame_search_on_the_host_builder():
+    """Option "bvh_frame" (csrc/bvh_frame.hpp) on a host-only context: a scene along the world axes keeps them (the tree is the tree without the
+    option, bit for bit); the same scene turned off the axes gets the frame that turns it back -- frame x the scene's rotation is a signed
+    permutation of the axes to within the search's half-degree steps --, a tree of the size the unrotated scene has, node forms that pass
+    their containment checks, and the same frame and tree whatever the number of build threads; the option's range is checked."""
+    from vulkanhybridrenderer_amd import scenes
+    def build(scene, mode, threads=0):
+        c = lib.Context(64, 64, host_only=True)
+        try:
+            c.set_option("bvh_frame", mode)
+            c.set_option("bvh_build_threads", threads)
+            c.upload_scene(scene)
+            assert c.bvh_form_checks()[1:] == (0, 0, 0)
+            st = c.bvh_statistics()
+            return st["nodes"], c.bvh_frame(), c.bvh_fingerprint(), c.bvh_tree_fingerprint()
+        finally:
+            c.close()
+    for scene in (scenes.tiny_scene(), scenes.sponza_proc(0.35)):
+        off, on = build(scene, 0), build(scene, 1)
+        assert np.array_equal(on[1], np.eye(3, dtype=np.float32)) and (on[0], on[2], on[3]) == (off[0], off[2], off[3]), scene.name
+    for base in (scenes.tiny_scene(), scenes.sponza_proc(0.35)):
+        turned = scenes.rotated(base, rot_y=0.6, rot_x=0.25)
+        nodes, frame, fp, tree = build(turned, 1)
+        back = np.abs(frame.astype(np.float64) @ np.asarray(turned.camera["world"], np.float64)[:3, :3])      # ~ a permutation matrix
+        assert np.allclose(back.max(axis=1), 1.0, atol=2e-3) and np.allclose(np.sort(back, axis=1)[:, :2], 0.0, atol=3e-2), (turned.name, back)
+        assert abs(nodes - build(base, 0)[0]) <= 0.02 * nodes + 4 and nodes < build(turned, 0)[0], turned.name
+        for threads in (1, 3):
+            other = build(turned, 1, threads)
+            assert np.array_equal(other[1], frame) and other[2:] == (fp, tree)
+    c = lib.Context(64, 64, host_only=True)
+    try:
+        for bad in (-1, 2):
+            with pytest.raises(lib.VhrError):
+                c.set_option("bvh_frame", bad)
     finally:
         c.close()
 

@@ -8,6 +8,10 @@ run cfg2_1080p_shadows_only --ao-spp 0 --steps 16
 run cfg3_4k_4spp --width 3840 --height 2160 --ao-spp 4 --steps 16 --max-gbuffers 20
 run cfg4_bistro_1080p_full_hybrid --scene bistro_proc --reflections --steps 16
 run extra_sponza_hard_1080p --scene sponza_hard --steps 16
+run extra_sponza_hard_rot_1080p --scene sponza_hard_rot --steps 16
+run extra_sponza_hard_rot_1080p_world_axes --scene sponza_hard_rot --bvh-frame 0 --steps 16
+run extra_bistro_rot_1080p_full_hybrid --scene bistro_proc_rot --reflections --steps 16
+run extra_bistro_rot_1080p_full_hybrid_world_axes --scene bistro_proc_rot --reflections --bvh-frame 0 --steps 16
 run cfg5_bistro_4k_16spp_2bounce --scene bistro_proc --width 3840 --height 2160 --ao-spp 16 --refl-bounces 2 --steps 8 --max-gbuffers 12
 python3 - <<PY
 import json, glob, os

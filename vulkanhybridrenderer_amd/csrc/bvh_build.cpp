@@ -27,6 +27,7 @@
 
 #include "vhr_internal.hpp"
 #include "presplit.hpp"
+#include "bvh_frame.hpp"
 
 namespace vhr {
 namespace {
@@ -385,7 +386,7 @@ inline int32_t leaf_link(uint32_t first, uint32_t count) { return ~int32_t((firs
 }  // namespace
 
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads, int presplit_percent) {
+               uint32_t primitive_count, HostBvh &out, int leaf_tris, int threads, int presplit_percent, int frame_mode) {
     const bool k0trace = std::getenv("VHR_K0_TRACE") != nullptr; auto k0t = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (k0trace) { auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "K0 %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - k0t).count()); k0t = t; } };
     Builder b;
@@ -430,16 +431,41 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     b.centroid.resize(size_t(n) * 3);
     b.order.resize(n);
     const unsigned hw = host_threads(threads);
+    // "bvh_frame" 1: the frame the boxes are built in (bvh_frame.hpp; the device builder runs the same search with a kernel as the pass)
+    out.frame_on = false;
+    { const float identity[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy(out.frame, identity, sizeof(identity)); }
+    if (frame_mode == 1 && n >= 2u) {
+        float frame[9];
+        const bool found = bvh_frame::choose([&](const bvh_frame::Candidates &c, uint64_t *sums) {
+            for (int k = 0; k < c.n; ++k) sums[k] = 0;
+            std::mutex m;
+            const size_t stride = bvh_frame::sample_stride(n), samples = (size_t(n) + stride - 1) / stride;
+            parallel_for(samples, hw, [&](size_t i0, size_t i1) {
+                uint64_t part[bvh_frame::kMaxCandidates] = {};
+                for (size_t i = i0; i < i1; ++i)
+                    for (int k = 0; k < c.n; ++k) part[k] += bvh_frame::cost_term(c.r[k], b.tris[i * stride]);
+                std::lock_guard<std::mutex> lock(m);
+                for (int k = 0; k < c.n; ++k) sums[k] += part[k];
+            });
+        }, frame);
+        if (found) { std::memcpy(out.frame, frame, sizeof(frame)); out.frame_on = true; }
+        lap("frame search");
+    }
+    const bool framed = out.frame_on;
     parallel_for(n, hw, [&](size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; ++i) {
         const BvhTri &t = b.tris[i];
         Box bx;
         bx.reset();
-        float p1[3], p2[3];
-        for (int a = 0; a < 3; ++a) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
-        bx.grow(t.v0);
-        bx.grow(p1);
-        bx.grow(p2);
+        if (framed) {
+            bvh_frame::box_in_frame(out.frame, t, bx.lo, bx.hi);
+        } else {
+            float p1[3], p2[3];
+            for (int a = 0; a < 3; ++a) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
+            bx.grow(t.v0);
+            bx.grow(p1);
+            bx.grow(p2);
+        }
         b.tri_box[i] = bx;
         for (int a = 0; a < 3; ++a) b.centroid[size_t(i) * 3 + a] = 0.5f * (bx.lo[a] + bx.hi[a]);
         b.order[i] = uint32_t(i);
@@ -447,7 +473,7 @@ void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_pr
     });
     lap("triangles + boxes");
     out.presplit_level = -1;
-    if (presplit_percent > 0 && n >= 2u) {
+    if (presplit_percent > 0 && n >= 2u && !framed) {           // (a rotated frame takes the place of splitting: the option is not combined with it)
         // fat triangles entered once per grid cell they pass through (presplit.hpp; the device builder's k0_presplit_* kernels do the same)
         float clo[3] = { b.centroid[0], b.centroid[1], b.centroid[2] }, chi[3] = { b.centroid[0], b.centroid[1], b.centroid[2] };
         for (size_t i = 1; i < n; ++i)

@@ -55,6 +55,8 @@ vhr::DeviceScene vhr_context::device_scene() const {
     s.tri_count = tri_count;
     s.primitive_count = primitive_count;
     s.texture_count = uint32_t(textures.size());
+    for (int i = 0; i < 9; ++i) s.frame[i] = bvh_frame[i];
+    s.frame_on = bvh_frame_on ? 1u : 0u;
     return s;
 }
 
@@ -402,7 +404,7 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
         // (a primitive without triangles shares its prefix with the next one: the search below picks the LAST primitive whose prefix is
         // <= t, which is the one that owns triangle t, because an empty primitive's successor starts at the same value)
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris, ctx->bvh_presplit);
+        const int rc = device_build_bvh(ctx, prefix, uint32_t(total_triangles), ctx->bvh_leaf_tris, ctx->bvh_presplit, ctx->bvh_frame_mode);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == VHR_OK) {
             device_built = true;
@@ -424,9 +426,11 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
     }
     const auto t_build0 = std::chrono::steady_clock::now();
     if (!device_built) {
-        build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads, ctx->bvh_presplit);          // UpdateBLAS + UpdateTLAS
+        build_bvh(vertices, indices, primitives, primitive_count, bvh, ctx->bvh_leaf_tris, ctx->bvh_build_threads, ctx->bvh_presplit, ctx->bvh_frame_mode);          // UpdateBLAS + UpdateTLAS
         ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
         ctx->bvh_presplit_level = bvh.presplit_level;
+        for (int i = 0; i < 9; ++i) ctx->bvh_frame[i] = bvh.frame[i];
+        ctx->bvh_frame_on = bvh.frame_on;
     }
     if (uint64_t(device_built ? ctx->node_count : bvh.nodes48.size()) * sizeof(BvhNode48) >= (1ull << 31))     // an inner link of the 48-byte nodes is a non-negative 32-bit byte offset
         return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "UpdateGeometry: more than 44 million BVH nodes");
@@ -469,6 +473,12 @@ int vhr_update_geometry(vhr_context *ctx, const vhr_vertex *vertices, uint32_t v
 int vhr_get_bvh_builder(vhr_context *ctx, int32_t *used) {
     if (!ctx || !used) return VHR_ERROR_INVALID_ARGUMENT;
     *used = ctx->bvh_builder_used;
+    return VHR_OK;
+}
+
+int vhr_get_bvh_frame(vhr_context *ctx, float out[9]) {
+    if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
+    for (int i = 0; i < 9; ++i) out[i] = ctx->bvh_frame[i];
     return VHR_OK;
 }
 
@@ -622,6 +632,11 @@ int vhr_set_option(vhr_context *ctx, const char *key, int32_t value) {
     if (!std::strcmp(key, "bvh_builder")) {                  // applies to the next vhr_update_geometry
         if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_builder must be 0 (binned SAH on the host) or 1 (binned SAH on the device)");
         ctx->bvh_builder = value;
+        return VHR_OK;
+    }
+    if (!std::strcmp(key, "bvh_frame")) {                    // applies to the next vhr_update_geometry
+        if (value < 0 || value > 1) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "bvh_frame must be 0 (boxes along the world axes) or 1 (along the frame that minimises the triangles' summed box area)");
+        ctx->bvh_frame_mode = value;
         return VHR_OK;
     }
     if (!std::strcmp(key, "bvh_presplit")) {                 // applies to the next vhr_update_geometry

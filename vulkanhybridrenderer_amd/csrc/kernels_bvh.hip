@@ -40,6 +40,7 @@
 
 #include "vhr_internal.hpp"
 #include "presplit.hpp"
+#include "bvh_frame.hpp"
 
 namespace vhr {
 namespace {
@@ -747,6 +748,37 @@ __global__ __launch_bounds__(256) void k0_bfs_rank_kernel(const uint32_t *__rest
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k < kept) rank[sorted_vals[k]] = k;
 }
+// ---- "bvh_frame": the search's pass over the triangles (bvh_frame.hpp), and the boxes in the frame it found ----
+// sums[k] += sum over the triangles of cost_term(candidate k): integers, so the order of the atomics does not matter
+__global__ __launch_bounds__(256) void k0_frame_cost_kernel(const BvhTri *__restrict__ tris, uint32_t n, uint32_t stride, bvh_frame::Candidates c, unsigned long long *__restrict__ sums) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;            // sample t = triangle t * stride
+    BvhTri tri{};
+    if (t < n) tri = tris[size_t(t) * stride];
+    for (int k = 0; k < c.n; ++k) {
+        unsigned long long e = t < n ? bvh_frame::cost_term(c.r[k], tri) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        if ((threadIdx.x & 63u) == 0u && e) atomicAdd(&sums[k], e);
+    }
+}
+struct FrameMatrix { float r[9]; };
+__global__ __launch_bounds__(256) void k0_frame_boxes_kernel(const BvhTri *__restrict__ tris, uint32_t n, FrameMatrix frame, Box6 *__restrict__ boxes,
+                                                             uint32_t *__restrict__ centre_bounds) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    float c[3] = { 0.0f, 0.0f, 0.0f };
+    if (t < n) {
+        Box6 b;
+        bvh_frame::box_in_frame(frame.r, tris[t], b.lo, b.hi);
+        for (int a = 0; a < 3; ++a) c[a] = 0.5f * (b.lo[a] + b.hi[a]);
+        boxes[t] = b;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = t < n ? c[a] : 3.0e38f, mx = t < n ? c[a] : -3.0e38f;
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if ((threadIdx.x & 63u) == 0u) { atomic_min_checked(&centre_bounds[a], ordered(mn)); atomic_max_checked(&centre_bounds[3 + a], ordered(mx)); }
+    }
+}
+
 // ---- "bvh_presplit": the references of very fat triangles, one per grid cell they pass through (presplit.hpp, shared with the host builder) ----
 struct PresplitGrids { presplit::Grid g[presplit::kLevels]; };
 
@@ -835,7 +867,7 @@ struct Scratch {            // device allocations of one build, freed together
 // Builds the tree from the scene arrays already on the device (ctx->d_vertices / d_indices / d_primitives) into ctx->d_nodes,
 // d_nodes_ch, d_nodes48, d_nodes16, d_tris.  Returns VHR_OK, or VHR_ERROR_OUT_OF_SLOTS when the tree is deeper than the walkers'
 // stacks (kMaxBvhDepth) -- the caller then falls back to the host builder.  `tri_prefix`: first flat triangle of every primitive.
-int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in, int presplit_percent) {
+int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris_in, int presplit_percent, int frame_mode) {
     uint32_t n = total_tris;
     const uint32_t leaf_tris = uint32_t(std::max(1, std::min(kMaxLeafTris, leaf_tris_in)));
     if (n <= leaf_tris || n < 2u) return VHR_ERROR_OUT_OF_SLOTS;
@@ -869,8 +901,39 @@ int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, 
     uint32_t h_bounds[12];
     K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
     K0_TRY(hipStreamSynchronize(s));
+    // ---- "bvh_frame" 1: the frame search (the host builder's, with a kernel as its pass over the triangles), then the boxes in that frame ----
+    ctx->bvh_frame_on = false;
+    { const float identity[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }; std::memcpy(ctx->bvh_frame, identity, sizeof(identity)); }
+    if (frame_mode == 1) {
+        unsigned long long *d_sums;
+        K0_TRY(tmp.alloc(&d_sums, size_t(bvh_frame::kMaxCandidates)));
+        hipError_t pass_error = hipSuccess;
+        float frame[9];
+        const uint32_t stride = bvh_frame::sample_stride(n), samples = (n + stride - 1u) / stride;
+        const bool found = bvh_frame::choose([&](const bvh_frame::Candidates &c, uint64_t *sums) {
+            static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "64-bit sums");
+            hipError_t e = hipMemsetAsync(d_sums, 0, sizeof(unsigned long long) * bvh_frame::kMaxCandidates, s);
+            if (e == hipSuccess) { hipLaunchKernelGGL(k0_frame_cost_kernel, grid(samples), block, 0, s, d_tris_flat, samples, stride, c, d_sums); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipMemcpyAsync(sums, d_sums, sizeof(uint64_t) * size_t(c.n), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { pass_error = e; for (int k = 0; k < c.n; ++k) sums[k] = ~0ull; }
+        }, frame);
+        K0_TRY(pass_error);
+        if (found) {
+            FrameMatrix fm;
+            std::memcpy(fm.r, frame, sizeof(frame));
+            K0_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k0_frame_boxes_kernel, grid(n), block, 0, s, d_tris_flat, n, fm, d_boxes, d_bounds);
+            K0_TRY(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, s));
+            K0_TRY(hipStreamSynchronize(s));
+            K0_TRY(hipGetLastError());
+            std::memcpy(ctx->bvh_frame, frame, sizeof(frame));
+            ctx->bvh_frame_on = true;
+        }
+        lap("frame search");
+    }
     ctx->bvh_presplit_level = -1;
-    if (presplit_percent > 0) {
+    if (presplit_percent > 0 && !ctx->bvh_frame_on) {           // (a rotated frame takes the place of splitting: the option is not combined with it)
         float clo[3], chi[3];
         for (int a = 0; a < 3; ++a) { clo[a] = unordered(h_bounds[a]); chi[a] = unordered(h_bounds[3 + a]); }
         PresplitGrids grids;

@@ -92,6 +92,29 @@ __device__ __forceinline__ bool box_test(float lox, float loy, float loz, float 
     return tn <= tf;
 }
 
+// "bvh_frame": what the slab tests see of a ray.  The boxes of all node forms live in the frame DeviceScene::frame (row i = axis i in world
+// coordinates); a walker rotates origin and direction once per ray for them and intersects triangles in world space as ever (boxes only cull:
+// the rotation's rounding, ~1e-6 |x|, is two orders below the boxes' padding).  frame_on is uniform: a scalar branch around 18 FMAs.
+__device__ __forceinline__ f3 frame_rotate(const float *R, f3 p) {
+    return f3{ (R[0] * p.x + R[1] * p.y) + R[2] * p.z, (R[3] * p.x + R[4] * p.y) + R[5] * p.z, (R[6] * p.x + R[7] * p.y) + R[8] * p.z };
+}
+__device__ __forceinline__ void box_ray(const DeviceScene &sc, f3 ro, f3 rd, f3 &bo, f3 &bd) {
+    bo = ro; bd = rd;
+    if (sc.frame_on) { bo = frame_rotate(sc.frame, ro); bd = frame_rotate(sc.frame, rd); }
+}
+// the bounds of a tile's ray origins in the frame: the box of the rotated box (centre R c, half extent |R| h -- a superset of the rotated origins)
+__device__ __forceinline__ void box_bounds(const DeviceScene &sc, f3 &omin, f3 &omax) {
+    if (!sc.frame_on || !(omin.x <= omax.x)) return;
+    const float *R = sc.frame;
+    const f3 c = f3{ 0.5f * omin.x + 0.5f * omax.x, 0.5f * omin.y + 0.5f * omax.y, 0.5f * omin.z + 0.5f * omax.z };
+    const f3 h = f3{ (omax.x - c.x) * 1.000001f + 1e-6f, (omax.y - c.y) * 1.000001f + 1e-6f, (omax.z - c.z) * 1.000001f + 1e-6f };
+    const f3 rc = frame_rotate(R, c);
+    const f3 rh = f3{ (fabsf(R[0]) * h.x + fabsf(R[1]) * h.y) + fabsf(R[2]) * h.z, (fabsf(R[3]) * h.x + fabsf(R[4]) * h.y) + fabsf(R[5]) * h.z,
+                      (fabsf(R[6]) * h.x + fabsf(R[7]) * h.y) + fabsf(R[8]) * h.z };
+    omin = f3{ rc.x - rh.x, rc.y - rh.y, rc.z - rh.z };
+    omax = f3{ rc.x + rh.x, rc.y + rh.y, rc.z + rh.z };
+}
+
 // Per-lane BVH2 walk with the traversal stack in LDS (stack[level * kTraceBlock + thread]: conflict free).
 // ANY_HIT: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (raygen.rgen:39,51) -- returns at the
 // first accepted triangle; the boolean result does not depend on the visiting order.
@@ -105,7 +128,9 @@ template <bool ANY_HIT, bool ALPHA = false>
 __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, int *stack, Hit &best,
                                          uint32_t &overflow) {
     if (sc.node_count == 0) return false;
-    const f3 inv = f3{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+    f3 bo, bd;
+    box_ray(sc, o, d, bo, bd);                                  // "bvh_frame": the slab tests' ray; the triangle tests below keep (o, d)
+    const f3 inv = f3{ 1.0f / bd.x, 1.0f / bd.y, 1.0f / bd.z };
     bool found = false;
     float tbest = tmax;
     int sp = 0;
@@ -116,8 +141,8 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
             const float4 q0 = np[0], q1 = np[1], q2 = np[2];
             const int4 q3 = reinterpret_cast<const int4 *>(np)[3];
             float tn0, tn1;
-            const bool h0 = box_test(q0.x, q0.z, q1.x, q0.y, q0.w, q1.y, o, inv, tmin, tbest, tn0);
-            const bool h1 = box_test(q1.z, q2.x, q2.z, q1.w, q2.y, q2.w, o, inv, tmin, tbest, tn1);
+            const bool h0 = box_test(q0.x, q0.z, q1.x, q0.y, q0.w, q1.y, bo, inv, tmin, tbest, tn0);
+            const bool h1 = box_test(q1.z, q2.x, q2.z, q1.w, q2.y, q2.w, bo, inv, tmin, tbest, tn1);
             if (h0 && h1) {
                 const bool first0 = tn0 <= tn1;
                 const int nearc = first0 ? q3.x : q3.y, farc = first0 ? q3.y : q3.x;
@@ -717,7 +742,7 @@ typedef const __attribute__((address_space(4))) v4i *uniform_i4_ptr;
 // The same descent written on wave-uniform values (rounds 2-4): every comparison and every move of a box is a vector instruction for the whole
 // wave, ~100 per level.  Kept for the closest-hit walks and the raytraced path, whose launches are not bound by vector issue (and whose kernels
 // the lane-parallel form below does not compile for: the backend's verifier rejects a private-to-flat cast next to it).
-__device__ __forceinline__ uint32_t build_tile_cut_uniform(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
+__device__ __forceinline__ uint32_t build_tile_cut_uniform(const DeviceScene &sc, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
                                                    const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), const f3 centre = f3{ 0.0f, 0.0f, 0.0f }) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
@@ -729,6 +754,7 @@ __device__ __forceinline__ uint32_t build_tile_cut_uniform(const BvhNode *nodes,
     // wave-uniform from here on, and told so: the descent then runs on scalar registers and scalar branches
     auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    box_bounds(sc, omin, omax);                          // "bvh_frame": the nodes' boxes are in the frame
     reach = uni(reach);
     const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
     // The cut while it is being built: entry e lives in lane e (box, link).
@@ -755,7 +781,7 @@ __device__ __forceinline__ uint32_t build_tile_cut_uniform(const BvhNode *nodes,
     for (int it = 0; it < max_entries - 2; ++it) {
         // a uniform address in the constant address space: the node arrives through the scalar cache (s_load), not through the
         // vector memory path the walk itself is bound by
-        const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(nodes + node);
+        const uniform_f4_ptr np = (uniform_f4_ptr)(uintptr_t)(sc.nodes + node);
         const v4f q0 = np[0], q1 = np[1], q2 = np[2];
         const v4i vl = ((uniform_i4_ptr)np)[3];
         const int2 links = int2{ vl.x, vl.y };
@@ -841,7 +867,7 @@ __device__ __forceinline__ void cut_add_entry(const CutLane cl, float4 (*s_cut)[
 // rays can get from its origin, tmax * |d|.  A subtree whose box lies farther than that from the bounds of the origins cannot
 // hold a hit of any of them and is left out of the cut -- decided once per tile instead of by a box test per ray.
 // `link_bytes`: inner links of the finished cut are multiplied by it (48 for the walkers of the 48-byte nodes, whose links are byte offsets).
-__device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
+__device__ __forceinline__ uint32_t build_tile_cut(const DeviceScene &sc, f3 omin, f3 omax, float4 (*s_cut)[2], uint32_t lane, float reach = 3.0e38f,
                                                    const int max_entries = kCutMax, const int link_bytes = int(sizeof(BvhNode48)), const f3 centre = f3{ 0.0f, 0.0f, 0.0f }) {
     // ---- bounds of the origins (wave reduction), then the descent; every lane computes the same thing ----
 #pragma unroll
@@ -852,6 +878,7 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     }
     auto uni = [](float f) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(f))); };
     omin = f3{ uni(omin.x), uni(omin.y), uni(omin.z) }; omax = f3{ uni(omax.x), uni(omax.y), uni(omax.z) };
+    box_bounds(sc, omin, omax);                          // "bvh_frame": the nodes' boxes are in the frame
     reach = uni(reach);
     const float reach2 = reach * reach;                 // inf for "no pruning" (and for anything that overflows)
     // The descent is wave-uniform, but this chip's scalar unit has no float arithmetic: written on uniform values, every comparison, every
@@ -879,7 +906,7 @@ __device__ __forceinline__ uint32_t build_tile_cut(const BvhNode *nodes, f3 omin
     float pword = is_hi ? 3.0e38f : -3.0e38f;                                              // the words `node`'s own box came in: for the root, "everything" as child 0
     int pchild = 0;
     bool open = true;                                                                      // `node` still waits for its entry
-    const char *const base = reinterpret_cast<const char *>(nodes);
+    const char *const base = reinterpret_cast<const char *>(sc.nodes);
     for (int it = 0; it < max_entries - 2; ++it) {
         const float word = *reinterpret_cast<const float *>(base + (uint32_t(node) * uint32_t(sizeof(BvhNode)) + word_offset));
         const uint32_t inside = uint32_t(cmp_le_mask(__uint_as_float(__float_as_uint(word) ^ flip), ref));      // bit w: word w keeps the origins inside
@@ -1039,7 +1066,7 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     wave_lds_sync();
     const uint32_t total = (a.scene.node_count == 0) ? 0u : ncov * (1u + last_kind - first_kind);
     uint32_t cut_n = 0;
-    if (total) cut_n = build_tile_cut(a.scene.nodes, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)),
+    if (total) cut_n = build_tile_cut(a.scene, omin, omax, s_cut, lane, ao_only ? ao_reach : 3.0e38f, kCutMax, COMPACT ? int(sizeof(BvhNode16)) : int(sizeof(BvhNode48)),
                                       COMPACT ? f3{ a.scene.centre[0], a.scene.centre[1], a.scene.centre[2] } : f3{ 0.0f, 0.0f, 0.0f });
     const uint32_t n_cut_entries = cut_n;
     uint32_t emask = 0;                               // cut entries this lane's ray hits that did not fit its LDS stack
@@ -1085,9 +1112,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 rd = ray_direction(a.tp, seed_thread((py * H + px) * a.pfd.frame_index), kind, L,                            // rgen:17
                                    f3{ half_bits_to_float(uint16_t(nxy & 0xffffu)), half_bits_to_float(uint16_t(nxy >> 16)), half_bits_to_float(uint16_t(nzw & 0xffffu)) });
                 tmax = kind == 0 ? a.tp.tmax : a.tp.ao_tmax;                                 // rgen:40,52
-                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
+                f3 bo, bd;
+                box_ray(a.scene, ro, rd, bo, bd);             // "bvh_frame": the slab tests' ray (ro, rd stay the triangle tests')
+                rinv = f3{ cull_reciprocal(bd.x), cull_reciprocal(bd.y), cull_reciprocal(bd.z) };
                 // COMPACT boxes are relative to the scene centre: shift the origin used by the slab test (only)
-                const f3 oc = COMPACT ? f3{ ro.x - a.scene.centre[0], ro.y - a.scene.centre[1], ro.z - a.scene.centre[2] } : ro;
+                const f3 oc = COMPACT ? f3{ bo.x - a.scene.centre[0], bo.y - a.scene.centre[1], bo.z - a.scene.centre[2] } : bo;
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 sbase = 0;
@@ -1391,8 +1420,10 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
             if (STATS && lane == 0) ++wc->refills;
             if (!has && r < total) {
                 fetch(r, pix, ro, rd);
-                rinv = f3{ cull_reciprocal(rd.x), cull_reciprocal(rd.y), cull_reciprocal(rd.z) };
-                noi = f3{ -(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z) };
+                f3 bo, bd;
+                box_ray(sc, ro, rd, bo, bd);                  // "bvh_frame": the slab tests' ray (ro, rd stay the triangle tests')
+                rinv = f3{ cull_reciprocal(bd.x), cull_reciprocal(bd.y), cull_reciprocal(bd.z) };
+                noi = f3{ -(bo.x * rinv.x), -(bo.y * rinv.y), -(bo.z * rinv.z) };
                 ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 tbest = tmax; best_tri = kNoHit; best_flat = 0; best_u = 0.0f; best_v = 0.0f;
                 cur = 0; sp = 0;
@@ -1569,7 +1600,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     for (int bounce = 0; bounce < BOUNCES; ++bounce) {
     const int orow = bounce ? 6 : 0;                      // where this bounce's origins sit and its hit records go
     // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
-    const uint32_t cut_n = total && bounce == 0 ? build_tile_cut_uniform(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    const uint32_t cut_n = total && bounce == 0 ? build_tile_cut_uniform(a.scene, omin, omax, s_cut_all[wave], lane) : 0u;
     const unsigned long long tw0 = STATS ? __builtin_readcyclecounter() : 0ull;
     wave_queue_walk<SPILL, false, STATS>(
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
@@ -2108,7 +2139,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     uint32_t overflow = 0;
     // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
     // (one origin for every ray: the shared descent follows the boxes around the camera)
-    uint32_t cut_n = traced && total ? build_tile_cut_uniform(a.scene.nodes, origin, origin, s_cut_all[wave], lane) : 0u;
+    uint32_t cut_n = traced && total ? build_tile_cut_uniform(a.scene, origin, origin, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
@@ -2144,7 +2175,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
     wave_lds_sync();
     // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
-    cut_n = nhit ? build_tile_cut_uniform(a.scene.nodes, omin, omax, s_cut_all[wave], lane) : 0u;
+    cut_n = nhit ? build_tile_cut_uniform(a.scene, omin, omax, s_cut_all[wave], lane) : 0u;
     wave_queue_walk<SPILL, ALPHA>(
         a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {

@@ -121,6 +121,10 @@ struct DeviceScene {
     const float *normal_matrices;    // 9 floats per primitive, column-major inverseTranspose(mat3(transform))
     const DeviceTexture *textures;
     uint32_t node_count, tri_count, primitive_count, texture_count;
+    // "bvh_frame": the boxes of all node forms live in this frame (row i = axis i in world coordinates); a walker rotates its ray once for the
+    // slab tests -- box_ray() -- and intersects triangles in world space as ever.  frame_on == 0: the world axes, nothing to rotate.
+    float frame[9];
+    uint32_t frame_on;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -149,6 +153,8 @@ struct HostBvh {
     std::vector<BvhNode48> nodes48;
     float centre[3] = { 0, 0, 0 };
     bool nodes16_valid = false;        // false: some box does not fit the half range around `centre` (the walkers then stay on nodes48)
+    float frame[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };     // "bvh_frame": the frame the boxes are in (identity: the world axes)
+    bool frame_on = false;
     std::vector<BvhTri> tris;          // one per REFERENCE ("bvh_presplit": a fat triangle is in several leaves)
     uint32_t max_depth = 0;
     int presplit_level = -1;           // the grid level the references were split on, -1 = none were
@@ -160,10 +166,10 @@ bool nodes16_in_range(const HostBvh &bvh);      // no inf / NaN / subnormal half
 uint64_t bvh_fingerprint(const HostBvh &bvh);
 uint64_t bvh_tree_fingerprint(const HostBvh &bvh);      // of the tree, not of its arrays: equal for the host's and the device's build of a scene
 void build_bvh(const vhr_vertex *vertices, const uint32_t *indices, const vhr_primitive *primitives,
-               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0, int presplit_percent = 0);
+               uint32_t primitive_count, HostBvh &out, int leaf_tris = kMaxLeafTris, int threads = 0, int presplit_percent = 0, int frame_mode = 0);
 // the device-side builder (csrc/kernels_bvh.hip, option "bvh_builder" 1): from ctx->d_vertices / d_indices / d_primitives into the
 // context's node and triangle arrays; VHR_ERROR_OUT_OF_SLOTS = fall back to the host builder (tree deeper than the walkers' stacks)
-int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris, int presplit_percent);
+int device_build_bvh(vhr_context *ctx, const std::vector<uint32_t> &tri_prefix, uint32_t total_tris, int leaf_tris, int presplit_percent, int frame_mode);
 
 enum class PassKind { Graphics, Raytracing, Compute };
 
@@ -366,6 +372,9 @@ struct vhr_context {
     uint32_t vertex_count = 0, index_count = 0, primitive_count = 0, node_count = 0, tri_count = 0, bvh_depth = 0;
     int bvh_leaf_tris = vhr::kDefaultLeafTris;   // "bvh_leaf_triangles": leaf size of this context's next build
     int bvh_build_threads = 0;                   // "bvh_build_threads": host threads of the next build (0 = up to 16 of the machine's)
+    int bvh_frame_mode = 1;                      // "bvh_frame": 1 (default) = the boxes in the frame that minimises the triangles' summed box area (csrc/bvh_frame.hpp; the world axes if none gains 5 %), 0 = world axes
+    float bvh_frame[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };      // the current tree's frame
+    bool bvh_frame_on = false;
     int bvh_presplit = 0;                        // "bvh_presplit": budget of extra triangle references in percent (csrc/presplit.hpp), 0 = off
     int bvh_presplit_level = -1;                 // the grid level the current tree's references were split on (-1: none)
     int bvh_builder = 1;                         // "bvh_builder": 1 = binned SAH on the device (csrc/kernels_bvh.hip, default), 0 = on the host (csrc/bvh_build.cpp)

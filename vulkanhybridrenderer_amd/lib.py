@@ -33,7 +33,7 @@ EXPORTS = [
     "vhr_upload_storage_image", "vhr_download_storage_image", "vhr_standin_gbuffer", "vhr_standin_gbuffer_with_albedo", "vhr_standin_composition", "vhr_standin_shadow_map", "vhr_set_strip", "vhr_set_tile",
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
-    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
+    "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
@@ -236,6 +236,7 @@ def load():
     L.vhr_get_current_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
     L.vhr_get_bvh_builder.argtypes = [vp, C.POINTER(i32)]
     L.vhr_get_bvh_presplit_level.argtypes = [vp, C.POINTER(i32)]
+    L.vhr_get_bvh_frame.argtypes = [vp, C.POINTER(C.c_float)]
     L.vhr_get_bvh_fingerprint.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_bvh_tree_fingerprint.argtypes = [vp, C.POINTER(u64)]
     L.vhr_set_option.argtypes = [vp, C.c_char_p, i32]
@@ -593,6 +594,13 @@ class Context:
         out = (C.c_uint64 * 4)()
         self.check(self.L.vhr_get_bvh_form_checks(self.handle, out), "bvh_form_checks")
         return tuple(int(v) for v in out)
+
+    def bvh_frame(self):
+        """Option "bvh_frame": the frame the current tree's boxes are in, a 3 x 3 array (row i = axis i in world coordinates; the identity = the world axes)."""
+        import numpy as np
+        out = (C.c_float * 9)()
+        self.check(self.L.vhr_get_bvh_frame(self.handle, out), "get_bvh_frame")
+        return np.array(list(out), np.float32).reshape(3, 3)
 
     def bvh_presplit_level(self):
         """Option "bvh_presplit": the grid level the current tree's references were split on, -1 = one reference per triangle."""
