@@ -72,7 +72,7 @@ def parse():
                    help="the timed block of --steps frames is repeated until this much time has been measured; value = the median block")
     p.add_argument("--no-extras", action="store_true", help="skip the extra blocks (mirror-ray frame, frames in flight) of the N = 1 line")
     p.add_argument("--grid", default="auto", help="N > 1: the screen decomposition -- auto = the planner's grid of screen tiles (2x4 at N = 8: the busiest "
-                   "rank computes +19 % instead of a row strip's +44 %), strips = row strips, or ROWSxCOLS")
+                   "rank computes +19 %% instead of a row strip's +44 %%), strips = row strips, or ROWSxCOLS")
     p.add_argument("--comm", default="auto", choices=["auto", "torch", "c_abi"],
                    help="N > 1: who moves the halos and the gather -- torch = torch.distributed P2P (tiling.py), c_abi = the library's own RCCL calls "
                         "(vhr_comm_*, csrc/comm.cpp), auto = c_abi on the nccl backend if it comes up and reproduces the single-context frame, else torch")

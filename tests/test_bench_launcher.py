@@ -121,3 +121,11 @@ def test_committed_counter_files_name_their_workload_and_one_library():
         assert "raygen_queue_kernel" in ta["kernel"] and 0.0 < ta["ta_busy_frac"] < 1.0 and 10.0 < ta["ta_cycles_per_load_instruction"] < 64.0
         prints.add(d["fingerprint"])
     assert len(prints) == 1
+
+
+def test_help_text_formats():
+    """`python bench.py --help` prints the usage (argparse formats every help string with %: a bare per-cent sign in one of them used to abort it)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--bvh-frame" in out.stdout and "--gpus" in out.stdout, out.stderr[-500:]
