@@ -258,6 +258,50 @@ def test_gpu_kernel_variants_bit_identical(scene_name, Wv, Hv):
 
 
 @pytest.mark.gpu
+def test_gpu_bvh_frame_leaves_the_raytraced_path_unchanged():
+    """Option "bvh_frame" under the raytraced render path (its primary rays' closest-hit walk, the shadow rays' walk from the hit points, both
+    kernel forms, with and without the alpha test): a scene turned off the world axes traced with the boxes in the frame the builder finds
+    gives the image, and the ray count, of the same scene traced with boxes along the world axes -- bit for bit."""
+    from vulkanhybridrenderer_amd import scenes
+    sc = scenes.rotated(scenes.sponza_proc(0.3), rot_y=0.6, rot_x=0.25)
+    Wv, Hv = 300, 170
+    pfds = camera.dolly_frames(sc, Wv, Hv, 2)
+    out = {}
+    for mode in (0, 1):
+        ctx = lib.Context(Wv, Hv)
+        ctx.set_option("bvh_frame", mode)
+        ctx.upload_scene(sc)
+        assert np.array_equal(ctx.bvh_frame(), np.eye(3, dtype=np.float32)) == (mode == 0)
+        ctx.set_ray_statistics(True)
+        path = lib.RaytracedRenderPath(ctx, use_anyhit_shader=False)
+        path.build()
+        try:
+            for alpha in (False, True):
+                path.rebuild(alpha)
+                for i, pfd in enumerate(pfds):
+                    ctx.update_per_frame_ubo(0, pfd)
+                    for variant in (1, 0):
+                        ctx.set_option("raytraced_variant", variant)
+                        ctx.execute(0, 0)
+                        ctx.synchronize()
+                        out[(mode, alpha, i, variant)] = (ctx.download(lib.RAYTRACED_OUTPUT), ctx.ray_statistics()["unique_rays"])
+        finally:
+            path.destroy()
+            ctx.close()
+    # (the reference is the default kernel on the world-axes tree.  The per-pixel kernel on that tree is left out of the comparison: on frame 1
+    # one shadow ray runs within rounding of a triangle's plane, Moeller-Trumbore accepts a point 4 cm outside that triangle's box -- the oracle's
+    # arithmetic does the same, so "shadowed" is the contract's answer -- and whether the leaf is visited at all then depends on the last bits
+    # of the box form: the fp32 (lo, hi) boxes of that kernel cull it, the other forms do not.  DESIGN.md section 4, "what exact means".)
+    for (mode, alpha, i, variant), (img, rays) in out.items():
+        if (mode, variant) == (0, 0):
+            assert (img != out[(0, alpha, i, 1)][0]).any(-1).sum() <= 2
+            continue
+        ref_img, ref_rays = out[(0, alpha, i, 1)]
+        assert np.array_equal(img, ref_img) and rays == ref_rays, f"bvh_frame {mode}, alpha {alpha}, frame {i}, variant {variant}"
+    assert len(np.unique(out[(0, False, 1, 0)][0].reshape(-1, 4), axis=0)) > 50      # (a picture, not a constant)
+
+
+@pytest.mark.gpu
 def test_gpu_empty_scene_is_all_miss_colour():
     """No geometry: every primary ray runs miss.rmiss (both kernels, both shader sets), nothing is traced towards the light."""
     from vulkanhybridrenderer_amd import scenes
