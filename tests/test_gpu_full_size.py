@@ -110,31 +110,34 @@ def test_1080p_eight_virtual_screen_tiles_equal_single_context():
     _check_against_reference(plans, results, ref)
 
 
-def test_presplit_references_leave_the_1080p_frame_unchanged():
-    """Option "bvh_presplit" at full size on the scene built for it (sponza_hard turned off the world axes: two-triangle walls whose boxes fill the
-    atrium): the tree with split references -- 6 % more of them -- gives the Raytraced, Reflections and Denoised images of the tree without,
-    bit for bit, over three dolly frames (what a ray hits cannot depend on which boxes lead to the triangle)."""
+def test_another_tree_leaves_the_1080p_frame_unchanged():
+    """Options "bvh_presplit" and "bvh_frame" at full size on the scene built for them (sponza_hard turned off the world axes: two-triangle walls
+    whose boxes fill the atrium): the tree with split references (6 % more of them) and the tree whose boxes live in the frame the builder finds
+    each give the Raytraced, Reflections and Denoised images of the plain world-axes tree, bit for bit, over three dolly frames (what a ray
+    hits cannot depend on which boxes lead to the triangle)."""
     W, H = 1920, 1080
     sc = scenes.sponza_hard_rot()
     tp = abi.default_trace_params()
     pfds = camera.dolly_frames(sc, W, H, 3)
-    images = []
-    for presplit in (0, 25):
-        g = GpuHybrid(sc, W, H, trace_params=tp, gbuffer="standin", geometry_options={"bvh_presplit": presplit, "bvh_frame": 0})
+    images = {}
+    for name, opts in (("plain", {"bvh_presplit": 0, "bvh_frame": 0}), ("presplit", {"bvh_presplit": 25, "bvh_frame": 0}), ("frame", {"bvh_presplit": 0, "bvh_frame": 1})):
+        g = GpuHybrid(sc, W, H, trace_params=tp, gbuffer="standin", geometry_options=opts)
         try:
-            refs, level = g.ctx.bvh_statistics()["triangles"], g.ctx.bvh_presplit_level()
-            assert (level, refs) == (-1, sc.triangle_count) if presplit == 0 else (level >= 0 and sc.triangle_count < refs <= sc.triangle_count * 3 // 2)
+            refs, level, framed = g.ctx.bvh_statistics()["triangles"], g.ctx.bvh_presplit_level(), not np.array_equal(g.ctx.bvh_frame(), np.eye(3, dtype=np.float32))
+            assert framed == (name == "frame")
+            assert (level >= 0 and sc.triangle_count < refs <= sc.triangle_count * 3 // 2) if name == "presplit" else (level, refs) == (-1, sc.triangle_count)
             frames = []
             for pfd in pfds:
                 g.frame(pfd)
                 frames.append(tuple(g.ctx.download(k).copy() for k in (lib.RAYTRACED, lib.REFLECTIONS, lib.DENOISED)))
-            images.append(frames)
+            images[name] = frames
         finally:
             g.close()
-    for i, (a, b) in enumerate(zip(*images)):
-        for name, x, y in zip(("Raytraced", "Reflections", "Denoised"), a, b):
-            assert np.array_equal(x, y), f"frame {i}: {name} differs with split references"
-    assert (f16(images[0][1][0])[..., 0] == 0).mean() > 0.05            # (shadowed pixels exist)
+    for other in ("presplit", "frame"):
+        for i, (a, b) in enumerate(zip(images["plain"], images[other])):
+            for what, x, y in zip(("Raytraced", "Reflections", "Denoised"), a, b):
+                assert np.array_equal(x, y), f"frame {i}: {what} differs on the {other} tree ({(x != y).any(-1).sum()} pixels)"
+    assert (f16(images["plain"][1][0])[..., 0] == 0).mean() > 0.05            # (shadowed pixels exist)
 
 
 @pytest.mark.parametrize("bounces,options", [(1, (("reflection_async", 1), ("svgf_async_unread", 1))), (1, (("reflection_async", 2), ("svgf_async_unread", 2))),
