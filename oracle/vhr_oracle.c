@@ -12,7 +12,14 @@
  *   (iv)  an RG16F image read as vec4 yields (r, g, 0, 1);
  *   (v)   pow(x, 128) = x^128 by seven squarings for x > 0, 0 for x <= 0;
  *   (vi)  triangle hit iff tmin < t < tmax, two-sided, Moeller-Trumbore in the op order
- *         written below, no FMA contraction (build with -ffp-contract=off), det == 0 -> miss;
+ *         written below, no FMA contraction (build with -ffp-contract=off), det == 0 -> miss,
+ *         AND the hit lies on the triangle: the ray's point o + t d and the triangle's point
+ *         v0 + u e1 + v e2 agree per axis to within 5e-4 + 5e-6 |coordinate| (half the padding of
+ *         any box around the triangle).  For a ray within rounding of the triangle's plane the
+ *         determinant is rounding noise and (t, u, v) can pass every other comparison for a point
+ *         centimetres beside the triangle; a hardware intersector (the reference's) reports no
+ *         such hit, and with the rule whatever is accepted lies inside every box that leads to the
+ *         triangle, so a box hierarchy cannot change the result;
  *         closest hit = min t, ties broken by the smaller flat triangle index;
  *   (vii) sin/cos come from the 3-term Cody-Waite + Cephes-polynomial routine below,
  *         normalize(v) = v * (1 / sqrt(dot(v, v))), dot = (x*x' + y*y') + z*z';
@@ -348,6 +355,12 @@ static inline int ray_triangle(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, floa
     if (!(vv >= 0.0f) || uu + vv > 1.0f) return 0;
     float tt = dot3(e2, qvec) * inv;
     if (!(tt > tmin && tt < tmax)) return 0;
+    /* the hit lies on the triangle (decision vi): o + t d against v0 + u e1 + v e2, axis by axis */
+    {
+        const float px = o.x + d.x * tt, py = o.y + d.y * tt, pz = o.z + d.z * tt;
+        const float qx = (v0.x + e1.x * uu) + e2.x * vv, qy = (v0.y + e1.y * uu) + e2.y * vv, qz = (v0.z + e1.z * uu) + e2.z * vv;
+        if (!(fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz))) return 0;
+    }
     *t = tt; *u = uu; *v = vv;
     return 1;
 }

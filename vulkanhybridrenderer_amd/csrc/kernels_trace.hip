@@ -28,7 +28,18 @@ struct Hit {
     uint32_t flat;
 };
 
-// Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax (decision vi in DESIGN.md)
+// Decision (vi), second half: an accepted hit lies ON the triangle -- the ray's point o + t d and the triangle's point v0 + u e1 + v e2 agree per
+// axis to within 5e-4 + 5e-6 |coordinate|, half the padding of any box around the triangle.  For a ray within rounding of the triangle's plane the
+// determinant is rounding noise and (t, u, v) can pass every other comparison for a point centimetres beside the triangle (found in r5 at the
+// shadow terminators of the raytraced path); with the rule, whatever is accepted lies inside every box that leads to the triangle, in any frame, so
+// the boxes cannot change a result.  Individually rounded operations in the oracle's order; a NaN fails.
+__device__ __forceinline__ bool hit_on_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float t, float u, float v) {
+    const float px = o.x + d.x * t, py = o.y + d.y * t, pz = o.z + d.z * t;
+    const float qx = (v0.x + e1.x * u) + e2.x * v, qy = (v0.y + e1.y * u) + e2.y * v, qz = (v0.z + e1.z * u) + e2.z * v;
+    return fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz);
+}
+
+// Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax and the hit lies on the triangle (decision vi in DESIGN.md)
 __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax,
                                              float &t, float &u, float &v) {
     f3 pvec = cross3(d, e2);
@@ -43,6 +54,7 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, fl
     if (!(vv >= 0.0f) || uu + vv > 1.0f) return false;
     float tt = dot3(e2, qvec) * inv;
     if (!(tt > tmin && tt < tmax)) return false;
+    if (!hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv)) return false;
     t = tt; u = uu; v = vv;
     return true;
 }
@@ -61,7 +73,8 @@ __device__ __forceinline__ bool ray_triangle_any(f3 o, f3 d, f3 v0, f3 e1, f3 e2
     const f3 qvec = cross3(tvec, e1);
     const float vv = dot3(d, qvec) * inv;
     const float tt = dot3(e2, qvec) * inv;
-    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
+    // (the on-triangle test behind the candidates only: few tests get this far, and a wave whose lanes all failed skips it)
+    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax && hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv);
 }
 
 // the same for closest-hit walks: t, u, v of the candidate come back too
@@ -75,7 +88,7 @@ __device__ __forceinline__ bool ray_triangle_nb(f3 o, f3 d, f3 v0, f3 e1, f3 e2,
     const float vv = dot3(d, qvec) * inv;
     const float tt = dot3(e2, qvec) * inv;
     t = tt; u = uu; v = vv;
-    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
+    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax && hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv);
 }
 
 // Slab test of one child box against [tmin, tlimit]; NaNs from 0 * inf drop out of fminf/fmaxf
@@ -1234,24 +1247,21 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
             // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
-            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test)
-            // ... and the NEXT triangle's loads are in flight while this one is tested (r3c: the leaf's up to three tests were three
-            // dependent round trips; the last trip reloads its own triangle, which keeps the loop free of branches; measured -1.3 %
-            // on sponza_proc, +0.7 % on bistro_proc: the leaf stage does not wait for memory much)
+            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test).
+            // (r3c-r5 the NEXT triangle's loads were in flight while this one was tested: -1.3 % on sponza_proc, +0.7 % on bistro_proc.  With the
+            // on-triangle half of decision (vi) the triangle's nine floats live to the end of the test, and next to a second triangle's nine the
+            // kernel needed 68 registers -- a wave per SIMD; without the prefetch 59.  Measured equal: 0.4558 / 0.4569 ms.  Verifying candidates
+            // outside the loop on a triangle fetched again kept the prefetch at 62 registers and cost more: 0.469 ms -- a found ray is no rarity.)
             {
                 const BvhTri *const leaf = a.scene.tris + first;
-                float4 ta = reinterpret_cast<const float4 *>(leaf)[0], tb = reinterpret_cast<const float4 *>(leaf)[1];
-                float tcx = reinterpret_cast<const float *>(leaf)[8];
                 for (uint32_t i = 0; i < count; ++i) {
                     ++n_tris;
-                    const BvhTri *const nt = leaf + min(i + 1u, count - 1u);
-                    const float4 na = reinterpret_cast<const float4 *>(nt)[0], nb = reinterpret_cast<const float4 *>(nt)[1];
-                    const float ncx = reinterpret_cast<const float *>(nt)[8];
+                    const float4 ta = reinterpret_cast<const float4 *>(leaf + i)[0], tb = reinterpret_cast<const float4 *>(leaf + i)[1];
+                    const float tcx = reinterpret_cast<const float *>(leaf + i)[8];
                     if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
                         found = true;
                         break;
                     }
-                    ta = na; tb = nb; tcx = ncx;
                 }
             }
             if (!found) {                                                          // pop (the sentinel if nothing is pending)
