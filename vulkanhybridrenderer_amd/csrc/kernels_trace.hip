@@ -1536,15 +1536,34 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
 // ---------------------------------------------------------------------------------------------
 constexpr int kReflRays = 128;
 
+// raygen.rgen:15-16, 26-29, 60-61 for one covered pixel: the mirror ray's origin and direction.  One function for the set-up phase and for the
+// queue's fetch (one-bounce kernels recompute the ray there instead of parking it in LDS): the same operations, the same bits.
+__device__ __forceinline__ void mirror_ray_of_pixel(const RaygenArgs &a, f3 cam, uint32_t x, uint32_t y, float depth, f3 &origin, f3 &rdir) {
+    const uint32_t W = a.width, H = a.height;
+    const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);          // rgen:15-16
+    const f3 P = get_world_space_position(a.pfd, depth, u, v);                               // rgen:26
+    const f4 nid = load_rgba16f(a.normals, W, x, y);                                         // rgen:28
+    const f3 N = f3{ nid.x, nid.y, nid.z };
+    origin = P + N * a.tp.normal_bias;                                                       // rgen:29
+    const f3 I = normalize3(P - cam);                                                        // rgen:60
+    const float ni2 = 2.0f * dot3(N, I);
+    rdir = I - N * ni2;                                                                      // rgen:61 reflect(I, N)
+}
+
 template <bool SPILL, int BOUNCES, bool STATS = false>
-__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(5, 6))) void reflection_queue_kernel(
+__global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(7, 7))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
     const uint32_t early_exit, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
-    // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
-    // and rows 3-5 are rewritten with the second direction between the two walks
-    constexpr int ROWS = BOUNCES > 1 ? 9 : 6;
+    // Two bounces: rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction, rows 6-8 second origin -> second record, and rows 3-5 are
+    // rewritten with the second direction between the two walks.  ONE bounce (the reference's mirror ray): rows 0-2 hold the hit records only --
+    // a ray is recomputed from its pixel when the queue hands it out (mirror_ray_of_pixel: two cached G-buffer reads + ~120 instructions per ray).
+    // The launch waits on the latency of its walks -- 4 KB of LDS padding per workgroup, 5.5 -> 4.5 waves per SIMD, cost it 16-23 % (r5) -- and its
+    // LDS, not its registers, set the occupancy: 14 080 B per workgroup of two waves = 11 workgroups per CU; without the six ray rows 11 008 B =
+    // 14 workgroups = 7 waves per SIMD, which amdgpu_waves_per_eu(7, 7) makes the registers admit (71, 16 bytes spilled).  Upwards the launch
+    // saturates: 5.5 -> 7 waves bought 1 % (sponza_proc) / 2.5 % (bistro_proc) net of the recomputation, 8 waves nothing more.
+    constexpr int ROWS = BOUNCES > 1 ? 9 : 3;
     __shared__ float s_ray_all[2][ROWS][kReflRays];
     __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
@@ -1580,16 +1599,12 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (in_range && !covered) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);   // rgen:22
         const uint32_t p = sub * 64u + lane;
         if (covered) {
-            const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);  // rgen:15-16
-            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
-            const f4 nid = load_rgba16f(a.normals, W, x, y);                                 // rgen:28
-            const f3 N = f3{ nid.x, nid.y, nid.z };
-            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
-            const f3 I = normalize3(P - cam);                                                // rgen:60
-            const float ni2 = 2.0f * dot3(N, I);
-            const f3 rdir = I - N * ni2;                                                     // rgen:61 reflect(I, N)
-            s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
-            s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
+            f3 origin, rdir;
+            mirror_ray_of_pixel(a, cam, x, y, depth, origin, rdir);
+            if constexpr (BOUNCES > 1) {
+                s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
+                s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
+            }
             grow(origin);
         }
         const unsigned long long m = __ballot(covered);
@@ -1616,8 +1631,13 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
-            ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
-            rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+            if constexpr (BOUNCES > 1) {
+                ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
+                rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
+            } else {                                      // the pixel behind slot `pix` of the 16 x 8 tile, and its ray again
+                const uint32_t x = a.col_begin + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u), y = a.row_begin + tile_y * 8u + ((pix & 63u) >> 3);
+                mirror_ray_of_pixel(a, cam, x, y, a.depth[size_t(y) * W + x], ro, rd);
+            }
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
