@@ -1564,8 +1564,12 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // 14 workgroups = 7 waves per SIMD, which amdgpu_waves_per_eu(7, 7) makes the registers admit (71, 16 bytes spilled).  Upwards the launch
     // saturates: 5.5 -> 7 waves bought 1 % (sponza_proc) / 2.5 % (bistro_proc) net of the recomputation, 8 waves nothing more.
     constexpr int ROWS = BOUNCES > 1 ? 9 : 3;
-    __shared__ float s_ray_all[2][ROWS][kReflRays];
-    __shared__ uint8_t s_list_all[2][kReflRays];          // compacted covered pixels
+    // A wave's tile: 16 x 8 pixels (two per lane) for one bounce; 8 x 8 for two -- nine rows of 128 rays were 10 496 B of LDS per workgroup, with the
+    // stack 17 152 B = 9 workgroups per CU = 4.5 waves per SIMD, and this launch lives on its occupancy (see above); 64 rays: 12 416 B, 6.5 waves.
+    constexpr uint32_t SUBS = BOUNCES > 1 ? 1u : 2u;
+    constexpr int RAYS = 64 * int(SUBS);
+    __shared__ float s_ray_all[2][ROWS][RAYS];
+    __shared__ uint8_t s_list_all[2][RAYS];               // compacted covered pixels
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     // "raygen_cost_order" for this launch (see raygen_queue_kernel): the first block sorts the previous launch's blocks before its own tiles
@@ -1574,8 +1578,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const uint32_t block = a.co.block_order ? a.co.block_order[blockIdx.x] : blockIdx.x;
     const uint32_t tile = block * 2u + wave;
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
-    float (&s_ray)[ROWS][kReflRays] = s_ray_all[wave];
-    uint8_t (&s_list)[kReflRays] = s_list_all[wave];
+    float (&s_ray)[ROWS][RAYS] = s_ray_all[wave];
+    uint8_t (&s_list)[RAYS] = s_list_all[wave];
     int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
     const uint32_t W = a.width, H = a.height;
@@ -1583,7 +1587,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
 
     // ---- phase 1: per-pixel ray setup, whole wave ----
-    unsigned long long covered_mask[2];
+    unsigned long long covered_mask[SUBS];
     uint32_t ncov = 0;
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of this walk's ray origins
     auto grow = [&](f3 o) {
@@ -1591,8 +1595,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         omax = f3{ fmaxf(omax.x, o.x), fmaxf(omax.y, o.y), fmaxf(omax.z, o.z) };
     };
 #pragma unroll
-    for (uint32_t sub = 0; sub < 2; ++sub) {
-        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+    for (uint32_t sub = 0; sub < SUBS; ++sub) {
+        const uint32_t x = a.col_begin + tile_x * (8u * SUBS) + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
         const bool in_range = x < a.col_end && y < a.row_end;
         const float depth = in_range ? a.depth[size_t(y) * W + x] : 0.0f;                    // rgen:19
         const bool covered = depth != 0.0f;
@@ -1635,7 +1639,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
                 ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
                 rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
             } else {                                      // the pixel behind slot `pix` of the 16 x 8 tile, and its ray again
-                const uint32_t x = a.col_begin + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u), y = a.row_begin + tile_y * 8u + ((pix & 63u) >> 3);
+                const uint32_t x = a.col_begin + tile_x * (8u * SUBS) + (pix >> 6) * 8u + (pix & 7u), y = a.row_begin + tile_y * 8u + ((pix & 63u) >> 3);
                 mirror_ray_of_pixel(a, cam, x, y, a.depth[size_t(y) * W + x], ro, rd);
             }
         },
@@ -1648,7 +1652,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         // ---- second-bounce rays (trace_reflection's arithmetic), whole wave: a mirror ray from every first hit ----
         uint32_t n2 = 0;
 #pragma unroll
-        for (uint32_t sub = 0; sub < 2; ++sub) {
+        for (uint32_t sub = 0; sub < SUBS; ++sub) {
             const uint32_t p = sub * 64u + lane;
             const bool was_covered = traced && ((covered_mask[sub] >> lane) & 1ull);
             const uint32_t tri = was_covered ? __float_as_uint(s_ray[0][p]) : kNoHit;
@@ -1679,9 +1683,9 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 
     // ---- phase 3: reflection_hit.rchit / reflection_miss.rmiss on the records, whole wave ----
 #pragma unroll
-    for (uint32_t sub = 0; sub < 2; ++sub) {
+    for (uint32_t sub = 0; sub < SUBS; ++sub) {
         if (!((covered_mask[sub] >> lane) & 1ull)) continue;
-        const uint32_t x = a.col_begin + tile_x * 16u + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
+        const uint32_t x = a.col_begin + tile_x * (8u * SUBS) + sub * 8u + (lane & 7u), y = a.row_begin + tile_y * 8u + (lane >> 3);
         const uint32_t p = sub * 64u + lane;
         f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                           // reflection_miss.rmiss:7
         const uint32_t tri = traced ? __float_as_uint(s_ray[0][p]) : kNoHit;
@@ -1960,7 +1964,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptReflectionLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptReflectionEarlyExit])));
-            const uint32_t tiles_x = (m.col_end - m.col_begin + 15) / 16, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
+            const uint32_t tile_w = m.tp.reflections == 2 ? 8u : 16u;       // (reflection_queue_kernel: 8 x 8 pixels per wave for two bounces, 16 x 8 for one)
+            const uint32_t tiles_x = (m.col_end - m.col_begin + tile_w - 1u) / tile_w, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
             m.co = CostOrderArgs{};
             if (levels >= 5u && !m.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
