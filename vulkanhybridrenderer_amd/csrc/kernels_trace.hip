@@ -1536,8 +1536,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
 // ---------------------------------------------------------------------------------------------
 constexpr int kReflRays = 128;
 
-// raygen.rgen:15-16, 26-29, 60-61 for one covered pixel: the mirror ray's origin and direction.  One function for the set-up phase and for the
-// queue's fetch (one-bounce kernels recompute the ray there instead of parking it in LDS): the same operations, the same bits.
+// raygen.rgen:15-16, 26-29, 60-61 for one covered pixel: the mirror ray's origin and direction
 __device__ __forceinline__ void mirror_ray_of_pixel(const RaygenArgs &a, f3 cam, uint32_t x, uint32_t y, float depth, f3 &origin, f3 &rdir) {
     const uint32_t W = a.width, H = a.height;
     const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);          // rgen:15-16
@@ -1556,17 +1555,16 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     const uint32_t early_exit, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
-    // Two bounces: rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction, rows 6-8 second origin -> second record, and rows 3-5 are
-    // rewritten with the second direction between the two walks.  ONE bounce (the reference's mirror ray): rows 0-2 hold the hit records only --
-    // a ray is recomputed from its pixel when the queue hands it out (mirror_ray_of_pixel: two cached G-buffer reads + ~120 instructions per ray).
-    // The launch waits on the latency of its walks -- 4 KB of LDS padding per workgroup, 5.5 -> 4.5 waves per SIMD, cost it 16-23 % (r5) -- and its
-    // LDS, not its registers, set the occupancy: 14 080 B per workgroup of two waves = 11 workgroups per CU; without the six ray rows 11 008 B =
-    // 14 workgroups = 7 waves per SIMD, which amdgpu_waves_per_eu(7, 7) makes the registers admit (71, 16 bytes spilled).  Upwards the launch
-    // saturates: 5.5 -> 7 waves bought 1 % (sponza_proc) / 2.5 % (bistro_proc) net of the recomputation, 8 waves nothing more.
-    constexpr int ROWS = BOUNCES > 1 ? 9 : 3;
-    // A wave's tile: 16 x 8 pixels (two per lane) for one bounce; 8 x 8 for two -- nine rows of 128 rays were 10 496 B of LDS per workgroup, with the
-    // stack 17 152 B = 9 workgroups per CU = 4.5 waves per SIMD, and this launch lives on its occupancy (see above); 64 rays: 12 416 B, 6.5 waves.
-    constexpr uint32_t SUBS = BOUNCES > 1 ? 1u : 2u;
+    // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
+    // and rows 3-5 are rewritten with the second direction between the two walks.
+    // A wave's tile is 8 x 8 pixels, one ray per lane (r5; 16 x 8 before).  The launch waits on the latency of its walks -- 4 KB of LDS padding per
+    // workgroup, 5.5 -> 4.5 waves per SIMD, cost it 16-23 % -- and its LDS, not its registers, set the occupancy: with 128 rays per wave 14 080 B
+    // per workgroup of two waves (11 workgroups per CU = 5.5 waves per SIMD; two bounces 17 152 B = 4.5 waves).  With 64 rays 10 880 / 12 416 B:
+    // 7 / 6.5 waves (69-72 registers admit 7).  One bounce 261-265 -> 244-250 us (sponza_proc 1080p), 444-450 -> 435 us (bistro_proc); two bounces
+    // 626 -> 508 us, 963 -> 854 us.  (Recomputing a ray from its pixel at the queue's fetch instead of parking it in LDS -- 9 344 B -- was equal
+    // or slower than parking it: the ~120 instructions per ray eat what the last half wave per SIMD buys; 8 waves at 64 registers bought nothing.)
+    constexpr int ROWS = BOUNCES > 1 ? 9 : 6;
+    constexpr uint32_t SUBS = 1u;                         // 8-pixel-wide sub-tiles per wave (the loops below are written for any number)
     constexpr int RAYS = 64 * int(SUBS);
     __shared__ float s_ray_all[2][ROWS][RAYS];
     __shared__ uint8_t s_list_all[2][RAYS];               // compacted covered pixels
@@ -1582,7 +1580,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     uint8_t (&s_list)[RAYS] = s_list_all[wave];
     int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
-    const uint32_t W = a.width, H = a.height;
+    const uint32_t W = a.width;
     const uint32_t tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
 
@@ -1605,10 +1603,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         if (covered) {
             f3 origin, rdir;
             mirror_ray_of_pixel(a, cam, x, y, depth, origin, rdir);
-            if constexpr (BOUNCES > 1) {
-                s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
-                s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
-            }
+            s_ray[0][p] = origin.x; s_ray[1][p] = origin.y; s_ray[2][p] = origin.z;
+            s_ray[3][p] = rdir.x; s_ray[4][p] = rdir.y; s_ray[5][p] = rdir.z;
             grow(origin);
         }
         const unsigned long long m = __ballot(covered);
@@ -1635,13 +1631,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
-            if constexpr (BOUNCES > 1) {
-                ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
-                rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
-            } else {                                      // the pixel behind slot `pix` of the 16 x 8 tile, and its ray again
-                const uint32_t x = a.col_begin + tile_x * (8u * SUBS) + (pix >> 6) * 8u + (pix & 7u), y = a.row_begin + tile_y * 8u + ((pix & 63u) >> 3);
-                mirror_ray_of_pixel(a, cam, x, y, a.depth[size_t(y) * W + x], ro, rd);
-            }
+            ro = f3{ s_ray[orow][pix], s_ray[orow + 1][pix], s_ray[orow + 2][pix] };
+            rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
@@ -1964,7 +1955,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             const uint32_t levels = std::max<uint32_t>(1u, std::min<uint32_t>(ctx->bvh_depth + 1u, uint32_t(std::max(1, ctx->options[kOptReflectionLdsStackLevels]))));
             const uint32_t threshold = uint32_t(std::max(1, std::min(64, ctx->options[kOptRefillThreshold])));
             const uint32_t early_exit = uint32_t(std::max(0, std::min(15, ctx->options[kOptReflectionEarlyExit])));
-            const uint32_t tile_w = m.tp.reflections == 2 ? 8u : 16u;       // (reflection_queue_kernel: 8 x 8 pixels per wave for two bounces, 16 x 8 for one)
+            const uint32_t tile_w = 8u;                                    // (reflection_queue_kernel: 8 x 8 pixels per wave)
             const uint32_t tiles_x = (m.col_end - m.col_begin + tile_w - 1u) / tile_w, tiles_total = tiles_x * ((owned_end - owned_begin + 7) / 8);
             const size_t lds = size_t(levels + 3) * kQueueBlock * sizeof(int) * 2;
             m.co = CostOrderArgs{};
