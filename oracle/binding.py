@@ -89,6 +89,13 @@ def lib():
         L.orc_svgf_image.restype = vp
         L.orc_svgf_image.argtypes = [vp, i32]
         L.orc_max_threads.restype = i32
+        L.orc_audit_begin.argtypes = [i32, u32]
+        L.orc_audit_end.restype = u32
+        L.orc_audit_end.argtypes = [vp, vp]
+        L.orc_ray_triangle_exact.restype = i32
+        L.orc_ray_triangle_exact.argtypes = [vp, vp, vp, vp, vp, f32, f32, vp]
+        L.orc_ray_triangle_rules.restype = i32
+        L.orc_ray_triangle_rules.argtypes = [vp, vp, vp, vp, vp, f32, f32, vp]
         _LIB = L
     return _LIB
 
@@ -313,3 +320,51 @@ class SVGF:
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+# ---- the audit of decision (vi) (round 6; oracle/vhr_exact.h) ----
+AUDIT_RULES = ("Moeller-Trumbore alone", "round 5: reject what contradicts itself", "(dropped) point in the triangle's box", "IN FORCE: binary64 for what contradicts itself")
+audit_counts_dtype = np.dtype([
+    ("rays", "<u8", (2,)), ("rays_undecided", "<u8"), ("rays_not_finite", "<u8"), ("pairs", "<u8"), ("undecided", "<u8"),
+    ("exact_hits", "<u8"), ("mt_hits", "<u8"), ("mt_miss_exact_hit", "<u8"), ("cls", "<u8", (4, 4)),
+    ("any_leak", "<u8", (4,)), ("any_spurious", "<u8", (4,)), ("closest_hit_miss", "<u8", (4,)),
+    ("closest_differs", "<u8", (4,)), ("closest_differs_far", "<u8", (4,)), ("records_dropped", "<u8"), ("escalated", "<u8")])
+audit_record_dtype = np.dtype([
+    ("o", "<f4", (3,)), ("d", "<f4", (3,)), ("tmin", "<f4"), ("tmax", "<f4"), ("v0", "<f4", (3,)), ("e1", "<f4", (3,)), ("e2", "<f4", (3,)),
+    ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("det", "<f4"), ("xdet", "<f8"), ("xu", "<f8"), ("xv", "<f8"), ("xt", "<f8"),
+    ("flat", "<u4"), ("mt", "u1"), ("pass_mask", "u1"), ("any_hit", "u1"), ("exact", "i1"), ("cls", "S1"), ("pad_", "u1", (3,))], align=True)
+
+
+class Audit:
+    """with Audit(brute_force=False) as a: <oracle calls that trace rays>; then a.counts (audit_counts_dtype scalar), a.records."""
+
+    def __init__(self, brute_force=False, max_records=200000):
+        self.brute, self.cap = brute_force, max_records
+        self.counts, self.records = None, None
+
+    def __enter__(self):
+        lib().orc_audit_begin(int(self.brute), self.cap)
+        return self
+
+    def __exit__(self, *exc):
+        counts = np.zeros((), audit_counts_dtype)
+        records = np.zeros(self.cap, audit_record_dtype)
+        n = lib().orc_audit_end(_p(counts), _p(records))
+        self.counts, self.records = counts, records[:n].copy()
+        return False
+
+
+def ray_triangle_exact(o, d, v0, e1, e2, tmin, tmax):
+    """(decision, (det, u, v, t) in binary64): 1 hit, 0 miss, -1 undecided by the binary64 filter."""
+    a = [_c(x, np.float32) for x in (o, d, v0, e1, e2)]
+    out = np.zeros(4, np.float64)
+    r = lib().orc_ray_triangle_exact(*[_p(x) for x in a], float(np.float32(tmin)), float(np.float32(tmax)), _p(out))
+    return r, out
+
+
+def ray_triangle_rules(o, d, v0, e1, e2, tmin, tmax):
+    """(mask, (t, u, v, det) fp32): bit 0 Moeller-Trumbore's comparisons pass, bit 1 round 5's rule accepts, bit 2 the rule in force accepts."""
+    a = [_c(x, np.float32) for x in (o, d, v0, e1, e2)]
+    out = np.zeros(4, np.float32)
+    r = lib().orc_ray_triangle_rules(*[_p(x) for x in a], float(np.float32(tmin)), float(np.float32(tmax)), _p(out))
+    return r, out

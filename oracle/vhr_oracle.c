@@ -11,15 +11,16 @@
  *   (iii) image stores round fp32->fp16 round-to-nearest-even, loads widen exactly;
  *   (iv)  an RG16F image read as vec4 yields (r, g, 0, 1);
  *   (v)   pow(x, 128) = x^128 by seven squarings for x > 0, 0 for x <= 0;
- *   (vi)  triangle hit iff tmin < t < tmax, two-sided, Moeller-Trumbore in the op order
- *         written below, no FMA contraction (build with -ffp-contract=off), det == 0 -> miss,
- *         AND the hit lies on the triangle: the ray's point o + t d and the triangle's point
- *         v0 + u e1 + v e2 agree per axis to within 5e-4 + 5e-6 |coordinate| (half the padding of
- *         any box around the triangle).  For a ray within rounding of the triangle's plane the
- *         determinant is rounding noise and (t, u, v) can pass every other comparison for a point
- *         centimetres beside the triangle; a hardware intersector (the reference's) reports no
- *         such hit, and with the rule whatever is accepted lies inside every box that leads to the
- *         triangle, so a box hierarchy cannot change the result;
+ *   (vi)  triangle hit iff tmin < t < tmax, two-sided, Moeller-Trumbore in the op order written below, no FMA contraction (build with
+ *         -ffp-contract=off), det == 0 -> miss.  A candidate whose solution is CONSISTENT -- the ray's point o + t d and the triangle's point
+ *         v0 + u e1 + v e2 agree per axis to within 5e-4 + 5e-6 |coordinate|, half the padding of any box around the triangle -- is accepted as
+ *         it is (it lies inside every box that leads to the triangle, in any frame: a box hierarchy cannot change the result).  For a ray within
+ *         rounding of the triangle's plane the determinant is rounding noise and (t, u, v) contradict themselves: such a candidate is DECIDED
+ *         AGAIN IN BINARY64 (mt_binary64: the same formulas, the same comparisons; round 6 -- round 5 rejected it, which lost true hits at
+ *         grazing incidence).  The arbiter behind this rule: vhr_exact.h (the comparisons without rounding), the audit further down
+ *         (orc_audit_begin), tools/audit_decision_vi.py -> profiles/r6_decision_vi.txt: of 1.6e8 exact hits on five scenes the rule rejects none,
+ *         and every hit it removes is a miss in exact arithmetic.  What remains different from exact arithmetic is fp32 Moeller-Trumbore's own
+ *         edge band (classes D and E of the audit), which this decision -- SURVEY.md section 8c (vi) names the formula -- keeps;
  *         closest hit = min t, ties broken by the smaller flat triangle index;
  *   (vii) sin/cos come from the 3-term Cody-Waite + Cephes-polynomial routine below,
  *         normalize(v) = v * (1 / sqrt(dot(v, v))), dot = (x*x' + y*y') + z*z';
@@ -342,9 +343,11 @@ static v3 diffuse_brdf(float metallic, v3 albedo, v3 F) {
 /* ------------------------------------------------------------------------------------------
  * ray / triangle (decision vi)
  * ---------------------------------------------------------------------------------------- */
-static inline int ray_triangle(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, float tmax, float *t, float *u, float *v) {
+/* Moeller-Trumbore's comparisons (first half of decision vi); *det comes back for the audit */
+static inline int mt_candidate(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, float tmax, float *t, float *u, float *v, float *det_out) {
     v3 pvec = cross3(d, e2);
     float det = dot3(e1, pvec);
+    *det_out = det;
     if (det == 0.0f) return 0;
     float inv = 1.0f / det;
     v3 tvec = v3sub(o, v0);
@@ -355,14 +358,57 @@ static inline int ray_triangle(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, floa
     if (!(vv >= 0.0f) || uu + vv > 1.0f) return 0;
     float tt = dot3(e2, qvec) * inv;
     if (!(tt > tmin && tt < tmax)) return 0;
-    /* the hit lies on the triangle (decision vi): o + t d against v0 + u e1 + v e2, axis by axis */
-    {
-        const float px = o.x + d.x * tt, py = o.y + d.y * tt, pz = o.z + d.z * tt;
-        const float qx = (v0.x + e1.x * uu) + e2.x * vv, qy = (v0.y + e1.y * uu) + e2.y * vv, qz = (v0.z + e1.z * uu) + e2.z * vv;
-        if (!(fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz))) return 0;
-    }
     *t = tt; *u = uu; *v = vv;
     return 1;
+}
+/* Second half of decision (vi), round 6: the reported point o + t d lies in the triangle's own bounding box grown by half the
+ * padding of the hierarchy's boxes.  Per axis: p = fma(d, t, o); lo = v0 + min(0, e1, e2); hi = v0 + max(0, e1, e2);
+ * accept iff lo - p <= tol and p - hi <= tol with tol = fma(|p|, 5e-6, 5e-4).  A NaN fails. */
+static inline int hit_in_triangle_box(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float t) {
+    const float o_[3] = { o.x, o.y, o.z }, d_[3] = { d.x, d.y, d.z }, v_[3] = { v0.x, v0.y, v0.z };
+    const float a_[3] = { e1.x, e1.y, e1.z }, b_[3] = { e2.x, e2.y, e2.z };
+    for (int i = 0; i < 3; ++i) {
+        const float p = fmaf(d_[i], t, o_[i]);
+        const float lo = v_[i] + fminf(0.0f, fminf(a_[i], b_[i])), hi = v_[i] + fmaxf(0.0f, fmaxf(a_[i], b_[i]));
+        const float tol = fmaf(fabsf(p), 5e-6f, 5e-4f);
+        if (!(lo - p <= tol && p - hi <= tol)) return 0;
+    }
+    return 1;
+}
+/* round 5's form of the second half (the ray's point against the barycentric point, 5e-4 + 5e-6 |coordinate| per axis): no longer part of
+ * the decision -- the audit evaluates it beside the rule in force so that profiles/r6_decision_vi.txt can show what it cost in true hits */
+static inline int hit_on_triangle_r5(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tt, float uu, float vv) {
+    const float px = o.x + d.x * tt, py = o.y + d.y * tt, pz = o.z + d.z * tt;
+    const float qx = (v0.x + e1.x * uu) + e2.x * vv, qy = (v0.y + e1.y * uu) + e2.y * vv, qz = (v0.z + e1.z * uu) + e2.z * vv;
+    return fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz);
+}
+/* Moeller-Trumbore once more in binary64, for the pairs whose fp32 solution contradicts itself (below).  The fp32 operands are exact in
+ * binary64 and so is every product of two of them; every other operation rounds once, in the order written (no contraction), and the three
+ * quotients are IEEE divisions.  The comparisons are ray_triangle()'s; (t, u, v) come back rounded to fp32. */
+static inline int mt_binary64(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, float tmax, float *t, float *u, float *v) {
+    const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z, ax = e1.x, ay = e1.y, az = e1.z, bx = e2.x, by = e2.y, bz = e2.z;
+    const double px = dy * bz - dz * by, py = dz * bx - dx * bz, pz = dx * by - dy * bx;                 /* pvec = d x e2 */
+    const double det = (ax * px + ay * py) + az * pz;
+    if (det == 0.0) return 0;
+    const double tx = ox - (double)v0.x, ty = oy - (double)v0.y, tz = oz - (double)v0.z;                /* tvec = o - v0 */
+    const double uu = ((tx * px + ty * py) + tz * pz) / det;
+    if (!(uu >= 0.0) || uu > 1.0) return 0;
+    const double qx = ty * az - tz * ay, qy = tz * ax - tx * az, qz = tx * ay - ty * ax;                 /* qvec = tvec x e1 */
+    const double vv = ((dx * qx + dy * qy) + dz * qz) / det;
+    if (!(vv >= 0.0) || uu + vv > 1.0) return 0;
+    const double tt = ((bx * qx + by * qy) + bz * qz) / det;
+    if (!(tt > (double)tmin && tt < (double)tmax)) return 0;
+    *t = (float)tt; *u = (float)uu; *v = (float)vv;
+    return 1;
+}
+/* Decision (vi): fp32 Moeller-Trumbore; a candidate whose solution is consistent -- the ray's point o + t d and the triangle's point
+ * v0 + u e1 + v e2 agree per axis to 5e-4 + 5e-6 |coordinate|, half the padding of the hierarchy's boxes -- is accepted as it is; one whose
+ * solution contradicts itself is DECIDED AGAIN IN BINARY64 (round 6; round 5 rejected it, which lost true hits at grazing incidence). */
+static inline int ray_triangle(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float tmin, float tmax, float *t, float *u, float *v) {
+    float det;
+    if (!mt_candidate(o, d, v0, e1, e2, tmin, tmax, t, u, v, &det)) return 0;
+    if (hit_on_triangle_r5(o, d, v0, e1, e2, *t, *u, *v)) return 1;
+    return mt_binary64(o, d, v0, e1, e2, tmin, tmax, t, u, v);
 }
 int orc_ray_triangle(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3],
                      float tmin, float tmax, float *t, float *u, float *v) {
@@ -523,6 +569,181 @@ static inline int box_hit(const orc_node *n, v3 o, v3 inv, float tmin, float tma
 
 typedef struct { int hit; float t, u, v; uint32_t flat; } orc_hit;
 
+/* ------------------------------------------------------------------------------------------
+ * The audit of decision (vi) (round 6; tools/audit_decision_vi.py, tests/test_exact_arbiter.py).
+ * While an audit is open, every ray that reaches trace_filtered() without the alpha test is ALSO walked in binary64 through
+ * the oracle's padded boxes (a superset of what any fp32 walk visits of the triangles that matter: an exact hit point lies in
+ * the unpadded box of every ancestor), and every (ray, triangle) pair met is decided three ways: fp32 Moeller-Trumbore
+ * (mt_candidate), the second half of decision (vi) in its round-5 and round-6 forms, and exact arithmetic (vhr_exact.h).
+ * Rules: index 0 = Moeller-Trumbore alone, 1 = round 5's residual rule (reject what contradicts itself), 2 = a candidate that was weighed and
+ * dropped in round 6 (the reported point in the triangle's world-axes box: not frame-independent), 3 = the rule in force (ray_triangle():
+ * what contradicts itself is decided again in binary64).
+ * ---------------------------------------------------------------------------------------- */
+#include "vhr_exact.h"
+
+typedef struct {
+    orc_audit_counts c;
+    char pad[64];
+} audit_slot;
+static struct {
+    int on, brute;
+    uint32_t cap, nrec;
+    orc_audit_record *rec;
+    audit_slot slot[256];
+} g_audit;
+
+static void audit_push(const orc_audit_record *r) {
+#pragma omp critical(vhr_audit_records)
+    { if (g_audit.nrec < g_audit.cap) g_audit.rec[g_audit.nrec++] = *r; else g_audit.slot[0].c.records_dropped++; }
+}
+
+typedef struct { int hit; double t; uint32_t flat; } audit_best;
+
+static void audit_pair(const orc_scene *s, uint32_t flat, v3 o, v3 d, float tmin, float tmax, int any_hit, orc_audit_counts *c,
+                       int *ray_undecided, int occluded[AUD_RULES], int *exact_occluded, audit_best best[AUD_RULES], audit_best *exact_best) {
+    const orc_tri *tr = &s->tris[flat];
+    float t = 0, u = 0, v = 0, det = 0;
+    const int mt = mt_candidate(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t, &u, &v, &det);
+    int pass[AUD_RULES] = { mt, 0, 0, 0 };
+    float tr_[AUD_RULES] = { t, t, t, t };             /* the t each rule reports */
+    if (mt) {
+        pass[1] = hit_on_triangle_r5(o, d, tr->v0, tr->e1, tr->e2, t, u, v);
+        pass[2] = hit_in_triangle_box(o, d, tr->v0, tr->e1, tr->e2, t);
+        float t3 = t, u3 = u, v3_ = v;
+        pass[3] = pass[1] ? 1 : mt_binary64(o, d, tr->v0, tr->e1, tr->e2, tmin, tmax, &t3, &u3, &v3_);
+        tr_[3] = t3;
+        if (!pass[1]) c->escalated++;
+    }
+    const float of[3] = { o.x, o.y, o.z }, df[3] = { d.x, d.y, d.z }, v0f[3] = { tr->v0.x, tr->v0.y, tr->v0.z };
+    const float e1f[3] = { tr->e1.x, tr->e1.y, tr->e1.z }, e2f[3] = { tr->e2.x, tr->e2.y, tr->e2.z };
+    const orc_exact_result ex = exact_ray_triangle(of, df, v0f, e1f, e2f, tmin, tmax);
+    c->pairs++;
+    char cls = 0;
+    if (ex.decision < 0) { c->undecided++; *ray_undecided = 1; cls = 'U'; }
+    else {
+        if (ex.decision) {
+            c->exact_hits++; *exact_occluded = 1;
+            if (!exact_best->hit || ex.t < exact_best->t || (ex.t == exact_best->t && flat < exact_best->flat)) { exact_best->hit = 1; exact_best->t = ex.t; exact_best->flat = flat; }
+        }
+        if (mt) c->mt_hits++;
+        if (!mt && ex.decision) { c->mt_miss_exact_hit++; cls = 'E'; }
+        for (int r = 0; r < AUD_RULES; ++r) {
+            if (!mt) break;
+            const int k = pass[r] ? (ex.decision ? 0 : 3) : (ex.decision ? 2 : 1);      /* A, B, C, D */
+            c->cls[r][k]++;
+        }
+        if (mt && ex.decision && !(pass[1] && pass[2] && pass[3])) cls = 'C';
+        else if (mt && !ex.decision && (pass[1] || pass[2] || pass[3])) cls = 'D';
+        else if (mt && !ex.decision) cls = 'B';
+    }
+    for (int r = 0; r < AUD_RULES; ++r) if (pass[r]) {
+        occluded[r] = 1;
+        const float tt_ = tr_[r];
+        if (!best[r].hit || tt_ < best[r].t || ((double)tt_ == best[r].t && flat < best[r].flat)) { best[r].hit = 1; best[r].t = tt_; best[r].flat = flat; }
+    }
+    if (cls) {
+        orc_audit_record rec;
+        memset(&rec, 0, sizeof rec);
+        memcpy(rec.o, of, sizeof of); memcpy(rec.d, df, sizeof df); memcpy(rec.v0, v0f, sizeof v0f); memcpy(rec.e1, e1f, sizeof e1f); memcpy(rec.e2, e2f, sizeof e2f);
+        rec.tmin = tmin; rec.tmax = tmax; rec.t = t; rec.u = u; rec.v = v; rec.det = det;
+        rec.xdet = ex.det; rec.xu = ex.u; rec.xv = ex.v; rec.xt = ex.t;
+        rec.flat = flat; rec.mt = (uint8_t)mt; rec.pass_mask = (uint8_t)(pass[0] | pass[1] << 1 | pass[2] << 2 | pass[3] << 3);
+        rec.exact = (int8_t)ex.decision; rec.any_hit = (uint8_t)any_hit; rec.cls = cls;
+        audit_push(&rec);
+    }
+}
+
+static inline int box_hit_f64(const orc_node *n, const double o[3], const double inv[3], double tmin, double tmax) {
+    double tn = tmin, tf = tmax;
+    for (int a = 0; a < 3; ++a) {
+        const double t0 = ((double)n->lo[a] - o[a]) * inv[a], t1 = ((double)n->hi[a] - o[a]) * inv[a];
+        tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));       /* a NaN (0 * inf) drops out: conservative */
+    }
+    return tn <= tf;
+}
+
+static void audit_ray(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit) {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num() & 255;
+#endif
+    orc_audit_counts *c = &g_audit.slot[tid].c;
+    if (!(isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(d.x) && isfinite(d.y) && isfinite(d.z))) { c->rays_not_finite++; return; }
+    int ray_undecided = 0, exact_occluded = 0, occluded[AUD_RULES] = { 0, 0, 0, 0 };
+    audit_best best[AUD_RULES] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, exact_best = { 0, 0, 0 };
+    if (g_audit.brute) {
+        for (uint32_t i = 0; i < s->ntris; ++i) audit_pair(s, i, o, d, tmin, tmax, any_hit, c, &ray_undecided, occluded, &exact_occluded, best, &exact_best);
+    } else {
+        const double od[3] = { o.x, o.y, o.z }, inv[3] = { 1.0 / (double)d.x, 1.0 / (double)d.y, 1.0 / (double)d.z };
+        int32_t stack[128];
+        int sp = 0;
+        stack[sp++] = 0;
+        while (sp) {
+            const orc_node *n = &s->nodes[stack[--sp]];
+            if (!box_hit_f64(n, od, inv, tmin, tmax)) continue;
+            if (n->left >= 0) { stack[sp++] = n->left; stack[sp++] = n->right; continue; }
+            for (uint32_t i = n->first; i < n->first + n->count; ++i)
+                audit_pair(s, s->order[i], o, d, tmin, tmax, any_hit, c, &ray_undecided, occluded, &exact_occluded, best, &exact_best);
+        }
+    }
+    c->rays[any_hit ? 0 : 1]++;
+    if (ray_undecided) { c->rays_undecided++; return; }
+    for (int r = 0; r < AUD_RULES; ++r) {
+        if (any_hit) {
+            if (!occluded[r] && exact_occluded) c->any_leak[r]++;
+            if (occluded[r] && !exact_occluded) c->any_spurious[r]++;
+        } else {
+            if (best[r].hit != exact_best.hit) c->closest_hit_miss[r]++;
+            else if (best[r].hit && best[r].flat != exact_best.flat) {
+                c->closest_differs[r]++;
+                if (fabs(best[r].t - exact_best.t) > 1e-4 * fmax(1.0, fabs(exact_best.t))) c->closest_differs_far[r]++;
+            }
+        }
+    }
+}
+
+void orc_audit_begin(int brute_force, uint32_t max_records) {
+    memset(&g_audit, 0, sizeof g_audit);
+    g_audit.brute = brute_force;
+    g_audit.cap = max_records;
+    g_audit.rec = (orc_audit_record *)malloc(sizeof(orc_audit_record) * (max_records ? max_records : 1));
+    g_audit.on = 1;
+}
+uint32_t orc_audit_end(orc_audit_counts *out, orc_audit_record *records) {
+    g_audit.on = 0;
+    orc_audit_counts sum;
+    memset(&sum, 0, sizeof sum);
+    for (int i = 0; i < 256; ++i) {
+        const uint64_t *a = (const uint64_t *)&g_audit.slot[i].c;
+        uint64_t *b = (uint64_t *)&sum;
+        for (size_t k = 0; k < sizeof(orc_audit_counts) / sizeof(uint64_t); ++k) b[k] += a[k];
+    }
+    if (out) *out = sum;
+    if (records) memcpy(records, g_audit.rec, sizeof(orc_audit_record) * g_audit.nrec);
+    free(g_audit.rec);
+    g_audit.rec = NULL;
+    return g_audit.nrec;
+}
+int orc_ray_triangle_exact(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3], float tmin, float tmax,
+                           double out_det_u_v_t[4]) {
+    const orc_exact_result r = exact_ray_triangle(o, d, v0, e1, e2, tmin, tmax);
+    if (out_det_u_v_t) { out_det_u_v_t[0] = r.det; out_det_u_v_t[1] = r.u; out_det_u_v_t[2] = r.v; out_det_u_v_t[3] = r.t; }
+    return r.decision;
+}
+/* the three fp32 decisions of one pair, for the known-answer tests: bit 0 Moeller-Trumbore's comparisons, bit 1 round 5's rule, bit 2 the box rule, bit 3 the rule in force */
+int orc_ray_triangle_rules(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3], float tmin, float tmax,
+                           float out_t_u_v_det[4]) {
+    float t = 0, u = 0, v = 0, det = 0;
+    const v3 O = V3(o[0], o[1], o[2]), D = V3(d[0], d[1], d[2]), A = V3(v0[0], v0[1], v0[2]), E1 = V3(e1[0], e1[1], e1[2]), E2 = V3(e2[0], e2[1], e2[2]);
+    const int mt = mt_candidate(O, D, A, E1, E2, tmin, tmax, &t, &u, &v, &det);
+    if (out_t_u_v_det) { out_t_u_v_det[0] = t; out_t_u_v_det[1] = u; out_t_u_v_det[2] = v; out_t_u_v_det[3] = det; }
+    if (!mt) return 0;
+    const int r5 = hit_on_triangle_r5(O, D, A, E1, E2, t, u, v);
+    float t3 = t, u3 = u, v3_ = v;
+    const int r6 = r5 ? 1 : mt_binary64(O, D, A, E1, E2, tmin, tmax, &t3, &u3, &v3_);
+    return 1 | r5 << 1 | hit_in_triangle_box(O, D, A, E1, E2, t) << 2 | r6 << 3;
+}
+
 /* any_hit != 0: return on the first accepted triangle (gl_RayFlagsTerminateOnFirstHitEXT,
  * raygen.rgen:39); otherwise closest hit with the flat-index tie break (decision vi) */
 /* alpha_test != 0: every candidate first runs shadow_anyhit.rahit (rays traced with gl_RayFlagsNoOpaqueEXT by the
@@ -531,6 +752,7 @@ static int alpha_ignored(const orc_scene *s, uint32_t flat, float u, float v);
 static orc_hit trace_filtered(const orc_scene *s, v3 o, v3 d, float tmin, float tmax, int any_hit, int use_bvh, int alpha_test) {
     orc_hit best = { 0, tmax, 0, 0, 0xffffffffu };
     if (s->ntris == 0) return best;
+    if (g_audit.on && !alpha_test) audit_ray(s, o, d, tmin, tmax, any_hit);
     if (!use_bvh) {
         for (uint32_t i = 0; i < s->ntris; ++i) {
             const orc_tri *tr = &s->tris[i];

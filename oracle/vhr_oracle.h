@@ -176,6 +176,46 @@ void orc_svgf_frame(orc_svgf_state *st, const orc_per_frame_data *pfd, const uin
 /* which: 0 integrated.x, 1 integrated.y, 2 prev normals, 3 history (RGBA16F each), 4 moments (RG16F) */
 const uint16_t *orc_svgf_image(const orc_svgf_state *st, int which);
 
+/* ---- the audit of decision (vi) (round 6): exact-arithmetic arbiter behind the fp32 ray / triangle decision ----
+ * orc_ray_triangle_exact: the decision of Moeller-Trumbore's comparisons without rounding on the same fp32 inputs (vhr_exact.h):
+ * 1 hit, 0 miss, -1 undecided in binary64 (settle with tests/exact_rational.py).  out (optional): det, u, v, t as binary64 values.
+ * orc_ray_triangle_rules: bit 0 = the fp32 comparisons pass, bit 1 = round 5's residual rule accepts, bit 2 = the box rule (weighed in round 6,
+ * dropped) accepts, bit 3 = the rule in force accepts (consistent, or confirmed in binary64).
+ * orc_audit_begin / _end: while open, every non-alpha-tested ray the oracle traces is also decided pair by pair in exact arithmetic
+ * (brute_force != 0: against every triangle; else through the padded boxes walked in binary64).  Not re-entrant; one audit at a time. */
+enum { AUD_RULES = 4 };
+typedef struct {
+    uint64_t rays[2];                 /* [any-hit, closest-hit] rays audited */
+    uint64_t rays_undecided;          /* rays with at least one pair the binary64 filter left undecided: left out of the per-ray counts */
+    uint64_t rays_not_finite;
+    uint64_t pairs, undecided;        /* (ray, triangle) pairs decided / left undecided */
+    uint64_t exact_hits, mt_hits;     /* pairs that are exact hits / whose fp32 comparisons pass */
+    uint64_t mt_miss_exact_hit;       /* class E: fp32 Moeller-Trumbore itself misses an exact hit */
+    uint64_t cls[AUD_RULES][4];       /* of the pairs whose fp32 comparisons pass, per rule: A accepted & exact hit, B rejected & exact miss,
+                                         C rejected & exact hit, D accepted & exact miss */
+    uint64_t any_leak[AUD_RULES], any_spurious[AUD_RULES];   /* any-hit rays: fp32 unoccluded & exactly occluded / the converse */
+    uint64_t closest_hit_miss[AUD_RULES];                    /* closest-hit rays: one side hits, the other misses */
+    uint64_t closest_differs[AUD_RULES], closest_differs_far[AUD_RULES];   /* another triangle wins / and its t is > 1e-4 max(1, t) away */
+    uint64_t records_dropped;
+    uint64_t escalated;               /* pairs whose fp32 solution contradicted itself and went to binary64 */
+} orc_audit_counts;
+typedef struct {
+    float o[3], d[3], tmin, tmax, v0[3], e1[3], e2[3];
+    float t, u, v, det;               /* fp32 Moeller-Trumbore's values (t, u, v only where it got that far) */
+    double xdet, xu, xv, xt;          /* binary64 values */
+    uint32_t flat;
+    uint8_t mt, pass_mask, any_hit;
+    int8_t exact;
+    char cls;                         /* 'B' 'C' 'D' 'E' as above, 'U' undecided */
+    char pad_[3];
+} orc_audit_record;
+void     orc_audit_begin(int brute_force, uint32_t max_records);
+uint32_t orc_audit_end(orc_audit_counts *out, orc_audit_record *records /* room for max_records */);
+int      orc_ray_triangle_exact(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3],
+                                float tmin, float tmax, double out_det_u_v_t[4]);
+int      orc_ray_triangle_rules(const float o[3], const float d[3], const float v0[3], const float e1[3], const float e2[3],
+                                float tmin, float tmax, float out_t_u_v_det[4]);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

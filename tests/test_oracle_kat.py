@@ -119,9 +119,10 @@ def test_ray_triangle_rules(oracle):
     assert not hit(f(0.25, 0.25, 1), f(0, 0, -1), tmin=1.0)      # t > tmin strictly
     assert hit(f(0.0, 0.0, 1), f(0, 0, -1))                      # u = v = 0 corner is inside
     assert not hit(f(0.75, 0.75, 1), f(0, 0, -1))                # u + v > 1
-    # Decision (vi), second half: the hit lies ON the triangle.  A shadow ray of the raytraced path's rotated test scene (round 5), within rounding of
-    # this triangle's plane: det = -2^-20 * 1.25 is rounding noise, (t, u, v) = (0.6, -0, 0.887) pass every comparison, and the point o + t d is
-    # 31 cm beside v0 + u e1 + v e2 -- outside every box around the triangle.  Not a hit.
+    # Decision (vi), second half.  A shadow ray of the raytraced path's rotated test scene (round 5), within rounding of this triangle's plane:
+    # det = -2^-20 * 1.25 is rounding noise, (t, u, v) = (0.6, -0, 0.887) pass every comparison, and the point o + t d is 31 cm beside
+    # v0 + u e1 + v e2 -- outside every box around the triangle.  The solution contradicts itself, so the pair is decided again in binary64
+    # (round 6; round 5 rejected it outright): not a hit, and exact arithmetic agrees (tests/test_exact_arbiter.py has a pair of every class).
     h = lambda *a: np.array([float.fromhex(x) for x in a], np.float32)   # noqa: E731
     v0, e1, e2 = (h("0x1.287664p+4", "0x1.2d010ap+3", "-0x1.0ac8dcp+3"), h("0x1.40202p+0", "-0x1.21888p-1", "0x1.d3edp+0"), h("0x1.87a64p+0", "0x1.5f511p+0", "0x1.1e3c6p+1"))
     o, d = h("0x1.4216bp+4", "0x1.42c918p+3", "-0x1.7fbd2p+2"), h("-0x1.bcaf8cp-5", "0x1.fda0e4p-1", "-0x1.44ff66p-4")

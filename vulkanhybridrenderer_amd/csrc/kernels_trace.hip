@@ -20,6 +20,9 @@ namespace vhr {
 
 __constant__ float c_srgb_lut[256];
 
+#ifndef VHR_K1_WAVES_MIN
+#define VHR_K1_WAVES_MIN 7          // waves per SIMD the any-hit queue kernel is allocated for (7: <= 72 registers, 8: <= 64)
+#endif
 constexpr int kTraceBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile of a 16x16 block tile
 
 struct Hit {
@@ -28,19 +31,48 @@ struct Hit {
     uint32_t flat;
 };
 
-// Decision (vi), second half: an accepted hit lies ON the triangle -- the ray's point o + t d and the triangle's point v0 + u e1 + v e2 agree per
-// axis to within 5e-4 + 5e-6 |coordinate|, half the padding of any box around the triangle.  For a ray within rounding of the triangle's plane the
-// determinant is rounding noise and (t, u, v) can pass every other comparison for a point centimetres beside the triangle (found in r5 at the
-// shadow terminators of the raytraced path); with the rule, whatever is accepted lies inside every box that leads to the triangle, in any frame, so
-// the boxes cannot change a result.  Individually rounded operations in the oracle's order; a NaN fails.
-__device__ __forceinline__ bool hit_on_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float t, float u, float v) {
+// Decision (vi), second half.  A candidate of fp32 Moeller-Trumbore whose solution is CONSISTENT -- the ray's point
+// o + t d and the triangle's point v0 + u e1 + v e2 agree per axis to within 5e-4 + 5e-6 |coordinate|, half the padding of any box around the
+// triangle -- is accepted as it is: whatever it is, it lies inside every box that leads to the triangle, in any frame.  For a ray within rounding
+// of the triangle's plane the determinant is rounding noise and (t, u, v) contradict themselves: round 5 rejected such a candidate, which removed
+// the hits that are not there (a point centimetres beside the triangle) and, at grazing incidence on large triangles, true ones with them
+// (profiles/r6_decision_vi.txt: 21 059 of 387 896 exact hits on the raytraced path's terminator rays).  Since round 6 it is DECIDED AGAIN IN
+// BINARY64 (mt_binary64 below): the audit against exact arithmetic counts no lost and no invented hit among them.
+// Individually rounded operations in the oracle's order; a NaN is inconsistent.
+__device__ __forceinline__ bool solution_consistent(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float t, float u, float v) {
     const float px = o.x + d.x * t, py = o.y + d.y * t, pz = o.z + d.z * t;
     const float qx = (v0.x + e1.x * u) + e2.x * v, qy = (v0.y + e1.y * u) + e2.y * v, qz = (v0.z + e1.z * u) + e2.z * v;
     return fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz);
 }
 
-// Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax and the hit lies on the triangle (decision vi in DESIGN.md)
-__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax,
+// Moeller-Trumbore in binary64 (the oracle's mt_binary64, operation for operation): the fp32 operands and every product of two of them
+// are exact, every other operation rounds once in the order written (this unit is built with -ffp-contract=off), the quotients are IEEE
+// divisions; the comparisons are ray_triangle()'s and (t, u, v) come back rounded to fp32.  Not inlined: the rare path (none of the headline
+// frame's pairs, 6 % of the raytraced path's candidates) must not cost the walkers' loops a register.
+__device__ __attribute__((noinline)) bool mt_binary64(float ox_, float oy_, float oz_, float dx_, float dy_, float dz_, const BvhTri *tri, float tmin, float tmax,
+                                                      float &t, float &u, float &v) {
+    const float4 ta = reinterpret_cast<const float4 *>(tri)[0], tb = reinterpret_cast<const float4 *>(tri)[1];
+    const float tcx = reinterpret_cast<const float *>(tri)[8];
+    const double ox = ox_, oy = oy_, oz = oz_, dx = dx_, dy = dy_, dz = dz_;
+    const double ax = ta.w, ay = tb.x, az = tb.y, bx = tb.z, by = tb.w, bz = tcx;
+    const double px = dy * bz - dz * by, py = dz * bx - dx * bz, pz = dx * by - dy * bx;              // pvec = d x e2
+    const double det = (ax * px + ay * py) + az * pz;
+    if (det == 0.0) return false;
+    const double tx = ox - double(ta.x), ty = oy - double(ta.y), tz = oz - double(ta.z);              // tvec = o - v0
+    const double uu = ((tx * px + ty * py) + tz * pz) / det;
+    if (!(uu >= 0.0) || uu > 1.0) return false;
+    const double qx = ty * az - tz * ay, qy = tz * ax - tx * az, qz = tx * ay - ty * ax;              // qvec = tvec x e1
+    const double vv = ((dx * qx + dy * qy) + dz * qz) / det;
+    if (!(vv >= 0.0) || uu + vv > 1.0) return false;
+    const double tt = ((bx * qx + by * qy) + bz * qz) / det;
+    if (!(tt > double(tmin) && tt < double(tmax))) return false;
+    t = float(tt); u = float(uu); v = float(vv);
+    return true;
+}
+
+// Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax; a candidate whose solution contradicts itself is decided again in
+// binary64 (decision vi in DESIGN.md).  `tri` is the record v0 / e1 / e2 were read from.
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, const BvhTri *tri, float tmin, float tmax,
                                              float &t, float &u, float &v) {
     f3 pvec = cross3(d, e2);
     float det = dot3(e1, pvec);
@@ -54,31 +86,18 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, fl
     if (!(vv >= 0.0f) || uu + vv > 1.0f) return false;
     float tt = dot3(e2, qvec) * inv;
     if (!(tt > tmin && tt < tmax)) return false;
-    if (!hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv)) return false;
     t = tt; u = uu; v = vv;
-    return true;
+    if (solution_consistent(o, d, v0, e1, e2, tt, uu, vv)) return true;
+    return mt_binary64(o.x, o.y, o.z, d.x, d.y, d.z, tri, tmin, tmax, t, u, v);
 }
 
-// ray_triangle() without its early returns: the same operations in the same order on the same operands (a lane the branching
-// form would have sent home early computes on and fails the same comparison at the end; det == 0 gives inf / NaN quotients, which
-// fail every comparison, and is tested explicitly as well).  Used by the queue kernels' leaf stage, where the early returns buy
-// nothing (some lane of the wave always goes on) and cost a second memory round trip: the compiler sinks the load of v0 behind
-// the `det == 0` return, so every triangle test waited for memory twice.
-__device__ __forceinline__ bool ray_triangle_any(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax) {
-    const f3 pvec = cross3(d, e2);
-    const float det = dot3(e1, pvec);
-    const float inv = 1.0f / det;
-    const f3 tvec = o - v0;
-    const float uu = dot3(tvec, pvec) * inv;
-    const f3 qvec = cross3(tvec, e1);
-    const float vv = dot3(d, qvec) * inv;
-    const float tt = dot3(e2, qvec) * inv;
-    // (the on-triangle test behind the candidates only: few tests get this far, and a wave whose lanes all failed skips it)
-    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax && hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv);
-}
-
-// the same for closest-hit walks: t, u, v of the candidate come back too
-__device__ __forceinline__ bool ray_triangle_nb(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
+// Moeller-Trumbore's comparisons without ray_triangle()'s early returns: the same operations in the same order on the same operands (a lane the
+// branching form would have sent home early computes on and fails the same comparison at the end; det == 0 gives inf / NaN quotients, which fail
+// every comparison, and is tested explicitly as well).  Used by the queue kernels' leaf stage, where the early returns buy nothing (some lane of
+// the wave always goes on) and cost a second memory round trip: the compiler sinks the load of v0 behind the `det == 0` return, so every triangle
+// test waited for memory twice.  true = a CANDIDATE; the caller accepts it if solution_consistent() and otherwise leaves the ray's pixel to the
+// redo launch (redo_append below): the binary64 path stays out of the queue kernels.
+__device__ __forceinline__ bool mt_candidate(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
     const f3 pvec = cross3(d, e2);
     const float det = dot3(e1, pvec);
     const float inv = 1.0f / det;
@@ -88,7 +107,14 @@ __device__ __forceinline__ bool ray_triangle_nb(f3 o, f3 d, f3 v0, f3 e1, f3 e2,
     const float vv = dot3(d, qvec) * inv;
     const float tt = dot3(e2, qvec) * inv;
     t = tt; u = uu; v = vv;
-    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax && hit_on_triangle(o, d, v0, e1, e2, tt, uu, vv);
+    return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
+}
+
+// A queue kernel leaves the pixel of a ray with a self-contradicting candidate to the launch that follows (vhr::RedoList).  Duplicates are
+// harmless (the redo is idempotent); past the capacity the redo launch traces its whole rectangle.
+__device__ __forceinline__ void redo_append(const RedoList &r, uint32_t pixel) {
+    const uint32_t i = atomicAdd(r.count, 1u);
+    if (i < r.capacity) r.pixels[i] = pixel;
 }
 
 // Slab test of one child box against [tmin, tlimit]; NaNs from 0 * inf drop out of fminf/fmaxf
@@ -173,7 +199,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
                 const float4 a = tp[0], b = tp[1];
                 const float4 c = tp[2];
                 float t, u, w;
-                if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, tmin, tmax, t, u, w)) {
+                if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, sc.tris + first + i, tmin, tmax, t, u, w)) {
                     if (ALPHA && alpha_ignored(sc, first + i, u, w)) continue;
                     if (ANY_HIT) return true;
                     const uint32_t flat = __float_as_uint(c.w);
@@ -418,6 +444,7 @@ struct RaygenArgs {
     uint32_t fuse_temporal;  // 0 = off
     TemporalArgs temporal;
     CostOrderArgs co;        // "raygen_cost_order" (the default queue kernel, the mirror-ray queue kernel)
+    RedoList redo;           // the queue kernels: where a ray with a self-contradicting candidate leaves its pixel (decision vi)
 };
 
 __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
@@ -425,6 +452,69 @@ __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     y = row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+// raygen.rgen:14-66 for one pixel, its rays one after another (the walker with the whole of decision (vi): traverse<> -> ray_triangle)
+__device__ __forceinline__ void raygen_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, uint32_t &overflow, bool &covered, bool &second_ray) {
+    const uint32_t W = a.width, H = a.height;
+    const float u = (float(x) + 0.5f) / float(W);                                        // rgen:15-16
+    const float v = (float(y) + 0.5f) / float(H);
+    uint32_t rng = seed_thread((y * H + x) * a.pfd.frame_index);                         // rgen:17 (LaunchSize.y)
+    const float depth = a.depth[size_t(y) * W + x];                                      // rgen:19
+    if (depth == 0.0f) {                                                                 // rgen:20-24
+        store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);
+        if (a.reflections) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    covered = true;
+    const f3 P = get_world_space_position(a.pfd, depth, u, v);                           // rgen:26
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1],
+                      a.pfd.directional_light.direction[2] };                            // rgen:27
+    const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
+    const f3 N = f3{ nid.x, nid.y, nid.z };
+    const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
+    Hit hit;
+
+    float rnd1 = random01(rng);                                                          // rgen:32-33
+    float rnd2 = random01(rng);
+    float shadow_payload = 1.0f;
+    if (a.tp.shadow_enable) {
+        const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));   // rgen:34
+        const f3 dir = onb_transform(L, cone_dir);                                       // rgen:35,40
+        // rgen:37-41 issues this trace four times with identical arguments; once is equivalent
+        const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.tmax, stack, hit, overflow);
+        shadow_payload = occluded ? 0.0f : 1.0f;                                         // miss.rmiss:7
+    }
+    float ao_payload = 0.0f;                                                             // rgen:44-55
+    for (uint32_t i = 0; i < a.tp.ao_spp; ++i) {
+        rnd1 = random01(rng);
+        rnd2 = random01(rng);
+        const f3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
+        const f3 dir = onb_transform(N, rnd_dir);
+        const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.ao_tmax, stack, hit, overflow);
+        ao_payload += occluded ? 0.0f : 1.0f;
+    }
+    if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
+    store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
+    if (a.fuse_temporal) {                // (the redo launch behind a queue kernel that ran svgf.comp in its tiles' epilogues: once more for this pixel)
+        const TemporalArgs &t = a.temporal;
+        if (x >= t.col_begin && x < t.limit_x && y >= t.row_begin && y < t.row_end && y < t.limit_y) {
+            const float2 cur = unpack_rg16f(pack_rg16f(shadow_payload, ao_payload));     // what the RG16F image holds
+            svgf_temporal_pixel(t, x, y, nid, cur.x, cur.y);
+        }
+    }
+
+    if (a.reflections) {
+        f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        if (a.tp.reflections) {                                                          // rgen:60-65
+            const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
+            const f3 I = normalize3(P - cam);
+            const float ni2 = 2.0f * dot3(N, I);
+            const f3 rdir = I - N * ni2;                                                 // reflect(I, N)
+            payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
+        }
+        store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+    }
 }
 
 __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a, const Stamps st) {
@@ -435,60 +525,7 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a,
     pixel_of_thread(x, y, a.row_begin);
     uint32_t overflow = 0;
     bool covered = false, second_ray = false;
-    if (x < a.width && y < a.row_end) {
-        const uint32_t W = a.width, H = a.height;
-        const float u = (float(x) + 0.5f) / float(W);                                        // rgen:15-16
-        const float v = (float(y) + 0.5f) / float(H);
-        uint32_t rng = seed_thread((y * H + x) * a.pfd.frame_index);                         // rgen:17 (LaunchSize.y)
-        const float depth = a.depth[size_t(y) * W + x];                                      // rgen:19
-        if (depth == 0.0f) {                                                                 // rgen:20-24
-            store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);
-            if (a.reflections) store_rgba16f(a.reflections, W, x, y, 0.0f, 0.0f, 0.0f, 0.0f);
-        } else {
-            covered = true;
-            const f3 P = get_world_space_position(a.pfd, depth, u, v);                       // rgen:26
-            const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1],
-                              a.pfd.directional_light.direction[2] };                        // rgen:27
-            const f4 nid = load_rgba16f(a.normals, W, x, y);                                 // rgen:28
-            const f3 N = f3{ nid.x, nid.y, nid.z };
-            const f3 origin = P + N * a.tp.normal_bias;                                      // rgen:29
-            Hit hit;
-
-            float rnd1 = random01(rng);                                                      // rgen:32-33
-            float rnd2 = random01(rng);
-            float shadow_payload = 1.0f;
-            if (a.tp.shadow_enable) {
-                const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));   // rgen:34
-                const f3 dir = onb_transform(L, cone_dir);                                   // rgen:35,40
-                // rgen:37-41 issues this trace four times with identical arguments; once is equivalent
-                const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.tmax, stack, hit, overflow);
-                shadow_payload = occluded ? 0.0f : 1.0f;                                     // miss.rmiss:7
-            }
-            float ao_payload = 0.0f;                                                         // rgen:44-55
-            for (uint32_t i = 0; i < a.tp.ao_spp; ++i) {
-                rnd1 = random01(rng);
-                rnd2 = random01(rng);
-                const f3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
-                const f3 dir = onb_transform(N, rnd_dir);
-                const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.ao_tmax, stack, hit, overflow);
-                ao_payload += occluded ? 0.0f : 1.0f;
-            }
-            if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
-            store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                   // rgen:57
-
-            if (a.reflections) {
-                f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-                if (a.tp.reflections) {                                                      // rgen:60-65
-                    const f3 cam = f3{ a.pfd.camera_view_inverse[12], a.pfd.camera_view_inverse[13], a.pfd.camera_view_inverse[14] };
-                    const f3 I = normalize3(P - cam);
-                    const float ni2 = 2.0f * dot3(N, I);
-                    const f3 rdir = I - N * ni2;                                             // reflect(I, N)
-                    payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
-                }
-                store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
-            }
-        }
-    }
+    if (x < a.width && y < a.row_end) raygen_pixel(a, x, y, stack, overflow, covered, second_ray);
     if (a.stats) {
         const unsigned long long cov = __ballot(covered), ovf = __ballot(overflow != 0), sec = __ballot(second_ray);
         if ((threadIdx.x & 63u) == 0) {
@@ -497,6 +534,36 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a,
             if (sec) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)__popcll(sec));
         }
     }
+}
+
+// The launch behind a queue kernel's (decision (vi), vhr::RedoList): the listed pixels once more, one per thread, by the per-pixel body --
+// whose walker decides a self-contradicting candidate in binary64.  `rect` = (col_begin, col_end, row_begin, row_end) of the queue kernel's launch,
+// traced as a whole if the list overflowed.  The launch also zeroes the counter of the list's next launch.
+template <typename Body>
+__device__ __forceinline__ void redo_pixels(const RedoList &r, const uint32_t W, const uint32_t col_begin, const uint32_t col_end, const uint32_t row_begin,
+                                            const uint32_t row_end, Body body) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *r.count_next = 0u;
+    const uint32_t appended = *r.count;
+    if (appended == 0u) return;
+    const bool all = appended > r.capacity;
+    const uint32_t cols = col_end - col_begin;
+    const uint32_t n = all ? cols * (row_end - row_begin) : appended;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t pixel = all ? (row_begin + i / cols) * W + col_begin + i % cols : r.pixels[i];
+        body(pixel % W, pixel / W);
+    }
+}
+constexpr int kRedoBlocks = 16;
+
+__global__ __launch_bounds__(kTraceBlock) void raygen_redo_kernel(const RaygenArgs a, const Stamps st) {
+    vhr_stamp(st);
+    __shared__ int s_stack[kTraceStack * kTraceBlock];
+    int *stack = s_stack + threadIdx.x;
+    redo_pixels(a.redo, a.width, a.col_begin, a.col_end, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
+        uint32_t overflow = 0;
+        bool covered = false, second_ray = false;
+        raygen_pixel(a, x, y, stack, overflow, covered, second_ray);
+    });
 }
 
 
@@ -1005,7 +1072,7 @@ __device__ __forceinline__ void order_blocks_by_cost(const uint32_t *__restrict_
 // origin and the G-buffer normal as the halves it is -- and recomputes the pixel's seed and the ray's direction at refill with raygen.rgen's
 // exact arithmetic.
 template <int WAVES, bool COMPACT, bool SPILL, bool STATS, bool FUSE = false>
-__global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
+__global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per_eu(VHR_K1_WAVES_MIN, 8))) void raygen_queue_kernel(const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold,
                                                                           const uint32_t block_tiles_x, const uint32_t early_exit, const uint32_t tile_rows, const uint32_t steal_threshold, const Stamps st) {
     vhr_stamp(st);
     RayStats *const stats = STATS ? a.stats : nullptr;    // !STATS: counters and timers below are dead code (fewer VGPRs)
@@ -1258,9 +1325,16 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     ++n_tris;
                     const float4 ta = reinterpret_cast<const float4 *>(leaf + i)[0], tb = reinterpret_cast<const float4 *>(leaf + i)[1];
                     const float tcx = reinterpret_cast<const float *>(leaf + i)[8];
-                    if (ray_triangle_any(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tcx }, tmin, tmax)) {
-                        found = true;
-                        break;
+                    const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tcx };
+                    float ct, cu, cv;
+                    // (the consistency test behind the candidates only: few tests get this far, and a wave whose lanes all failed skips it)
+                    if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, ct, cu, cv)) {
+                        if (solution_consistent(ro, rd, v0, e1, e2, ct, cu, cv)) {
+                            found = true;
+                            break;
+                        }
+                        // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
+                        redo_append(a.redo, (y - (lane >> 3) + (pix >> 3)) * W + (x - (lane & 7u) + (pix & 7u)));
                     }
                 }
             }
@@ -1356,18 +1430,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     }
 }
 
-// Mirror ray of raygen.rgen:59-65 (closest hit, reflection_hit.rchit / reflection_miss.rmiss), one pixel per thread.
-__global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArgs a, const Stamps st) {
-    vhr_stamp(st);
-    __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
-    int *stack = s_refl_stack + threadIdx.x;
-    uint32_t x, y;
-    pixel_of_thread(x, y, a.row_begin);
-    bool second_ray = false;
-    const bool inside = x < a.width && y < a.row_end;
+// Mirror ray of raygen.rgen:59-65 (closest hit, reflection_hit.rchit / reflection_miss.rmiss) for one pixel of the image
+__device__ __forceinline__ void reflection_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, bool &second_ray) {
     const uint32_t W = a.width, H = a.height;
     f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    const float depth = inside ? a.depth[size_t(y) * W + x] : 0.0f;
+    const float depth = a.depth[size_t(y) * W + x];
     if (depth != 0.0f && a.tp.reflections) {
         const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
         const f3 P = get_world_space_position(a.pfd, depth, u, v);
@@ -1381,16 +1448,39 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
         uint32_t overflow = 0;
         payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
     }
-    if (inside) store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+    store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+}
+
+// ... one pixel per thread
+__global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArgs a, const Stamps st) {
+    vhr_stamp(st);
+    __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
+    int *stack = s_refl_stack + threadIdx.x;
+    uint32_t x, y;
+    pixel_of_thread(x, y, a.row_begin);
+    bool second_ray = false;
+    if (x < a.width && y < a.row_end) reflection_pixel(a, x, y, stack, second_ray);
     if (a.stats) {
         const unsigned long long sec = __ballot(second_ray);
         if ((threadIdx.x & 63u) == 0 && sec) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)__popcll(sec));
     }
 }
 
+// ... the pixels the mirror ray's queue kernel left to the binary64 path (decision (vi), vhr::RedoList)
+__global__ __launch_bounds__(kTraceBlock) void reflection_redo_kernel(const RaygenArgs a, const Stamps st) {
+    vhr_stamp(st);
+    __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
+    int *stack = s_refl_stack + threadIdx.x;
+    redo_pixels(a.redo, a.width, a.col_begin, a.col_end, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
+        bool second_ray = false;
+        reflection_pixel(a, x, y, stack, second_ray);
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // One pass of a wave over its ray queue (`total` rays; fetch(r, pix, origin, direction) delivers the r-th one and the id of
-// its pixel, commit(pix, triangle, u, v) takes its result, kNoHit = miss).  Lanes pull rays whenever `refill_threshold` of
+// its pixel (< 2^31), commit(pix, triangle, u, v) takes its result, kNoHit = miss; bit 31 of pix set = the ray met a candidate
+// that contradicts itself and its pixel belongs on the redo list -- decision (vi), vhr::RedoList).  Lanes pull rays whenever `refill_threshold` of
 // them are idle and walk the BVH "while-while" with the node step of raygen_queue_kernel: packed-FMA slabs against 1/d and
 // -o/d, near child first, far child pushed, boxes culled against the closest t so far (tn <= tbest keeps equal-t candidates:
 // decision vi), early exit of the node loop, LDS stack + scratch spill.  Leaves: every triangle, Moeller-Trumbore against the
@@ -1483,7 +1573,11 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 const float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 float t, uu, ww;
                 if (STATS) ++my_tris;
-                if (ray_triangle_nb(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) {
+                const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
+                if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) {
+                    // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
+                    // (bit 31 of the pixel id tells commit(); the walk goes on as if the candidate were a miss)
+                    if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) { pix |= 0x80000000u; continue; }
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
                     const uint32_t flat = __float_as_uint(tc.w);
                     if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
@@ -1635,6 +1729,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
+            if (pix >> 31) {              // decision (vi): the pixel goes to the redo launch (its record here is whatever the walk ended with)
+                pix &= 0x7fffffffu;
+                redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + a.col_begin + tile_x * (8u * SUBS) + (pix >> 6) * 8u + (pix & 7u));
+            }
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
         }, &wc);
     wave_lds_sync();
@@ -1767,9 +1865,10 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
 }
 
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
-    (void)height;
     RaygenArgs a = a_in;
     a.co = CostOrderArgs{};
+    a.redo = RedoList{};
+    if (ctx->options[kOptRaygenVariant] != 0 && ctx->next_redo(ctx->redo_raygen, width * height, a.redo) != VHR_OK) return;
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
         launch(ctx, raygen_kernel, dim3((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16), dim3(kTraceBlock), 0, a);
@@ -1823,6 +1922,11 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
         if (wv == 4u) by_flags(std::integral_constant<int, 4>{});
         else if (wv == 2u) by_flags(std::integral_constant<int, 2>{});
         else by_flags(std::integral_constant<int, 1>{});
+        // decision (vi): the pixels whose rays met a self-contradicting candidate, once more by the per-pixel body (shadow / AO only: the mirror
+        // ray has a launch and a list of its own)
+        RaygenArgs r = a;
+        r.reflections = nullptr; r.stats = nullptr; r.co = CostOrderArgs{};
+        launch(ctx, raygen_redo_kernel, dim3(kRedoBlocks), dim3(kTraceBlock), 0, r);
     }
     ctx->time_end(kKernelRaygen);
 }
@@ -1965,10 +2069,16 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
+            if (ctx->next_redo(ctx->redo_reflection, width * height, m.redo) != VHR_OK) return VHR_ERROR_DEVICE;
             if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }
             else { if (spill) VHR_LAUNCH_REFL_S(true, 1); else VHR_LAUNCH_REFL_S(false, 1); }
 #undef VHR_LAUNCH_REFL_S
 #undef VHR_LAUNCH_REFL
+            {   // decision (vi): the pixels whose mirror ray met a self-contradicting candidate, once more by the per-pixel body
+                RaygenArgs r = m;
+                r.stats = nullptr; r.co = CostOrderArgs{};
+                launch(ctx, reflection_redo_kernel, dim3(kRedoBlocks), dim3(kTraceBlock), 0, r);
+            }
         } else {
             launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m);
         }
@@ -2063,9 +2173,37 @@ struct RaytracedArgs {
     uint32_t row_begin, row_end;
     RayStats *stats;         // nullptr = off; covered_pixels counts the primary hits (= shadow rays)
     CostOrderArgs co;        // "raygen_cost_order" (the queue kernel)
+    RedoList redo;           // the queue kernel: where a ray with a self-contradicting candidate leaves its pixel (decision vi)
 };
 
 __device__ __forceinline__ uint32_t unorm8(float f);
+
+// raytraced_render_path/raygen.rgen:10-23 for one pixel
+template <bool ALPHA>
+__device__ __forceinline__ void raytraced_pixel(const RaytracedArgs &a, const uint32_t x, const uint32_t y, int *stack, uint32_t &overflow, bool &hit_any) {
+    const uint32_t W = a.width, H = a.height;
+    const float ux = ((float(x) + 0.5f) / float(W)) * 2.0f - 1.0f;                   // rgen:11-13
+    const float uy = ((float(y) + 0.5f) / float(H)) * 2.0f - 1.0f;
+    const f4 origin = mat4_mul(a.pfd.camera_view_inverse, f4{ 0.0f, 0.0f, 0.0f, 1.0f });       // rgen:15
+    const f4 target = mat4_mul(a.pfd.camera_proj_inverse, f4{ ux, uy, 1.0f, 1.0f });           // rgen:16
+    const f3 tn = normalize3(f3{ target.x, target.y, target.z });
+    const f4 direction = mat4_mul(a.pfd.camera_view_inverse, f4{ tn.x, tn.y, tn.z, 0.0f });    // rgen:17
+    f4 payload = f4{ 0.3f, 0.8f, 0.2f, 1.0f };                                       // miss.rmiss:7
+    Hit h;
+    if (traverse<false, ALPHA>(a.scene, f3{ origin.x, origin.y, origin.z }, f3{ direction.x, direction.y, direction.z }, 0.1f, 10000.0f,
+                               stack, h, overflow)) {                                // rgen:20
+        hit_any = true;
+        f3 position, unused_normal;
+        hit_position_normal(a.scene, h, position, unused_normal);                    // rchit:24
+        const f3 light_dir = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
+        Hit sh;
+        // shadow ray, rchit:48-50 (alpha :41-43): shadow_payload stays true unless shadow_miss.rmiss:7 runs
+        const bool shadowed = traverse<true, ALPHA>(a.scene, position, light_dir, 0.1f, 10000.0f, stack, sh, overflow);
+        payload = raytraced_hit_payload<ALPHA>(a.scene, a.pfd, h, shadowed);
+    }
+    a.out[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(payload.z)), uint8_t(unorm8(payload.y)), uint8_t(unorm8(payload.x)),
+                                           uint8_t(unorm8(payload.w)));             // rgen:22 imageStore, B8G8R8A8
+}
 
 template <bool ALPHA>
 __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedArgs a, const Stamps st) {
@@ -2076,30 +2214,7 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
     pixel_of_thread(x, y, a.row_begin);
     bool hit_any = false;
     uint32_t overflow = 0;
-    if (x < a.width && y < a.row_end) {
-        const uint32_t W = a.width, H = a.height;
-        const float ux = ((float(x) + 0.5f) / float(W)) * 2.0f - 1.0f;                   // rgen:11-13
-        const float uy = ((float(y) + 0.5f) / float(H)) * 2.0f - 1.0f;
-        const f4 origin = mat4_mul(a.pfd.camera_view_inverse, f4{ 0.0f, 0.0f, 0.0f, 1.0f });       // rgen:15
-        const f4 target = mat4_mul(a.pfd.camera_proj_inverse, f4{ ux, uy, 1.0f, 1.0f });           // rgen:16
-        const f3 tn = normalize3(f3{ target.x, target.y, target.z });
-        const f4 direction = mat4_mul(a.pfd.camera_view_inverse, f4{ tn.x, tn.y, tn.z, 0.0f });    // rgen:17
-        f4 payload = f4{ 0.3f, 0.8f, 0.2f, 1.0f };                                       // miss.rmiss:7
-        Hit h;
-        if (traverse<false, ALPHA>(a.scene, f3{ origin.x, origin.y, origin.z }, f3{ direction.x, direction.y, direction.z }, 0.1f, 10000.0f,
-                                   stack, h, overflow)) {                                // rgen:20
-            hit_any = true;
-            f3 position, unused_normal;
-            hit_position_normal(a.scene, h, position, unused_normal);                    // rchit:24
-            const f3 light_dir = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
-            Hit sh;
-            // shadow ray, rchit:48-50 (alpha :41-43): shadow_payload stays true unless shadow_miss.rmiss:7 runs
-            const bool shadowed = traverse<true, ALPHA>(a.scene, position, light_dir, 0.1f, 10000.0f, stack, sh, overflow);
-            payload = raytraced_hit_payload<ALPHA>(a.scene, a.pfd, h, shadowed);
-        }
-        a.out[size_t(y) * W + x] = make_uchar4(uint8_t(unorm8(payload.z)), uint8_t(unorm8(payload.y)), uint8_t(unorm8(payload.x)),
-                                               uint8_t(unorm8(payload.w)));             // rgen:22 imageStore, B8G8R8A8
-    }
+    if (x < a.width && y < a.row_end) raytraced_pixel<ALPHA>(a, x, y, stack, overflow, hit_any);
     if (a.stats) {
         const unsigned long long cov = __ballot(hit_any), ovf = __ballot(overflow != 0);
         if ((threadIdx.x & 63u) == 0) {
@@ -2107,6 +2222,19 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
             if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
         }
     }
+}
+
+// ... the pixels the queue kernel left to the binary64 path (decision (vi), vhr::RedoList)
+template <bool ALPHA>
+__global__ __launch_bounds__(kTraceBlock) void raytraced_redo_kernel(const RaytracedArgs a, const Stamps st) {
+    vhr_stamp(st);
+    __shared__ int s_rt_stack[kTraceStack * kTraceBlock];
+    int *stack = s_rt_stack + threadIdx.x;
+    redo_pixels(a.redo, a.width, 0u, a.width, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
+        uint32_t overflow = 0;
+        bool hit_any = false;
+        raytraced_pixel<ALPHA>(a, x, y, stack, overflow, hit_any);
+    });
 }
 
 // Work-queue form (default, `raytraced_variant` 1): a wave owns a 16x8-pixel tile and runs wave_queue_walk twice -- the
@@ -2174,6 +2302,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             rd = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {
+            if (pix >> 31) { pix &= 0x7fffffffu; redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u)); }   // decision (vi)
             s_ray[0][pix] = __uint_as_float(tri); s_ray[1][pix] = u; s_ray[2][pix] = v;
         });
     wave_lds_sync();
@@ -2209,7 +2338,10 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             ro = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
             rd = light_dir;
         },
-        [&](uint32_t pix, uint32_t tri, float, float) { s_ray[3][pix] = __uint_as_float(tri); });
+        [&](uint32_t pix, uint32_t tri, float, float) {
+            if (pix >> 31) { pix &= 0x7fffffffu; redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u)); }   // decision (vi)
+            s_ray[3][pix] = __uint_as_float(tri);
+        });
     wave_lds_sync();
     // ---- closesthit.rchit / miss.rmiss and the image store, whole wave ----
 #pragma unroll
@@ -2263,9 +2395,16 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
             prepare_cost_order(ctx, ctx->cost_order_raytraced, (tiles_total + 1u) / 2u, 2u,
                                (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co);
 #define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
+        if (ctx->next_redo(ctx->redo_raytraced, width * height, a.redo) != VHR_OK) return VHR_ERROR_DEVICE;
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
 #undef VHR_LAUNCH_RT
+        {   // decision (vi): the pixels whose rays met a self-contradicting candidate, once more by the per-pixel body
+            RaytracedArgs r = a;
+            r.stats = nullptr; r.co = CostOrderArgs{};
+            if (alpha_test) launch(ctx, raytraced_redo_kernel<true>, dim3(kRedoBlocks * 16), dim3(kTraceBlock), 0, r);
+            else launch(ctx, raytraced_redo_kernel<false>, dim3(kRedoBlocks * 16), dim3(kTraceBlock), 0, r);
+        }
     } else if (alpha_test) {
         launch(ctx, raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, a);
     } else {
