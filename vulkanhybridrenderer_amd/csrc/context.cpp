@@ -299,7 +299,8 @@ int vhr_context::next_redo(RedoBuffers &b, uint32_t pixels, vhr::RedoList &out) 
         if (b.base) { (void)hipDeviceSynchronize(); (void)hipFree(b.base); b = RedoBuffers{}; }
         uint32_t *base = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&base), (size_t(pixels) + 2) * 4) != hipSuccess) return fail(VHR_ERROR_DEVICE, "redo list: hipMalloc failed");
-        if (hipMemset(base, 0, 8) != hipSuccess) { (void)hipFree(base); return fail(VHR_ERROR_DEVICE, "redo list: hipMemset failed"); }
+        // (on the stream the list's first launch goes to: a memset on the null stream is not ordered against a non-blocking stream)
+        if (hipMemsetAsync(base, 0, 8, stream) != hipSuccess) { (void)hipFree(base); return fail(VHR_ERROR_DEVICE, "redo list: hipMemsetAsync failed"); }
         b.base = base; b.capacity = pixels; b.slot = 0;
     }
     // the two counters are handed from launch to launch in stream order: a list that changes streams (frames in flight or the mirror ray's own

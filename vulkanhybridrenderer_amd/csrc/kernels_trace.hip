@@ -20,6 +20,9 @@ namespace vhr {
 
 __constant__ float c_srgb_lut[256];
 
+#ifndef VHR_K1_POSTPONE
+#define VHR_K1_POSTPONE 0            // 1: a scratch build of the any-hit queue kernel WITH the postponed-leaf step (measured slower: profiles/r6_k1_postponed_leaf.txt)
+#endif
 #ifndef VHR_K1_WAVES_MIN
 #define VHR_K1_WAVES_MIN 7          // waves per SIMD the any-hit queue kernel is allocated for (7: <= 72 registers, 8: <= 64)
 #endif
@@ -602,6 +605,7 @@ __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; a
 // mask, four per node visit, r5); masks combine on the scalar unit.  (Lanes that are switched off read 0.)
 __device__ __forceinline__ unsigned long long cmp_le_mask(float a, float b) { unsigned long long m; asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ __forceinline__ unsigned long long cmp_gt_i32_mask_s(int uniform_a, int b) { unsigned long long m; asm("v_cmp_gt_i32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_a), "v"(b)); return m; }
+__device__ __forceinline__ unsigned long long cmp_eq_i32_mask_s(int uniform_a, int b) { unsigned long long m; asm("v_cmp_eq_i32_e64 %0, %1, %2" : "=s"(m) : "s"(uniform_a), "v"(b)); return m; }
 __device__ __forceinline__ int select_mask(int if_clear, int if_set, unsigned long long m) { int d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(m)); return d; }
 
 __device__ __forceinline__ bool box_test_pk(f2v bx, f2v by, f2v bz, f3 inv, f3 noi, float tmin, float tlimit, float &tnear) {
@@ -1155,6 +1159,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tmax = 0.0f;
     int cur = 0, sp = 0;
+#if VHR_K1_POSTPONE
+    int parked = kStackSentinel;                      // "postponed leaf": a leaf this lane has reached and not tested yet (kStackSentinel = none)
+#endif
     int sbase = 0;                                    // "raygen_steal": stack rows 1 .. sbase have been taken by other lanes (row sbase holds a sentinel)
     uint32_t pix = 0, kind = 0;
     bool has = false;
@@ -1200,6 +1207,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 noi = f3{ -(oc.x * rinv.x), -(oc.y * rinv.y), -(oc.z * rinv.z) };
                 if (!COMPACT) ainv = f3{ fabsf(rinv.x), fabsf(rinv.y), fabsf(rinv.z) };
                 sbase = 0;
+#if VHR_K1_POSTPONE
+                parked = kStackSentinel;
+#endif
                 cut_to_stack(s_cut, cut_n, stack, stack_levels, rinv, noi, tmin_v, tmax, cur, sp, emask);      // (its boxes are relative to the centre `noi` is)
                 has = true;
             }
@@ -1238,6 +1248,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     if (!COMPACT) ainv = f3{ t_ax, t_ay, t_az };
                     tmax = t_tmax; pix = t_pk & 0xffu; kind = t_pk >> 8;
                     cur = link; sp = 0; sbase = 0; emask = 0;
+#if VHR_K1_POSTPONE
+                    parked = kStackSentinel;          // (a lane that dropped a ray another lane had found blocked may still hold one)
+#endif
                     has = true;
                 }
                 if (stats) ++n_refills;
@@ -1299,6 +1312,24 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                     else overflow |= uint32_t((h0 & h1) >> lane) & 1u;            // cannot happen (builder depth bound); counted
                 }
             }
+#if VHR_K1_POSTPONE
+            // Postponed leaf (round 6): a lane whose next stop would be a LEAF parks it -- one slot per lane -- and goes on with what the stack holds
+            // instead of sitting out the rest of the loop (10 % of the loop's lane-trips on sponza_proc, 15 % on bistro_proc, were lanes holding a
+            // leaf: profiles/r6_k1_postponed_leaf.txt).  Both children hit: the far child is entered at once (it was just written above the top, sp stays);
+            // one child hit: the old top is popped.  The parked leaf is tested in the leaf stage below; any hit = OR over the leaves a ray touches, in
+            // any order.  Five vector instructions per trip, the masks on the scalar unit.
+            const unsigned long long any_hit = h0 | h1;
+            const unsigned long long park = cmp_gt_i32_mask_s(0, nearc) & any_hit & cmp_eq_i32_mask_s(kStackSentinel, parked);
+            parked = select_mask(parked, nearc, park);
+            cur = select_mask(select_mask(top, nearc, any_hit & ~park), farc, park & h0 & h1);
+            {   // sp += h0 + h1 - 1 - park
+                int t;
+                unsigned long long carry_out;
+                asm("v_addc_co_u32_e64 %0, %1, %2, -1, %3" : "=v"(t), "=s"(carry_out) : "v"(sp), "s"(h0));
+                asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(t), "=s"(carry_out) : "v"(t), "s"(h1));
+                asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(t), "s"(park));
+            }
+#else
             cur = select_mask(top, nearc, h0 | h1);                               // no child hit: popping the empty stack yields the sentinel
             {   // sp += h0 + h1 - 1: +1 both, 0 one, -1 none (with the sentinel) -- two add-with-carry, the hit masks as the carries
                 int t;
@@ -1306,38 +1337,61 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 asm("v_addc_co_u32_e64 %0, %1, %2, -1, %3" : "=v"(t), "=s"(carry_out) : "v"(sp), "s"(h0));
                 asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(sp), "=s"(carry_out) : "v"(t), "s"(h1));
             }
+#endif
         }
+#ifdef VHR_K1_COUNT_IDLE
+        // (scratch builds, profiles/r6_k1_postponed_leaf.txt) who sat out how many trips of this pass through the node loop: lanes holding a leaf -- what a
+        // postponed-leaf step could have kept walking -- and lanes without a ray.  [drain_le4, drain_le8, drain_le16] = lane-trips of walkers, holders, the rest.
+        if (stats) {
+            const uint32_t mine = n_nodes - nodes_before;
+            uint32_t tot = mine;
+            for (int off = 32; off > 0; off >>= 1) tot = max(tot, uint32_t(__shfl_xor(int(tot), off)));
+            const bool holder = has && cur < 0 && cur != kStackSentinel;
+            uint32_t w = mine, hl = holder ? tot - mine : 0u, fr = holder ? 0u : tot - mine;
+            for (int off = 32; off > 0; off >>= 1) { w += uint32_t(__shfl_xor(int(w), off)); hl += uint32_t(__shfl_xor(int(hl), off)); fr += uint32_t(__shfl_xor(int(fr), off)); }
+            n_drain_le4 += w; n_drain_le8 += hl; n_drain_le16 += fr;
+        }
+#endif
         const unsigned long long t2 = stats ? __builtin_readcyclecounter() : 0ull;
         // ---- leaf ----
-        if (has && cur < 0 && cur != kStackSentinel) {
-            const uint32_t vv = ~uint32_t(cur);
+        // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
+        // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test).
+        // (r3c-r5 the NEXT triangle's loads were in flight while this one was tested: -1.3 % on sponza_proc, +0.7 % on bistro_proc.  With the
+        // consistency test of decision (vi) the triangle's nine floats live to the end of the test, and next to a second triangle's nine the
+        // kernel needed 68 registers -- a wave per SIMD; without the prefetch 59.  Measured equal: 0.4558 / 0.4569 ms.  Verifying candidates
+        // outside the loop on a triangle fetched again kept the prefetch at 62 registers and cost more: 0.469 ms -- a found ray is no rarity.)
+        auto test_leaf = [&](const int code) {
+            const uint32_t vv = ~uint32_t(code);
             const uint32_t first = vv >> 2, count = (vv & 3u) + 1u;
             ++n_leaves;
-            // one memory round trip per triangle: its three loads are issued together and the test has no early return (with
-            // ray_triangle() the compiler sinks the load of v0 behind the `det == 0` return: two dependent round trips per test).
-            // (r3c-r5 the NEXT triangle's loads were in flight while this one was tested: -1.3 % on sponza_proc, +0.7 % on bistro_proc.  With the
-            // on-triangle half of decision (vi) the triangle's nine floats live to the end of the test, and next to a second triangle's nine the
-            // kernel needed 68 registers -- a wave per SIMD; without the prefetch 59.  Measured equal: 0.4558 / 0.4569 ms.  Verifying candidates
-            // outside the loop on a triangle fetched again kept the prefetch at 62 registers and cost more: 0.469 ms -- a found ray is no rarity.)
-            {
-                const BvhTri *const leaf = a.scene.tris + first;
-                for (uint32_t i = 0; i < count; ++i) {
-                    ++n_tris;
-                    const float4 ta = reinterpret_cast<const float4 *>(leaf + i)[0], tb = reinterpret_cast<const float4 *>(leaf + i)[1];
-                    const float tcx = reinterpret_cast<const float *>(leaf + i)[8];
-                    const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tcx };
-                    float ct, cu, cv;
-                    // (the consistency test behind the candidates only: few tests get this far, and a wave whose lanes all failed skips it)
-                    if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, ct, cu, cv)) {
-                        if (solution_consistent(ro, rd, v0, e1, e2, ct, cu, cv)) {
-                            found = true;
-                            break;
-                        }
-                        // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
-                        redo_append(a.redo, (y - (lane >> 3) + (pix >> 3)) * W + (x - (lane & 7u) + (pix & 7u)));
+            const BvhTri *const leaf = a.scene.tris + first;
+            for (uint32_t i = 0; i < count; ++i) {
+                ++n_tris;
+                const float4 ta = reinterpret_cast<const float4 *>(leaf + i)[0], tb = reinterpret_cast<const float4 *>(leaf + i)[1];
+                const float tcx = reinterpret_cast<const float *>(leaf + i)[8];
+                const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tcx };
+                float ct, cu, cv;
+                // (the consistency test behind the candidates only: few tests get this far, and a wave whose lanes all failed skips it)
+                if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, ct, cu, cv)) {
+                    if (solution_consistent(ro, rd, v0, e1, e2, ct, cu, cv)) {
+                        found = true;
+                        break;
                     }
+                    // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
+                    redo_append(a.redo, (y - (lane >> 3) + (pix >> 3)) * W + (x - (lane & 7u) + (pix & 7u)));
                 }
             }
+        };
+#if VHR_K1_POSTPONE
+        if (has && parked != kStackSentinel) {                                      // the leaf the lane parked on its way
+            test_leaf(parked);
+            parked = kStackSentinel;
+        }
+        if (has && !found && cur < 0 && cur != kStackSentinel) {                    // ... and the one it stopped at
+#else
+        if (has && cur < 0 && cur != kStackSentinel) {
+#endif
+            test_leaf(cur);
             if (!found) {                                                          // pop (the sentinel if nothing is pending)
                 cur = stack[min(uint32_t(sp), stack_levels + 1u) * kQueueBlock];
                 if (SPILL && __any(uint32_t(sp) > stack_levels)) {
@@ -1371,9 +1425,11 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                 n_drain_trips += tn + tt;    // trips made after the tile's queue ran dry (nothing left to refill with)
 #endif
                 const uint32_t live = uint32_t(__popcll(__ballot(has)));   // rays still in flight after this round of trips
+#ifndef VHR_K1_COUNT_IDLE
                 if (live <= 4u) n_drain_le4 += tn + tt;
                 if (live <= 8u) n_drain_le8 += tn + tt;
                 if (live <= 16u) n_drain_le16 += tn + tt;
+#endif
             }
         }
     }
