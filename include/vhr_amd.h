@@ -82,6 +82,14 @@ typedef struct vhr_create_info {
 
 int  vhr_create(const vhr_create_info *info, vhr_context **out);
 void vhr_destroy(vhr_context *ctx);
+/* VulkanContext::Resize (vulkan_context.cpp:118-120), the first half of the reference's one recovery route -- renderer.cpp:113-118,146-154:
+ * `context->Resize(); active_render_path->Build();` when the swapchain is out of date.  The display extent changes; what was sized by the old one
+ * is released: the graph (transient images, pass registry: RenderPath::Build would destroy it first anyway, render_path.cpp:14-20) and every image
+ * of the storage pool (the render path's SVGF history, which its RegisterPath allocates again).  Geometry, the acceleration structure (K0 is NOT
+ * rebuilt: vhr_get_build_times keeps its values), textures, options, trace parameters and kernel timers stay; the screen tile (vhr_set_tile) is the
+ * whole image again.  Then the path registers and builds at the new extent: vhr_hybrid_build / vhr_raytraced_build (which read the extent from
+ * the context) or RenderPath::Build() behind DeviceContext::Resize() (vhr_render_graph.hpp).  Frames after that equal a fresh context's bit for bit. */
+int  vhr_resize(vhr_context *ctx, uint32_t width, uint32_t height);
 const char *vhr_last_error(const vhr_context *ctx);   /* ctx may be NULL: error of the last failed vhr_create */
 int  vhr_synchronize(vhr_context *ctx);               /* hipStreamSynchronize on the context stream */
 /* The HIP stream (hipStream_t) the library is enqueueing on right now.  Outside vhr_graph_execute that is the stream given to

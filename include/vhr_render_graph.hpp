@@ -115,6 +115,12 @@ public:
         if (vhr_create(&info, &handle) < 0) throw std::runtime_error(std::string("vhr_create: ") + vhr_last_error(nullptr));
     }
     ~DeviceContext() { if (owned) vhr_destroy(handle); }
+    // vulkan_context.cpp:118-120 (renderer.cpp:113-118: `context->Resize(); active_render_path->Build();`): the new display extent; the graph and the
+    // storage pool's images are released, geometry / acceleration structure / textures stay.  Follow with RenderPath::Build().
+    void Resize(uint32_t width, uint32_t height) {
+        if (vhr_resize(handle, width, height) < 0) throw std::runtime_error(std::string("Resize: ") + vhr_last_error(handle));
+        swapchain.extent = { width, height };
+    }
     DeviceContext(const DeviceContext &) = delete;
     DeviceContext &operator=(const DeviceContext &) = delete;
     vhr_context *handle = nullptr;

@@ -33,6 +33,7 @@ def test_example_runs(tmp_path):
     # the run above saved the path's state half way (HybridRenderPath::SaveState), rebuilt the path and restored it (LoadState): its last frame is the
     # uninterrupted run's, bit for bit
     assert "checkpoint after frame 4" in r.stdout
+    assert "resized to 640 x 360 after frame 1" in r.stdout            # DeviceContext::Resize + RenderPath::Build (renderer.cpp:113-118) ran first
     straight = subprocess.run([EXE, "8", str(tmp_path / "straight.ppm"), "straight"], capture_output=True, text=True, timeout=300)
     assert straight.returncode == 0 and "checkpoint" not in straight.stdout.replace("denoised checksum", ""), straight.stdout + straight.stderr
     pick = lambda text: [l for l in text.splitlines() if l.startswith("denoised checksum")]

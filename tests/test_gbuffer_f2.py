@@ -50,11 +50,9 @@ def test_gpu_producer_matches_oracle(oracle):
             ctx.synchronize()
         n0, m0, d0, al0 = osc.gbuffer(pfd, W, H, with_albedo=True)
         n, d, al = ctx.download(lib.NORMALS), ctx.download(lib.DEPTH), ctx.download(lib.ALBEDO)
-        same = n[..., 3] == n0[..., 3]
-        assert same.mean() > 0.995                               # same surface chosen after the discards (silhouettes may differ)
-        assert np.array_equal(d != 0, d0 != 0) or ((d != 0) == (d0 != 0)).mean() > 0.999
-        assert np.abs(f16(n)[same][:, :3] - f16(n0)[same][:, :3]).max() < 4e-3        # perturbed normals included
-        assert (np.abs(al.astype(int) - al0.astype(int))[same] <= 1).mean() > 0.995
+        m = ctx.download(lib.MOTION)
+        # bit for bit (round 6): the surface chosen after the discards, the perturbed normals, motion, depth and albedo
+        assert np.array_equal(n, n0) and np.array_equal(m, m0) and np.array_equal(d.view(np.uint32), d0.view(np.uint32)) and np.array_equal(al, al0)
         # and the hot path runs on it: shadows of the fence have holes (ray tracing treats the fence as opaque geometry,
         # resource_manager.cpp:633, so this only checks that the pass consumed the perturbed G-buffer without trouble)
         den = f16(ctx.download(lib.DENOISED))

@@ -77,25 +77,36 @@ def test_ray_statistics(oracle):
         g.close()
 
 
-def test_standin_gbuffer_close_to_oracle(oracle):
-    """The GPU stand-in G-buffer producer agrees with the oracle's producer away from silhouettes."""
-    scene = scenes.tiny_scene()
-    W, H = 96, 64
+@pytest.mark.parametrize("scene_name,detail,size", [("tiny_scene", None, (96, 64)), ("sponza_proc", 0.3, (480, 270)), ("bistro_proc", 0.2, (480, 270))])
+def test_standin_gbuffer_is_the_oracles_bit_for_bit(oracle, scene_name, detail, size):
+    """The stand-in G-buffer producer (gbuf.vert:19-28, gbuf.frag:17-59 through primary rays) against the oracle's producer: normals / object ids,
+    motion / metallic / roughness, depth and albedo IDENTICAL, every texel, signed zeros included -- the producer shares the intersector, decision
+    (vi) and every rounding with the oracle.  (Rounds 1-5 allowed 0.5 % of the pixels on another surface and 4e-3 on the normals; what was left in
+    round 6 were 142 of 2 M normals one fp16 step off: the compiler had folded the normalisation's last multiply into the fp16 conversion --
+    one rounding instead of decision (iii)'s two; device_math.hpp float_to_half_bits pins the fp32 value now.)"""
+    maker = getattr(scenes, scene_name)
+    scene = maker() if detail is None else maker(detail)
+    W, H = size
     osc = oracle.Scene(scene)
     pfds = camera.dolly_frames(scene, W, H, 2)
-    g = GpuHybrid(scene, W, H, denoise=False, gbuffer="standin")
+    ctx = lib.Context(W, H)
+    ctx.upload_scene(scene)
+    path = lib.HybridRenderPath(ctx, 0, 0, 2, False, 5, lambda c: c.standin_gbuffer_with_albedo(0))
+    path.build()
     try:
-        g.frame(pfds[0])
-        g.frame(pfds[1])
-        n, m, d = (g.ctx.download(k) for k in (lib.NORMALS, lib.MOTION, lib.DEPTH))
-        n0, m0, d0 = osc.gbuffer(pfds[1], W, H)
-        same_id = f16(n)[..., 3] == f16(n0)[..., 3]
-        assert same_id.mean() > 0.995
-        assert np.allclose(d[same_id], d0[same_id], rtol=1e-4, atol=1e-7)
-        assert np.abs(f16(n)[same_id][:, :3] - f16(n0)[same_id][:, :3]).max() < 4e-3
-        assert np.abs(f16(m)[same_id][:, :2] - f16(m0)[same_id][:, :2]).max() < 1e-3
+        for pfd in pfds:
+            ctx.update_per_frame_ubo(0, pfd)
+            ctx.execute(0, 0)
+            ctx.synchronize()
+        want = osc.gbuffer(pfds[1], W, H, with_albedo=True)
+        got = [ctx.download(k) for k in (lib.NORMALS, lib.MOTION, lib.DEPTH, lib.ALBEDO)]
+        for name, g_img, w_img in zip(("normals / ids", "motion / metallic / roughness", "depth", "albedo"), got, want):
+            g_img, w_img = np.asarray(g_img), np.asarray(w_img)
+            same = g_img.view(np.uint32) == w_img.view(np.uint32) if g_img.dtype == np.float32 else g_img == w_img
+            assert same.all(), f"{name}: {int((~same).reshape(H, W, -1).any(-1).sum())} texels differ, first at {np.argwhere(~same)[:3].tolist()}"
     finally:
-        g.close()
+        path.destroy()
+        ctx.close()
 
 
 @pytest.mark.parametrize("scene_name,W,H", [("tiny", 100, 37), ("sponza", 480, 270), ("bistro_small", 200, 120)])

@@ -332,3 +332,33 @@ def test_svgf_state_blob_header_is_validated_before_anything_is_touched(ctx):
         with pytest.raises(lib.VhrError, match=message):
             p.load_state(np.frombuffer(blob, np.uint8) if blob else np.zeros(0, np.uint8))
     p.destroy()
+
+
+def test_resize_releases_what_the_extent_sized_and_keeps_the_rest(vhr):
+    """vhr_resize on a host-only context (renderer.cpp:113-118 -> vulkan_context.cpp:118-120 + render_path.cpp:14-20): the graph and the storage
+    pool go, the display size changes, transient images of the next Build have the new extent, the tile is the whole image, the options stay."""
+    c = lib.Context(640, 360, host_only=True)
+    try:
+        c.set_option("raygen_early_exit", 4)
+        c.set_tile(320, 640, 0, 180, 0, 0, 0)
+        path = lib.HybridRenderPath(c, 0, 0, 2, True, 5, None)
+        path.build()
+        ids = [int(v) for v in path.push_constants()["integrated_shadow_and_ao"]]
+        size = lambda i: (int(i.width), int(i.height))   # noqa: E731
+        assert size(c.storage_info(ids[0])) == (640, 360) and size(c.transient_info(lib.RAYTRACED)) == (640, 360)
+        c.resize(1280, 720)
+        assert c.display_size() == (1280, 720) and c.get_option("raygen_early_exit") == 4
+        with pytest.raises(lib.VhrError):
+            c.storage_info(ids[0])
+        with pytest.raises(lib.VhrError):
+            c.transient_info(lib.RAYTRACED)
+        with pytest.raises(lib.VhrError, match="zero extent"):
+            c.resize(0, 720)
+        path.build()                                          # RenderPath::Build: registers again, at the context's extent
+        ids2 = [int(v) for v in path.push_constants()["integrated_shadow_and_ao"]]
+        assert size(c.storage_info(ids2[0])) == (1280, 720) and size(c.transient_info(lib.RAYTRACED)) == (1280, 720) and size(c.transient_info(lib.DENOISED)) == (1280, 720)
+        c.set_tile(640, 1280, 0, 720, 0, 0, 0)               # (the new extent's columns are legal now)
+        assert "SVGF Denoise Pass" in c.execution_order()
+        path.destroy()
+    finally:
+        c.close()

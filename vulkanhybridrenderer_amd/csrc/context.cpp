@@ -818,6 +818,40 @@ int vhr_get_bvh_form_checks(vhr_context *ctx, uint64_t out[4]) {
     return VHR_OK;
 }
 
+// VulkanContext::Resize (vulkan_context.cpp:118-120 -> InitSwapchain) as far as it concerns this library: a new display extent.  What depends on
+// the extent goes -- the graph with its transient images and pass registry (RenderPath::Build destroys it first anyway, render_path.cpp:14-20), every image
+// of the storage pool (the path's SVGF history: the reference's RegisterPath allocates its five again on Build) -- and what does not stays:
+// geometry, acceleration structure, textures, options, trace parameters, timers.  The screen tile is the whole image again.
+int vhr_resize(vhr_context *ctx, uint32_t width, uint32_t height) {
+    if (!ctx) return VHR_ERROR_INVALID_ARGUMENT;
+    if (width == 0 || height == 0) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_resize: zero extent");
+    if (ctx->recording || ctx->cur_pass) return ctx->fail(VHR_ERROR_GRAPH, "vhr_resize: called from inside a pass");
+    if (!ctx->host_only) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ctx->deferred_raygen) { const int drc = vhr::flush_deferred_raygen(ctx, nullptr); if (drc != VHR_OK) return drc; }
+        { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
+    }
+    const int grc = vhr_graph_destroy_resources(ctx);
+    if (grc != VHR_OK) return grc;
+    for (Image &im : ctx->storage_images) {
+        if (!im.used) continue;
+        if (!ctx->host_only) {
+            void *a = im.ptr, *b = im.alt;
+            hipFree(a);
+            if (b && b != a) hipFree(b);
+        }
+        im = Image{};
+    }
+    ctx->width = width;
+    ctx->height = height;
+    ctx->row_begin = 0; ctx->row_end = height;
+    ctx->col_begin = 0; ctx->col_end = width;
+    ctx->overlap = 0; ctx->halo = 0; ctx->halo_cols = 0;
+    ctx->last_resource_idx = 0;
+    ctx->error.clear();
+    return VHR_OK;
+}
+
 int vhr_get_display_size(vhr_context *ctx, uint32_t *width, uint32_t *height) {
     if (!ctx || !width || !height) return VHR_ERROR_INVALID_ARGUMENT;
     *width = ctx->width;

@@ -49,7 +49,10 @@ __device__ __forceinline__ f3 mat4_mul_point(const float *m, f3 p) {
 
 // ---- fp16 image storage: stores round to nearest even, loads widen exactly ----
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ uint16_t float_to_half_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+// (the empty asm pins the fp32 VALUE: left alone, the compiler folds the multiply that produced f into the conversion -- v_fma_mixlo_f16 rounds the
+// unrounded product to a half ONCE, and where the fp32 product is a tie between two halves that lands one step off the store of the rounded fp32
+// value (decision iii; found in round 6 on 142 of 2 M normals of the stand-in G-buffer, the one image whose stored values are products))
+__device__ __forceinline__ uint16_t float_to_half_bits(float f) { asm("" : "+v"(f)); return __half_as_ushort(__float2half_rn(f)); }
 
 // ---- data/shaders/common.glsl:47-76 RNG (integer exact) ----
 __device__ __forceinline__ uint32_t seed_thread(uint32_t seed) {

@@ -102,6 +102,10 @@ void vhr_raytraced_destroy(vhr_raytraced_render_path *p) {
 
 int vhr_raytraced_build(vhr_raytraced_render_path *p) {
     if (!p) return VHR_ERROR_INVALID_ARGUMENT;
+    // (the display extent as the context has it NOW: after vhr_resize this is the second half of the reference's resize route, renderer.cpp:113-118)
+    uint32_t w = 0, h = 0;
+    if (vhr_get_display_size(p->context.handle, &w, &h) < 0) return VHR_ERROR_INVALID_ARGUMENT;
+    p->context.swapchain.extent = { w, h };
     return guarded(p, [&] { p->path.Build(); });
 }
 

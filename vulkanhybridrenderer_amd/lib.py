@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libvhr_amd.so")
 
 # every symbol include/vhr_amd.h declares (tests/test_abi.py checks the .so exports each of them)
 EXPORTS = [
-    "vhr_create", "vhr_destroy", "vhr_last_error", "vhr_synchronize", "vhr_version", "vhr_abi_struct_sizes",
+    "vhr_create", "vhr_destroy", "vhr_resize", "vhr_last_error", "vhr_synchronize", "vhr_version", "vhr_abi_struct_sizes",
     "vhr_default_trace_params", "vhr_update_geometry", "vhr_upload_texture_from_data", "vhr_upload_new_storage_image",
     "vhr_destroy_storage_image", "vhr_update_per_frame_ubo", "vhr_set_trace_params", "vhr_graph_destroy_resources",
     "vhr_graph_add_graphics_pass", "vhr_graph_add_raytracing_pass", "vhr_graph_add_compute_pass", "vhr_graph_build",
@@ -162,6 +162,7 @@ def load():
     L.vhr_last_error.argtypes = [vp]
     L.vhr_last_error.restype = C.c_char_p
     L.vhr_synchronize.argtypes = [vp]
+    L.vhr_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.vhr_version.restype = C.c_char_p
     L.vhr_abi_struct_sizes.argtypes = [C.POINTER(u32)]
     L.vhr_default_trace_params.argtypes = [vp]
@@ -361,6 +362,17 @@ class Context:
 
     def synchronize(self):
         self.check(self.L.vhr_synchronize(self.handle), "synchronize")
+
+    def display_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self.check(self.L.vhr_get_display_size(self.handle, C.byref(w), C.byref(h)), "display_size")
+        return int(w.value), int(h.value)
+
+    def resize(self, width, height):
+        """VulkanContext::Resize (renderer.cpp:113-118): the new display extent; the graph and the storage pool's images are released, geometry, the
+        acceleration structure, textures and options stay.  Follow with the render path's build()."""
+        self.check(self.L.vhr_resize(self.handle, int(width), int(height)), "resize")
+        self.width, self.height = int(width), int(height)
 
     # ---- ResourceManager ----
     def update_geometry(self, vertices, indices, primitives):
