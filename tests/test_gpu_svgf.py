@@ -359,8 +359,7 @@ def test_svgf_comp_fused_into_the_ray_tracing_tiles_changes_no_image():
             path.destroy()
         finally:
             c.close()
-    # ("raygen" counts two launches per frame: the queue kernel and the redo launch behind it, decision (vi))
-    assert outs[0][1:3] == (10, 20) and outs[1][1:3] == (0, 20)
+    assert outs[0][1:3] == (10, 10) and outs[1][1:3] == (0, 10)
     assert all(t > 0.0 for t in outs[0][3] + outs[1][3]), (outs[0][3], outs[1][3])
     for s, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         for k, (x, y) in enumerate(zip(a, b)):

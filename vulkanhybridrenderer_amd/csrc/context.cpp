@@ -286,29 +286,10 @@ void vhr_destroy(vhr_context *ctx) {
     hipFree(ctx->d_tile_counter);
     for (vhr_context::CostOrder *co : { &ctx->cost_order_raygen, &ctx->cost_order_reflection, &ctx->cost_order_raytraced })
         for (int i = 0; i < 2; ++i) { hipFree(co->cost[i]); hipFree(co->order[i]); }
-    for (vhr_context::RedoBuffers *r : { &ctx->redo_raygen, &ctx->redo_reflection, &ctx->redo_raytraced }) hipFree(r->base);
     for (auto &t : ctx->kernel_timers)
         for (hipEvent_t e : t.events) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
-}
-
-// one allocation per list: [count 0, count 1, pixels...]; both counters start at 0, launch n counts in counter n & 1 and its redo kernel zeroes the other
-int vhr_context::next_redo(RedoBuffers &b, uint32_t pixels, vhr::RedoList &out) {
-    if (b.capacity < pixels || !b.base) {
-        if (b.base) { (void)hipDeviceSynchronize(); (void)hipFree(b.base); b = RedoBuffers{}; }
-        uint32_t *base = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&base), (size_t(pixels) + 2) * 4) != hipSuccess) return fail(VHR_ERROR_DEVICE, "redo list: hipMalloc failed");
-        // (on the stream the list's first launch goes to: a memset on the null stream is not ordered against a non-blocking stream)
-        if (hipMemsetAsync(base, 0, 8, stream) != hipSuccess) { (void)hipFree(base); return fail(VHR_ERROR_DEVICE, "redo list: hipMemsetAsync failed"); }
-        b.base = base; b.capacity = pixels; b.slot = 0;
-    }
-    // the two counters are handed from launch to launch in stream order: a list that changes streams (frames in flight or the mirror ray's own
-    // stream switched on or off) waits once for whatever its last launch may still be doing
-    if (b.stream != stream) { if (b.stream) (void)hipDeviceSynchronize(); b.stream = stream; }
-    out.count = b.base + b.slot; out.count_next = b.base + (b.slot ^ 1u); out.pixels = b.base + 2; out.capacity = b.capacity;
-    b.slot ^= 1u;
-    return VHR_OK;
 }
 
 const char *vhr_last_error(const vhr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }

@@ -48,34 +48,35 @@ __device__ __forceinline__ bool solution_consistent(f3 o, f3 d, f3 v0, f3 e1, f3
     return fabsf(px - qx) <= 5e-4f + 5e-6f * fabsf(qx) && fabsf(py - qy) <= 5e-4f + 5e-6f * fabsf(qy) && fabsf(pz - qz) <= 5e-4f + 5e-6f * fabsf(qz);
 }
 
-// Moeller-Trumbore in binary64 (the oracle's mt_binary64, operation for operation): the fp32 operands and every product of two of them
-// are exact, every other operation rounds once in the order written (this unit is built with -ffp-contract=off), the quotients are IEEE
-// divisions; the comparisons are ray_triangle()'s and (t, u, v) come back rounded to fp32.  Not inlined: the rare path (none of the headline
-// frame's pairs, 6 % of the raytraced path's candidates) must not cost the walkers' loops a register.
-__device__ __attribute__((noinline)) bool mt_binary64(float ox_, float oy_, float oz_, float dx_, float dy_, float dz_, const BvhTri *tri, float tmin, float tmax,
-                                                      float &t, float &u, float &v) {
-    const float4 ta = reinterpret_cast<const float4 *>(tri)[0], tb = reinterpret_cast<const float4 *>(tri)[1];
-    const float tcx = reinterpret_cast<const float *>(tri)[8];
-    const double ox = ox_, oy = oy_, oz = oz_, dx = dx_, dy = dy_, dz = dz_;
-    const double ax = ta.w, ay = tb.x, az = tb.y, bx = tb.z, by = tb.w, bz = tcx;
-    const double px = dy * bz - dz * by, py = dz * bx - dx * bz, pz = dx * by - dy * bx;              // pvec = d x e2
-    const double det = (ax * px + ay * py) + az * pz;
+// Moeller-Trumbore in binary64 (the oracle's mt_binary64, operation for operation): the fp32 operands and every product of two of them are exact,
+// every other operation rounds once in the order written (this unit is built with -ffp-contract=off), the quotients are IEEE divisions; the comparisons
+// are ray_triangle()'s and (t, u, v) come back rounded to fp32.  Written for few live registers -- operands are widened where they are used, pvec and
+// tvec are the only vectors kept -- because it sits INSIDE the walkers' leaf tests: the any-hit queue kernel needs 72 registers with it (62 without;
+// seven instead of eight waves per SIMD: +1.3 % of the frame).  What was measured against that in round 6 (profiles/r6_decision_vi_cost.txt): a call
+// from the leaf test (13 registers and spills around the call: +5 % / +28 % on the two queue kernels), the same inlined under a forced 64-register
+// budget (+2.9 % of the frame), and the candidates' pixels handed to a second launch of the per-pixel kernel (a dependent launch on the frame's
+// critical path: the same +1.3 %, and 5-12 us per launch on a screen tile's short frame).
+__device__ __forceinline__ bool mt_binary64(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
+    const double px = double(d.y) * double(e2.z) - double(d.z) * double(e2.y);
+    const double py = double(d.z) * double(e2.x) - double(d.x) * double(e2.z);
+    const double pz = double(d.x) * double(e2.y) - double(d.y) * double(e2.x);
+    const double det = (double(e1.x) * px + double(e1.y) * py) + double(e1.z) * pz;
     if (det == 0.0) return false;
-    const double tx = ox - double(ta.x), ty = oy - double(ta.y), tz = oz - double(ta.z);              // tvec = o - v0
+    const double tx = double(o.x) - double(v0.x), ty = double(o.y) - double(v0.y), tz = double(o.z) - double(v0.z);
     const double uu = ((tx * px + ty * py) + tz * pz) / det;
     if (!(uu >= 0.0) || uu > 1.0) return false;
-    const double qx = ty * az - tz * ay, qy = tz * ax - tx * az, qz = tx * ay - ty * ax;              // qvec = tvec x e1
-    const double vv = ((dx * qx + dy * qy) + dz * qz) / det;
+    const double qx = ty * double(e1.z) - tz * double(e1.y), qy = tz * double(e1.x) - tx * double(e1.z), qz = tx * double(e1.y) - ty * double(e1.x);
+    const double vv = ((double(d.x) * qx + double(d.y) * qy) + double(d.z) * qz) / det;
     if (!(vv >= 0.0) || uu + vv > 1.0) return false;
-    const double tt = ((bx * qx + by * qy) + bz * qz) / det;
+    const double tt = ((double(e2.x) * qx + double(e2.y) * qy) + double(e2.z) * qz) / det;
     if (!(tt > double(tmin) && tt < double(tmax))) return false;
     t = float(tt); u = float(uu); v = float(vv);
     return true;
 }
 
 // Moeller-Trumbore, two-sided, det == 0 -> miss, accept iff tmin < t < tmax; a candidate whose solution contradicts itself is decided again in
-// binary64 (decision vi in DESIGN.md).  `tri` is the record v0 / e1 / e2 were read from.
-__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, const BvhTri *tri, float tmin, float tmax,
+// binary64 (decision vi in DESIGN.md).
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax,
                                              float &t, float &u, float &v) {
     f3 pvec = cross3(d, e2);
     float det = dot3(e1, pvec);
@@ -91,15 +92,14 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, co
     if (!(tt > tmin && tt < tmax)) return false;
     t = tt; u = uu; v = vv;
     if (solution_consistent(o, d, v0, e1, e2, tt, uu, vv)) return true;
-    return mt_binary64(o.x, o.y, o.z, d.x, d.y, d.z, tri, tmin, tmax, t, u, v);
+    return mt_binary64(o, d, v0, e1, e2, tmin, tmax, t, u, v);
 }
 
 // Moeller-Trumbore's comparisons without ray_triangle()'s early returns: the same operations in the same order on the same operands (a lane the
 // branching form would have sent home early computes on and fails the same comparison at the end; det == 0 gives inf / NaN quotients, which fail
 // every comparison, and is tested explicitly as well).  Used by the queue kernels' leaf stage, where the early returns buy nothing (some lane of
 // the wave always goes on) and cost a second memory round trip: the compiler sinks the load of v0 behind the `det == 0` return, so every triangle
-// test waited for memory twice.  true = a CANDIDATE; the caller accepts it if solution_consistent() and otherwise leaves the ray's pixel to the
-// redo launch (redo_append below): the binary64 path stays out of the queue kernels.
+// test waited for memory twice.  true = a CANDIDATE; the caller accepts it if solution_consistent() and decides it again with mt_binary64() if not.
 __device__ __forceinline__ bool mt_candidate(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
     const f3 pvec = cross3(d, e2);
     const float det = dot3(e1, pvec);
@@ -111,13 +111,6 @@ __device__ __forceinline__ bool mt_candidate(f3 o, f3 d, f3 v0, f3 e1, f3 e2, fl
     const float tt = dot3(e2, qvec) * inv;
     t = tt; u = uu; v = vv;
     return det != 0.0f && uu >= 0.0f && !(uu > 1.0f) && vv >= 0.0f && !(uu + vv > 1.0f) && tt > tmin && tt < tmax;
-}
-
-// A queue kernel leaves the pixel of a ray with a self-contradicting candidate to the launch that follows (vhr::RedoList).  Duplicates are
-// harmless (the redo is idempotent); past the capacity the redo launch traces its whole rectangle.
-__device__ __forceinline__ void redo_append(const RedoList &r, uint32_t pixel) {
-    const uint32_t i = atomicAdd(r.count, 1u);
-    if (i < r.capacity) r.pixels[i] = pixel;
 }
 
 // Slab test of one child box against [tmin, tlimit]; NaNs from 0 * inf drop out of fminf/fmaxf
@@ -202,7 +195,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
                 const float4 a = tp[0], b = tp[1];
                 const float4 c = tp[2];
                 float t, u, w;
-                if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, sc.tris + first + i, tmin, tmax, t, u, w)) {
+                if (ray_triangle(o, d, f3{ a.x, a.y, a.z }, f3{ a.w, b.x, b.y }, f3{ b.z, b.w, c.x }, tmin, tmax, t, u, w)) {
                     if (ALPHA && alpha_ignored(sc, first + i, u, w)) continue;
                     if (ANY_HIT) return true;
                     const uint32_t flat = __float_as_uint(c.w);
@@ -447,7 +440,6 @@ struct RaygenArgs {
     uint32_t fuse_temporal;  // 0 = off
     TemporalArgs temporal;
     CostOrderArgs co;        // "raygen_cost_order" (the default queue kernel, the mirror-ray queue kernel)
-    RedoList redo;           // the queue kernels: where a ray with a self-contradicting candidate leaves its pixel (decision vi)
 };
 
 __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32_t row_begin) {
@@ -499,13 +491,6 @@ __device__ __forceinline__ void raygen_pixel(const RaygenArgs &a, const uint32_t
     }
     if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
     store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
-    if (a.fuse_temporal) {                // (the redo launch behind a queue kernel that ran svgf.comp in its tiles' epilogues: once more for this pixel)
-        const TemporalArgs &t = a.temporal;
-        if (x >= t.col_begin && x < t.limit_x && y >= t.row_begin && y < t.row_end && y < t.limit_y) {
-            const float2 cur = unpack_rg16f(pack_rg16f(shadow_payload, ao_payload));     // what the RG16F image holds
-            svgf_temporal_pixel(t, x, y, nid, cur.x, cur.y);
-        }
-    }
 
     if (a.reflections) {
         f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -537,36 +522,6 @@ __global__ __launch_bounds__(kTraceBlock) void raygen_kernel(const RaygenArgs a,
             if (sec) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)__popcll(sec));
         }
     }
-}
-
-// The launch behind a queue kernel's (decision (vi), vhr::RedoList): the listed pixels once more, one per thread, by the per-pixel body --
-// whose walker decides a self-contradicting candidate in binary64.  `rect` = (col_begin, col_end, row_begin, row_end) of the queue kernel's launch,
-// traced as a whole if the list overflowed.  The launch also zeroes the counter of the list's next launch.
-template <typename Body>
-__device__ __forceinline__ void redo_pixels(const RedoList &r, const uint32_t W, const uint32_t col_begin, const uint32_t col_end, const uint32_t row_begin,
-                                            const uint32_t row_end, Body body) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *r.count_next = 0u;
-    const uint32_t appended = *r.count;
-    if (appended == 0u) return;
-    const bool all = appended > r.capacity;
-    const uint32_t cols = col_end - col_begin;
-    const uint32_t n = all ? cols * (row_end - row_begin) : appended;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t pixel = all ? (row_begin + i / cols) * W + col_begin + i % cols : r.pixels[i];
-        body(pixel % W, pixel / W);
-    }
-}
-constexpr int kRedoBlocks = 16;
-
-__global__ __launch_bounds__(kTraceBlock) void raygen_redo_kernel(const RaygenArgs a, const Stamps st) {
-    vhr_stamp(st);
-    __shared__ int s_stack[kTraceStack * kTraceBlock];
-    int *stack = s_stack + threadIdx.x;
-    redo_pixels(a.redo, a.width, a.col_begin, a.col_end, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
-        uint32_t overflow = 0;
-        bool covered = false, second_ray = false;
-        raygen_pixel(a, x, y, stack, overflow, covered, second_ray);
-    });
 }
 
 
@@ -1377,8 +1332,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                         found = true;
                         break;
                     }
-                    // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
-                    redo_append(a.redo, (y - (lane >> 3) + (pix >> 3)) * W + (x - (lane & 7u) + (pix & 7u)));
+                    // decision (vi): a candidate that contradicts itself is decided again in binary64
+                    if (mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, ct, cu, cv)) { found = true; break; }
                 }
             }
         };
@@ -1522,21 +1477,9 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
     }
 }
 
-// ... the pixels the mirror ray's queue kernel left to the binary64 path (decision (vi), vhr::RedoList)
-__global__ __launch_bounds__(kTraceBlock) void reflection_redo_kernel(const RaygenArgs a, const Stamps st) {
-    vhr_stamp(st);
-    __shared__ int s_refl_stack[kTraceStack * kTraceBlock];
-    int *stack = s_refl_stack + threadIdx.x;
-    redo_pixels(a.redo, a.width, a.col_begin, a.col_end, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
-        bool second_ray = false;
-        reflection_pixel(a, x, y, stack, second_ray);
-    });
-}
-
 // ---------------------------------------------------------------------------------------------
 // One pass of a wave over its ray queue (`total` rays; fetch(r, pix, origin, direction) delivers the r-th one and the id of
-// its pixel (< 2^31), commit(pix, triangle, u, v) takes its result, kNoHit = miss; bit 31 of pix set = the ray met a candidate
-// that contradicts itself and its pixel belongs on the redo list -- decision (vi), vhr::RedoList).  Lanes pull rays whenever `refill_threshold` of
+// its pixel, commit(pix, triangle, u, v) takes its result, kNoHit = miss).  Lanes pull rays whenever `refill_threshold` of
 // them are idle and walk the BVH "while-while" with the node step of raygen_queue_kernel: packed-FMA slabs against 1/d and
 // -o/d, near child first, far child pushed, boxes culled against the closest t so far (tn <= tbest keeps equal-t candidates:
 // decision vi), early exit of the node loop, LDS stack + scratch spill.  Leaves: every triangle, Moeller-Trumbore against the
@@ -1631,9 +1574,8 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 if (STATS) ++my_tris;
                 const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
                 if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) {
-                    // decision (vi): a candidate that contradicts itself is decided in binary64 -- by the redo launch, for the whole pixel
-                    // (bit 31 of the pixel id tells commit(); the walk goes on as if the candidate were a miss)
-                    if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) { pix |= 0x80000000u; continue; }
+                    // decision (vi): a candidate that contradicts itself is decided again in binary64
+                    if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww) && !mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) continue;
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
                     const uint32_t flat = __float_as_uint(tc.w);
                     if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
@@ -1785,10 +1727,6 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             rd = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
-            if (pix >> 31) {              // decision (vi): the pixel goes to the redo launch (its record here is whatever the walk ended with)
-                pix &= 0x7fffffffu;
-                redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + a.col_begin + tile_x * (8u * SUBS) + (pix >> 6) * 8u + (pix & 7u));
-            }
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
         }, &wc);
     wave_lds_sync();
@@ -1923,8 +1861,7 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
     RaygenArgs a = a_in;
     a.co = CostOrderArgs{};
-    a.redo = RedoList{};
-    if (ctx->options[kOptRaygenVariant] != 0 && ctx->next_redo(ctx->redo_raygen, width * height, a.redo) != VHR_OK) return;
+    (void)height;
     ctx->time_begin(kKernelRaygen);
     if (ctx->options[kOptRaygenVariant] == 0) {
         launch(ctx, raygen_kernel, dim3((width + 15) / 16, (a.row_end - a.row_begin + 15) / 16), dim3(kTraceBlock), 0, a);
@@ -1978,11 +1915,6 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
         if (wv == 4u) by_flags(std::integral_constant<int, 4>{});
         else if (wv == 2u) by_flags(std::integral_constant<int, 2>{});
         else by_flags(std::integral_constant<int, 1>{});
-        // decision (vi): the pixels whose rays met a self-contradicting candidate, once more by the per-pixel body (shadow / AO only: the mirror
-        // ray has a launch and a list of its own)
-        RaygenArgs r = a;
-        r.reflections = nullptr; r.stats = nullptr; r.co = CostOrderArgs{};
-        launch(ctx, raygen_redo_kernel, dim3(kRedoBlocks), dim3(kTraceBlock), 0, r);
     }
     ctx->time_end(kKernelRaygen);
 }
@@ -2125,16 +2057,10 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
 #define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
-            if (ctx->next_redo(ctx->redo_reflection, width * height, m.redo) != VHR_OK) return VHR_ERROR_DEVICE;
             if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }
             else { if (spill) VHR_LAUNCH_REFL_S(true, 1); else VHR_LAUNCH_REFL_S(false, 1); }
 #undef VHR_LAUNCH_REFL_S
 #undef VHR_LAUNCH_REFL
-            {   // decision (vi): the pixels whose mirror ray met a self-contradicting candidate, once more by the per-pixel body
-                RaygenArgs r = m;
-                r.stats = nullptr; r.co = CostOrderArgs{};
-                launch(ctx, reflection_redo_kernel, dim3(kRedoBlocks), dim3(kTraceBlock), 0, r);
-            }
         } else {
             launch(ctx, reflection_kernel, dim3((width + 15) / 16, (owned_end - owned_begin + 15) / 16), dim3(kTraceBlock), 0, m);
         }
@@ -2229,7 +2155,6 @@ struct RaytracedArgs {
     uint32_t row_begin, row_end;
     RayStats *stats;         // nullptr = off; covered_pixels counts the primary hits (= shadow rays)
     CostOrderArgs co;        // "raygen_cost_order" (the queue kernel)
-    RedoList redo;           // the queue kernel: where a ray with a self-contradicting candidate leaves its pixel (decision vi)
 };
 
 __device__ __forceinline__ uint32_t unorm8(float f);
@@ -2278,19 +2203,6 @@ __global__ __launch_bounds__(kTraceBlock) void raytraced_kernel(const RaytracedA
             if (ovf) atomicAdd(&a.stats->stack_overflows, (unsigned long long)__popcll(ovf));
         }
     }
-}
-
-// ... the pixels the queue kernel left to the binary64 path (decision (vi), vhr::RedoList)
-template <bool ALPHA>
-__global__ __launch_bounds__(kTraceBlock) void raytraced_redo_kernel(const RaytracedArgs a, const Stamps st) {
-    vhr_stamp(st);
-    __shared__ int s_rt_stack[kTraceStack * kTraceBlock];
-    int *stack = s_rt_stack + threadIdx.x;
-    redo_pixels(a.redo, a.width, 0u, a.width, a.row_begin, a.row_end, [&](uint32_t x, uint32_t y) {
-        uint32_t overflow = 0;
-        bool hit_any = false;
-        raytraced_pixel<ALPHA>(a, x, y, stack, overflow, hit_any);
-    });
 }
 
 // Work-queue form (default, `raytraced_variant` 1): a wave owns a 16x8-pixel tile and runs wave_queue_walk twice -- the
@@ -2358,7 +2270,6 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             rd = f3{ s_ray[0][pix], s_ray[1][pix], s_ray[2][pix] };
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {
-            if (pix >> 31) { pix &= 0x7fffffffu; redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u)); }   // decision (vi)
             s_ray[0][pix] = __uint_as_float(tri); s_ray[1][pix] = u; s_ray[2][pix] = v;
         });
     wave_lds_sync();
@@ -2394,10 +2305,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             ro = f3{ s_ray[3][pix], s_ray[4][pix], s_ray[5][pix] };
             rd = light_dir;
         },
-        [&](uint32_t pix, uint32_t tri, float, float) {
-            if (pix >> 31) { pix &= 0x7fffffffu; redo_append(a.redo, (a.row_begin + tile_y * 8u + ((pix & 63u) >> 3)) * W + tile_x * 16u + (pix >> 6) * 8u + (pix & 7u)); }   // decision (vi)
-            s_ray[3][pix] = __uint_as_float(tri);
-        });
+        [&](uint32_t pix, uint32_t tri, float, float) { s_ray[3][pix] = __uint_as_float(tri); });
     wave_lds_sync();
     // ---- closesthit.rchit / miss.rmiss and the image store, whole wave ----
 #pragma unroll
@@ -2451,16 +2359,9 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
             prepare_cost_order(ctx, ctx->cost_order_raytraced, (tiles_total + 1u) / 2u, 2u,
                                (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co);
 #define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
-        if (ctx->next_redo(ctx->redo_raytraced, width * height, a.redo) != VHR_OK) return VHR_ERROR_DEVICE;
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }
 #undef VHR_LAUNCH_RT
-        {   // decision (vi): the pixels whose rays met a self-contradicting candidate, once more by the per-pixel body
-            RaytracedArgs r = a;
-            r.stats = nullptr; r.co = CostOrderArgs{};
-            if (alpha_test) launch(ctx, raytraced_redo_kernel<true>, dim3(kRedoBlocks * 16), dim3(kTraceBlock), 0, r);
-            else launch(ctx, raytraced_redo_kernel<false>, dim3(kRedoBlocks * 16), dim3(kTraceBlock), 0, r);
-        }
     } else if (alpha_test) {
         launch(ctx, raytraced_kernel<true>, grid, dim3(kTraceBlock), 0, a);
     } else {

@@ -107,20 +107,6 @@ struct DeviceTexture {
     int32_t pad;
 };
 
-// Decision (vi), second half, in the work-queue kernels: a candidate of fp32 Moeller-Trumbore whose solution contradicts
-// itself is decided again in binary64 -- not inside the queue kernels (a call there costs the walk 13 registers and 5-28 % of its time, measured in
-// round 6) but by a launch of its own: the queue kernel treats the candidate as a miss and APPENDS THE PIXEL here, and the launch that follows
-// traces the listed pixels again with the per-pixel kernel, whose walker has the binary64 path.  count may run past capacity (duplicates, a
-// pathological scene): the redo launch then traces every pixel of the launch's rectangle.  Two counters, used in turn: the redo launch behind the
-// queue kernel that counted in `count` zeroes `count_next`, the one the next queue kernel of this list will count in (nothing else touches it
-// in between: launches of one list are issued on one stream, in order) -- no memset, no ticket.
-struct RedoList {
-    uint32_t *count = nullptr;       // pixels appended by this launch's queue kernel
-    uint32_t *count_next = nullptr;  // the counter of the list's next launch: zeroed by this launch's redo kernel
-    uint32_t *pixels = nullptr;      // y * width + x
-    uint32_t capacity = 0;
-};
-
 struct DeviceScene {
     const BvhNode *nodes;
     const BvhNode16 *nodes16;
@@ -469,11 +455,6 @@ struct vhr_context {
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
     };
     CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
-    // the pixels a queue kernel's launch leaves to the per-pixel kernel (vhr::RedoList): one list per queue kernel (their launches may run on
-    // different streams), grown to the image's pixel count on first use
-    struct RedoBuffers { uint32_t *base = nullptr; uint32_t capacity = 0, slot = 0; hipStream_t stream = nullptr; };
-    RedoBuffers redo_raygen, redo_reflection, redo_raytraced;
-    int next_redo(RedoBuffers &b, uint32_t pixels, vhr::RedoList &out);      // the list of the launch about to be issued (allocates on first use)
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never
     // pushes it to that pipeline (hybrid_render_path.cpp:151-167; the blur pass gets the constants instead, :182-197)
     float ssao_radius = 0.75f;
