@@ -371,6 +371,7 @@ typedef struct vhr_strip_plan {
 typedef struct vhr_row_exchange { int32_t peer; uint32_t send_begin, send_end, recv_begin, recv_end; } vhr_row_exchange;
 /* Screen tiles: a grid of grid_rows x grid_cols rectangles, rank = tile_row * grid_cols + tile_col; tile (r, c) owns columns
  * [c*W/C, (c+1)*W/C) and rows [r*H/R, (r+1)*H/R).  Row strips are the one-column grid. */
+#define VHR_TILE_MAX_GRID 16        /* tiles per axis */
 typedef struct vhr_tile_plan {
     uint32_t rank, world, width, height;
     uint32_t grid_rows, grid_cols;
@@ -378,6 +379,10 @@ typedef struct vhr_tile_plan {
     uint32_t overlap;                /* E: pixels the SVGF kernels recompute beyond the rectangle, on every cut side */
     uint32_t halo_rows, halo_cols;   /* E + ceil(max |motion| * extent) + 2 on a cut axis (E on an axis that is not cut): the margin of
                                       * history / moments fetched from the neighbours */
+    /* the grid's cut lines: tile (r, c) owns columns [col_cut[c], col_cut[c + 1]) and rows [row_cut[c][r], row_cut[c][r + 1]) -- every COLUMN of tiles has its
+     * own row cuts (vhr_tile_plan_make: the same in every column, at equal pixels; vhr_tile_plan_make_weighted: the columns split the cost, then every column
+     * splits its own).  col_cut[0] = row_cut[c][0] = 0, col_cut[grid_cols] = width, row_cut[c][grid_rows] = height.  Entries past the grid are 0. */
+    uint32_t col_cut[VHR_TILE_MAX_GRID + 1], row_cut[VHR_TILE_MAX_GRID][VHR_TILE_MAX_GRID + 1];
 } vhr_tile_plan;
 typedef struct vhr_rect { uint32_t x0, x1, y0, y1; } vhr_rect;                 /* [x0, x1) x [y0, y1) */
 typedef struct vhr_rect_exchange { int32_t peer; vhr_rect send, recv; } vhr_rect_exchange;     /* an empty rectangle is all zeros */
@@ -396,6 +401,16 @@ int vhr_tile_grid_choose(uint32_t width, uint32_t height, uint32_t world, uint32
 /* grid_rows == 0 or grid_cols == 0: vhr_tile_grid_choose picks the grid.  VHR_ERROR_OUT_OF_SLOTS when a tile is thinner than its halo. */
 int vhr_tile_plan_make(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
                        uint32_t max_motion_cols, uint32_t atrous_steps, vhr_tile_plan *out);
+/* The same grid cut at EQUAL COST instead of equal pixels (round 6).  cost[cy * cost_cols + cx] = what the (cell x cell)-pixel block at
+ * (cx * cell, cy * cell) costs to trace -- e.g. the any-hit queue kernel's wave lifetimes of a whole-image frame (vhr_debug_wave_lifetimes: one
+ * word per 8 x 8 tile, cell = 8); cost_cols >= ceil(width / cell), cost_rows >= ceil(height / cell).  Column cuts split the column sums, row cuts the
+ * cost inside each column of tiles (a column's row cuts are its own: tiles of neighbouring columns meet at different heights, which the exchanges -- rectangle
+ * intersections with every peer -- do not mind): cut j is the first cell boundary at which the running sum reaches j / n of the total, moved as far as the
+ * halos require (no tile thinner than its halo).  cost == NULL or an all-zero map: equal pixels.  Placement
+ * only: the images are those of any other plan, bit for bit.  Every rank must be given the same map. */
+int vhr_tile_plan_make_weighted(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
+                                uint32_t max_motion_cols, uint32_t atrous_steps, const uint32_t *cost, uint32_t cost_cols, uint32_t cost_rows, uint32_t cell,
+                                vhr_tile_plan *out);
 /* the rectangles a margin of (halo_rows, halo_cols) pixels takes from / gives to each peer (up to 8); returns their number or < 0 */
 int vhr_tile_plan_exchanges(const vhr_tile_plan *plan, uint32_t halo_rows, uint32_t halo_cols, vhr_rect_exchange *out, uint32_t capacity);
 
@@ -540,6 +555,10 @@ const char *vhr_source_fingerprint(void);
 /* Diagnostics: the lifetimes (shader clock ticks) of the last ray-tracing launch's waves, as left for "raygen_cost_order"
  * (index = tile pair * waves per workgroup + wave); *count = entries written. */
 int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity, uint32_t *count);
+/* What the last frame's rays cost, where: those lifetimes -- the any-hit launch's and the mirror ray's -- summed into a map of 8 x 8-pixel cells,
+ * out[cy * cols + cx], cols >= ceil(width / 8), rows >= ceil(height / 8).  The cost map vhr_tile_plan_make_weighted cuts a grid by (cell = 8).
+ * VHR_ERROR_NOT_FOUND when no queue kernel has left lifetimes ("raygen_cost_order" 0, or 1 on launches below 2 048 workgroups: set it to 2). */
+int vhr_get_tile_cost_map(vhr_context *ctx, uint32_t *out, uint32_t cols, uint32_t rows);
 
 int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
 /* The same for the mirror-ray launch of the last vhr_trace_rays (raygen.rgen:59-65 + reflection_hit.rchit; the queue kernel, statistics

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None, tp=None):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None, tp=None, cost=None):
     """`world` contexts on one GPU, one thread each, each computing its strip (grid "strips") or screen tile (grid (rows, cols) or None =
     the planner's choice) with host-side copies standing in for the RCCL exchanges.  Returns (plans, per-rank per-frame (raytraced,
     denoised, reflections or None) cut to the owned rectangle).  `tp`: the trace parameters (default: shadows + 2 AO rays, no mirror ray);
@@ -23,7 +23,7 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
     if tp is None:
         tp = abi.default_trace_params(reflections=False)
     refl = bool(tp["reflections"])
-    plans = [tiling.make_tile_plan(W, H, world, r, max_motion_rows, max_motion_cols, grid=grid) for r in range(world)]
+    plans = [tiling.make_tile_plan(W, H, world, r, max_motion_rows, max_motion_cols, grid=grid, cost=cost) for r in range(world)]
     ranks = [GpuHybrid(scene, W, H, shadow=bool(tp["shadow_enable"]), ao=bool(tp["ao_spp"]), reflections=refl, trace_params=tp, gbuffer="standin") for _ in range(world)]
     barrier = threading.Barrier(world)
     results = [[] for _ in range(world)]
@@ -134,6 +134,39 @@ def test_virtual_screen_tiles_bit_identical(world, grid, trace_overlap, shrink):
     if grid:
         assert (plans[0].grid_rows, plans[0].grid_cols) == grid
     _check_against_reference(plans, results, ref)
+
+
+def test_cost_balanced_tiles_bit_identical_and_the_library_cost_map():
+    """The grid cut at equal COST (round 6): the cost map is the library's own (vhr_get_tile_cost_map: the wave lifetimes of a whole-image frame's ray
+    launches per 8 x 8 cell), the plan vhr_tile_plan_make_weighted's / tiling's; the columns of tiles are cut at their own heights -- and six contexts on
+    those rectangles reproduce the single context's frames bit for bit, the mirror ray included.  Placement only."""
+    scene = scenes.sponza_proc(0.3)
+    W, H = 320, 264
+    tp = abi.default_trace_params(ao_spp=2, reflections=1)
+    pfds = camera.dolly_frames(scene, W, H, 4)
+    ref, mv_rows, mv_cols = _single_context_reference(scene, W, H, pfds, tp)
+    g = GpuHybrid(scene, W, H, trace_params=tp, gbuffer="standin")
+    try:
+        g.ctx.set_option("raygen_cost_order", 2)             # every launch leaves its wave lifetimes
+        for pfd in pfds[:2]:
+            g.frame(pfd)
+        cost = g.ctx.tile_cost_map()
+    finally:
+        g.close()
+    assert cost.shape == ((H + 7) // 8, (W + 7) // 8) and cost.sum(dtype=np.uint64) > 0 and (cost > 0).mean() > 0.5
+    plans, results = _run_strips(scene, W, H, 6, pfds, mv_rows, True, True, grid=(2, 3), max_motion_cols=mv_cols, tp=tp, cost=cost)
+    equal = [tiling.make_tile_plan(W, H, 6, r, mv_rows, mv_cols, grid=(2, 3)) for r in range(6)]
+    assert [p.rect for p in plans] != [p.rect for p in equal]
+    for r, p in enumerate(plans):                            # the C planner: the same rectangles from the same map
+        c = lib.tile_plan(W, H, 6, r, 2, 3, mv_rows, mv_cols, 5, cost=cost)
+        assert (c.col_begin, c.col_end, c.row_begin, c.row_end) == p.rect
+    _check_against_reference(plans, results, ref)
+    # the feedback step: a rank that took twice as long gets a smaller rectangle next time
+    times = [1.0] * 6
+    times[0] = 2.0
+    again = [tiling.make_tile_plan(W, H, 6, r, mv_rows, mv_cols, grid=(2, 3), cost=tiling.refine_cost_map(cost, plans, times)) for r in range(6)]
+    area = lambda p: (p.col_end - p.col_begin) * (p.row_end - p.row_begin)   # noqa: E731
+    assert area(again[0]) < area(plans[0])
 
 
 @pytest.mark.parametrize("bounces,ao_spp,refl_async,side", [(1, 2, 0, 0), (1, 2, 1, 2), (1, 2, 2, 2), (2, 2, 1, 1), (2, 5, 2, 2)])

@@ -62,18 +62,19 @@ def test_strips_equal_single_process_gloo(oracle, tmp_path, world, shrink, strip
     assert int(overlap) == 30
 
 
-@pytest.mark.parametrize("world,grid,strip_shrink,shrink", [(4, "2x2", 1, 0), (4, "2x2", 0, 0), (2, "1x2", 1, 0), (4, "2x2", 0, 1)])
-def test_screen_tiles_equal_single_process_gloo(oracle, tmp_path, world, grid, strip_shrink, shrink):
+@pytest.mark.parametrize("world,grid,strip_shrink,shrink,cost", [(4, "2x2", 1, 0, 0), (4, "2x2", 0, 0, 0), (2, "1x2", 1, 0, 0), (4, "2x2", 0, 1, 0), (4, "2x2", 1, 0, 1)])
+def test_screen_tiles_equal_single_process_gloo(oracle, tmp_path, world, grid, strip_shrink, shrink, cost):
     """The same check for SCREEN TILES (a grid of rows x cols rectangles, corner neighbours included): every pixel a rank did not
     compute or receive is NaN, each rank's owned rectangle and the frame gathered on rank 0 equal the single-process result; one
-    pixel less of overlap (the negative control) is caught."""
+    pixel less of overlap (the negative control) is caught.  cost = 1: the grid cut at equal COST (tiling.make_tile_plan(cost=...), round 6): the two columns
+    of tiles are cut at different heights, a tile has two neighbours on that side -- placement only, the same images."""
     out = tmp_path / "result.txt"
-    port = 29811 + world + 10 * strip_shrink + 40 * shrink + (5 if grid == "1x2" else 0)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", VHR_TEST_GRID=grid,
+    port = 29811 + world + 10 * strip_shrink + 40 * shrink + (5 if grid == "1x2" else 0) + 7 * cost
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", VHR_TEST_GRID=grid, VHR_TEST_COST_MAP="1" if cost else "",
                VHR_TEST_SHRINK_OVERLAP=str(shrink), VHR_TEST_STRIP_SHRINK=str(strip_shrink), VHR_TEST_STRIP_SHRINK_BIAS="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "96", "112", "4"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", str(port), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out)] + (["160", "184", "3"] if cost else ["96", "112", "4"])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)      # (the larger image: room for the cuts to move beside the 33-pixel halos)
     assert r.returncode == 0, r.stderr[-2000:]
     bad, overlap, halo = out.read_text().split()
     if shrink:

@@ -42,7 +42,13 @@ def main():
         return max(float(np.nanmax(np.abs(g[1].view(np.float16)[..., ch].astype(np.float32)[g[2] != 0]), initial=0.0)) * extent for g in gbufs[1:])
     grid = os.environ.get("VHR_TEST_GRID", "strips")          # "strips" or "RxC" screen tiles
     grid = "strips" if grid == "strips" else tuple(int(v) for v in grid.split("x"))
-    plan = tiling.make_tile_plan(W, H, world, rank, int(np.ceil(max_motion(1, H))), int(np.ceil(max_motion(0, W))), grid=grid)
+    cost = None
+    if os.environ.get("VHR_TEST_COST_MAP"):                    # a hot spot low on the left: the grid is cut at equal cost, every column of tiles at its own heights
+        ys, xs = np.mgrid[0:(H + 7) // 8, 0:(W + 7) // 8]
+        cost = (10 + 500 * np.exp(-((xs - 2) ** 2 + (ys - (H // 8 - 3)) ** 2) / 8.0)).astype(np.uint32)
+    plan = tiling.make_tile_plan(W, H, world, rank, int(np.ceil(max_motion(1, H))), int(np.ceil(max_motion(0, W))), grid=grid, cost=cost)
+    if cost is not None and plan.grid_rows > 1 and plan.grid_cols > 1:
+        assert len(set(plan.row_cuts)) > 1 and plan != tiling.make_tile_plan(W, H, world, rank, int(np.ceil(max_motion(1, H))), int(np.ceil(max_motion(0, W))), grid=grid)
     shrink = int(os.environ.get("VHR_TEST_SHRINK_OVERLAP", "0"))      # negative control: a too-small overlap must be caught
     if shrink:
         import dataclasses

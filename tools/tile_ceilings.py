@@ -7,6 +7,9 @@ frame (Raytrace Pass + SVGF Denoise Pass) is timed by wall clock: what an N-GPU 
 --sweep: at every N the options that can matter for a thin launch are toggled ONE AT A TIME against the defaults, the ones that gain more than
          1 % are combined and re-measured (one JSON line per arm; the winners go to harness.TILE_TUNING by tile area)
 --tuned: apply harness.tuned_tile_options(computed pixels) at every N (what HybridFrameLoop does for world > 1)
+--balance: (round 6) instead of the ceilings: at N = 4 and 8, EVERY rank's frame time on the equal-pixel grid and on the grid cut at equal cost
+         (vhr_tile_plan_make_weighted on the whole-image frame's wave lifetimes, Context.tile_cost_map()): busiest, mean, busiest / mean -- what a
+         cost-balanced planner takes off the slowest rank
 Also prints, per N, the projection of DESIGN.md section 5: exchange bytes of the busiest rank (history + moments halo, gather share), their
 time at one xGMI link's 153 GB/s, and ceiling + that time (exposed) next to max(ceiling, that time) (overlapped behind the next frame's rays)."""
 import json, os, sys, time
@@ -72,6 +75,41 @@ def exchange_bytes(plan):
 
 
 area = lambda p: (p.computed_rect()[1] - p.computed_rect()[0]) * (p.computed_rect()[3] - p.computed_rect()[2])
+if "--balance" in flags:
+    loop.ctx.set_option("raygen_cost_order", 2)            # every launch leaves its wave lifetimes
+    for i in range(6):
+        loop.frame(i)
+    torch.cuda.synchronize(); loop.ctx.synchronize()
+    rays = loop.ctx.tile_cost_map()
+    # what the map does not see: the SVGF pass, whose cost goes by pixels -- added as a constant per cell, in the pass times' proportion
+    loop.ctx.gather_performance_statistics()
+    rt_ms, svgf_ms = loop.ctx.pass_time_ms("Raytrace Pass")[1], loop.ctx.pass_time_ms("SVGF Denoise Pass")[1]
+    per_cell = float(rays.sum(dtype=np.float64)) / rays.size * (svgf_ms / max(1e-9, rt_ms))
+    cost = (rays.astype(np.float64) + per_cell).astype(np.uint32)
+    whole = tiling.make_tile_plan(W, H, 1, 0)
+    t1 = measure(whole, 1)
+    print(json.dumps({"config": name, "n": 1, "ms_per_frame": round(t1, 4), "pass_ms": [round(rt_ms, 4), round(svgf_ms, 4)], "cost_map": {"cells": list(cost.shape), "rays_max_over_mean": round(float(rays.max() / max(1.0, rays.mean())), 2), "per_cell_constant_for_the_svgf_pass": round(per_cell)}}), flush=True)
+    for n in (4, 8):
+        refined = cost
+        arms = [("equal pixels", None), ("equal cost", cost)] + [(f"equal cost, refined by the ranks' measured times ({k})", "refine") for k in (1, 2, 3)]
+        for label, c in arms:
+            if isinstance(c, str):
+                # what a running system has for free: every rank's frame time (8 floats to all-gather).  Inside each rank's rectangle the map is scaled by
+                # (the rank's share of the summed times) / (its share of the map): the next plan moves the cuts towards the ranks that took longer than their cost said
+                refined = tiling.refine_cost_map(refined, plans, ts)
+                c = refined
+            try:
+                plans = [tiling.make_tile_plan(W, H, n, r, loop.max_motion_rows, loop.max_motion_cols, grid=None, cost=c) for r in range(n)]
+            except ValueError as e:
+                print(f"{name} N={n} {label}: {e}", flush=True); continue
+            ts = [measure(p, n) for p in plans]
+            full = np.kron(cost.astype(np.float64) / 64.0, np.ones((8, 8)))[:H, :W]
+            shares = [float(full[p.row_begin:p.row_end, p.col_begin:p.col_end].sum() / full.sum()) for p in plans]
+            print(json.dumps({"config": name, "n": n, "plan": label, "grid": f"{plans[0].grid_rows}x{plans[0].grid_cols}", "col_cuts": list(plans[0].col_cuts), "row_cuts": [list(rc) for rc in plans[0].row_cuts],
+                              "ms_per_rank": [round(t, 4) for t in ts], "busiest_ms": round(max(ts), 4), "mean_ms": round(float(np.mean(ts)), 4), "busiest_over_mean": round(max(ts) / float(np.mean(ts)), 3),
+                              "share_of_linear_pct_by_the_busiest": round(100.0 * t1 / (n * max(ts)), 1), "cost_share_of_the_busiest_rank": round(max(shares), 4), "cost_share_ideal": round(1.0 / n, 4)}), flush=True)
+    loop.close()
+    sys.exit(0)
 base = None
 for n in (1, 2, 4, 8):
     try:

@@ -92,6 +92,54 @@ void tile_bounds(uint32_t width, uint32_t height, uint32_t grid_rows, uint32_t g
     out.y0 = uint32_t(uint64_t(tr) * height / grid_rows);
     out.y1 = uint32_t(uint64_t(tr + 1) * height / grid_rows);
 }
+// ... of a plan: by its cut lines
+void plan_tile(const vhr_tile_plan &p, uint32_t tr, uint32_t tc, vhr_rect &out) {
+    out.x0 = p.col_cut[tc]; out.x1 = p.col_cut[tc + 1];
+    out.y0 = p.row_cut[tc][tr]; out.y1 = p.row_cut[tc][tr + 1];
+}
+// n + 1 cut lines of [0, extent) at equal cost: `marginal` holds the cost of every cell-pixel-wide slab.  Cut j = the first cell boundary at which the running
+// sum reaches j / n of the total, then moved so that every tile is at least min_px wide (the halo) -- left to right, then right to left.  Returns false
+// if n tiles of min_px do not fit.
+bool balanced_cuts(const std::vector<uint64_t> &marginal, uint32_t cell, uint32_t extent, uint32_t n, uint32_t min_px, uint32_t *cuts) {
+    bool weighted = false;
+    const uint32_t cells = uint32_t(marginal.size());
+    uint64_t total = 0;
+    for (uint64_t v : marginal) total += v;
+    cuts[0] = 0; cuts[n] = extent;
+    if (total == 0 || cells == 0) { for (uint32_t j = 1; j < n; ++j) cuts[j] = uint32_t(uint64_t(j) * extent / n); }
+    else {
+        weighted = true;
+        uint64_t run = 0;
+        uint32_t b = 0;
+        for (uint32_t j = 1; j < n; ++j) {
+            while (b < cells && run * n < total * j) run += marginal[b++];
+            cuts[j] = uint32_t(std::min<uint64_t>(extent, uint64_t(b) * cell));
+        }
+    }
+    if (n > 1 && uint64_t(min_px) * n > extent) return false;
+    if (weighted) {                                    // (equal-pixel cuts are never moved: a tile thinner than its halo is the caller's to hear about)
+        for (uint32_t j = 1; j < n; ++j) cuts[j] = std::max(cuts[j], cuts[j - 1] + std::max(1u, min_px));
+        for (uint32_t j = n - 1; j >= 1; --j) cuts[j] = std::min(cuts[j], cuts[j + 1] - std::max(1u, min_px));
+    }
+    for (uint32_t j = 1; j <= n; ++j) if (cuts[j] <= cuts[j - 1] || cuts[j] - cuts[j - 1] < min_px) return false;
+    return true;
+}
+// what vhr_comm_create checks of a plan it is handed: the cut lines are a partition of the image, the rectangle is the rank's cell, no tile is thinner than a halo
+bool plan_consistent(const vhr_tile_plan &p) {
+    if (p.world == 0 || p.rank >= p.world || p.grid_rows == 0 || p.grid_cols == 0 || uint64_t(p.grid_rows) * p.grid_cols != p.world) return false;
+    if (p.grid_rows > VHR_TILE_MAX_GRID || p.grid_cols > VHR_TILE_MAX_GRID) return false;
+    if (p.col_cut[0] != 0 || p.col_cut[p.grid_cols] != p.width) return false;
+    for (uint32_t c = 0; c < p.grid_cols; ++c) {
+        if (p.col_cut[c + 1] <= p.col_cut[c] || (p.grid_cols > 1 && p.col_cut[c + 1] - p.col_cut[c] < p.halo_cols)) return false;
+        if (p.row_cut[c][0] != 0 || p.row_cut[c][p.grid_rows] != p.height) return false;
+        for (uint32_t r = 0; r < p.grid_rows; ++r) if (p.row_cut[c][r + 1] <= p.row_cut[c][r] || (p.grid_rows > 1 && p.row_cut[c][r + 1] - p.row_cut[c][r] < p.halo_rows)) return false;
+    }
+    vhr_rect own;
+    plan_tile(p, p.rank / p.grid_cols, p.rank % p.grid_cols, own);
+    if (own.x0 != p.col_begin || own.x1 != p.col_end || own.y0 != p.row_begin || own.y1 != p.row_end) return false;
+    if (p.world > 1 && (p.halo_rows < p.overlap || p.halo_cols < p.overlap)) return false;
+    return true;
+}
 vhr_rect grown(const vhr_rect &r, uint32_t dx, uint32_t dy, uint32_t width, uint32_t height) {
     return vhr_rect{ r.x0 > dx ? r.x0 - dx : 0u, uint32_t(std::min<uint64_t>(width, uint64_t(r.x1) + dx)), r.y0 > dy ? r.y0 - dy : 0u,
                      uint32_t(std::min<uint64_t>(height, uint64_t(r.y1) + dy)) };
@@ -166,32 +214,60 @@ int vhr_tile_grid_choose(uint32_t width, uint32_t height, uint32_t world, uint32
     return best == ~0ull ? VHR_ERROR_INVALID_ARGUMENT : VHR_OK;
 }
 
-int vhr_tile_plan_make(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
-                       uint32_t max_motion_cols, uint32_t atrous_steps, vhr_tile_plan *out) {
+int vhr_tile_plan_make_weighted(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
+                                uint32_t max_motion_cols, uint32_t atrous_steps, const uint32_t *cost, uint32_t cost_cols, uint32_t cost_rows, uint32_t cell,
+                                vhr_tile_plan *out) {
     if (!out || world == 0 || rank >= world || height == 0 || width == 0) return VHR_ERROR_INVALID_ARGUMENT;
     const uint32_t overlap = world > 1 ? vhr_atrous_overlap(atrous_steps) : 0u;
     if (grid_rows == 0 || grid_cols == 0) {
         const int rc = vhr_tile_grid_choose(width, height, world, overlap, &grid_rows, &grid_cols);
         if (rc != VHR_OK) return rc;
     }
-    if (uint64_t(grid_rows) * grid_cols != world || grid_rows > height || grid_cols > width) return VHR_ERROR_INVALID_ARGUMENT;
+    if (uint64_t(grid_rows) * grid_cols != world || grid_rows > height || grid_cols > width || grid_rows > VHR_TILE_MAX_GRID || grid_cols > VHR_TILE_MAX_GRID)
+        return VHR_ERROR_INVALID_ARGUMENT;
+    if (cost && (cell == 0 || uint64_t(cost_cols) * cell < width || uint64_t(cost_rows) * cell < height)) return VHR_ERROR_INVALID_ARGUMENT;
     vhr_tile_plan p = {};
     p.rank = rank; p.world = world; p.width = width; p.height = height;
     p.grid_rows = grid_rows; p.grid_cols = grid_cols;
-    vhr_rect own;
-    tile_bounds(width, height, grid_rows, grid_cols, rank / grid_cols, rank % grid_cols, own);
-    p.col_begin = own.x0; p.col_end = own.x1; p.row_begin = own.y0; p.row_end = own.y1;
     if (world > 1) {
         p.overlap = overlap;
         // svgf.comp reads the reprojected position +-1 (svgf.comp:52-60,81-84); an axis that is not cut needs no halo
         p.halo_rows = grid_rows > 1 ? overlap + max_motion_rows + 2u : overlap;
         p.halo_cols = grid_cols > 1 ? overlap + max_motion_cols + 2u : overlap;
-        // a halo must come from the adjacent tile alone
-        for (uint32_t r = 0; r < grid_rows; ++r) { vhr_rect t; tile_bounds(width, height, grid_rows, grid_cols, r, 0, t); if (grid_rows > 1 && p.halo_rows > t.y1 - t.y0) return VHR_ERROR_OUT_OF_SLOTS; }
-        for (uint32_t c = 0; c < grid_cols; ++c) { vhr_rect t; tile_bounds(width, height, grid_rows, grid_cols, 0, c, t); if (grid_cols > 1 && p.halo_cols > t.x1 - t.x0) return VHR_ERROR_OUT_OF_SLOTS; }
     }
+    // the cut lines: at equal cost where a map is given, else (and on an all-zero map) at equal pixels; a halo must come from the adjacent tile alone.
+    // Columns of tiles first (the column sums of the map), then every column of tiles cuts its own rows (the row sums of the map inside its columns).
+    std::vector<uint64_t> mcol;
+    const uint32_t ccols = cost ? (width + cell - 1) / cell : 0u, crows = cost ? (height + cell - 1) / cell : 0u;
+    if (cost) {
+        mcol.assign(ccols, 0);
+        for (uint32_t cy = 0; cy < crows; ++cy)
+            for (uint32_t cx = 0; cx < ccols; ++cx) mcol[cx] += cost[size_t(cy) * cost_cols + cx];
+    }
+    if (!balanced_cuts(mcol, cost ? cell : 1u, width, grid_cols, grid_cols > 1 ? p.halo_cols : 0u, p.col_cut)) return VHR_ERROR_OUT_OF_SLOTS;
+    for (uint32_t c = 0; c < grid_cols; ++c) {
+        std::vector<uint64_t> mrow;
+        if (cost) {
+            mrow.assign(crows, 0);
+            // (a cell belongs to the column of tiles its first pixel column lies in)
+            for (uint32_t cx = 0; cx < ccols; ++cx) {
+                const uint32_t x = cx * cell;
+                if (x < p.col_cut[c] || x >= p.col_cut[c + 1]) continue;
+                for (uint32_t cy = 0; cy < crows; ++cy) mrow[cy] += cost[size_t(cy) * cost_cols + cx];
+            }
+        }
+        if (!balanced_cuts(mrow, cost ? cell : 1u, height, grid_rows, grid_rows > 1 ? p.halo_rows : 0u, p.row_cut[c])) return VHR_ERROR_OUT_OF_SLOTS;
+    }
+    vhr_rect own;
+    plan_tile(p, rank / grid_cols, rank % grid_cols, own);
+    p.col_begin = own.x0; p.col_end = own.x1; p.row_begin = own.y0; p.row_end = own.y1;
     *out = p;
     return VHR_OK;
+}
+
+int vhr_tile_plan_make(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t grid_rows, uint32_t grid_cols, uint32_t max_motion_rows,
+                       uint32_t max_motion_cols, uint32_t atrous_steps, vhr_tile_plan *out) {
+    return vhr_tile_plan_make_weighted(width, height, world, rank, grid_rows, grid_cols, max_motion_rows, max_motion_cols, atrous_steps, nullptr, 0, 0, 0, out);
 }
 
 // For a margin of (halo_rows, halo_cols) pixels: what this rank receives from each peer = the peer's owned pixels inside my
@@ -206,7 +282,7 @@ int vhr_tile_plan_exchanges(const vhr_tile_plan *p, uint32_t halo_rows, uint32_t
     for (uint32_t peer = 0; peer < p->world; ++peer) {
         if (peer == p->rank) continue;
         vhr_rect theirs;
-        tile_bounds(p->width, p->height, p->grid_rows, p->grid_cols, peer / p->grid_cols, peer % p->grid_cols, theirs);
+        plan_tile(*p, peer / p->grid_cols, peer % p->grid_cols, theirs);
         const vhr_rect their_need = grown(theirs, p->grid_cols > 1 ? halo_cols : 0u, p->grid_rows > 1 ? halo_rows : 0u, p->width, p->height);
         vhr_rect_exchange e{};
         e.peer = int32_t(peer);
@@ -264,19 +340,10 @@ int vhr_comm_create_tiled(vhr_context *ctx, const vhr_tile_plan *plan, const uin
         return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: invalid arguments") : VHR_ERROR_INVALID_ARGUMENT;
     if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
     if (plan->height != ctx->height || plan->width != ctx->width) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan's extent is not the context's");
-    // A plan the planner would not have made -- bounds off the grid, a halo that reaches past the adjacent tile -- makes the two ends
-    // of an exchange disagree on its size, which hangs RCCL: recompute it from its own parameters and compare.
-    {
-        vhr_tile_plan check;
-        const uint32_t mr = plan->grid_rows > 1 && plan->halo_rows >= plan->overlap + 2u ? plan->halo_rows - plan->overlap - 2u : 0u;
-        const uint32_t mc = plan->grid_cols > 1 && plan->halo_cols >= plan->overlap + 2u ? plan->halo_cols - plan->overlap - 2u : 0u;
-        uint32_t steps = 0;
-        while (steps < 16 && vhr_atrous_overlap(steps) < plan->overlap) ++steps;
-        if (plan->world == 1) steps = 5;
-        const int rc = vhr_tile_plan_make(plan->width, plan->height, plan->world, plan->rank, plan->grid_rows, plan->grid_cols, mr, mc, steps, &check);
-        if (rc != VHR_OK || std::memcmp(&check, plan, sizeof(check)) != 0)
-            return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan is not one vhr_tile_plan_make / vhr_strip_plan_make returns");
-    }
+    // A plan the planner would not have made -- cut lines that are no partition, a rectangle off the grid, a halo that reaches past the adjacent tile -- makes
+    // the two ends of an exchange disagree on its size, which hangs RCCL.  (Equal-cost plans have no closed form to recompute: what is checked is
+    // the plan's consistency with itself; that every rank holds the SAME cut lines is the caller's contract, as it is for the cost map they come from.)
+    if (!plan_consistent(*plan)) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: the plan is not one vhr_tile_plan_make / vhr_strip_plan_make returns");
     Rccl &r = rccl();
     if (!r.error.empty()) return ctx->fail(VHR_ERROR_NO_DEVICE, r.error);
     vhr_comm *c = new vhr_comm;
@@ -308,6 +375,9 @@ int vhr_comm_create(vhr_context *ctx, const vhr_strip_plan *plan, const uint8_t 
     t.grid_rows = plan->world; t.grid_cols = 1;
     t.col_begin = 0; t.col_end = ctx->width; t.row_begin = plan->row_begin; t.row_end = plan->row_end;
     t.overlap = plan->overlap; t.halo_rows = plan->world > 1 ? plan->halo : 0u; t.halo_cols = plan->overlap;
+    if (plan->world > VHR_TILE_MAX_GRID) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_comm_create: more strips than VHR_TILE_MAX_GRID");
+    t.col_cut[0] = 0; t.col_cut[1] = ctx->width;
+    for (uint32_t r = 0; r <= plan->world; ++r) t.row_cut[0][r] = uint32_t(uint64_t(r) * plan->height / plan->world);
     return vhr_comm_create_tiled(ctx, &t, unique_id, out);
 }
 
@@ -480,7 +550,7 @@ int vhr_comm_start_frame_exchanges(vhr_comm *c, int32_t history_storage_image, i
             for (uint32_t peer = 0; peer < c->plan.world; ++peer) {
                 if (int32_t(peer) == root) continue;
                 vhr_rect theirs;
-                tile_bounds(c->plan.width, c->plan.height, c->plan.grid_rows, c->plan.grid_cols, peer / c->plan.grid_cols, peer % c->plan.grid_cols, theirs);
+                plan_tile(c->plan, peer / c->plan.grid_cols, peer % c->plan.grid_cols, theirs);
                 pieces.push_back(Piece{ &gathered, theirs, int(peer), false, 0 });
             }
         } else {

@@ -765,6 +765,37 @@ int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity,
     return VHR_OK;
 }
 
+// What the last frame's rays cost, where: the wave lifetimes the queue kernels leave for "raygen_cost_order" -- the any-hit launch's and the mirror ray's --
+// summed into a map of 8 x 8-pixel cells (a tile of fewer rows is charged to the cell of its first row).  The input of vhr_tile_plan_make_weighted.
+int vhr_get_tile_cost_map(vhr_context *ctx, uint32_t *out, uint32_t cols, uint32_t rows) {
+    if (!ctx || !out || cols == 0 || rows == 0) return VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_NO_DEVICE, "host-only context: no device work");
+    if (uint64_t(cols) * 8 < ctx->width || uint64_t(rows) * 8 < ctx->height) return ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "tile cost map: the map does not cover the image");
+    const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_;
+    std::fill(out, out + size_t(cols) * rows, 0u);
+    std::vector<uint32_t> host;
+    int found = 0;
+    for (const vhr_context::CostOrder *co : { &ctx->cost_order_raygen, &ctx->cost_order_reflection }) {
+        const uint32_t slot = co->slot;
+        const vhr_context::CostOrder::Shape &sh = co->shape[slot];
+        const uint32_t n = co->cost_blocks[slot] ? std::min(co->cost_waves[slot], co->capacity) : 0u;
+        if (!n || !sh.tiles_x) continue;
+        host.resize(n);
+        if (hipMemcpy(host.data(), co->cost[slot], size_t(n) * 4, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(VHR_ERROR_DEVICE, "tile cost map: copy failed");
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t block = i / sh.wv, wave = i % sh.wv;
+            const uint32_t by = block / sh.blocks_x, bx = block % sh.blocks_x;
+            const uint32_t x = sh.col_begin + (bx * sh.wv + wave) * sh.tile_w, y = sh.row_begin + by * sh.tile_h;
+            if (x >= ctx->width || y >= ctx->height) continue;
+            uint32_t &cell = out[size_t(y / 8) * cols + x / 8];
+            cell = uint32_t(std::min<uint64_t>(0xffffffffull, uint64_t(cell) + host[i]));
+        }
+        ++found;
+    }
+    if (!found) return ctx->fail(VHR_ERROR_NOT_FOUND, "tile cost map: no queue-kernel launch has left its wave lifetimes (\"raygen_cost_order\" 0, or a launch below 2 048 workgroups with the option at 1)");
+    return VHR_OK;
+}
+
 static int fingerprints_of_device_tree(vhr_context *ctx) {      // a device-built tree: fetched when somebody asks, hashed like the host's
     if (ctx->bvh_fingerprint_valid || ctx->host_only || !ctx->d_nodes || !ctx->node_count) return VHR_OK;
     HostBvh bvh;

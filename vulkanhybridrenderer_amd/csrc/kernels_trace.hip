@@ -1820,7 +1820,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
 // "raygen_cost_order": the cost / order pointers of a queue-kernel launch of `n_blocks` blocks of `wv` waves (see vhr_context::CostOrder).
 // 1 (default) = launches of at least 2 048 blocks (a full round of waves or more), 2 = any launch (tests); the two launches an order connects must
 // have been issued on the same stream -- the order is written and read in stream order, nothing else guards it.
-static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, CostOrderArgs &out) {
+static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, const uint32_t n_blocks, const uint32_t wv, const uint32_t key, CostOrderArgs &out,
+                               const vhr_context::CostOrder::Shape &shape) {
     const int mode = ctx->options[kOptRaygenCostOrder];
     if (!mode) return;
     if (co.stream != ctx->stream) {
@@ -1856,6 +1857,7 @@ static void prepare_cost_order(vhr_context *ctx, vhr_context::CostOrder &co, con
     }
     co.cost_blocks[slot] = n_blocks; co.cost_key[slot] = key;
     co.cost_waves[slot] = n_waves;
+    co.shape[slot] = shape;
 }
 
 static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_t width, const uint32_t height) {
@@ -1890,7 +1892,7 @@ static void issue_raygen(vhr_context *ctx, const RaygenArgs &a_in, const uint32_
         const uint32_t n_blocks = ((tiles_x + wv - 1u) / wv) * tiles_y;
         {   // "raygen_cost_order" (see vhr_context::CostOrder)
             const uint32_t key = (tiles_x * 2654435761u) ^ (tiles_y * 40503u) ^ (wv << 28) ^ (tile_rows << 24) ^ (a.row_begin * 97u) ^ (a.col_begin * 193u);
-            if (!a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, n_blocks, wv, key, a.co);
+            if (!a.stats && levels >= 5u) prepare_cost_order(ctx, ctx->cost_order_raygen, n_blocks, wv, key, a.co, { tiles_x, (tiles_x + wv - 1u) / wv, wv, 8u, tile_rows, a.col_begin, a.row_begin });
         }
         const uint32_t steal = uint32_t(std::max(0, std::min(63, ctx->options[kOptRaygenSteal])));
         auto go = [&](auto kernel) { launch(ctx, kernel, dim3(n_blocks), dim3(kQueueBlock * wv), stack_bytes * wv, a, levels, threshold, (tiles_x + wv - 1u) / wv, early_exit, tile_rows, steal); };
@@ -2053,7 +2055,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             m.co = CostOrderArgs{};
             if (levels >= 5u && !m.stats)                  // "raygen_cost_order" for the mirror-ray launch (its own lifetimes and orders)
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
-                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co);
+                                   (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co,
+                                   { tiles_x, tiles_x, 1u, 8u, 8u, m.col_begin, m.row_begin });
 #define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
@@ -2357,7 +2360,7 @@ int launch_raytraced(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t w
         a.co = CostOrderArgs{};
         if (levels >= 5u && !a.stats)                      // "raygen_cost_order" for this path's launch (its own lifetimes and orders)
             prepare_cost_order(ctx, ctx->cost_order_raytraced, (tiles_total + 1u) / 2u, 2u,
-                               (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co);
+                               (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(alpha_test) << 28) ^ (a.row_begin * 97u), a.co, { tiles_x, tiles_x, 1u, 16u, 8u, 0u, a.row_begin });
 #define VHR_LAUNCH_RT(SP, AL) launch(ctx, (raytraced_queue_kernel<SP, AL>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, a, levels, threshold, tiles_x, tiles_total, early_exit)
         if (alpha_test) { if (spill) VHR_LAUNCH_RT(true, true); else VHR_LAUNCH_RT(false, true); }
         else { if (spill) VHR_LAUNCH_RT(true, false); else VHR_LAUNCH_RT(false, false); }

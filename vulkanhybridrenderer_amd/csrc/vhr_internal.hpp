@@ -453,6 +453,9 @@ struct vhr_context {
         uint32_t cost_blocks[2] = { 0, 0 }, cost_key[2] = { 0, 0 };        // the launch shape cost[slot] was written by (0 blocks = nothing)
         uint32_t cost_waves[2] = { 0, 0 };                                 // ... and the words it wrote there (blocks x the waves per block the launch ran with)
         uint32_t order_blocks[2] = { 0, 0 }, order_key[2] = { 0, 0 };      // the launch shape order[slot] is an order of
+        // where on the screen the waves of cost[slot] worked (vhr_get_tile_cost_map): wave i = tile (i % tiles_x, i / tiles_x) of tile_w x tile_h pixels from
+        // (col_begin, row_begin) -- for the any-hit kernel with its workgroups of wv tiles side by side, i = (by * blocks_x + bx) * wv + wave <-> tile x = bx * wv + wave
+        struct Shape { uint32_t tiles_x = 0, blocks_x = 0, wv = 0, tile_w = 8, tile_h = 8, col_begin = 0, row_begin = 0; } shape[2];
     };
     CostOrder cost_order_raygen, cost_order_reflection, cost_order_raytraced;
     // SSAOPushConstants as last pushed by any dispatch of this context: ssao.comp reads its radius although the reference never

@@ -52,10 +52,12 @@ class CommBringUpError(RuntimeError):
 class HybridFrameLoop:
     def __init__(self, scene, width, height, n_frames, shadow=True, ao_spp=2, reflections=False, denoise=True,
                  atrous_steps=5, device=0, rank=0, world=1, dist=None, start_frame_index=0, trace_overlap=True, gather=True,
-                 frames_in_flight=1, allow_degraded=False, grid=None, comm="torch", geometry_options=None):
+                 frames_in_flight=1, allow_degraded=False, grid=None, comm="torch", geometry_options=None, tile_cost=None):
         """grid: the screen decomposition for world > 1 -- None = the planner's choice (tiling.choose_grid), "strips" = row strips,
         or (grid_rows, grid_cols).  comm: "torch" = the exchanges through torch.distributed (tiling.StripExchanges), "c_abi" = through
-        the library's own RCCL calls (vhr_comm_*, csrc/comm.cpp; the unique id travels over torch.distributed's store)."""
+        the library's own RCCL calls (vhr_comm_*, csrc/comm.cpp; the unique id travels over torch.distributed's store).  tile_cost: a map of what the
+        frame's rays cost per 8 x 8-pixel cell (Context.tile_cost_map() of a whole-image run, the SAME array on every rank): the grid is cut at equal
+        cost instead of equal pixels (vhr_tile_plan_make_weighted; placement only)."""
         import torch
         self.torch = torch
         self.scene, self.W, self.H = scene, width, height
@@ -88,7 +90,8 @@ class HybridFrameLoop:
         self.denoise = denoise
         self.atrous_steps = atrous_steps
         self._precompute_gbuffers()
-        self.plan = tiling.make_tile_plan(width, height, world, rank, self.max_motion_rows, self.max_motion_cols, atrous_steps, grid=grid)
+        self.tile_cost = tile_cost
+        self.plan = tiling.make_tile_plan(width, height, world, rank, self.max_motion_rows, self.max_motion_cols, atrous_steps, grid=grid, cost=tile_cost)
         self.comm_mode, self.comm, self._gather_buffer = comm, None, None
         if world > 1:
             p = self.plan
@@ -134,7 +137,7 @@ class HybridFrameLoop:
         uid, cplan, why = None, None, None
         try:
             uid = lib.Comm.unique_id()                       # loads librccl.so, resolves its symbols, ncclGetUniqueId
-            cplan = lib.tile_plan(self.W, self.H, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps)
+            cplan = lib.tile_plan(self.W, self.H, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps, cost=self.tile_cost)
             if cplan is None:
                 why = "the C planner refuses this rank's tile"
         except Exception as e:   # noqa: BLE001

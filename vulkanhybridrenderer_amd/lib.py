@@ -35,7 +35,7 @@ EXPORTS = [
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
-    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
@@ -97,7 +97,7 @@ class RowExchangeC(C.Structure):
 class TilePlanC(C.Structure):
     """vhr_tile_plan (include/vhr_amd.h): the C planner's screen tile, field for field tiling.TilePlan."""
     _fields_ = [(n, C.c_uint32) for n in ("rank", "world", "width", "height", "grid_rows", "grid_cols", "col_begin", "col_end", "row_begin", "row_end",
-                                          "overlap", "halo_rows", "halo_cols")]
+                                          "overlap", "halo_rows", "halo_cols")] + [("col_cut", C.c_uint32 * 17), ("row_cut", (C.c_uint32 * 17) * 16)]      # VHR_TILE_MAX_GRID = 16
 
 
 class RectC(C.Structure):
@@ -261,6 +261,7 @@ def load():
     L.vhr_strip_plan_exchanges.argtypes = [C.POINTER(StripPlanC), u32, C.POINTER(RowExchangeC)]
     L.vhr_tile_grid_choose.argtypes = [u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     L.vhr_tile_plan_make.argtypes = [u32, u32, u32, u32, u32, u32, u32, u32, u32, C.POINTER(TilePlanC)]
+    L.vhr_tile_plan_make_weighted.argtypes = [u32, u32, u32, u32, u32, u32, u32, u32, u32, vp, u32, u32, u32, C.POINTER(TilePlanC)]
     L.vhr_tile_plan_exchanges.argtypes = [C.POINTER(TilePlanC), u32, u32, C.POINTER(RectExchangeC), u32]
     L.vhr_comm_create_tiled.argtypes = [vp, C.POINTER(TilePlanC), C.c_char_p, C.POINTER(vp)]
     L.vhr_comm_get_unique_id.argtypes = [C.c_char_p]
@@ -596,6 +597,15 @@ class Context:
         self.check(self.L.vhr_debug_wave_lifetimes(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), capacity, C.byref(n)), "wave_lifetimes")
         return out[:n.value].copy()
 
+    def tile_cost_map(self):
+        """vhr_get_tile_cost_map: the last frame's wave lifetimes (any-hit + mirror-ray launch) per 8 x 8-pixel cell, (ceil(H / 8), ceil(W / 8)) uint32."""
+        import numpy as np
+        rows, cols = (self.height + 7) // 8, (self.width + 7) // 8
+        out = np.zeros((rows, cols), np.uint32)
+        self.L.vhr_get_tile_cost_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        self.check(self.L.vhr_get_tile_cost_map(self.handle, out.ctypes.data_as(C.c_void_p), cols, rows), "tile_cost_map")
+        return out
+
     def traversal_cycles(self):
         out = (C.c_uint64 * 8)()
         self.check(self.L.vhr_get_traversal_cycles(self.handle, out), "traversal_cycles")
@@ -833,10 +843,16 @@ def tile_grid(width, height, world, overlap):
     return int(r.value), int(c.value)
 
 
-def tile_plan(width, height, world, rank, grid_rows=0, grid_cols=0, max_motion_rows=0, max_motion_cols=0, atrous_steps=5):
-    """vhr_tile_plan_make: the C planner (csrc/comm.cpp).  None when a tile is thinner than its history halo."""
+def tile_plan(width, height, world, rank, grid_rows=0, grid_cols=0, max_motion_rows=0, max_motion_cols=0, atrous_steps=5, cost=None, cost_cell=8):
+    """vhr_tile_plan_make / _make_weighted: the C planner (csrc/comm.cpp).  None when a tile is thinner than its history halo.  cost: a 2-D uint32
+    array, one value per cost_cell x cost_cell pixel block -- the grid is cut at equal cost."""
     p = TilePlanC()
-    rc = load().vhr_tile_plan_make(width, height, world, rank, grid_rows, grid_cols, max_motion_rows, max_motion_cols, atrous_steps, C.byref(p))
+    if cost is None:
+        rc = load().vhr_tile_plan_make(width, height, world, rank, grid_rows, grid_cols, max_motion_rows, max_motion_cols, atrous_steps, C.byref(p))
+    else:
+        cm = np.ascontiguousarray(cost, np.uint32)
+        rc = load().vhr_tile_plan_make_weighted(width, height, world, rank, grid_rows, grid_cols, max_motion_rows, max_motion_cols, atrous_steps,
+                                                cm.ctypes.data_as(C.c_void_p), cm.shape[1], cm.shape[0], cost_cell, C.byref(p))
     if rc == -4:                      # VHR_ERROR_OUT_OF_SLOTS
         return None
     if rc != 0:

@@ -150,6 +150,15 @@ class TilePlan:
     overlap: int          # E: pixels recomputed beyond the rectangle by the SVGF kernels, on every cut side
     halo_rows: int        # margin of history / moments fetched from the neighbours (E on an axis that is not cut)
     halo_cols: int
+    col_cuts: tuple = ()  # the grid's cut lines: tile (r, c) owns columns [col_cuts[c], col_cuts[c + 1]) and rows [row_cuts[c][r], row_cuts[c][r + 1]):
+    row_cuts: tuple = ()  # every column of tiles has its own row cuts (equal pixels: the same in all; () = equal pixels, plans made by hand)
+
+    def tile_rect(self, rank):
+        """(x0, x1, y0, y1) owned by `rank`."""
+        tr, tc = rank // self.grid_cols, rank % self.grid_cols
+        if self.col_cuts and self.row_cuts:
+            return (self.col_cuts[tc], self.col_cuts[tc + 1], self.row_cuts[tc][tr], self.row_cuts[tc][tr + 1])
+        return tile_bounds(self.width, self.height, self.grid_rows, self.grid_cols, tr, tc)
 
     @property
     def halo(self):
@@ -176,15 +185,47 @@ class TilePlan:
         for peer in range(self.world):
             if peer == self.rank:
                 continue
-            theirs = tile_bounds(self.width, self.height, self.grid_rows, self.grid_cols, peer // self.grid_cols, peer % self.grid_cols)
+            theirs = self.tile_rect(peer)
             recv, send = _intersect(my_need, theirs), _intersect(_grown(theirs, dx, dy, self.width, self.height), mine)
             if recv or send:
                 out.append((peer, send, recv))
         return out
 
 
-def make_tile_plan(width, height, world, rank, max_motion_rows=0, max_motion_cols=0, atrous_steps=5, grid=None):
-    """grid: None = choose_grid, "strips" = row strips, or (grid_rows, grid_cols)."""
+def balanced_cuts(marginal, cell, extent, n, min_px):
+    """n + 1 cut lines of [0, extent) at equal cost (csrc/comm.cpp balanced_cuts, line for line): cut j = the first cell boundary at which the running sum of
+    `marginal` (cost per cell-pixel-wide slab) reaches j / n of the total, then moved so that no tile is thinner than min_px; no map = equal pixels."""
+    total = int(sum(int(v) for v in marginal)) if marginal is not None else 0
+    cuts = [0] * (n + 1)
+    cuts[n] = extent
+    weighted = total != 0 and len(marginal) != 0
+    if not weighted:
+        for j in range(1, n):
+            cuts[j] = j * extent // n
+    else:
+        run, b = 0, 0
+        for j in range(1, n):
+            while b < len(marginal) and run * n < total * j:
+                run += int(marginal[b])
+                b += 1
+            cuts[j] = min(extent, b * cell)
+    if n > 1 and min_px * n > extent:
+        return None
+    if weighted:
+        for j in range(1, n):
+            cuts[j] = max(cuts[j], cuts[j - 1] + max(1, min_px))
+        for j in range(n - 1, 0, -1):
+            cuts[j] = min(cuts[j], cuts[j + 1] - max(1, min_px))
+    for j in range(1, n + 1):
+        if cuts[j] <= cuts[j - 1] or cuts[j] - cuts[j - 1] < min_px:
+            return None
+    return tuple(cuts)
+
+
+def make_tile_plan(width, height, world, rank, max_motion_rows=0, max_motion_cols=0, atrous_steps=5, grid=None, cost=None, cost_cell=8):
+    """grid: None = choose_grid, "strips" = row strips, or (grid_rows, grid_cols).  cost: a 2-D array, cost[cy, cx] = what the cost_cell x cost_cell pixel
+    block at (cx, cy) * cost_cell costs to trace (the any-hit queue kernel's wave lifetimes, say): the grid is cut at equal cost instead of equal pixels
+    (vhr_tile_plan_make_weighted; placement only -- the images do not change)."""
     overlap = atrous_overlap(atrous_steps) if world > 1 else 0
     if grid is None:
         grid = choose_grid(width, height, world, overlap)
@@ -193,20 +234,53 @@ def make_tile_plan(width, height, world, rank, max_motion_rows=0, max_motion_col
     gr, gc = grid
     if gr * gc != world or gr > height or gc > width:
         raise ValueError(f"a {gr} x {gc} grid does not hold {world} ranks")
-    x0, x1, y0, y1 = tile_bounds(width, height, gr, gc, rank // gc, rank % gc)
     if world == 1:
-        return TilePlan(rank, world, width, height, 1, 1, 0, width, 0, height, 0, 0, 0)
+        return TilePlan(rank, world, width, height, 1, 1, 0, width, 0, height, 0, 0, 0, (0, width), ((0, height),))
     halo_rows = overlap + int(max_motion_rows) + 2 if gr > 1 else overlap
     halo_cols = overlap + int(max_motion_cols) + 2 if gc > 1 else overlap
-    for r in range(gr):
-        b = tile_bounds(width, height, gr, gc, r, 0)
-        if gr > 1 and halo_rows > b[3] - b[2]:
-            raise ValueError(f"tiles of {b[3] - b[2]} rows are thinner than the {halo_rows}-row history halo: use fewer GPUs or another grid")
-    for c in range(gc):
-        b = tile_bounds(width, height, gr, gc, 0, c)
-        if gc > 1 and halo_cols > b[1] - b[0]:
-            raise ValueError(f"tiles of {b[1] - b[0]} columns are thinner than the {halo_cols}-column history halo: use fewer GPUs or another grid")
-    return TilePlan(rank, world, width, height, gr, gc, x0, x1, y0, y1, overlap, halo_rows, halo_cols)
+    cell = cost_cell if cost is not None else 1
+    mcol = None
+    if cost is not None:
+        import numpy as np
+        cost = np.asarray(cost, np.uint64)
+        ccols, crows = (width + cost_cell - 1) // cost_cell, (height + cost_cell - 1) // cost_cell
+        if cost.shape[0] < crows or cost.shape[1] < ccols:
+            raise ValueError("the cost map does not cover the image")
+        cost = cost[:crows, :ccols]
+        mcol = cost.sum(0).tolist()
+    col_cuts = balanced_cuts(mcol, cell, width, gc, halo_cols if gc > 1 else 0)
+    if col_cuts is None:
+        raise ValueError(f"tiles of {width // gc} columns are thinner than the {halo_cols}-column history halo: use fewer GPUs or another grid")
+    row_cuts = []
+    for c in range(gc):            # every column of tiles cuts its own rows: by the cost inside it (a cell belongs to the column its first pixel column lies in)
+        mrow = None
+        if cost is not None:
+            xs = np.arange(cost.shape[1]) * cost_cell
+            mrow = cost[:, (xs >= col_cuts[c]) & (xs < col_cuts[c + 1])].sum(1).tolist()
+        cuts = balanced_cuts(mrow, cell, height, gr, halo_rows if gr > 1 else 0)
+        if cuts is None:
+            raise ValueError(f"tiles of {height // gr} rows are thinner than the {halo_rows}-row history halo: use fewer GPUs or another grid")
+        row_cuts.append(cuts)
+    row_cuts = tuple(row_cuts)
+    tr, tc = rank // gc, rank % gc
+    return TilePlan(rank, world, width, height, gr, gc, col_cuts[tc], col_cuts[tc + 1], row_cuts[tc][tr], row_cuts[tc][tr + 1], overlap, halo_rows, halo_cols, col_cuts, row_cuts)
+
+
+def refine_cost_map(cost, plans, times, cost_cell=8):
+    """The feedback step of the cost-balanced planner: inside every rank's rectangle the map is scaled by (the rank's share of the ranks' summed frame
+    times) / (its share of the map), so the next make_tile_plan(cost=...) moves the cuts towards the ranks that took longer than the map said.  What a
+    running system has for free -- `world` floats to all-gather -- corrects what the ray kernels' wave lifetimes do not see (the SVGF pass, launches too
+    small to fill the chip).  Two or three rounds bring busiest / mean from 1.15 to 1.01 on BASELINE config 5 at N = 8 (profiles/r6_tile_balance.txt).
+    Returns a uint32 map on the same cells (rescaled to use the 32 bits; only ratios matter)."""
+    import numpy as np
+    c = np.asarray(cost, np.float64)
+    total_t, total_c = float(sum(times)), float(c.sum())
+    out = c.copy()
+    for p, t in zip(plans, times):
+        y0, y1, x0, x1 = p.row_begin // cost_cell, -(-p.row_end // cost_cell), p.col_begin // cost_cell, -(-p.col_end // cost_cell)
+        share = float(c[y0:y1, x0:x1].sum()) / max(1e-30, total_c)
+        out[y0:y1, x0:x1] = c[y0:y1, x0:x1] * ((t / max(1e-30, total_t)) / max(1e-9, share))
+    return np.minimum(out * (6.0e7 / max(1e-30, out.max())), 6.0e7).astype(np.uint32)
 
 
 def _rects_of(plan, margin, width):
@@ -331,7 +405,7 @@ class StripGather:
             return
         H, W = image.shape[0], image.shape[1]
         if isinstance(plan, TilePlan):
-            self.rects = [tile_bounds(plan.width, plan.height, plan.grid_rows, plan.grid_cols, r // plan.grid_cols, r % plan.grid_cols) for r in range(plan.world)]
+            self.rects = [plan.tile_rect(r) for r in range(plan.world)]
         else:
             self.rects = [(0, W) + strip_bounds(plan.height, plan.world, r) for r in range(plan.world)]
         self.mine = self.rects[plan.rank]
