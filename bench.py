@@ -367,7 +367,7 @@ def main():
         return
     import torch
     import torch.distributed as dist
-    from vulkanhybridrenderer_amd import abi, scenes
+    from vulkanhybridrenderer_amd import abi, lib, scenes
     from vulkanhybridrenderer_amd.harness import HybridFrameLoop
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,7 +410,7 @@ def main():
     # library's own RCCL calls (--comm c_abi) need one GPU per rank (RCCL refuses two ranks on one device) and have not met a second
     # device yet, so they are never chosen silently: the launcher gives them a separate, time-bounded run (launch_ranks: c_abi_route).
     comm_mode = args.comm if args.comm != "auto" else "torch"
-    # (VHR_RCCL_LIBRARY: the library csrc/comm.cpp loads in RCCL's place.  With tests/rccl_shim's stand-in named there, vhr_comm_* runs
+    # (VHR_RCCL_LIBRARY: the library harness.HybridFrameLoop hands to vhr_comm_use_library, for csrc/comm.cpp to load in RCCL's place.  With tests/rccl_shim's stand-in named there, vhr_comm_* runs
     # N ranks on one GPU -- a functional run of the library's own exchange code, which the line then says)
     rccl_override = os.environ.get("VHR_RCCL_LIBRARY") or None
     if comm_mode == "c_abi" and world > 1 and (args.share_device or args.backend != "nccl") and not rccl_override:
@@ -434,6 +434,9 @@ def main():
             dist.destroy_process_group()
         raise SystemExit(3)
     ctx = loop.ctx
+    if comm_mode == "c_abi" and world > 1:             # the library says which file its RCCL entry points came from (vhr_comm_library)
+        comm_note = f"RCCL entry points resolved from {lib.comm_library()}" + (
+            " -- handed to vhr_comm_use_library in RCCL's place: a functional run of the library's exchange code, not a measurement" if rccl_override else "")
     build_ms, upload_ms = ctx.build_times_ms()
     k0_builder = "device (binned SAH)" if ctx.bvh_builder_used() == 1 else "host (binned SAH)"
     presplit_level = ctx.bvh_presplit_level()

@@ -356,10 +356,12 @@ int vhr_set_tile(vhr_context *ctx, uint32_t col_begin, uint32_t col_end, uint32_
  * row strips.  The row arithmetic follows the reference's SVGF schedule (hybrid_render_path.cpp:288-329:
  * the published image is the output of a-trous iteration n-2, iteration i reads +-2*2^i rows) and is the one
  * vulkanhybridrenderer_amd/tiling.py uses (tests/test_comm_plan.py compares the two).  RCCL is loaded on first use: the copy the process
- * already holds (a PyTorch process), else the ROCm installation's; the environment variable VHR_RCCL_LIBRARY=<path> names the library to
- * load instead (a site's own build).  N > 1 has not run on two DEVICES yet (rounds 1-5 had one GPU per box); world 2 and 4 run on one GPU
- * through tests/rccl_shim (a stand-in for the eight RCCL entry points this file uses, named through that variable), bit-identical to the
- * torch.distributed route and to the single context, with one injected failure per error path (tests/test_comm_shim.py).
+ * already holds (a PyTorch process), else the ROCm installation's; vhr_comm_use_library(path), called before any other vhr_comm_* call,
+ * names the library to load instead (a site's own build) -- the library reads no environment variable for this.  vhr_comm_library() says which
+ * file the entry points came from.  N > 1 has not run on two DEVICES yet (rounds 1-6 had one GPU per box); world 2, 3 and 4 run on one GPU
+ * through tests/rccl_shim (a stand-in for the eight RCCL entry points this file uses, handed over through vhr_comm_use_library), bit-identical to the
+ * torch.distributed route and to the single context, with one injected failure per error path (tests/test_comm_shim.py).  The stand-in copies with
+ * blocking host calls: the ORDER of this file's stream and event dependencies against real RCCL's asynchronous transport is what stays unverified.
  * Error handling: a failure inside a grouped batch closes the group, marks the communicator unusable and is reported; what was
  * enqueued before it is drained by vhr_comm_finish_frame_exchanges. */
 typedef struct vhr_strip_plan {
@@ -414,6 +416,11 @@ int vhr_tile_plan_make_weighted(uint32_t width, uint32_t height, uint32_t world,
 /* the rectangles a margin of (halo_rows, halo_cols) pixels takes from / gives to each peer (up to 8); returns their number or < 0 */
 int vhr_tile_plan_exchanges(const vhr_tile_plan *plan, uint32_t halo_rows, uint32_t halo_cols, vhr_rect_exchange *out, uint32_t capacity);
 
+/* The RCCL library to load, instead of the process's own / the ROCm installation's: before the first other vhr_comm_* call of the process
+ * (VHR_ERROR_GRAPH afterwards: the entry points are bound once); NULL or "" = the default resolution.  A path that does not load fails the next call. */
+int vhr_comm_use_library(const char *path);
+/* The file the RCCL entry points were resolved from (resolves them if nobody has yet), or the reason they could not be. */
+const char *vhr_comm_library(void);
 int vhr_comm_get_unique_id(uint8_t out[VHR_COMM_UNIQUE_ID_BYTES]);      /* ncclGetUniqueId on one rank; the caller hands it to the others */
 /* ncclCommInitRank + vhr_set_strip(plan) / vhr_set_tile(plan): collective over the `world` processes of the plan.  The plan must be one
  * the planner returns (it is recomputed and compared: two ranks that disagree on a rectangle would hang RCCL).  vhr_comm_destroy gives the

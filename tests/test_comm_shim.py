@@ -1,6 +1,6 @@
 """The library's own multi-GPU exchanges (vhr_comm_*, csrc/comm.cpp: plan -> pieces -> pack -> one grouped batch of ncclSend / ncclRecv ->
 unpack, the gather, the `broken` state) at world size 2 and 4 on ONE GPU.  RCCL refuses two ranks per device, so the eight RCCL entry
-points comm.cpp resolves come from tests/rccl_shim (a stand-in over /dev/shm files, named through VHR_RCCL_LIBRARY): every byte of the
+points comm.cpp resolves come from tests/rccl_shim (a stand-in over /dev/shm files; VHR_RCCL_LIBRARY tells bench.py / the worker, which hand it to vhr_comm_use_library): every byte of the
 N > 1 path moves through the product's code -- only the wire is replaced.  Checked: every rank's Denoised and Reflections tile and the
 frame gathered on rank 0 equal the single context's bit for bit (bench.py's own pre-timing verification), the same through
 torch.distributed (tiling.StripExchanges over gloo); one injected failure per error path of a batch -- every rank ends by itself
@@ -105,10 +105,26 @@ def test_a_communicator_that_fails_to_come_up_is_refused_on_every_rank(shim):
 
 
 def test_a_forced_rccl_library_that_does_not_load_is_an_error(monkeypatch):
-    """VHR_RCCL_LIBRARY names the library to use and no other: a path that does not load fails vhr_comm_get_unique_id, it does not fall through
-    to the installation's RCCL (checked in a child process: the loader's choice is made once per process)."""
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from vulkanhybridrenderer_amd import lib\n"
-            "try:\n    lib.Comm.unique_id()\n    print('LOADED')\nexcept lib.VhrError as e:\n    print('REFUSED', e)\n" % ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VHR_RCCL_LIBRARY="/nonexistent/librccl.so"), capture_output=True, text=True, timeout=300)
+    """vhr_comm_use_library names the library to use and no other: a path that does not load fails vhr_comm_get_unique_id, it does not fall through to the
+    installation's RCCL; the library itself reads NO environment variable for this (round 6: VHR_RCCL_LIBRARY is honoured by the host tooling's explicit call,
+    lib.comm_use_library_from_environment, nowhere else); vhr_comm_library names the file the entry points came from; once they are bound the choice is closed.
+    (Child processes: the loader's choice is made once per process.)"""
+    head = "import sys; sys.path.insert(0, %r)\nfrom vulkanhybridrenderer_amd import lib\n" % ROOT
+    tail = "try:\n    lib.Comm.unique_id()\n    print('LOADED', lib.comm_library())\nexcept lib.VhrError as e:\n    print('REFUSED', lib.comm_library())\n"
+    run = lambda code, env: subprocess.run([sys.executable, "-c", head + code + tail], env=env, capture_output=True, text=True, timeout=300)   # noqa: E731
+    bad = dict(os.environ, VHR_RCCL_LIBRARY="/nonexistent/librccl.so")
+    r = run("lib.comm_use_library('/nonexistent/librccl.so')\n", dict(os.environ))
+    assert "REFUSED" in r.stdout and "LOADED" not in r.stdout and "vhr_comm_use_library" in r.stdout, r.stdout + r.stderr
+    r = run("", bad)                                     # the variable alone steers nothing
+    assert ("LOADED" in r.stdout and "nonexistent" not in r.stdout) or "RCCL not found" in r.stdout, r.stdout + r.stderr
+    r = run("lib.comm_use_library_from_environment()\n", bad)      # ... until the host program passes it on
     assert "REFUSED" in r.stdout and "LOADED" not in r.stdout, r.stdout + r.stderr
+    r = run("lib.comm_library()\ntry:\n    lib.comm_use_library('/tmp/x.so')\n    print('ACCEPTED LATE')\nexcept lib.VhrError as e:\n    print('TOO LATE')\n", dict(os.environ))
+    assert "TOO LATE" in r.stdout and "ACCEPTED LATE" not in r.stdout, r.stdout + r.stderr
+
+
+def test_the_stand_in_is_named_by_the_library(shim):
+    """vhr_comm_library reports the stand-in when the host handed it over."""
+    code = ("import sys; sys.path.insert(0, %r)\nfrom vulkanhybridrenderer_amd import lib\nlib.comm_use_library(%r)\nlib.Comm.unique_id()\nprint('FROM', lib.comm_library())\n" % (ROOT, shim))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VHR_RCCL_SHIM_TIMEOUT_S="5"), capture_output=True, text=True, timeout=300)
+    assert "FROM" in r.stdout and "librccl_shim" in r.stdout, r.stdout + r.stderr

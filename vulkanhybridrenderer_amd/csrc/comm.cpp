@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "vhr_internal.hpp"
@@ -47,8 +48,11 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
+    std::string error, path;
 };
+
+std::string &forced_library() { static std::string path; return path; }
+std::atomic<bool> g_rccl_resolved{ false };
 
 Rccl &rccl() {
     static Rccl r;
@@ -57,11 +61,12 @@ Rccl &rccl() {
         // A copy the process already holds first (the loader knows libraries by soname, librccl.so.1: a PyTorch process has its
         // own build loaded), else the ROCm installation's -- with local scope, so that this library's choice never rebinds
         // anybody else's ncclXxx references.
-        // VHR_RCCL_LIBRARY=<path>: that library and no other (a site's own RCCL build; tests/rccl_shim's stand-in, which lets the exchanges of
-        // N ranks run on ONE GPU, where RCCL itself refuses two ranks per device).  A path that does not load is an error, not a fall-through.
-        if (const char *forced = std::getenv("VHR_RCCL_LIBRARY"); forced && *forced) {
-            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-            if (!r.handle) { const char *e = dlerror(); r.error = std::string("VHR_RCCL_LIBRARY: ") + (e ? e : forced); return; }
+        // vhr_comm_use_library(path), called before this: that library and no other (a site's own RCCL build; tests/rccl_shim's stand-in, which lets the
+        // exchanges of N ranks run on ONE GPU, where RCCL itself refuses two ranks per device).  A path that does not load is an error, not a fall-through.
+        // (Rounds 4-5 read the path from an environment variable: code loading steered from outside the process's own calls -- gone.)
+        if (!forced_library().empty()) {
+            r.handle = dlopen(forced_library().c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) { const char *e = dlerror(); r.error = std::string("vhr_comm_use_library: ") + (e ? e : forced_library().c_str()); return; }
         }
         for (int flags : { RTLD_NOW | RTLD_NOLOAD, RTLD_NOW | RTLD_LOCAL }) {
             if (r.handle) break;
@@ -81,7 +86,11 @@ Rccl &rccl() {
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        // which file the entry points came from (what vhr_comm_library reports)
+        Dl_info info;
+        if (r.GetUniqueId && dladdr(reinterpret_cast<void *>(r.GetUniqueId), &info) && info.dli_fname) r.path = info.dli_fname;
     });
+    g_rccl_resolved = true;
     return r;
 }
 
@@ -325,6 +334,17 @@ int vhr_strip_plan_exchanges(const vhr_strip_plan *p, uint32_t n_rows, vhr_row_e
 }
 
 // ---- the communicator ----
+int vhr_comm_use_library(const char *path) {
+    if (g_rccl_resolved) return VHR_ERROR_GRAPH;                     // too late: the entry points are bound
+    forced_library() = path ? path : "";
+    return VHR_OK;
+}
+
+const char *vhr_comm_library(void) {
+    Rccl &r = rccl();
+    return r.error.empty() ? r.path.c_str() : r.error.c_str();
+}
+
 int vhr_comm_get_unique_id(uint8_t out[VHR_COMM_UNIQUE_ID_BYTES]) {
     if (!out) return VHR_ERROR_INVALID_ARGUMENT;
     Rccl &r = rccl();

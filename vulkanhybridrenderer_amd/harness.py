@@ -136,6 +136,7 @@ class HybridFrameLoop:
         dist, rank, world = self.dist, self.rank, self.world
         uid, cplan, why = None, None, None
         try:
+            lib.comm_use_library_from_environment()          # (VHR_RCCL_LIBRARY: the bench's / the tests' explicit choice of the library to load)
             uid = lib.Comm.unique_id()                       # loads librccl.so, resolves its symbols, ncclGetUniqueId
             cplan = lib.tile_plan(self.W, self.H, world, rank, p.grid_rows, p.grid_cols, self.max_motion_rows, self.max_motion_cols, atrous_steps, cost=self.tile_cost)
             if cplan is None:

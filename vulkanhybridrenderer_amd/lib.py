@@ -35,7 +35,7 @@ EXPORTS = [
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
-    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
@@ -867,6 +867,31 @@ def tile_plan_exchanges(plan, halo_rows, halo_cols):
         raise VhrError(f"vhr_tile_plan_exchanges: {n}")
     rect = lambda r: (r.x0, r.x1, r.y0, r.y1)
     return [(out[i].peer, rect(out[i].send), rect(out[i].recv)) for i in range(n)]
+
+
+def comm_use_library(path):
+    """vhr_comm_use_library: the RCCL library csrc/comm.cpp loads (before the process's first vhr_comm_* call); None = the default resolution."""
+    L = load()
+    L.vhr_comm_use_library.argtypes = [C.c_char_p]
+    rc = L.vhr_comm_use_library(path.encode() if path else None)
+    if rc != 0:
+        raise VhrError(f"vhr_comm_use_library: {rc} (the RCCL entry points are already bound)")
+
+
+def comm_library():
+    """vhr_comm_library: the file the RCCL entry points came from, or the reason they could not be resolved."""
+    L = load()
+    L.vhr_comm_library.restype = C.c_char_p
+    return L.vhr_comm_library().decode()
+
+
+def comm_use_library_from_environment():
+    """Test and bench tooling: VHR_RCCL_LIBRARY=<path> (tests/rccl_shim's stand-in, a site's own build) is honoured HERE, by the host program's explicit call
+    -- the library itself reads no environment variable.  Returns the path or None."""
+    path = os.environ.get("VHR_RCCL_LIBRARY") or None
+    if path:
+        comm_use_library(path)
+    return path
 
 
 class Comm:
