@@ -94,7 +94,9 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
     memset(id->internal, 0, sizeof id->internal);
     struct timespec t;
     clock_gettime(CLOCK_REALTIME, &t);
-    snprintf(id->internal, sizeof id->internal, "/dev/shm/vhr_rccl_shim_%d_%lld_%ld", (int)getpid(), (long long)t.tv_sec, t.tv_nsec);
+    /* VHR_RCCL_SHIM_TAG: a run's own mark in the directory name, so that whoever cleans up after an injected failure removes ITS directories only */
+    const char *tag = getenv("VHR_RCCL_SHIM_TAG");
+    snprintf(id->internal, sizeof id->internal, "/dev/shm/vhr_rccl_shim_%.24s_%d_%lld_%ld", tag && *tag ? tag : "run", (int)getpid(), (long long)t.tv_sec, t.tv_nsec);
     return ncclSuccess;
 }
 

@@ -4,7 +4,9 @@ points comm.cpp resolves come from tests/rccl_shim (a stand-in over /dev/shm fil
 N > 1 path moves through the product's code -- only the wire is replaced.  Checked: every rank's Denoised and Reflections tile and the
 frame gathered on rank 0 equal the single context's bit for bit (bench.py's own pre-timing verification), the same through
 torch.distributed (tiling.StripExchanges over gloo); one injected failure per error path of a batch -- every rank ends by itself
-with a non-zero code, none hangs."""
+with a non-zero code, none hangs.  NOT checked by this route: the stand-in synchronises its streams on the host and copies with blocking calls at
+ncclGroupEnd, so a missing stream or event dependency in comm.cpp (its own stream against the context's, the reuse of its staging buffers)
+cannot show here -- the order of those dependencies against RCCL's asynchronous transport waits for a box with two devices."""
 import os
 import subprocess
 import sys
@@ -33,6 +35,7 @@ def test_c_abi_exchanges_on_one_gpu_equal_the_single_context_and_the_torch_route
     args = ["--gpus", str(world), "--share-device", "--scene", "tiny", "--width", "320", "--height", "200", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
             "--no-cpu-baseline", "--no-extras", "--verify-frames", "3", "--reflections"] + extra
     monkeypatch.setenv("VHR_RCCL_LIBRARY", shim)
+    monkeypatch.setenv("VHR_RCCL_SHIM_TAG", _TAG)
     monkeypatch.setenv("VHR_RCCL_SHIM_TIMEOUT_S", "60")
     r, line = _bench(args + ["--comm", "c_abi"], timeout=600)
     assert r.returncode == 0 and line and "error" not in line, (r.stdout[-2000:], r.stderr[-3000:])
@@ -48,8 +51,8 @@ def test_c_abi_exchanges_on_one_gpu_equal_the_single_context_and_the_torch_route
 
 
 def _run_ranks(shim, world, frames, fail, fail_rank, mode="", timeout_s=8):
-    port = str(29600 + (os.getpid() + int(time.time())) % 300)
-    env = dict(os.environ, VHR_RCCL_LIBRARY=shim, VHR_RCCL_SHIM_TIMEOUT_S=str(timeout_s), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(_free_port())
+    env = dict(os.environ, VHR_RCCL_LIBRARY=shim, VHR_RCCL_SHIM_TAG=_TAG, VHR_RCCL_SHIM_TIMEOUT_S=str(timeout_s), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("VHR_RCCL_SHIM_FAIL", None)
     if fail:
         env.update(VHR_RCCL_SHIM_FAIL=fail, VHR_RCCL_SHIM_FAIL_RANK=str(fail_rank))
@@ -70,12 +73,22 @@ def _run_ranks(shim, world, frames, fail, fail_rank, mode="", timeout_s=8):
     return codes, outs, hung
 
 
+_TAG = "t%d%x" % (os.getpid(), int(time.time() * 1e3) & 0xffffff)      # this module run's mark in the shim's directory names (VHR_RCCL_SHIM_TAG)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def _sweep_shim_directories():
     """A run that ends in an injected failure leaves its message directory behind (the shim removes it when the last rank destroys its
-    communicator): /dev/shm is memory, so the test cleans up what the shim of THIS test module created."""
+    communicator): /dev/shm is memory, so the test cleans up what the shim created FOR THIS MODULE RUN (its tag in the name) -- not another run's."""
     import glob
     import shutil
-    for d in glob.glob("/dev/shm/vhr_rccl_shim_*"):
+    for d in glob.glob(f"/dev/shm/vhr_rccl_shim_{_TAG}_*"):
         shutil.rmtree(d, ignore_errors=True)
 
 

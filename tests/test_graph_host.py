@@ -266,6 +266,12 @@ def test_bvh_frame_search_on_the_host_builder():
         for threads in (1, 3):
             other = build(turned, 1, threads)
             assert np.array_equal(other[1], frame) and other[2:] == (fp, tree)
+    # a scene tilted by a few degrees only lies between the coarse grid's points: found all the same
+    slightly = scenes.rotated(scenes.sponza_proc(0.35), rot_y=np.radians(3.0), rot_x=np.radians(3.0))
+    nodes, frame, _, _ = build(slightly, 1)
+    assert not np.array_equal(frame, np.eye(3, dtype=np.float32)) and nodes < build(slightly, 0)[0]
+    back = np.abs(frame.astype(np.float64) @ np.asarray(slightly.camera["world"], np.float64)[:3, :3])
+    assert np.allclose(back.max(axis=1), 1.0, atol=2e-3), back
     c = lib.Context(64, 64, host_only=True)
     try:
         for bad in (-1, 2):

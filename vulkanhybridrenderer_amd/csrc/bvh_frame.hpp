@@ -109,6 +109,11 @@ inline bool choose(Evaluate &&evaluate, float out[9]) {
                 if (level == 0) {
                     const double lo = angle == 0 ? 0.0 : -42.0, hi = angle == 0 ? 84.0 : 42.0;
                     for (double v = lo; v <= hi + 1e-9 && n < kMaxCandidates; v += steps[0]) values[n++] = v;
+                    // ... and half a step either side of the world axes: a scene tilted by a few degrees lies BETWEEN the grid's points, where both
+                    // neighbours cost about what the world axes cost, and the early exit below would keep the world axes (3 deg about y and x on
+                    // sponza_proc: 10.7 % of the summed half area lost)
+                    values[n++] = 3.0;
+                    values[n++] = angle == 0 ? 87.0 : -3.0;
                 } else {
                     for (int k = -4; k <= 4; ++k) if (k) values[n++] = best[angle] + k * steps[level];
                 }

@@ -382,8 +382,11 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
         const lds_u4 pa = s_a[k + 2][tx + 2 * STEP];
         const f2v p_xy = f2v{ u2f(pa.x), u2f(pa.y) };
         const lds_u2 pn = s_n[k + 2][tx + 2 * STEP];
-        // The centre's normal at HALF length (exact: a power of two): n.n' then arrives as dd / 2 <= 0.501, and the dot product's own output
-        // clamp to [0, 1] (v_fma_mix_f32's) IS the shader's max(0, .) (:46) -- no v_max per tap; the factor comes back as +128 in the tap's constant below.
+        // The centre's normal at HALF length: n.n' then arrives as dd / 2 <= 0.501, and the dot product's own output clamp to [0, 1] (v_fma_mix_f32's) IS
+        // the shader's max(0, .) (:46) -- no v_max per tap; the factor comes back as +128 in the tap's constant below.  Preconditions, both met by the
+        // G-buffer's unit normals (gbuf.frag:43 normalises) and outside the bit-exact contract anyway (this kernel's parity is a tolerance,
+        // tests/test_gpu_svgf.py): the halving of a HALF is exact only for components >= 2^-13 (smaller ones round in the half multiply: an
+        // error of <= 2^-25 in a dot product compared at 2^-11), and the clamp replaces max(0, .) only while n.n' <= 2, i.e. |n| |n'| <= 2.
         const half2_t np_xy = as_half2(pn.x) * half2_t{ _Float16(0.5f), _Float16(0.5f) };
         const float np_z = 0.5f * float(as_half2(pn.y).y);
         const _Float16 idp = as_half2(pn.y).x;
