@@ -285,9 +285,11 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
             const uint32_t off = texel_offset(y0 + (ty + 4 * kq) * STEP - 1, x0 + tx) + 4u;       // .zw = the two variances
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                pv_own[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + off + uint32_t(j) * row_bytes);
+                // (ONE 32-bit offset per load: `base + off + j * row_bytes` is two pointer additions, which the compiler carries out in 64 bits -- six
+                // v_lshl_add_u64 per thread, r6)
+                pv_own[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + (off + uint32_t(j) * row_bytes));
                 pv_edge[kq][j] = 0u;
-                if (edge_lane) pv_edge[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + (tx == 0 ? off - 8u : off + 8u) + uint32_t(j) * row_bytes);
+                if (edge_lane) pv_edge[kq][j] = *reinterpret_cast<const uint32_t *>(in_base + ((tx == 0 ? off - 8u : off + 8u) + uint32_t(j) * row_bytes));
             }
         }
     } else {
@@ -444,6 +446,8 @@ __global__ __launch_bounds__(256) void svgf_atrous_tile_kernel(const AtrousArgs 
             // 128 log2(n.n') + log2 k for two taps per instruction (a packed fp32 FMA occupies the SIMD like a plain one)
             const f2v L01 = __builtin_elementwise_fma(f2v{ lg[0], lg[1] }, f2v{ k128, k128 }, kc[0]);
             const f2v L23 = __builtin_elementwise_fma(f2v{ lg[2], lg[3] }, f2v{ k128, k128 }, kc[1]);
+            // (r6, measured and not kept: skipping these four selects where a wave sees ONE object in all four taps -- the masks and-ed on the scalar
+            // unit, one test per group -- makes the launch 3-6 % SLOWER: the branch costs the unrolled groups their interleaving; profiles/r6_atrous.txt)
             L[0] = same[0] ? L01.x : -__builtin_inff();                                 // :87 in the exponent
             L[1] = same[1] ? L01.y : -__builtin_inff();
             L[2] = same[2] ? L23.x : -__builtin_inff();
