@@ -35,6 +35,7 @@ out = {"fingerprint": lib.source_fingerprint(), "workload": "$KEY", "bench_argum
        "svgf_atrous_mean_traffic_bytes_per_launch": traffic.get("svgf_atrous_mean_traffic_bytes_per_launch"),
        "fetch_size_correction_by_bytes_per_lane": traffic.get("fetch_size_correction_by_bytes_per_lane"),
        "traffic_per_kernel": {k: v["traffic_bytes"] for k, v in traffic.get("kernels", {}).items()},
+       "traffic_split_per_kernel": {k: {"fetch_corrected_bytes": v["fetch_corrected_bytes"], "write_bytes": v["write_bytes"]} for k, v in traffic.get("kernels", {}).items()},
        "svgf_atrous_valu_insts_per_launch": round(sum(v["SQ_INSTS_VALU"] for v in atrous.values()) / max(1, len(atrous))) if atrous else None,
        "svgf_atrous_wait_inst_any_per_launch": round(sum(v["SQ_WAIT_INST_ANY"] for v in atrous.values()) / max(1, len(atrous))) if atrous else None,
        "svgf_atrous_wave_cycles_per_launch": round(sum(v["SQ_WAVE_CYCLES"] for v in atrous.values()) / max(1, len(atrous))) if atrous else None,
