@@ -2,6 +2,8 @@ import sys, hashlib
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from vulkanhybridrenderer_amd import scenes, lib, camera
+import os
+if os.environ.get('VHR_LIB_VARIANT'): lib.LIB_PATH = os.path.abspath(os.environ['VHR_LIB_VARIANT'])
 for name in ("sponza_proc", "bistro_proc"):
     sc = getattr(scenes, name)()
     W, H = 1920, 1080

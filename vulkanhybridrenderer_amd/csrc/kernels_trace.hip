@@ -1488,12 +1488,35 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 // candidate first runs shadow_anyhit.rahit (alpha_ignored).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr int kPendingCandidates = 16;
 
 // what a walk did (STATS builds only): node visits, leaf visits and triangle tests summed over lanes, and the trips of the two inner loops
 // counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
 struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
 
-template <bool SPILL, bool ALPHA, bool STATS = false, typename Fetch, typename Commit>
+// Decision (vi) in the queue walkers: the triangles whose fp32 solution contradicted itself (a lane's scratch list) against the lane's ray, in binary64, folded
+// into the closest hit so far by (t, flat index).  NOT inlined, and called where a ray is committed: the walk's loops then carry none of its registers --
+// inlined into the leaf test it made the two-bounce mirror kernel spill 45 registers (launch +14 %), inlined at the commit still 48; as a call in the
+// leaf test it cost the walk 13 registers (round 6, profiles/r6_decision_vi_cost.txt).  The call is taken by one ray in 10^5 on the hybrid path's scenes.
+struct PendingBest { float t, u, v; uint32_t tri, flat; };
+template <bool ALPHA>
+__device__ __attribute__((noinline)) PendingBest resolve_pending(const DeviceScene *sc, const int *pend, uint32_t npend, f3 ro, f3 rd, float tmin, float tmax, bool any_hit,
+                                                                  PendingBest best) {
+    for (uint32_t k = 0; k < npend; ++k) {
+        if (any_hit && best.tri != kNoHit) break;
+        const uint32_t ti = uint32_t(pend[k]);
+        const float4 *tp = reinterpret_cast<const float4 *>(sc->tris + ti);
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        float t, uu, ww;
+        if (!mt_binary64(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) continue;
+        if (ALPHA && alpha_ignored(*sc, ti, uu, ww)) continue;
+        const uint32_t flat = __float_as_uint(tc.w);
+        if (best.tri == kNoHit || t < best.t || (t == best.t && flat < best.flat)) best = PendingBest{ t, uu, ww, ti, flat };
+    }
+    return best;
+}
+
+template <bool SPILL, bool ALPHA, bool DEFER, bool STATS = false, typename Fetch, typename Commit>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
@@ -1508,6 +1531,10 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
     // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
     // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
     volatile int spill[SPILL ? kSpillStack : 1];
+    // decision (vi): the triangles whose fp32 solution contradicted itself, waiting for the ray's commit (scratch; kPendingCandidates of them -- one more sets
+    // bit 1 of `overflow`, which the statistics report as a stack overflow: tests/ assert there is none)
+    volatile int pend[DEFER ? kPendingCandidates : 1];
+    uint32_t npend = 0;
     float tmin_v = tmin;
     asm volatile("" : "+v"(tmin_v));
     for (;;) {
@@ -1574,8 +1601,19 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 if (STATS) ++my_tris;
                 const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
                 if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) {
-                    // decision (vi): a candidate that contradicts itself is decided again in binary64
-                    if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww) && !mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) continue;
+                    // decision (vi): a candidate that contradicts itself is decided again in binary64.  DEFER (the mirror ray's kernels, where one ray in
+                    // 10^5 has one): not here, where the walk's registers are all alive (inlined at this point the two-bounce kernel spilled 45 registers
+                    // and its launch grew by 13-14 %; deferred, by 7-8 %), but when the ray is committed -- the triangle waits in the lane's scratch list,
+                    // the walk goes on as if it had missed (boxes are culled against a closest t that does not know of it: that only visits more).
+                    // !DEFER (the raytraced path, whose shadow rays leave the hit point itself: 6 % of its rays have one): inline -- taken that often
+                    // the call gains nothing (launch 390-400 us either way) and the list of 16 would overflow into the per-pixel kernel.
+                    if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) {
+                        if (DEFER) {
+                            if (npend < uint32_t(kPendingCandidates)) pend[npend++] = int(first + i); else overflow |= 2u;
+                            continue;
+                        }
+                        if (!mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) continue;
+                    }
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
                     const uint32_t flat = __float_as_uint(tc.w);
                     if (best_tri == kNoHit || t < tbest || (t == tbest && flat < best_flat)) {
@@ -1603,6 +1641,12 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         }
         if (has && cur == kStackSentinel) {
             has = false;
+            if (DEFER && npend) {                             // decision (vi): the self-contradicting candidates of this ray, decided in binary64
+                const PendingBest pb = resolve_pending<ALPHA>(&sc, const_cast<const int *>(pend), npend, ro, rd, tmin, tmax, any_hit,
+                                                              PendingBest{ tbest, best_u, best_v, best_tri, best_flat });
+                tbest = pb.t; best_u = pb.u; best_v = pb.v; best_tri = pb.tri; best_flat = pb.flat;
+                npend = 0;
+            }
             commit(pix, best_tri, best_u, best_v);
         }
         if (STATS) {
@@ -1719,7 +1763,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // (first bounce only: the second bounce's origins are scattered over the scene, their descent ends at once -- measured: no gain)
     const uint32_t cut_n = total && bounce == 0 ? build_tile_cut_uniform(a.scene, omin, omax, s_cut_all[wave], lane) : 0u;
     const unsigned long long tw0 = STATS ? __builtin_readcyclecounter() : 0ull;
-    wave_queue_walk<SPILL, false, STATS>(
+    wave_queue_walk<SPILL, false, true, STATS>(
         a.scene, stack, stack_levels, lane, total, refill_threshold, early_exit, a.tp.tmin, a.tp.tmax, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
@@ -2265,7 +2309,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // ---- walk 1: closest hit of the primary rays (rgen:20; ALPHA: gl_RayFlagsNoOpaqueEXT -> the any-hit filter) ----
     // (one origin for every ray: the shared descent follows the boxes around the camera)
     uint32_t cut_n = traced && total ? build_tile_cut_uniform(a.scene, origin, origin, s_cut_all[wave], lane) : 0u;
-    wave_queue_walk<SPILL, ALPHA>(
+    wave_queue_walk<SPILL, ALPHA, false>(
         a.scene, stack, stack_levels, lane, traced ? total : 0u, refill_threshold, early_exit, 0.1f, 10000.0f, false, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
@@ -2301,7 +2345,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     wave_lds_sync();
     // ---- walk 2: any hit towards the light; the answer (an occluder's triangle or kNoHit) lands in row 3 ----
     cut_n = nhit ? build_tile_cut_uniform(a.scene, omin, omax, s_cut_all[wave], lane) : 0u;
-    wave_queue_walk<SPILL, ALPHA>(
+    wave_queue_walk<SPILL, ALPHA, false>(
         a.scene, stack, stack_levels, lane, nhit, refill_threshold, early_exit, 0.1f, 10000.0f, true, overflow, s_cut_all[wave], cut_n,
         [&](uint32_t r, uint32_t &pix, f3 &ro, f3 &rd) {
             pix = s_list[r];
