@@ -23,9 +23,13 @@ __constant__ float c_srgb_lut[256];
 #ifndef VHR_K1_POSTPONE
 #define VHR_K1_POSTPONE 0            // 1: a scratch build of the any-hit queue kernel WITH the postponed-leaf step (measured slower: profiles/r6_k1_postponed_leaf.txt)
 #endif
-#ifndef VHR_K1_WAVES_MIN
-#define VHR_K1_WAVES_MIN 7          // waves per SIMD the any-hit queue kernel is allocated for (7: <= 72 registers, 8: <= 64)
+#ifndef VHR_REDO_INLINE
+#define VHR_REDO_INLINE __attribute__((noinline))
 #endif
+#ifndef VHR_K1_WAVES_MIN
+#define VHR_K1_WAVES_MIN 8          // waves per SIMD the any-hit queue kernel is allocated for (7: <= 72 registers, 8: <= 64; redo_pixel_visibility() inherits it)
+#endif
+constexpr uint32_t kRedoPixel = 0x80000000u;   // raygen_queue_kernel's visibility word: the pixel is computed again by redo_pixel_visibility (decision (vi))
 constexpr int kTraceBlock = 256;          // 4 waves; each wave owns an 8x8 pixel tile of a 16x16 block tile
 
 struct Hit {
@@ -150,7 +154,7 @@ __device__ __forceinline__ void box_bounds(const DeviceScene &sc, f3 &omin, f3 &
     omax = f3{ rc.x + rh.x, rc.y + rh.y, rc.z + rh.z };
 }
 
-// Per-lane BVH2 walk with the traversal stack in LDS (stack[level * kTraceBlock + thread]: conflict free).
+// Per-lane BVH2 walk with the traversal stack in LDS (stack[level * kTraceBlock + thread]: conflict free; STRIDE 1: a private array).
 // ANY_HIT: gl_RayFlagsTerminateOnFirstHitEXT | SkipClosestHitShader (raygen.rgen:39,51) -- returns at the
 // first accepted triangle; the boolean result does not depend on the visiting order.
 // !ANY_HIT: closest hit = min t, ties broken by the smaller flat triangle index; subtrees are pruned with
@@ -159,7 +163,7 @@ __device__ __forceinline__ void box_bounds(const DeviceScene &sc, f3 &omin, f3 &
 // closesthit_test_alpha.rchit:42): every candidate first runs shadow_anyhit.rahit, an ignored candidate does not exist.
 __device__ bool alpha_ignored(const DeviceScene &sc, uint32_t tri_index, float u, float v);
 
-template <bool ANY_HIT, bool ALPHA = false>
+template <bool ANY_HIT, bool ALPHA = false, int STRIDE = kTraceBlock>
 __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, float tmin, float tmax, int *stack, Hit &best,
                                          uint32_t &overflow) {
     if (sc.node_count == 0) return false;
@@ -181,7 +185,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
             if (h0 && h1) {
                 const bool first0 = tn0 <= tn1;
                 const int nearc = first0 ? q3.x : q3.y, farc = first0 ? q3.y : q3.x;
-                if (sp < kTraceStack) { stack[sp * kTraceBlock] = farc; ++sp; } else { overflow = 1; }
+                if (sp < kTraceStack) { stack[sp * STRIDE] = farc; ++sp; } else { overflow = 1; }
                 cur = nearc;
                 continue;
             }
@@ -209,7 +213,7 @@ __device__ __forceinline__ bool traverse(const DeviceScene &sc, f3 o, f3 d, floa
         }
         if (sp == 0) break;
         --sp;
-        cur = stack[sp * kTraceBlock];
+        cur = stack[sp * STRIDE];
     }
     return found;
 }
@@ -449,12 +453,62 @@ __device__ __forceinline__ void pixel_of_thread(uint32_t &x, uint32_t &y, uint32
     y = row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
-// raygen.rgen:14-66 for one pixel, its rays one after another (the walker with the whole of decision (vi): traverse<> -> ray_triangle)
-__device__ __forceinline__ void raygen_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, uint32_t &overflow, bool &covered, bool &second_ray) {
+// raygen.rgen:26-55 for one covered pixel: its shadow ray and its AO rays one after another (the walker with the whole of decision (vi): traverse<> ->
+// ray_triangle).  STRIDE: the stack's (kTraceBlock: the per-pixel kernels' LDS columns; 1: a private array).
+template <int STRIDE>
+__device__ __forceinline__ void pixel_visibility(const RaygenArgs &a, const uint32_t x, const uint32_t y, const float depth, int *stack, uint32_t &overflow,
+                                                 f3 &P, f3 &N, f3 &origin, float &shadow_payload, float &ao_payload) {
     const uint32_t W = a.width, H = a.height;
     const float u = (float(x) + 0.5f) / float(W);                                        // rgen:15-16
     const float v = (float(y) + 0.5f) / float(H);
     uint32_t rng = seed_thread((y * H + x) * a.pfd.frame_index);                         // rgen:17 (LaunchSize.y)
+    P = get_world_space_position(a.pfd, depth, u, v);                                    // rgen:26
+    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1],
+                      a.pfd.directional_light.direction[2] };                            // rgen:27
+    const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
+    N = f3{ nid.x, nid.y, nid.z };
+    origin = P + N * a.tp.normal_bias;                                                   // rgen:29
+    Hit hit;
+
+    float rnd1 = random01(rng);                                                          // rgen:32-33
+    float rnd2 = random01(rng);
+    shadow_payload = 1.0f;
+    if (a.tp.shadow_enable) {
+        const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));   // rgen:34
+        const f3 dir = onb_transform(L, cone_dir);                                       // rgen:35,40
+        // rgen:37-41 issues this trace four times with identical arguments; once is equivalent
+        const bool occluded = traverse<true, false, STRIDE>(a.scene, origin, dir, a.tp.tmin, a.tp.tmax, stack, hit, overflow);
+        shadow_payload = occluded ? 0.0f : 1.0f;                                         // miss.rmiss:7
+    }
+    ao_payload = 0.0f;                                                                   // rgen:44-55
+    for (uint32_t i = 0; i < a.tp.ao_spp; ++i) {
+        rnd1 = random01(rng);
+        rnd2 = random01(rng);
+        const f3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
+        const f3 dir = onb_transform(N, rnd_dir);
+        const bool occluded = traverse<true, false, STRIDE>(a.scene, origin, dir, a.tp.tmin, a.tp.ao_tmax, stack, hit, overflow);
+        ao_payload += occluded ? 0.0f : 1.0f;
+    }
+    if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
+}
+
+// Decision (vi) in the any-hit queue kernel: a pixel one of whose rays met a candidate that contradicts itself is computed again, whole, by the per-pixel
+// kernel's code (binary64 decisions inline) when its tile is done -- a call, so that the queue kernel's loops carry none of this (inlined in its leaf
+// test the binary64 arithmetic cost the kernel 13 registers = a wave per SIMD, 1.3-1.5 % of the frame: profiles/r6_decision_vi_cost.txt).  `a` points at
+// the launch's arguments where they lie in memory (the address of a by-value argument would copy all of it to every lane's scratch).  One pixel in
+// 30 000 on the BASELINE scenes.
+__device__ VHR_REDO_INLINE float2 redo_pixel_visibility(const RaygenArgs *a, const uint32_t x, const uint32_t y) {
+    int st[kTraceStack];
+    uint32_t overflow = 0;
+    f3 P, N, origin;
+    float shadow_payload, ao_payload;
+    pixel_visibility<1>(*a, x, y, a->depth[size_t(y) * a->width + x], st, overflow, P, N, origin, shadow_payload, ao_payload);
+    return float2{ shadow_payload, ao_payload };
+}
+
+// raygen.rgen:14-66 for one pixel
+__device__ __forceinline__ void raygen_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, uint32_t &overflow, bool &covered, bool &second_ray) {
+    const uint32_t W = a.width;
     const float depth = a.depth[size_t(y) * W + x];                                      // rgen:19
     if (depth == 0.0f) {                                                                 // rgen:20-24
         store_rg16f(a.shadow_ao, W, x, y, 1.0f, 1.0f);
@@ -462,34 +516,9 @@ __device__ __forceinline__ void raygen_pixel(const RaygenArgs &a, const uint32_t
         return;
     }
     covered = true;
-    const f3 P = get_world_space_position(a.pfd, depth, u, v);                           // rgen:26
-    const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1],
-                      a.pfd.directional_light.direction[2] };                            // rgen:27
-    const f4 nid = load_rgba16f(a.normals, W, x, y);                                     // rgen:28
-    const f3 N = f3{ nid.x, nid.y, nid.z };
-    const f3 origin = P + N * a.tp.normal_bias;                                          // rgen:29
-    Hit hit;
-
-    float rnd1 = random01(rng);                                                          // rgen:32-33
-    float rnd2 = random01(rng);
-    float shadow_payload = 1.0f;
-    if (a.tp.shadow_enable) {
-        const f3 cone_dir = normalize3(uniform_sample_cone(rnd1, rnd2, a.tp.cone_cos_max));   // rgen:34
-        const f3 dir = onb_transform(L, cone_dir);                                       // rgen:35,40
-        // rgen:37-41 issues this trace four times with identical arguments; once is equivalent
-        const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.tmax, stack, hit, overflow);
-        shadow_payload = occluded ? 0.0f : 1.0f;                                         // miss.rmiss:7
-    }
-    float ao_payload = 0.0f;                                                             // rgen:44-55
-    for (uint32_t i = 0; i < a.tp.ao_spp; ++i) {
-        rnd1 = random01(rng);
-        rnd2 = random01(rng);
-        const f3 rnd_dir = cosine_hemisphere(rnd1, rnd2);
-        const f3 dir = onb_transform(N, rnd_dir);
-        const bool occluded = traverse<true>(a.scene, origin, dir, a.tp.tmin, a.tp.ao_tmax, stack, hit, overflow);
-        ao_payload += occluded ? 0.0f : 1.0f;
-    }
-    if (a.tp.ao_spp) ao_payload /= float(a.tp.ao_spp); else ao_payload = 1.0f;
+    f3 P, N, origin;
+    float shadow_payload, ao_payload;
+    pixel_visibility<kTraceBlock>(a, x, y, depth, stack, overflow, P, N, origin, shadow_payload, ao_payload);
     store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
 
     if (a.reflections) {
@@ -1080,9 +1109,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     // the entries beyond their reach was measured: the test per entry costs sponza_proc what it saves bistro_proc, r4)
     const bool ao_only = first_kind != 0u;
     // A pixel's visibility word holds one "blocked" bit per ray kind (what lets several lanes share a ray: "raygen_steal") while the kinds fit a
-    // word; with more than 31 AO samples it holds bit 0 for the shadow ray and, from bit 8 up, the COUNT of AO rays that escaped, and a ray is
-    // walked by the one lane that fetched it.
-    const bool kind_bits = last_kind <= 31u;
+    // word; with more than 30 AO samples it holds bit 0 for the shadow ray and, from bit 8 up, the COUNT of AO rays that escaped, and a ray is
+    // walked by the one lane that fetched it.  Bit 31 (kRedoPixel) in either form: decision (vi) wants the pixel computed again (below).
+    const bool kind_bits = last_kind <= 30u;
     const f3 L = -f3{ a.pfd.directional_light.direction[0], a.pfd.directional_light.direction[1], a.pfd.directional_light.direction[2] };
     f3 omin = f3{ 3.0e38f, 3.0e38f, 3.0e38f }, omax = f3{ -3.0e38f, -3.0e38f, -3.0e38f };   // bounds of the tile's ray origins
     float ao_reach = 0.0f;                                                                   // bound of tmax * |d| over this pixel's AO rays
@@ -1332,8 +1361,9 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
                         found = true;
                         break;
                     }
-                    // decision (vi): a candidate that contradicts itself is decided again in binary64
-                    if (mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, ct, cu, cv)) { found = true; break; }
+                    // decision (vi): a candidate that contradicts itself is decided again in binary64 -- not here: the pixel is marked and computed
+                    // again when the tile is done (redo_pixel_visibility), the walk goes on as if the candidate had missed
+                    atomicOr(&s_vis[pix], kRedoPixel);
                 }
             }
         };
@@ -1390,10 +1420,17 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
     }
     wave_lds_sync();
     float shadow_payload = 1.0f, ao_payload = 1.0f;                                          // rgen:20-21 for a pixel without geometry
+    uint32_t n_redo = 0;
     if (covered) {
         const uint32_t vis = s_vis[lane];
         shadow_payload = (vis & 1u) ? 0.0f : 1.0f;
         if (a.tp.ao_spp) ao_payload = float(a.scene.node_count == 0 ? a.tp.ao_spp : (kind_bits ? a.tp.ao_spp - uint32_t(__popc(vis >> 1)) : (vis >> 8))) / float(a.tp.ao_spp);   // rgen:55: the AO rays that escaped
+        if (vis & kRedoPixel) {                           // decision (vi): one of this pixel's rays met a candidate that contradicts itself
+            static_assert(offsetof(RaygenArgs, scene) == 0, "the launch's arguments start with `a`");
+            const float2 again = redo_pixel_visibility(reinterpret_cast<const RaygenArgs *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()), x, y);
+            shadow_payload = again.x; ao_payload = again.y;
+            n_redo = 1;
+        }
         store_rg16f(a.shadow_ao, W, x, y, shadow_payload, ao_payload);                       // rgen:57
     }
     if (a.co.wave_cost && lane == 0) a.co.wave_cost[block_tile * uint32_t(WAVES) + wave] = uint32_t(min(__builtin_readcyclecounter() - t_cost0, 0xffffffffull));
@@ -1431,6 +1468,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
             atomicAdd(&stats->waves, 1ull);
             atomicAdd(&stats->cut_entries, (unsigned long long)n_cut_entries);
         }
+        const unsigned long long redo = __ballot(n_redo != 0);
+        if (redo && lane == 0) atomicAdd(&stats->pending_rays, (unsigned long long)__popcll(redo));
         // wave-reduced first: 64 same-address atomics per wave serialise at the memory side (the diagnostic launch took 3.4 ms)
         for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
         if (lane == 0) {
@@ -1492,16 +1531,25 @@ constexpr int kPendingCandidates = 16;
 
 // what a walk did (STATS builds only): node visits, leaf visits and triangle tests summed over lanes, and the trips of the two inner loops
 // counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
-struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
+struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0, pending_rays = 0, pending_retraces = 0; };
 
 // Decision (vi) in the queue walkers: the triangles whose fp32 solution contradicted itself (a lane's scratch list) against the lane's ray, in binary64, folded
 // into the closest hit so far by (t, flat index).  NOT inlined, and called where a ray is committed: the walk's loops then carry none of its registers --
 // inlined into the leaf test it made the two-bounce mirror kernel spill 45 registers (launch +14 %), inlined at the commit still 48; as a call in the
 // leaf test it cost the walk 13 registers (round 6, profiles/r6_decision_vi_cost.txt).  The call is taken by one ray in 10^5 on the hybrid path's scenes.
+// A ray that met more such triangles than the list holds (npend > kPendingCandidates; "decision_vi_list" sets the capacity in use, 0 = every such ray) is
+// traced again here from the root by the per-pixel kernels' walk, binary64 decisions inline, on a private stack: the list bounds the scratch, not the answer.
 struct PendingBest { float t, u, v; uint32_t tri, flat; };
 template <bool ALPHA>
 __device__ __attribute__((noinline)) PendingBest resolve_pending(const DeviceScene *sc, const int *pend, uint32_t npend, f3 ro, f3 rd, float tmin, float tmax, bool any_hit,
                                                                   PendingBest best) {
+    if (npend > uint32_t(kPendingCandidates)) {
+        int st[kTraceStack];
+        Hit h;
+        uint32_t ovf = 0;
+        if (!traverse<false, ALPHA, 1>(*sc, ro, rd, tmin, tmax, st, h, ovf)) return PendingBest{ tmax, 0.0f, 0.0f, kNoHit, 0u };
+        return PendingBest{ h.t, h.u, h.v, h.tri_index, h.flat };
+    }
     for (uint32_t k = 0; k < npend; ++k) {
         if (any_hit && best.tri != kNoHit) break;
         const uint32_t ti = uint32_t(pend[k]);
@@ -1520,7 +1568,8 @@ template <bool SPILL, bool ALPHA, bool DEFER, bool STATS = false, typename Fetch
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
-                                                const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit, WalkCounters *wc = nullptr) {
+                                                const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit, WalkCounters *wc = nullptr,
+                                                const uint32_t pend_cap = uint32_t(kPendingCandidates), const DeviceScene *const sc_mem = nullptr) {
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
@@ -1531,8 +1580,8 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
     // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
     // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
     volatile int spill[SPILL ? kSpillStack : 1];
-    // decision (vi): the triangles whose fp32 solution contradicted itself, waiting for the ray's commit (scratch; kPendingCandidates of them -- one more sets
-    // bit 1 of `overflow`, which the statistics report as a stack overflow: tests/ assert there is none)
+    // decision (vi): the triangles whose fp32 solution contradicted itself, waiting for the ray's commit (scratch; pend_cap <= kPendingCandidates of them --
+    // one more and the ray is traced again at its commit: npend = kPendingCandidates + 1 says so)
     volatile int pend[DEFER ? kPendingCandidates : 1];
     uint32_t npend = 0;
     float tmin_v = tmin;
@@ -1609,7 +1658,7 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                     // the call gains nothing (launch 390-400 us either way) and the list of 16 would overflow into the per-pixel kernel.
                     if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) {
                         if (DEFER) {
-                            if (npend < uint32_t(kPendingCandidates)) pend[npend++] = int(first + i); else overflow |= 2u;
+                            if (npend < pend_cap) pend[npend++] = int(first + i); else npend = uint32_t(kPendingCandidates) + 1u;
                             continue;
                         }
                         if (!mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) continue;
@@ -1642,7 +1691,8 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         if (has && cur == kStackSentinel) {
             has = false;
             if (DEFER && npend) {                             // decision (vi): the self-contradicting candidates of this ray, decided in binary64
-                const PendingBest pb = resolve_pending<ALPHA>(&sc, const_cast<const int *>(pend), npend, ro, rd, tmin, tmax, any_hit,
+                if (STATS) { ++wc->pending_rays; wc->pending_retraces += npend > uint32_t(kPendingCandidates) ? 1u : 0u; }
+                const PendingBest pb = resolve_pending<ALPHA>(sc_mem, const_cast<const int *>(pend), npend, ro, rd, tmin, tmax, any_hit,
                                                               PendingBest{ tbest, best_u, best_v, best_tri, best_flat });
                 tbest = pb.t; best_u = pb.u; best_v = pb.v; best_tri = pb.tri; best_flat = pb.flat;
                 npend = 0;
@@ -1688,7 +1738,7 @@ __device__ __forceinline__ void mirror_ray_of_pixel(const RaygenArgs &a, f3 cam,
 template <bool SPILL, int BOUNCES, bool STATS = false>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(7, 7))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const Stamps st) {
+    const uint32_t early_exit, const uint32_t pend_cap, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
     // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
@@ -1755,6 +1805,11 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // ---- phase 2: the queue (once per bounce) ----
     uint32_t overflow = 0, second_rays = 0;
     WalkCounters wc;
+    // the scene as resolve_pending() reads it: where the launch's arguments lie in memory (`a` is the first of them, the scene its first member).  The
+    // address of the by-value argument instead makes the compiler copy all of `a` to every lane's scratch -- 1.4 KB a lane, and the launch took four
+    // times as long for the waves the scratch ring then had room for (measured: 257 -> 1 008 us)
+    static_assert(offsetof(RaygenArgs, scene) == 0, "resolve_pending reads the scene at the head of the kernel arguments");
+    const DeviceScene *const scene_mem = reinterpret_cast<const DeviceScene *>((const void *)__builtin_amdgcn_kernarg_segment_ptr());
     const unsigned long long t_walk0 = STATS ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_walk = 0;
 #pragma unroll 1
@@ -1772,7 +1827,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
-        }, &wc);
+        }, &wc, pend_cap, scene_mem);
     wave_lds_sync();
     if (STATS) t_walk += __builtin_readcyclecounter() - tw0;
     if constexpr (BOUNCES > 1) if (bounce == 0) {
@@ -1841,8 +1896,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     if constexpr (STATS) {
         // the mirror-ray launch's own counters: the second RayStats of the buffer (vhr_get_reflection_statistics)
         RayStats *const rs = a.stats + 1;
-        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles;
-        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
+        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles, n_pend = wc.pending_rays | (wc.pending_retraces << 16);
+        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); n_pend += uint32_t(__shfl_xor(int(n_pend), off)); }
         if (lane == 0) {
             atomicAdd(&rs->node_visits, (unsigned long long)n_nodes);
             atomicAdd(&rs->leaf_visits, (unsigned long long)n_leaves);
@@ -1853,6 +1908,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             atomicAdd(&rs->second_bounce_rays, (unsigned long long)second_rays);
             atomicAdd(&rs->refills, (unsigned long long)wc.refills);
             atomicAdd(&rs->waves, 1ull);
+            if (n_pend) { atomicAdd(&rs->pending_rays, (unsigned long long)(n_pend & 0xffffu)); atomicAdd(&rs->pending_retraces, (unsigned long long)(n_pend >> 16)); }
             atomicAdd(&rs->cycles_total, __builtin_readcyclecounter() - t_walk0);          // set-up + walks + shading, this wave
             atomicAdd(&rs->cycles_nodes, t_walk);                                           // the walks alone (both bounces)
         }
@@ -2101,7 +2157,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
                                    (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co,
                                    { tiles_x, tiles_x, 1u, 8u, 8u, m.col_begin, m.row_begin });
-#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
+#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptDecisionViList]))
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }
