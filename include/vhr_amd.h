@@ -575,9 +575,8 @@ int vhr_get_traversal_statistics(vhr_context *ctx, uint64_t out[4]);
  * waves' lifetimes, out[9] = of those, inside the walks (the rest is ray set-up and shading). */
 int vhr_get_reflection_statistics(vhr_context *ctx, uint64_t out[10]);
 /* Decision (vi)'s binary64 half in the work-queue kernels of the last vhr_trace_rays (statistics enabled).  A candidate whose fp32 solution contradicts
- * itself is decided again in binary64 -- in the per-pixel kernels in place, in the queue kernels outside their loops: out[0] = pixels of the shadow / AO
- * launch computed again by the per-pixel code when their tile was done, out[1] = mirror rays that parked such candidates and decided them when the ray
- * was committed, out[2] = of those, rays with more candidates than option "decision_vi_list" holds, traced again in full, out[3] = 0. */
+ * itself is decided again in binary64 -- in the per-pixel kernels in place, in the queue kernels outside their loops: the pixel is marked and computed
+ * again by the per-pixel code when its tile is done.  out[0] = such pixels of the shadow / AO launch, out[1] = of the mirror ray's launch, out[2..3] = 0. */
 int vhr_get_binary64_statistics(vhr_context *ctx, uint64_t out[4]);
 
 /* Where the waves of the last work-queue raygen launch spent their time (statistics enabled; s_memtime ticks summed

@@ -724,7 +724,7 @@ int vhr_get_reflection_statistics(vhr_context *ctx, uint64_t out[10]) {
 int vhr_get_binary64_statistics(vhr_context *ctx, uint64_t out[4]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     if (!ctx->host_only) { const int src_ = ctx->sync_streams(); if (src_ != VHR_OK) return src_; }
-    out[0] = ctx->h_ray_stats.pending_rays; out[1] = ctx->h_refl_stats.pending_rays; out[2] = ctx->h_refl_stats.pending_retraces; out[3] = 0;
+    out[0] = ctx->h_ray_stats.pending_rays; out[1] = ctx->h_refl_stats.pending_rays; out[2] = 0; out[3] = 0;
     return VHR_OK;
 }
 

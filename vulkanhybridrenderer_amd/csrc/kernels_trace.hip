@@ -393,11 +393,12 @@ __device__ __forceinline__ void hit_position_normal(const DeviceScene &sc, const
 
 // The mirror ray of raygen.rgen:59-65 with the optional second bounce: a mirror ray from the first hit about the shader's N
 // (normalised, facing the incoming ray), origin biased like raygen.rgen:29, shaded by reflection_hit.rchit without recursion.
+template <int STRIDE = kTraceBlock>
 __device__ __forceinline__ f4 trace_reflection(const DeviceScene &sc, const vhr_per_frame_data &pfd, const vhr_trace_params &tp, f3 origin,
                                                f3 rdir, int *stack, uint32_t &overflow, bool &second_ray) {
     Hit hit;
     second_ray = false;
-    if (!traverse<false>(sc, origin, rdir, tp.tmin, tp.tmax, stack, hit, overflow)) return f4{ 0.0f, 0.0f, 0.0f, 0.0f };   // reflection_miss.rmiss:7
+    if (!traverse<false, false, STRIDE>(sc, origin, rdir, tp.tmin, tp.tmax, stack, hit, overflow)) return f4{ 0.0f, 0.0f, 0.0f, 0.0f };   // reflection_miss.rmiss:7
     if (tp.reflections < 2) return shade_reflection_hit(sc, pfd, hit);
     f3 hp, hn;
     (void)shade_reflection_hit(sc, pfd, hit, nullptr, &hp, &hn);
@@ -409,7 +410,7 @@ __device__ __forceinline__ f4 trace_reflection(const DeviceScene &sc, const vhr_
     second_ray = true;
     Hit hit2;
     f4 second = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    if (traverse<false>(sc, o2, d2, tp.tmin, tp.tmax, stack, hit2, overflow)) second = shade_reflection_hit(sc, pfd, hit2);
+    if (traverse<false, false, STRIDE>(sc, o2, d2, tp.tmin, tp.tmax, stack, hit2, overflow)) second = shade_reflection_hit(sc, pfd, hit2);
     return shade_reflection_hit(sc, pfd, hit, &second);
 }
 
@@ -1481,7 +1482,8 @@ __global__ __launch_bounds__(kQueueBlock *WAVES) __attribute__((amdgpu_waves_per
 }
 
 // Mirror ray of raygen.rgen:59-65 (closest hit, reflection_hit.rchit / reflection_miss.rmiss) for one pixel of the image
-__device__ __forceinline__ void reflection_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, bool &second_ray) {
+template <int STRIDE>
+__device__ __forceinline__ f4 reflection_payload(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, bool &second_ray) {
     const uint32_t W = a.width, H = a.height;
     f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     const float depth = a.depth[size_t(y) * W + x];
@@ -1496,9 +1498,28 @@ __device__ __forceinline__ void reflection_pixel(const RaygenArgs &a, const uint
         const float ni2 = 2.0f * dot3(N, I);
         const f3 rdir = I - N * ni2;
         uint32_t overflow = 0;
-        payload = trace_reflection(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
+        payload = trace_reflection<STRIDE>(a.scene, a.pfd, a.tp, origin, rdir, stack, overflow, second_ray);
     }
-    store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);
+    return payload;
+}
+__device__ __forceinline__ void reflection_pixel(const RaygenArgs &a, const uint32_t x, const uint32_t y, int *stack, bool &second_ray) {
+    const f4 payload = reflection_payload<kTraceBlock>(a, x, y, stack, second_ray);
+    store_rgba16f(a.reflections, a.width, x, y, payload.x, payload.y, payload.z, payload.w);
+}
+
+// Decision (vi) in the mirror ray's queue kernel: a pixel whose ray (first or second bounce) met a candidate whose fp32 solution contradicts itself is
+// computed again, whole, by the per-pixel kernel's code (binary64 decisions inline) when its tile is shaded -- a call, so that the queue's walk carries
+// none of this: inlined in its leaf test the binary64 arithmetic made the two-bounce kernel spill 45 registers (launch +13 %), a list of the candidates
+// per ray decided by a call at the ray's commit still cost +7 % (profiles/r6_decision_vi_cost.txt).  `a` points at the launch's arguments where they lie
+// in memory (the address of a by-value argument would copy all of it to every lane's scratch: 1.4 KB a lane, and the launch took four times as long for
+// the waves the scratch ring then had room for).  One ray in 10^5 on the BASELINE scenes.  `second`: a second-bounce ray was
+// traced (the launch's ray count).
+struct RedoReflection { f4 payload; uint32_t second; };
+__device__ __attribute__((noinline)) RedoReflection redo_pixel_reflection(const RaygenArgs *a, const uint32_t x, const uint32_t y) {
+    int st[kTraceStack];
+    bool second_ray = false;
+    const f4 payload = reflection_payload<1>(*a, x, y, st, second_ray);
+    return RedoReflection{ payload, second_ray ? 1u : 0u };
 }
 
 // ... one pixel per thread
@@ -1527,49 +1548,18 @@ __global__ __launch_bounds__(kTraceBlock) void reflection_kernel(const RaygenArg
 // candidate first runs shadow_anyhit.rahit (alpha_ignored).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kNoHit = 0xffffffffu;
-constexpr int kPendingCandidates = 16;
 
 // what a walk did (STATS builds only): node visits, leaf visits and triangle tests summed over lanes, and the trips of the two inner loops
 // counted once per wave (the slowest lane's) -- lane utilisation = (nodes + triangles) / (64 x wave_trips), as for raygen_queue_kernel
-struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0, pending_rays = 0, pending_retraces = 0; };
+struct WalkCounters { uint32_t nodes = 0, leaves = 0, triangles = 0, wave_trips = 0, refills = 0; };
 
-// Decision (vi) in the queue walkers: the triangles whose fp32 solution contradicted itself (a lane's scratch list) against the lane's ray, in binary64, folded
-// into the closest hit so far by (t, flat index).  NOT inlined, and called where a ray is committed: the walk's loops then carry none of its registers --
-// inlined into the leaf test it made the two-bounce mirror kernel spill 45 registers (launch +14 %), inlined at the commit still 48; as a call in the
-// leaf test it cost the walk 13 registers (round 6, profiles/r6_decision_vi_cost.txt).  The call is taken by one ray in 10^5 on the hybrid path's scenes.
-// A ray that met more such triangles than the list holds (npend > kPendingCandidates; "decision_vi_list" sets the capacity in use, 0 = every such ray) is
-// traced again here from the root by the per-pixel kernels' walk, binary64 decisions inline, on a private stack: the list bounds the scratch, not the answer.
-struct PendingBest { float t, u, v; uint32_t tri, flat; };
-template <bool ALPHA>
-__device__ __attribute__((noinline)) PendingBest resolve_pending(const DeviceScene *sc, const int *pend, uint32_t npend, f3 ro, f3 rd, float tmin, float tmax, bool any_hit,
-                                                                  PendingBest best) {
-    if (npend > uint32_t(kPendingCandidates)) {
-        int st[kTraceStack];
-        Hit h;
-        uint32_t ovf = 0;
-        if (!traverse<false, ALPHA, 1>(*sc, ro, rd, tmin, tmax, st, h, ovf)) return PendingBest{ tmax, 0.0f, 0.0f, kNoHit, 0u };
-        return PendingBest{ h.t, h.u, h.v, h.tri_index, h.flat };
-    }
-    for (uint32_t k = 0; k < npend; ++k) {
-        if (any_hit && best.tri != kNoHit) break;
-        const uint32_t ti = uint32_t(pend[k]);
-        const float4 *tp = reinterpret_cast<const float4 *>(sc->tris + ti);
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-        float t, uu, ww;
-        if (!mt_binary64(ro, rd, f3{ ta.x, ta.y, ta.z }, f3{ ta.w, tb.x, tb.y }, f3{ tb.z, tb.w, tc.x }, tmin, tmax, t, uu, ww)) continue;
-        if (ALPHA && alpha_ignored(*sc, ti, uu, ww)) continue;
-        const uint32_t flat = __float_as_uint(tc.w);
-        if (best.tri == kNoHit || t < best.t || (t == best.t && flat < best.flat)) best = PendingBest{ t, uu, ww, ti, flat };
-    }
-    return best;
-}
-
-template <bool SPILL, bool ALPHA, bool DEFER, bool STATS = false, typename Fetch, typename Commit>
+struct NoFlag { __device__ __forceinline__ void operator()(uint32_t) const {} };
+template <bool SPILL, bool ALPHA, bool DEFER, bool STATS = false, typename Fetch, typename Commit, typename Flag = NoFlag>
 __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stack, const uint32_t stack_levels, const uint32_t lane,
                                                 const uint32_t total, const uint32_t refill_threshold, const uint32_t early_exit,
                                                 const float tmin, const float tmax, const bool any_hit, uint32_t &overflow,
                                                 const float4 (*cut)[2], const uint32_t cut_n, Fetch fetch, Commit commit, WalkCounters *wc = nullptr,
-                                                const uint32_t pend_cap = uint32_t(kPendingCandidates), const DeviceScene *const sc_mem = nullptr) {
+                                                Flag flag = Flag{}) {
     f3 ro = f3{ 0, 0, 0 }, rd = f3{ 0, 0, 1 }, rinv = f3{ 0, 0, 0 }, noi = f3{ 0, 0, 0 }, ainv = f3{ 0, 0, 0 };
     float tbest = 0.0f, best_u = 0.0f, best_v = 0.0f;
     uint32_t best_tri = kNoHit, best_flat = 0;
@@ -1580,10 +1570,6 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
     // volatile: keeps the array in scratch.  Left alone, the compiler promotes it to 32 VGPRs with indirect indexing, which
     // pushes the kernels over their register budget (55 spilled VGPRs, 38 spilled SGPRs, 1.5x slower: measured)
     volatile int spill[SPILL ? kSpillStack : 1];
-    // decision (vi): the triangles whose fp32 solution contradicted itself, waiting for the ray's commit (scratch; pend_cap <= kPendingCandidates of them --
-    // one more and the ray is traced again at its commit: npend = kPendingCandidates + 1 says so)
-    volatile int pend[DEFER ? kPendingCandidates : 1];
-    uint32_t npend = 0;
     float tmin_v = tmin;
     asm volatile("" : "+v"(tmin_v));
     for (;;) {
@@ -1651,16 +1637,11 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
                 if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) {
                     // decision (vi): a candidate that contradicts itself is decided again in binary64.  DEFER (the mirror ray's kernels, where one ray in
-                    // 10^5 has one): not here, where the walk's registers are all alive (inlined at this point the two-bounce kernel spilled 45 registers
-                    // and its launch grew by 13-14 %; deferred, by 7-8 %), but when the ray is committed -- the triangle waits in the lane's scratch list,
-                    // the walk goes on as if it had missed (boxes are culled against a closest t that does not know of it: that only visits more).
-                    // !DEFER (the raytraced path, whose shadow rays leave the hit point itself: 6 % of its rays have one): inline -- taken that often
-                    // the call gains nothing (launch 390-400 us either way) and the list of 16 would overflow into the per-pixel kernel.
+                    // 10^5 has one): not here, where the walk's registers are all alive -- the ray's pixel is flagged and computed again by the per-pixel
+                    // code when the tile is shaded (redo_pixel_reflection); the walk goes on as if the candidate had missed.  !DEFER (the raytraced path,
+                    // whose shadow rays leave the hit point itself: 6 % of its rays have one): inline.
                     if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) {
-                        if (DEFER) {
-                            if (npend < pend_cap) pend[npend++] = int(first + i); else npend = uint32_t(kPendingCandidates) + 1u;
-                            continue;
-                        }
+                        if (DEFER) { flag(pix); continue; }
                         if (!mt_binary64(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) continue;
                     }
                     if (ALPHA && alpha_ignored(sc, first + i, uu, ww)) continue;
@@ -1690,13 +1671,6 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
         }
         if (has && cur == kStackSentinel) {
             has = false;
-            if (DEFER && npend) {                             // decision (vi): the self-contradicting candidates of this ray, decided in binary64
-                if (STATS) { ++wc->pending_rays; wc->pending_retraces += npend > uint32_t(kPendingCandidates) ? 1u : 0u; }
-                const PendingBest pb = resolve_pending<ALPHA>(sc_mem, const_cast<const int *>(pend), npend, ro, rd, tmin, tmax, any_hit,
-                                                              PendingBest{ tbest, best_u, best_v, best_tri, best_flat });
-                tbest = pb.t; best_u = pb.u; best_v = pb.v; best_tri = pb.tri; best_flat = pb.flat;
-                npend = 0;
-            }
             commit(pix, best_tri, best_u, best_v);
         }
         if (STATS) {
@@ -1738,7 +1712,7 @@ __device__ __forceinline__ void mirror_ray_of_pixel(const RaygenArgs &a, f3 cam,
 template <bool SPILL, int BOUNCES, bool STATS = false>
 __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu(7, 7))) void reflection_queue_kernel(
     const RaygenArgs a, const uint32_t stack_levels, const uint32_t refill_threshold, const uint32_t tiles_x, const uint32_t tiles_total,
-    const uint32_t early_exit, const uint32_t pend_cap, const Stamps st) {
+    const uint32_t early_exit, const Stamps st) {
     vhr_stamp(st);
     extern __shared__ int s_dyn[];                        // per wave: (stack_levels + 3) x 64 ints, see raygen_queue_kernel
     // rows 0-2 origin -> hit record (triangle, u, v), rows 3-5 direction; two bounces: rows 6-8 second origin -> second record,
@@ -1755,6 +1729,7 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     __shared__ float s_ray_all[2][ROWS][RAYS];
     __shared__ uint8_t s_list_all[2][RAYS];               // compacted covered pixels
     __shared__ float4 s_cut_all[2][kCutMax][2];           // the tile's shared descent (build_tile_cut), once per walk
+    __shared__ uint32_t s_redo_all[2][RAYS / 32];         // decision (vi): bit p = pixel p is computed again in phase 3 (redo_pixel_reflection)
     const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     // "raygen_cost_order" for this launch (see raygen_queue_kernel): the first block sorts the previous launch's blocks before its own tiles
     const unsigned long long t_cost0 = a.co.wave_cost ? __builtin_readcyclecounter() : 0ull;
@@ -1764,6 +1739,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     if (tile >= tiles_total) return;                      // waves of a block share nothing and never synchronise
     float (&s_ray)[ROWS][RAYS] = s_ray_all[wave];
     uint8_t (&s_list)[RAYS] = s_list_all[wave];
+    uint32_t (&s_redo)[RAYS / 32] = s_redo_all[wave];
+    if (lane < uint32_t(RAYS / 32)) s_redo[lane] = 0u;
     int *stack = s_dyn + wave * (stack_levels + 3u) * kQueueBlock + lane;
     stack[0] = kStackSentinel;
     const uint32_t W = a.width;
@@ -1805,11 +1782,6 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     // ---- phase 2: the queue (once per bounce) ----
     uint32_t overflow = 0, second_rays = 0;
     WalkCounters wc;
-    // the scene as resolve_pending() reads it: where the launch's arguments lie in memory (`a` is the first of them, the scene its first member).  The
-    // address of the by-value argument instead makes the compiler copy all of `a` to every lane's scratch -- 1.4 KB a lane, and the launch took four
-    // times as long for the waves the scratch ring then had room for (measured: 257 -> 1 008 us)
-    static_assert(offsetof(RaygenArgs, scene) == 0, "resolve_pending reads the scene at the head of the kernel arguments");
-    const DeviceScene *const scene_mem = reinterpret_cast<const DeviceScene *>((const void *)__builtin_amdgcn_kernarg_segment_ptr());
     const unsigned long long t_walk0 = STATS ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_walk = 0;
 #pragma unroll 1
@@ -1827,7 +1799,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         },
         [&](uint32_t pix, uint32_t tri, float u, float v) {                                  // the hit record replaces the ray's origin
             s_ray[orow][pix] = __uint_as_float(tri); s_ray[orow + 1][pix] = u; s_ray[orow + 2][pix] = v;
-        }, &wc, pend_cap, scene_mem);
+        }, &wc,
+        [&](uint32_t pix) { atomicOr(&s_redo[pix >> 5], 1u << (pix & 31u)); });                   // decision (vi): the pixel is computed again in phase 3
     wave_lds_sync();
     if (STATS) t_walk += __builtin_readcyclecounter() - tw0;
     if constexpr (BOUNCES > 1) if (bounce == 0) {
@@ -1864,6 +1837,8 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
     }
 
     // ---- phase 3: reflection_hit.rchit / reflection_miss.rmiss on the records, whole wave ----
+    uint32_t n_redo = 0;
+    int redo_second = 0;
 #pragma unroll
     for (uint32_t sub = 0; sub < SUBS; ++sub) {
         if (!((covered_mask[sub] >> lane) & 1ull)) continue;
@@ -1871,7 +1846,13 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         const uint32_t p = sub * 64u + lane;
         f4 payload = f4{ 0.0f, 0.0f, 0.0f, 0.0f };                                           // reflection_miss.rmiss:7
         const uint32_t tri = traced ? __float_as_uint(s_ray[0][p]) : kNoHit;
-        if (tri != kNoHit) {
+        if (traced && ((s_redo[p >> 5] >> (p & 31u)) & 1u)) {                                // decision (vi): this pixel's ray asked for binary64
+            static_assert(offsetof(RaygenArgs, scene) == 0, "the launch's arguments start with `a`");
+            const RedoReflection again = redo_pixel_reflection(reinterpret_cast<const RaygenArgs *>((const void *)__builtin_amdgcn_kernarg_segment_ptr()), x, y);
+            payload = again.payload;
+            ++n_redo;
+            if (BOUNCES > 1) redo_second += int(again.second) - int(tri != kNoHit);          // (the launch's count of second-bounce rays)
+        } else if (tri != kNoHit) {
             Hit h;
             h.t = 0.0f; h.u = s_ray[1][p]; h.v = s_ray[2][p]; h.tri_index = tri; h.flat = 0;
             if constexpr (BOUNCES > 1) {
@@ -1889,15 +1870,20 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
         }
         store_rgba16f(a.reflections, W, x, y, payload.x, payload.y, payload.z, payload.w);   // rgen:65
     }
-    if (a.stats && lane == 0) {
-        if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
-        if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
+    if (a.stats) {
+        for (int off = 32; off > 0; off >>= 1) { n_redo += uint32_t(__shfl_xor(int(n_redo), off)); redo_second += __shfl_xor(redo_second, off); }
+        second_rays = uint32_t(int(second_rays) + redo_second);
+        if (lane == 0) {
+            if (overflow) atomicAdd(&a.stats->stack_overflows, 1ull);
+            if (second_rays) atomicAdd(&a.stats->second_bounce_rays, (unsigned long long)second_rays);
+            if (n_redo) atomicAdd(&(a.stats + 1)->pending_rays, (unsigned long long)n_redo);
+        }
     }
     if constexpr (STATS) {
         // the mirror-ray launch's own counters: the second RayStats of the buffer (vhr_get_reflection_statistics)
         RayStats *const rs = a.stats + 1;
-        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles, n_pend = wc.pending_rays | (wc.pending_retraces << 16);
-        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); n_pend += uint32_t(__shfl_xor(int(n_pend), off)); }
+        uint32_t n_nodes = wc.nodes, n_leaves = wc.leaves, n_tris = wc.triangles;
+        for (int off = 32; off > 0; off >>= 1) { n_nodes += uint32_t(__shfl_xor(int(n_nodes), off)); n_leaves += uint32_t(__shfl_xor(int(n_leaves), off)); n_tris += uint32_t(__shfl_xor(int(n_tris), off)); }
         if (lane == 0) {
             atomicAdd(&rs->node_visits, (unsigned long long)n_nodes);
             atomicAdd(&rs->leaf_visits, (unsigned long long)n_leaves);
@@ -1908,7 +1894,6 @@ __global__ __launch_bounds__(kQueueBlock * 2) __attribute__((amdgpu_waves_per_eu
             atomicAdd(&rs->second_bounce_rays, (unsigned long long)second_rays);
             atomicAdd(&rs->refills, (unsigned long long)wc.refills);
             atomicAdd(&rs->waves, 1ull);
-            if (n_pend) { atomicAdd(&rs->pending_rays, (unsigned long long)(n_pend & 0xffffu)); atomicAdd(&rs->pending_retraces, (unsigned long long)(n_pend >> 16)); }
             atomicAdd(&rs->cycles_total, __builtin_readcyclecounter() - t_walk0);          // set-up + walks + shading, this wave
             atomicAdd(&rs->cycles_nodes, t_walk);                                           // the walks alone (both bounces)
         }
@@ -2157,7 +2142,7 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
                 prepare_cost_order(ctx, ctx->cost_order_reflection, (tiles_total + 1u) / 2u, 2u,
                                    (tiles_x * 2654435761u) ^ (tiles_total * 40503u) ^ (uint32_t(m.tp.reflections) << 28) ^ (m.row_begin * 97u) ^ (m.col_begin * 193u), m.co,
                                    { tiles_x, tiles_x, 1u, 8u, 8u, m.col_begin, m.row_begin });
-#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit, uint32_t(ctx->options[kOptDecisionViList]))
+#define VHR_LAUNCH_REFL(SP, B, ST) launch(ctx, (reflection_queue_kernel<SP, B, ST>), dim3((tiles_total + 1) / 2), dim3(kQueueBlock * 2), lds, m, levels, threshold, tiles_x, tiles_total, early_exit)
 #define VHR_LAUNCH_REFL_S(SP, B) do { if (m.stats) VHR_LAUNCH_REFL(SP, B, true); else VHR_LAUNCH_REFL(SP, B, false); } while (0)
             const bool spill = levels < ctx->bvh_depth + 1u;
             if (m.tp.reflections == 2) { if (spill) VHR_LAUNCH_REFL_S(true, 2); else VHR_LAUNCH_REFL_S(false, 2); }

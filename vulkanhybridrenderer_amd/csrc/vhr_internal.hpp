@@ -259,7 +259,7 @@ struct RayStats {
     unsigned long long cycles_total, cycles_setup, cycles_refill, cycles_nodes, cycles_leaves, refills, waves, drain_iterations;   // per-wave s_memtime sums
     unsigned long long cut_entries;
     unsigned long long drain_le4, drain_le8, drain_le16;     // drain trips made with at most 4 / 8 / 16 rays of the wave still in flight
-    unsigned long long pending_rays, pending_retraces;       // mirror rays that asked binary64 at their commit (decision (vi)); of them, traced again in full
+    unsigned long long pending_rays, pending_retraces;       // decision (vi): pixels a queue kernel computed again by the per-pixel code (binary64 inline); unused
 };
 
 // Options (vhr_set_option): ONE table -- name, default, smallest and largest value -- that vhr_set_option, vhr_get_option, vhr_option_info
@@ -281,7 +281,6 @@ struct RayStats {
     X(kOptReflectionEarlyExit, "reflection_early_exit", 8, 0, 15) /* the same for the mirror ray's walk (r4: 6 -> 8 = bistro_proc's launch -4 %, sponza_proc's equal) */ \
     X(kOptRaygenTileRows, "raygen_tile_rows", 0, 0, 8)          /* rows of a wave's tile; 0 = auto (6 for launches that fill < 70 % of the wave slots) */ \
     X(kOptRaygenCostOrder, "raygen_cost_order", 1, 0, 2)        /* start the longest-lived tiles first: 1 = launches of >= 2 048 workgroups, 2 = any */ \
-    X(kOptDecisionViList, "decision_vi_list", 16, 0, 16)        /* the mirror ray's walk: self-contradicting candidates a ray may park before it is traced again in full at its commit */ \
     X(kOptRaygenSteal, "raygen_steal", 8, 0, 63)                /* queue dry and >= n lanes idle: idle lanes take pending subtrees off busy lanes' stacks; 0 = never */ \
     /* the a-trous kernel */                                                                                                            \
     X(kOptAtrousSmallTiles, "atrous_small_tiles", -1, -1, 1)    /* 4-row tiles: -1 auto (below 32 8-row tiles per CU), 0 never, 1 always */ \

@@ -591,11 +591,11 @@ class Context:
         return d
 
     def binary64_statistics(self):
-        """Decision (vi)'s binary64 half in the queue kernels of the last vhr_trace_rays (statistics enabled): pixels the any-hit launch computed again,
-        mirror rays that asked at their commit, of those the rays traced again in full."""
+        """Decision (vi)'s binary64 half in the queue kernels of the last vhr_trace_rays (statistics enabled): pixels the any-hit launch and the mirror
+        ray's launch computed again by the per-pixel code."""
         out = (C.c_uint64 * 4)()
         self.check(self.L.vhr_get_binary64_statistics(self.handle, out), "binary64_statistics")
-        return dict(pixels_again=int(out[0]), mirror_rays=int(out[1]), mirror_rays_again=int(out[2]))
+        return dict(pixels_again=int(out[0]), mirror_pixels_again=int(out[1]))
 
     def wave_lifetimes(self, capacity=1 << 20):
         """Lifetimes (shader clock ticks) of the last ray-tracing launch's waves (what raygen_cost_order sorts by)."""
