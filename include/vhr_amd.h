@@ -562,6 +562,10 @@ const char *vhr_source_fingerprint(void);
 /* Diagnostics: the lifetimes (shader clock ticks) of the last ray-tracing launch's waves, as left for "raygen_cost_order"
  * (index = tile pair * waves per workgroup + wave); *count = entries written. */
 int vhr_debug_wave_lifetimes(vhr_context *ctx, uint32_t *out, uint32_t capacity, uint32_t *count);
+/* Decision (vi) -- the ray / triangle test every walker of the library makes (fp32 Moeller-Trumbore in a fixed order; a candidate whose solution contradicts
+ * itself decided again in binary64; the reference leaves this to the driver's traceRayEXT, raygen.rgen:39,51,64) -- on explicit pairs, for parity tests:
+ * pairs = count x 17 floats (o[3], d[3], v0[3], e1[3], e2[3], tmin, tmax), HOST memory; hit[count] = 0 / 1, tuv[count x 3] = (t, u, v) of a hit, else 0. */
+int vhr_debug_ray_triangle(vhr_context *ctx, const float *pairs, uint32_t count, uint32_t *hit, float *tuv);
 /* What the last frame's rays cost, where: those lifetimes -- the any-hit launch's and the mirror ray's -- summed into a map of 8 x 8-pixel cells,
  * out[cy * cols + cx], cols >= ceil(width / 8), rows >= ceil(height / 8).  The cost map vhr_tile_plan_make_weighted cuts a grid by (cell = 8).
  * VHR_ERROR_NOT_FOUND when no queue kernel has left lifetimes ("raygen_cost_order" 0, or 1 on launches below 2 048 workgroups: set it to 2). */

@@ -751,6 +751,12 @@ int vhr_calibration_stream_read(vhr_context *ctx, int32_t storage_image, uint32_
     return launch_calibration_read(ctx, ctx->storage_images[storage_image], bytes_per_lane, ctx->d_tile_counter);
 }
 
+int vhr_debug_ray_triangle(vhr_context *ctx, const float *pairs, uint32_t count, uint32_t *hit, float *tuv) {
+    if (!ctx || (count && (!pairs || !hit || !tuv))) return ctx ? ctx->fail(VHR_ERROR_INVALID_ARGUMENT, "vhr_debug_ray_triangle: null argument") : VHR_ERROR_INVALID_ARGUMENT;
+    if (ctx->host_only) return ctx->fail(VHR_ERROR_DEVICE, "vhr_debug_ray_triangle: host-only context");
+    return launch_ray_triangle_pairs(ctx, pairs, count, hit, tuv);
+}
+
 int vhr_get_bvh_statistics(vhr_context *ctx, uint64_t out[5]) {
     if (!ctx || !out) return VHR_ERROR_INVALID_ARGUMENT;
     out[0] = ctx->node_count; out[1] = ctx->tri_count; out[2] = ctx->bvh_depth;

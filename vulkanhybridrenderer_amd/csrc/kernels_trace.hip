@@ -2805,4 +2805,39 @@ int launch_raytraced_composition(vhr_context *ctx, const Image &in, Image &out) 
     return VHR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// vhr_debug_ray_triangle: decision (vi) as the walkers' triangle test computes it, on explicit (ray, triangle) pairs -- what tests/ hold against the oracle's
+// orc_ray_triangle and against exact arithmetic (tests/golden/kat_decision_vi.json), without a scene or a tree in between.  17 floats per pair:
+// o, d, v0, e1, e2, tmin, tmax; out: hit (0 / 1) and (t, u, v).  One pair per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ray_triangle_pairs_kernel(const float *pairs, const uint32_t n, uint32_t *hit, float *tuv, const Stamps st) {
+    vhr_stamp(st);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pairs + size_t(i) * 17u;
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    const bool h = ray_triangle(f3{ p[0], p[1], p[2] }, f3{ p[3], p[4], p[5] }, f3{ p[6], p[7], p[8] }, f3{ p[9], p[10], p[11] }, f3{ p[12], p[13], p[14] }, p[15], p[16], t, u, v);
+    hit[i] = h ? 1u : 0u;
+    tuv[size_t(i) * 3u] = h ? t : 0.0f; tuv[size_t(i) * 3u + 1u] = h ? u : 0.0f; tuv[size_t(i) * 3u + 2u] = h ? v : 0.0f;
+}
+
+int launch_ray_triangle_pairs(vhr_context *ctx, const float *pairs, uint32_t n, uint32_t *hit, float *tuv) {
+    if (n == 0) return VHR_OK;
+    float *d_pairs = nullptr, *d_tuv = nullptr;
+    uint32_t *d_hit = nullptr;
+    const size_t pb = size_t(n) * 17u * sizeof(float), tb = size_t(n) * 3u * sizeof(float), hb = size_t(n) * sizeof(uint32_t);
+    int rc = VHR_OK;
+    if (hipMalloc(&d_pairs, pb) != hipSuccess || hipMalloc(&d_tuv, tb) != hipSuccess || hipMalloc(&d_hit, hb) != hipSuccess)
+        rc = ctx->fail(VHR_ERROR_DEVICE, "vhr_debug_ray_triangle: device allocation failed");
+    if (rc == VHR_OK && hipMemcpyAsync(d_pairs, pairs, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = ctx->fail(VHR_ERROR_DEVICE, "vhr_debug_ray_triangle: upload failed");
+    if (rc == VHR_OK) {
+        launch(ctx, ray_triangle_pairs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<const float *>(d_pairs), n, d_hit, d_tuv);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(hit, d_hit, hb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(tuv, d_tuv, tb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = ctx->fail(VHR_ERROR_DEVICE, "vhr_debug_ray_triangle: launch or download failed");
+    }
+    (void)hipFree(d_pairs); (void)hipFree(d_tuv); (void)hipFree(d_hit);
+    return rc;
+}
+
 }  // namespace vhr

@@ -534,5 +534,6 @@ int launch_ssr(vhr_context *ctx, const vhr_per_frame_data &pfd, const Image &alb
 void launch_stamp(vhr_context *ctx);            // a one-thread kernel that takes the pending pass-end stamp (csrc/kernels_svgf.hip)
 int flush_recorded(vhr_context *ctx);          // issue the commands a compute pass recorded (no-op when there are none)
 int launch_calibration_read(vhr_context *ctx, const Image &img, uint32_t bytes_per_lane, uint32_t *sink);
+int launch_ray_triangle_pairs(vhr_context *ctx, const float *pairs, uint32_t n, uint32_t *hit, float *tuv);
 
 }  // namespace vhr

@@ -34,7 +34,7 @@ EXPORTS = [
     "vhr_standin_raytraced_composition", "vhr_raytraced_create", "vhr_raytraced_destroy", "vhr_raytraced_build", "vhr_raytraced_rebuild",
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
-    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_binary64_statistics", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
+    "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_binary64_statistics", "vhr_debug_ray_triangle", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
     "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
@@ -245,6 +245,7 @@ def load():
     L.vhr_get_traversal_cycles.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_reflection_statistics.argtypes = [vp, C.POINTER(u64)]
     L.vhr_get_binary64_statistics.argtypes = [vp, C.POINTER(u64)]
+    L.vhr_debug_ray_triangle.argtypes = [vp, C.c_void_p, u32, C.c_void_p, C.c_void_p]
     L.vhr_debug_wave_lifetimes.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.vhr_source_fingerprint.restype = C.c_char_p
     L.vhr_source_fingerprint.argtypes = []
@@ -589,6 +590,15 @@ class Context:
                  refills=out[6], waves=out[7], cycles_total=out[8], cycles_walk=out[9])
         d["active_lane_utilisation"] = (out[2] + out[4]) / (64.0 * out[5]) if out[5] else 0.0
         return d
+
+    def ray_triangle(self, pairs):
+        """Decision (vi) as the device computes it, on explicit pairs: pairs = (n, 17) float32 (o, d, v0, e1, e2, tmin, tmax) -> (hit (n,) bool, tuv (n, 3) float32)."""
+        import numpy as np
+        pairs = np.ascontiguousarray(pairs, dtype=np.float32).reshape(-1, 17)
+        hit = np.zeros(len(pairs), np.uint32)
+        tuv = np.zeros((len(pairs), 3), np.float32)
+        self.check(self.L.vhr_debug_ray_triangle(self.handle, pairs.ctypes.data, len(pairs), hit.ctypes.data, tuv.ctypes.data), "ray_triangle")
+        return hit != 0, tuv
 
     def binary64_statistics(self):
         """Decision (vi)'s binary64 half in the queue kernels of the last vhr_trace_rays (statistics enabled): pixels the any-hit launch and the mirror
