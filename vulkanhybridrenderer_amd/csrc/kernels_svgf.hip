@@ -951,8 +951,8 @@ int flush_recorded(vhr_context *ctx) {
         bool ok = true;
         if (!ctx->side_stream) {
             ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&ctx->side_ready, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&ctx->side_ready, VHR_JOIN_EVENT_FLAGS) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->side_done, VHR_JOIN_EVENT_FLAGS) == hipSuccess;
         }
         ok = ok && hipEventRecord(ctx->side_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->side_stream, ctx->side_ready, 0) == hipSuccess;
         if (!ok) {                                   // no side stream: the dispatch runs in order after all

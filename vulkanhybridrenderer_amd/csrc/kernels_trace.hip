@@ -2118,8 +2118,8 @@ int launch_raygen(vhr_context *ctx, const vhr_per_frame_data &pfd, uint32_t widt
             bool ok = true;
             if (!ctx->refl_stream)
                 ok = hipStreamCreateWithFlags(&ctx->refl_stream, hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&ctx->refl_ready, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&ctx->refl_done, hipEventDisableTiming) == hipSuccess;
+                     hipEventCreateWithFlags(&ctx->refl_ready, VHR_JOIN_EVENT_FLAGS) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->refl_done, VHR_JOIN_EVENT_FLAGS) == hipSuccess;
             if (ok && ctx->refl_pending) ok = ctx->join_refl() == VHR_OK;                    // (one launch at a time on that stream)
             ok = ok && hipEventRecord(ctx->refl_ready, ctx->stream) == hipSuccess && hipStreamWaitEvent(ctx->refl_stream, ctx->refl_ready, 0) == hipSuccess;
             if (ok) {

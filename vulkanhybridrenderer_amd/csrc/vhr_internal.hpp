@@ -417,6 +417,10 @@ struct vhr_context {
     // the images it reads or writes again.
     hipStream_t side_stream = nullptr;
     hipEvent_t side_ready = nullptr, side_done = nullptr;
+    // (events that only order the library's own streams on one device: no timing, and no system-scope release -- nothing on the host reads what they guard)
+#ifndef VHR_JOIN_EVENT_FLAGS
+#define VHR_JOIN_EVENT_FLAGS (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
     bool side_pending = false;
     const void *side_reads[2] = { nullptr, nullptr }, *side_writes = nullptr;      // the images the pending dispatch reads / writes (hazard checks)
     bool async_atrous = false;         // the a-trous launch being issued is the side stream's (kernel kind kKernelAtrousAsync)
