@@ -368,3 +368,15 @@ def test_resize_releases_what_the_extent_sized_and_keeps_the_rest(vhr):
         path.destroy()
     finally:
         c.close()
+
+
+def test_decision_vi_entries_on_a_host_only_context(vhr):
+    """vhr_debug_ray_triangle needs the device (there is no CPU path behind it: an error, not a fallback); vhr_get_binary64_statistics reads zeros."""
+    import numpy as np
+    c = lib.Context(64, 64, host_only=True)
+    try:
+        assert c.binary64_statistics() == dict(pixels_again=0, mirror_pixels_again=0)
+        with pytest.raises(lib.VhrError, match="host-only"):
+            c.ray_triangle(np.zeros((1, 17), np.float32))
+    finally:
+        c.close()
