@@ -54,6 +54,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=16, help="frames of the same workload the CPU oracle is timed on (~1.3 s each on the GPU box's 128 threads)")
     p.add_argument("--max-gbuffers", type=int, default=64, help="distinct precomputed G-buffer frames (wraps beyond)")
+    p.add_argument("--replan-frame", type=int, default=None,
+                   help="N > 1, torch.distributed route: after this verified frame the grid is cut again at equal cost -- a uniform map scaled by the ranks' measured "
+                        "frame times (tiling.refine_cost_map; VHR_BENCH_REPLAN_TIMES=t0,t1,... overrides them) -- and the SVGF history follows its pixels "
+                        "(HybridFrameLoop.replan); the remaining verified frames check the NEW rectangles against the single context")
     p.add_argument("--verify-frames", type=int, default=3,
                    help="N > 1 only: before timing, check that the gathered strips equal a single full-frame context bit for bit")
     p.add_argument("--backend", default=os.environ.get("VHR_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -216,9 +220,11 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
     ok = True
     cpu = args.backend == "gloo"
     for i in range(V):
+        t_frame = time.perf_counter()
         loop.frame(i)
         loop.finish_pending_exchange()
         torch.cuda.synchronize()
+        t_frame = time.perf_counter() - t_frame
         x0, x1, y0, y1 = loop.owned_rect()
         def tile_of(ctx_, image):
             t = alias_tensor(ctx_.transient_info(image)).view(torch.int16)
@@ -246,6 +252,21 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
                 ok &= bool(torch.equal(buf, full[b0:b1, a0:a1]))
         else:
             dist.send(mine, dst=0)
+        if args.replan_frame is not None and i == args.replan_frame and loop.comm is None:
+            # the re-plan while frames run: what a running system has for free -- every rank's last frame time, all-gathered -- scales a cost map inside
+            # the ranks' rectangles; the grid is cut again and the cross-frame state follows its pixels
+            import numpy as np
+            from vulkanhybridrenderer_amd import tiling
+            times = [None] * world
+            dist.all_gather_object(times, float(t_frame))
+            if os.environ.get("VHR_BENCH_REPLAN_TIMES"):
+                times = [float(v) for v in os.environ["VHR_BENCH_REPLAN_TIMES"].split(",")][:world]
+            base = loop.tile_cost if loop.tile_cost is not None else np.full(((H + 7) // 8, (W + 7) // 8), 1000, np.uint32)
+            old = loop.plan
+            plans = [tiling.make_tile_plan(W, H, world, r, loop.max_motion_rows, loop.max_motion_cols, loop.atrous_steps, grid=(old.grid_rows, old.grid_cols), cost=loop.tile_cost)
+                     for r in range(world)]
+            new = loop.replan(tiling.refine_cost_map(base, plans, times))
+            loop.replan_info = {"after_frame": i, "times_ms": [round(t * 1e3, 3) for t in times], "rect_before": list(old.rect), "rect_after": list(new.rect)}
     if ref is not None:
         ref.close()
     flag = torch.tensor([1 if ok else 0], device="cpu" if cpu else "cuda")
@@ -690,6 +711,7 @@ def main():
                 "strip_overlap_rows": plan.overlap, "history_halo_rows": plan.halo_rows, "history_halo_cols": plan.halo_cols if plan.grid_cols > 1 else None,
                 "overlap_rows_raytraced": ("recomputed locally" if trace_overlap else "exchanged") if world > 1 else None,
                 "strips_vs_single_context": strip_check,
+                "replan": getattr(loop, "replan_info", None),
                 # true only when every rank had a GPU of its own and the bytes moved over RCCL (xGMI between the GPUs of the node)
                 "multi_gpu_on_hardware": None if world == 1 else bool(not args.share_device and args.backend == "nccl"),
                 "multi_gpu_note": None if world == 1 else (f"{world} ranks on ONE GPU over gloo through host memory: a functional check of the tile path, not a scaling measurement"

@@ -206,6 +206,28 @@ def test_bench_launches_its_own_ranks_and_labels_a_shared_device_truthfully():
 
 
 @pytest.mark.gpu
+def test_bench_replans_between_verified_frames_on_a_shared_device():
+    """A re-plan while frames run, through the harness and torch.distributed (HybridFrameLoop.replan -> tiling.move_state): four ranks share the GPU over
+    gloo on 2 x 2 tiles, after verified frame 1 rank 0 is declared twice as slow as the others, the grid is cut again, the temporal history, the moments
+    history and the previous normals follow their pixels -- and verified frames 2-3, on the NEW rectangles, and the frame gathered on rank 0 still equal
+    the single context's bit for bit, mirror ray included."""
+    import os
+    os.environ["VHR_BENCH_REPLAN_TIMES"] = "2,1,1,1"
+    try:
+        r, line = _bench(["--gpus", "4", "--share-device", "--reflections", "--width", "640", "--height", "360", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
+                          "--no-cpu-baseline", "--verify-frames", "4", "--replan-frame", "1"])
+    finally:
+        del os.environ["VHR_BENCH_REPLAN_TIMES"]
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert line["ranks"] == 4 and line["config"]["strips_vs_single_context"] == "bit-identical"
+    rp = line["config"]["replan"]
+    assert rp["after_frame"] == 1 and rp["rect_before"] != rp["rect_after"]
+    x0, x1, y0, y1 = rp["rect_before"]
+    a0, a1, b0, b1 = rp["rect_after"]
+    assert (a1 - a0) * (b1 - b0) < (x1 - x0) * (y1 - y0)                  # the rank that took twice as long got a smaller rectangle
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 4, 8])
 def test_bench_refuses_more_gpus_than_the_box_has(n):
     """`python bench.py --gpus N` on a box with fewer than N devices (what the driver's scaling run would meet on a one-GPU box): ONE error

@@ -14,12 +14,15 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None, tp=None, cost=None):
+def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, shrink=False, grid="strips", max_motion_cols=0, options=(), counts=None, tp=None, cost=None,
+                replan=None):
     """`world` contexts on one GPU, one thread each, each computing its strip (grid "strips") or screen tile (grid (rows, cols) or None =
     the planner's choice) with host-side copies standing in for the RCCL exchanges.  Returns (plans, per-rank per-frame (raytraced,
     denoised, reflections or None) cut to the owned rectangle).  `tp`: the trace parameters (default: shadows + 2 AO rays, no mirror ray);
     with a mirror ray the Raytraced Reflections image of a tile is part of the result (raygen.rgen:59-65: per-pixel independent, nothing
-    of it is exchanged)."""
+    of it is exchanged).  replan = (frame, cost): after that frame every rank's rectangle is cut again from `cost` (None = equal pixels) and the
+    cross-frame state follows its pixels (tiling.replan_transfers, host copies); the results of the later frames are cut to the NEW rectangles and
+    `plans` returns one list of plans per frame."""
     if tp is None:
         tp = abi.default_trace_params(reflections=False)
     refl = bool(tp["reflections"])
@@ -27,6 +30,7 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
     ranks = [GpuHybrid(scene, W, H, shadow=bool(tp["shadow_enable"]), ao=bool(tp["ao_spp"]), reflections=refl, trace_params=tp, gbuffer="standin") for _ in range(world)]
     barrier = threading.Barrier(world)
     results = [[] for _ in range(world)]
+    plans_per_frame = [[] for _ in range(world)]
     errors = []
 
     def cut(img, rect):
@@ -62,14 +66,34 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
             if counts is not None:
                 g.ctx.set_kernel_timing(["svgf_atrous", "svgf_atrous_async"])
             if not trace_overlap:
-                g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], (plan.overlap, plan.overlap)))
+                g.ctx.set_pass_epilogue("Raytrace Pass", lambda c: exchange(rank, lambda h: [lib.RAYTRACED], (plans[rank].overlap, plans[rank].overlap)))
             g.ctx.set_pass_epilogue("SVGF Denoise Pass", lambda c: exchange(
-                rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], (plan.halo_rows, plan.halo_cols)))
-            for pfd in pfds:
+                rank, lambda h: [int(pc["shadow_and_ao_history"]), int(pc["shadow_and_ao_moments_history"])], (plans[rank].halo_rows, plans[rank].halo_cols)))
+            for f, pfd in enumerate(pfds):
                 g.frame(pfd)
+                plan = plans[rank]
                 results[rank].append((cut(g.ctx.download(lib.RAYTRACED), plan.rect).copy(), cut(g.ctx.download(lib.DENOISED), plan.rect).copy(),
                                       cut(g.ctx.download(lib.REFLECTIONS), plan.rect).copy() if refl else None))
+                plans_per_frame[rank].append(plan)
                 barrier.wait()
+                if replan is not None and f == replan[0]:
+                    # the re-plan between two frames: each pixel of the three cross-frame images from the rank that owned it (host copies for tiling.move_state)
+                    new = tiling.make_tile_plan(W, H, world, rank, max_motion_rows, max_motion_cols, grid=(plan.grid_rows, plan.grid_cols), cost=replan[1])
+                    keys = [int(pc[k]) for k in ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")]
+                    g.ctx.synchronize()
+                    barrier.wait()
+                    mine = [g.ctx.download(k) for k in keys]
+                    for peer, _, recv in tiling.replan_transfers(plan, new):
+                        if recv:
+                            peer_pc = ranks[peer].path.push_constants()
+                            for img, name in zip(mine, ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")):
+                                cut(img, recv)[...] = cut(ranks[peer].ctx.download(int(peer_pc[name])), recv)
+                    barrier.wait()          # everyone has read before anyone writes
+                    for k, img in zip(keys, mine):
+                        g.ctx.upload(k, img)
+                    g.ctx.set_tile(new.col_begin, new.col_end, new.row_begin, new.row_end, new.overlap, new.halo_rows, new.halo_cols)
+                    plans[rank] = new
+                    barrier.wait()
             if counts is not None:
                 counts[rank] = (g.ctx.kernel_time("svgf_atrous")[1], g.ctx.kernel_time("svgf_atrous_async")[1])
         except Exception as e:   # noqa: BLE001
@@ -85,7 +109,7 @@ def _run_strips(scene, W, H, world, pfds, max_motion_rows, trace_overlap=False, 
         g.close()
     if errors:
         raise errors[0]
-    return plans, results
+    return (plans_per_frame if replan is not None else plans), results
 
 
 def _single_context_reference(scene, W, H, pfds, tp=None):
@@ -167,6 +191,33 @@ def test_cost_balanced_tiles_bit_identical_and_the_library_cost_map():
     again = [tiling.make_tile_plan(W, H, 6, r, mv_rows, mv_cols, grid=(2, 3), cost=tiling.refine_cost_map(cost, plans, times)) for r in range(6)]
     area = lambda p: (p.col_end - p.col_begin) * (p.row_end - p.row_begin)   # noqa: E731
     assert area(again[0]) < area(plans[0])
+
+
+def test_replan_between_frames_follows_the_state():
+    """A re-plan while frames run (round 6; tiling.replan_transfers, harness.HybridFrameLoop.replan): six contexts run two frames on the equal-pixel grid, the grid
+    is cut again at equal cost from the library's own cost map, the temporal history, the moments history and the previous normals follow their pixels, vhr_set_tile
+    moves every context's rectangle -- and frames 3-5 on the NEW rectangles are the single context's, bit for bit, like frames 1-2 on the old ones."""
+    scene = scenes.sponza_proc(0.3)
+    W, H = 320, 264
+    tp = abi.default_trace_params(ao_spp=2, reflections=1)
+    pfds = camera.dolly_frames(scene, W, H, 5)
+    ref, mv_rows, mv_cols = _single_context_reference(scene, W, H, pfds, tp)
+    g = GpuHybrid(scene, W, H, trace_params=tp, gbuffer="standin")
+    try:
+        g.ctx.set_option("raygen_cost_order", 2)
+        for pfd in pfds[:2]:
+            g.frame(pfd)
+        cost = g.ctx.tile_cost_map()
+    finally:
+        g.close()
+    plans, results = _run_strips(scene, W, H, 6, pfds, mv_rows, True, True, grid=(2, 3), max_motion_cols=mv_cols, tp=tp, replan=(1, cost))
+    assert any(plans[r][1].rect != plans[r][2].rect for r in range(6)) and all(plans[r][0] == plans[r][1] and plans[r][2] == plans[r][4] for r in range(6))
+    for r in range(6):
+        for f, (rt, den, refl) in enumerate(results[r]):
+            x0, x1, y0, y1 = plans[r][f].rect
+            assert np.array_equal(rt, ref[f][0][y0:y1, x0:x1]), f"rank {r} frame {f}: raytraced rectangle differs"
+            assert np.array_equal(den, ref[f][1][y0:y1, x0:x1]), f"rank {r} frame {f}: denoised rectangle differs"
+            assert np.array_equal(refl, ref[f][2][y0:y1, x0:x1]), f"rank {r} frame {f}: reflections rectangle differs"
 
 
 @pytest.mark.parametrize("bounces,ao_spp,refl_async,side", [(1, 2, 0, 0), (1, 2, 1, 2), (1, 2, 2, 2), (2, 2, 1, 1), (2, 5, 2, 2)])

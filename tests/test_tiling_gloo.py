@@ -117,3 +117,49 @@ def test_frame_loop_ordering_with_replayed_exchanges(oracle, tmp_path, world):
     assert gathers_checked == 5                       # frames 0..4, each checked once its gather had landed
     assert n_prepared == 2 and n_gathers == 1         # one descriptor list per moments buffer, replayed; one gather
     assert degraded == 0
+
+
+@pytest.mark.parametrize("world,grid,cost_first,skip_move", [(4, "2x2", 0, 0), (4, "2x2", 1, 0), (2, "1x2", 0, 0), (4, "2x2", 0, 1)])
+def test_replan_between_frames_gloo(oracle, tmp_path, world, grid, cost_first, skip_move):
+    """A re-plan between two frames (tiling.replan_transfers / move_state, round 6): after frame 1 the grid is cut again -- equal pixels -> equal cost, or
+    the other way round --, the temporal history, the moments history and the previous normals follow their pixels in one grouped batch, everything
+    outside the new rectangle's reach is poisoned with NaN, and frames 2-3 still equal the single-process frames on every rank's NEW rectangle and
+    in the frame gathered on rank 0.  skip_move: the negative control -- the new rectangles without the transfer are caught."""
+    out = tmp_path / "result.txt"
+    port = 29871 + world + 3 * cost_first + (5 if grid == "1x2" else 0) + 11 * skip_move
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", VHR_TEST_GRID=grid, VHR_TEST_COST_MAP="1" if cost_first else "",
+               VHR_TEST_SHRINK_OVERLAP="0", VHR_TEST_STRIP_SHRINK="1", VHR_TEST_STRIP_SHRINK_BIAS="0", VHR_TEST_REPLAN="1", VHR_TEST_REPLAN_SKIP_MOVE="1" if skip_move else "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "tiling_worker.py"), str(out), "160", "184", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad, overlap, halo = out.read_text().split()
+    if skip_move:
+        assert int(bad) > 0
+        return
+    assert int(bad) == 0, f"{bad} (rank, frame) pairs differ from the single-process result"
+
+
+def test_replan_transfers_cover_the_new_rectangles():
+    """Every pixel of a rank's new rectangle grown by its halo comes from exactly one old owner (itself included), and what one rank receives from a peer is
+    what that peer sends to it -- for 2..8 ranks, equal pixels <-> equal cost, at 1080p."""
+    import numpy as np
+    W, H = 1920, 1080
+    ys, xs = np.mgrid[0:135, 0:240]
+    cost = (10 + 500 * np.exp(-((xs - 40) ** 2 + (ys - 100) ** 2) / 400.0)).astype(np.uint32)
+    for world in (2, 3, 4, 6, 8):
+        a = [tiling.make_tile_plan(W, H, world, r, 3, 4) for r in range(world)]
+        b = [tiling.make_tile_plan(W, H, world, r, 3, 4, cost=cost) for r in range(world)]
+        for old, new in ((a, b), (b, a)):
+            for r in range(world):
+                need = tiling._grown(new[r].tile_rect(r), new[r].halo_cols if new[r].grid_cols > 1 else 0, new[r].halo_rows if new[r].grid_rows > 1 else 0, W, H)
+                seen = np.zeros((H, W), np.int32)
+                own = tiling._intersect(need, old[r].tile_rect(r))
+                if own:
+                    seen[own[2]:own[3], own[0]:own[1]] += 1
+                for peer, send, recv in tiling.replan_transfers(old[r], new[r]):
+                    if recv:
+                        seen[recv[2]:recv[3], recv[0]:recv[1]] += 1
+                    back = [t for t in tiling.replan_transfers(old[peer], new[peer]) if t[0] == r]
+                    assert back and back[0][1] == recv and back[0][2] == send
+                assert (seen[need[2]:need[3], need[0]:need[1]] == 1).all() and int(seen.sum()) == (need[1] - need[0]) * (need[3] - need[2])

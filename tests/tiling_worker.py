@@ -107,6 +107,10 @@ def main():
         same = np.array_equal(denoised[y0:y1, x0:x1], ref[f][y0:y1, x0:x1])
         if not same:
             worst += 1
+            if os.environ.get("VHR_TEST_VERBOSE"):
+                d = (denoised[y0:y1, x0:x1] != ref[f][y0:y1, x0:x1]).any(-1)
+                yy, xx = np.nonzero(d)
+                print(f"rank {rank} frame {f}: {int(d.sum())} pixels differ in rect {plan.rect}, rows {yy.min() + y0}-{yy.max() + y0} cols {xx.min() + x0}-{xx.max() + x0}", flush=True)
         # C2: every rank's owned rows assembled on rank 0 must be the single-process frame, whatever the other rows held
         den_t.copy_(torch.from_numpy(denoised.view(np.int16)))
         pending = gather.start()
@@ -115,6 +119,28 @@ def main():
         if rank == 0 and world > 1 and not shrink and not int(os.environ.get("VHR_TEST_STRIP_SHRINK_BIAS", "0")):
             if not np.array_equal(gather.full.numpy().view(np.uint16), ref[f]):
                 worst += 1
+        if os.environ.get("VHR_TEST_REPLAN") and f == int(os.environ["VHR_TEST_REPLAN"]):
+            # a re-plan between two frames (tiling.move_state): the grid cut again -- at equal cost if it was cut at equal pixels, and the other way round --,
+            # the cross-frame state follows its pixels; everything outside the new rectangle's reach is poisoned before the next frame reads it
+            mm = (int(np.ceil(max_motion(1, H))), int(np.ceil(max_motion(0, W))))
+            if cost is None:
+                ys, xs = np.mgrid[0:(H + 7) // 8, 0:(W + 7) // 8]
+                new_cost = (10 + 500 * np.exp(-((xs - 2) ** 2 + (ys - (H // 8 - 3)) ** 2) / 8.0)).astype(np.uint32)
+            else:
+                new_cost = None
+            new_plan = tiling.make_tile_plan(W, H, world, rank, mm[0], mm[1], grid=(plan.grid_rows, plan.grid_cols), cost=new_cost)
+            assert world == 1 or new_plan.rect != plan.rect or any(tiling.make_tile_plan(W, H, world, r, mm[0], mm[1], grid=(plan.grid_rows, plan.grid_cols), cost=new_cost).rect !=
+                                                                     plan.tile_rect(r) for r in range(world))
+            tn = torch.from_numpy(prev_normals)
+            if not os.environ.get("VHR_TEST_REPLAN_SKIP_MOVE"):          # (negative control: a re-plan that leaves the state behind must be caught)
+                tiling.move_state(dist, [th, tm, tn], plan, new_plan)
+            plan = new_plan
+            x0, x1, y0, y1 = plan.rect
+            comp = plan.computed_rect()
+            bx0, bx1, by0, by1 = tiling._grown(plan.rect, plan.halo_cols if plan.grid_cols > 1 else 0, plan.halo_rows if plan.grid_rows > 1 else 0, W, H)
+            for img in (history, moments, prev_normals):
+                poison_outside(img, (bx0, bx1, by0, by1))
+            gather = tiling.StripGather(dist, den_t, plan)
     res = torch.tensor([worst], dtype=torch.int64)
     dist.all_reduce(res)
     if rank == 0:

@@ -261,6 +261,34 @@ class HybridFrameLoop:
         mom = self._alias(ctx.storage_info(int(self.pc["shadow_and_ao_moments_history"])))    # the buffer just written
         self.exchanges.after_svgf(den, hist, mom)
 
+    # ---- re-plan between two frames: the grid cut again at equal cost (tiling.make_tile_plan(cost=...), tiling.refine_cost_map) ----
+    def replan(self, tile_cost):
+        """Cut this rank's rectangle again from `tile_cost` (the SAME map on every rank: the ranks' frame times fed back through
+        tiling.refine_cost_map, all-gathered by the caller) and carry the path's cross-frame state -- temporal history, moments history, previous normals
+        (hybrid_render_path.cpp:247-262) -- to the new rectangles: one grouped batch of point-to-point transfers (tiling.move_state), each pixel from the rank
+        that owned it.  Collective: every rank calls it between the same two frames.  The torch.distributed route only (comm == "torch"); the grid keeps
+        its shape.  Placement only: the frames that follow are the ones the old plan would have produced."""
+        if self.world == 1:
+            return self.plan
+        if self.comm is not None:
+            raise NotImplementedError("replan: the vhr_comm_* route keeps the plan it was created with (vhr_comm_create_tiled)")
+        old = self.plan
+        new = tiling.make_tile_plan(self.W, self.H, self.world, self.rank, self.max_motion_rows, self.max_motion_cols, self.atrous_steps,
+                                    grid=(old.grid_rows, old.grid_cols), cost=tile_cost)
+        self.finish_pending_exchange()                     # the last frame's halo exchange and gather have landed
+        if self.denoise:
+            images = [self._alias(self.ctx.storage_info(int(self.pc[k]))) for k in ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")]
+            tiling.move_state(self.dist, images, old, new)
+        self.torch.cuda.current_stream().synchronize()
+        self.plan, self.tile_cost = new, tile_cost
+        if new.grid_cols == 1:
+            self.ctx.set_strip(new.row_begin, new.row_end, new.overlap, new.halo_rows)
+        else:
+            self.ctx.set_tile(new.col_begin, new.col_end, new.row_begin, new.row_end, new.overlap, new.halo_rows, new.halo_cols)
+        self.exchanges = tiling.StripExchanges(self.dist, new, trace_overlap=self.trace_overlap, denoise=self.denoise, gather=self._gather_requested,
+                                               allow_degraded=self._allow_degraded)
+        return new
+
     # ---- one frame of the hot path ----
     def frame(self, i):
         self.current = i

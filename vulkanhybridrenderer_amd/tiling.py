@@ -283,6 +283,33 @@ def refine_cost_map(cost, plans, times, cost_cell=8):
     return np.minimum(out * (6.0e7 / max(1e-30, out.max())), 6.0e7).astype(np.uint32)
 
 
+def replan_transfers(old, new):
+    """[(peer, send rect or None, recv rect or None)] that carry the path's cross-frame state -- temporal history, moments history, previous normals
+    (hybrid_render_path.cpp:247-262) -- from the rectangles of `old`'s grid to those of `new`'s (a re-plan between two frames: the grid cut again
+    at equal cost from the ranks' measured times, refine_cost_map).  Under the old plan a rank's values are exact where it OWNED the pixel, so
+    recv = the pixels of my new rectangle grown by the new halo that `peer` owned, send = the mirror image; what I owned myself stays where it is.
+    The old rectangles tile the image, so together with my own the receives cover everything the next frame's svgf.comp reads."""
+    assert (old.world, old.rank, old.width, old.height) == (new.world, new.rank, new.width, new.height)
+    dx, dy = (new.halo_cols if new.grid_cols > 1 else 0), (new.halo_rows if new.grid_rows > 1 else 0)
+    need = [_grown(new.tile_rect(r), dx, dy, new.width, new.height) for r in range(new.world)]
+    out = []
+    for peer in range(new.world):
+        if peer == new.rank:
+            continue
+        recv, send = _intersect(need[new.rank], old.tile_rect(peer)), _intersect(need[peer], old.tile_rect(old.rank))
+        if recv or send:
+            out.append((peer, send, recv))
+    return out
+
+
+def move_state(dist, tensors, old, new, group=None):
+    """The re-plan's transfer (replan_transfers) of each [H, W, ...] tensor, in place, blocking (in stream order for device tensors): one grouped batch
+    of point-to-point operations like every other exchange here.  Afterwards the tensors hold exact values on `new`'s rectangle grown by its halo."""
+    pending = start_exchange(dist, tensors, new, None, group, rects=replan_transfers(old, new))
+    if pending is not None:
+        pending.finish()
+
+
 def _rects_of(plan, margin, width):
     """The rectangle exchanges of a plan for a margin: `margin` is n_rows for a StripPlan, (halo_rows, halo_cols) or n for a TilePlan."""
     if isinstance(plan, TilePlan):
@@ -310,13 +337,13 @@ class PendingExchange:
         self.reqs, self.staged, self.keep = [], [], []
 
 
-def start_exchange(dist, tensors, plan, n_rows, group=None):
+def start_exchange(dist, tensors, plan, n_rows, group=None, rects=None):
     """Neighbour halo exchange of a margin of each [H, W, ...] tensor (device or host), in place; `n_rows` is the number of rows for a
     StripPlan, (halo_rows, halo_cols) or one number for a TilePlan.  Returns a PendingExchange (or None if there is nothing to exchange).
 
     One grouped batch of point-to-point ops (ncclGroupStart/End under the "nccl" = RCCL backend): each
     neighbour pair talks over its direct xGMI link; no collective involves more than two ranks."""
-    if plan.world == 1 or not n_rows:
+    if plan.world == 1 or (rects is None and not n_rows):
         return None
     # Device tensors travel device-to-device under "nccl" (RCCL).  Under "gloo" (CPU transport: the CI route
     # for exercising this code with several ranks on one GPU) they are staged through host memory.
@@ -324,7 +351,7 @@ def start_exchange(dist, tensors, plan, n_rows, group=None):
     ops = []
     keep = []
     staged = []
-    for peer, send_rect, recv_rect in _rects_of(plan, n_rows, tensors[0].shape[1]):
+    for peer, send_rect, recv_rect in (rects if rects is not None else _rects_of(plan, n_rows, tensors[0].shape[1])):      # (rects: a list of its own -- move_state)
         for t in tensors:
             if send_rect:
                 send = _view(t, send_rect)
