@@ -55,11 +55,11 @@ __device__ __forceinline__ bool solution_consistent(f3 o, f3 d, f3 v0, f3 e1, f3
 // Moeller-Trumbore in binary64 (the oracle's mt_binary64, operation for operation): the fp32 operands and every product of two of them are exact,
 // every other operation rounds once in the order written (this unit is built with -ffp-contract=off), the quotients are IEEE divisions; the comparisons
 // are ray_triangle()'s and (t, u, v) come back rounded to fp32.  Written for few live registers -- operands are widened where they are used, pvec and
-// tvec are the only vectors kept -- because it sits INSIDE the walkers' leaf tests: the any-hit queue kernel needs 72 registers with it (62 without;
-// seven instead of eight waves per SIMD: +1.3 % of the frame).  What was measured against that in round 6 (profiles/r6_decision_vi_cost.txt): a call
-// from the leaf test (13 registers and spills around the call: +5 % / +28 % on the two queue kernels), the same inlined under a forced 64-register
-// budget (+2.9 % of the frame), and the candidates' pixels handed to a second launch of the per-pixel kernel (a dependent launch on the frame's
-// critical path: the same +1.3 %, and 5-12 us per launch on a screen tile's short frame).
+// tvec are the only vectors kept.  It sits inside the leaf tests of the per-pixel walkers (traverse<>) and of the raytraced path's queue kernel; the two
+// queue kernels of the hybrid path keep it OUT of their loops: a self-contradicting candidate marks the pixel, and the tile's epilogue computes the pixel
+// again through traverse<> behind one call (redo_pixel_visibility / redo_pixel_reflection).  Inside the any-hit queue kernel's leaf test it cost 13
+// registers = a wave per SIMD = 1.5 % of the frame, inside the two-bounce mirror kernel's 45 spilled registers = 13 % of the launch; the forms measured on
+// the way (a call from the leaf test, a second launch, a list per ray decided at the ray's commit) are in profiles/r6_decision_vi_cost.txt.
 __device__ __forceinline__ bool mt_binary64(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float tmin, float tmax, float &t, float &u, float &v) {
     const double px = double(d.y) * double(e2.z) - double(d.z) * double(e2.y);
     const double py = double(d.z) * double(e2.x) - double(d.x) * double(e2.z);
