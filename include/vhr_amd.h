@@ -415,6 +415,12 @@ int vhr_tile_plan_make_weighted(uint32_t width, uint32_t height, uint32_t world,
                                 vhr_tile_plan *out);
 /* the rectangles a margin of (halo_rows, halo_cols) pixels takes from / gives to each peer (up to 8); returns their number or < 0 */
 int vhr_tile_plan_exchanges(const vhr_tile_plan *plan, uint32_t halo_rows, uint32_t halo_cols, vhr_rect_exchange *out, uint32_t capacity);
+/* A re-plan between two frames (the grid cut again, e.g. vhr_tile_plan_make_weighted on a cost map scaled by the ranks' measured frame times): what carries the
+ * path's cross-frame state -- the storage images SVGFPushConstants names shadow_and_ao_history, shadow_and_ao_moments_history and
+ * prev_frame_normals_and_object_ids (hybrid_render_path.cpp:247-262) -- to the new rectangles.  recv = the pixels of this rank's NEW rectangle grown by the new
+ * halo that `peer` OWNED under the old plan (its values are exact there), send = the mirror image; what the rank owned itself stays where it is.  Both plans of
+ * the same rank, world and image; up to world - 1 entries; returns their number or < 0.  After the transfers: vhr_set_tile with the new rectangle. */
+int vhr_tile_plan_replan(const vhr_tile_plan *old_plan, const vhr_tile_plan *new_plan, vhr_rect_exchange *out, uint32_t capacity);
 
 /* The RCCL library to load, instead of the process's own / the ROCm installation's: before the first other vhr_comm_* call of the process
  * (VHR_ERROR_GRAPH afterwards: the entry points are bound once); NULL or "" = the default resolution.  A path that does not load fails the next call. */

@@ -171,6 +171,25 @@ def test_comm_tiled_world_size_one_smoke():
         g.close()
 
 
+def test_replan_transfers_c_planner_equals_python():
+    """vhr_tile_plan_replan == tiling.replan_transfers: equal pixels <-> equal cost, 2..8 ranks, two sizes; plans of different ranks or images are refused."""
+    import numpy as np
+    for W, H in ((1920, 1080), (640, 360)):
+        ys, xs = np.mgrid[0:(H + 7) // 8, 0:(W + 7) // 8]
+        cost = (10 + 500 * np.exp(-((xs - W // 40) ** 2 + (ys - H // 10) ** 2) / 300.0)).astype(np.uint32)
+        for world in (2, 3, 4, 6, 8):
+            gr, gc = tiling.choose_grid(W, H, world, 30)
+            for r in range(world):
+                pa, pb = tiling.make_tile_plan(W, H, world, r, 3, 4), tiling.make_tile_plan(W, H, world, r, 3, 4, cost=cost)
+                ca, cb = lib.tile_plan(W, H, world, r, gr, gc, 3, 4, 5), lib.tile_plan(W, H, world, r, gr, gc, 3, 4, 5, cost=cost)
+                for (po, pn), (co, cn) in (((pa, pb), (ca, cb)), ((pb, pa), (cb, ca))):
+                    want = [(peer, send or (0, 0, 0, 0), recv or (0, 0, 0, 0)) for peer, send, recv in tiling.replan_transfers(po, pn)]
+                    assert lib.tile_plan_replan(co, cn) == want
+    a, b = lib.tile_plan(640, 360, 4, 0, 2, 2, 3, 4, 5), lib.tile_plan(640, 360, 4, 1, 2, 2, 3, 4, 5)
+    with pytest.raises(lib.VhrError):
+        lib.tile_plan_replan(a, b)
+
+
 def _bench(args, timeout=1200):
     import json
     import os

@@ -305,6 +305,36 @@ int vhr_tile_plan_exchanges(const vhr_tile_plan *p, uint32_t halo_rows, uint32_t
     return int(n);
 }
 
+// A re-plan between two frames (tiling.replan_transfers): the cross-frame state follows its pixels, each from the rank that owned it under the old plan.
+int vhr_tile_plan_replan(const vhr_tile_plan *old_plan, const vhr_tile_plan *new_plan, vhr_rect_exchange *out, uint32_t capacity) {
+    if (!old_plan || !new_plan || (!out && capacity)) return VHR_ERROR_INVALID_ARGUMENT;
+    const vhr_tile_plan &o = *old_plan, &p = *new_plan;
+    if (o.world != p.world || o.rank != p.rank || o.width != p.width || o.height != p.height) return VHR_ERROR_INVALID_ARGUMENT;
+    if (!plan_consistent(o) || !plan_consistent(p)) return VHR_ERROR_INVALID_ARGUMENT;
+    const uint32_t dx = p.grid_cols > 1 ? p.halo_cols : 0u, dy = p.grid_rows > 1 ? p.halo_rows : 0u;
+    vhr_rect mine_new, mine_old;
+    plan_tile(p, p.rank / p.grid_cols, p.rank % p.grid_cols, mine_new);
+    plan_tile(o, o.rank / o.grid_cols, o.rank % o.grid_cols, mine_old);
+    const vhr_rect my_need = grown(mine_new, dx, dy, p.width, p.height);
+    uint32_t n = 0;
+    for (uint32_t peer = 0; peer < p.world; ++peer) {
+        if (peer == p.rank) continue;
+        vhr_rect theirs_old, theirs_new;
+        plan_tile(o, peer / o.grid_cols, peer % o.grid_cols, theirs_old);
+        plan_tile(p, peer / p.grid_cols, peer % p.grid_cols, theirs_new);
+        const vhr_rect their_need = grown(theirs_new, dx, dy, p.width, p.height);
+        vhr_rect_exchange e{};
+        e.peer = int32_t(peer);
+        const bool r = intersect(my_need, theirs_old, e.recv), s = intersect(their_need, mine_old, e.send);
+        if (!r && !s) continue;
+        if (!r) e.recv = vhr_rect{ 0, 0, 0, 0 };
+        if (!s) e.send = vhr_rect{ 0, 0, 0, 0 };
+        if (n >= capacity) return VHR_ERROR_OUT_OF_SLOTS;
+        out[n++] = e;
+    }
+    return int(n);
+}
+
 // ---- row strips: the one-column grid, in its own vocabulary ----
 int vhr_strip_plan_make(uint32_t height, uint32_t world, uint32_t rank, uint32_t max_motion_rows, uint32_t atrous_steps, vhr_strip_plan *out) {
     if (!out || world == 0 || rank >= world || height == 0) return VHR_ERROR_INVALID_ARGUMENT;

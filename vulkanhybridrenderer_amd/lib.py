@@ -35,7 +35,7 @@ EXPORTS = [
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_binary64_statistics", "vhr_debug_ray_triangle", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
-    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_tile_plan_replan", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
@@ -265,6 +265,7 @@ def load():
     L.vhr_tile_plan_make.argtypes = [u32, u32, u32, u32, u32, u32, u32, u32, u32, C.POINTER(TilePlanC)]
     L.vhr_tile_plan_make_weighted.argtypes = [u32, u32, u32, u32, u32, u32, u32, u32, u32, vp, u32, u32, u32, C.POINTER(TilePlanC)]
     L.vhr_tile_plan_exchanges.argtypes = [C.POINTER(TilePlanC), u32, u32, C.POINTER(RectExchangeC), u32]
+    L.vhr_tile_plan_replan.argtypes = [C.POINTER(TilePlanC), C.POINTER(TilePlanC), C.POINTER(RectExchangeC), u32]
     L.vhr_comm_create_tiled.argtypes = [vp, C.POINTER(TilePlanC), C.c_char_p, C.POINTER(vp)]
     L.vhr_comm_get_unique_id.argtypes = [C.c_char_p]
     L.vhr_comm_create.argtypes = [vp, C.POINTER(StripPlanC), C.c_char_p, C.POINTER(vp)]
@@ -884,6 +885,16 @@ def tile_plan_exchanges(plan, halo_rows, halo_cols):
     if n < 0:
         raise VhrError(f"vhr_tile_plan_exchanges: {n}")
     rect = lambda r: (r.x0, r.x1, r.y0, r.y1)
+    return [(out[i].peer, rect(out[i].send), rect(out[i].recv)) for i in range(n)]
+
+
+def tile_plan_replan(old, new):
+    """vhr_tile_plan_replan: [(peer, send rect, recv rect)] that carry the cross-frame SVGF state from `old`'s rectangles to `new`'s (tiling.replan_transfers)."""
+    out = (RectExchangeC * 256)()
+    n = load().vhr_tile_plan_replan(C.byref(old), C.byref(new), out, 256)
+    if n < 0:
+        raise VhrError(f"vhr_tile_plan_replan: {n}")
+    rect = lambda r: (r.x0, r.x1, r.y0, r.y1)   # noqa: E731
     return [(out[i].peer, rect(out[i].send), rect(out[i].recv)) for i in range(n)]
 
 
