@@ -55,7 +55,7 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=16, help="frames of the same workload the CPU oracle is timed on (~1.3 s each on the GPU box's 128 threads)")
     p.add_argument("--max-gbuffers", type=int, default=64, help="distinct precomputed G-buffer frames (wraps beyond)")
     p.add_argument("--replan-frame", type=int, default=None,
-                   help="N > 1, torch.distributed route: after this verified frame the grid is cut again at equal cost -- a uniform map scaled by the ranks' measured "
+                   help="N > 1: after this verified frame the grid is cut again at equal cost -- a uniform map scaled by the ranks' measured "
                         "frame times (tiling.refine_cost_map; VHR_BENCH_REPLAN_TIMES=t0,t1,... overrides them) -- and the SVGF history follows its pixels "
                         "(HybridFrameLoop.replan); the remaining verified frames check the NEW rectangles against the single context")
     p.add_argument("--verify-frames", type=int, default=3,
@@ -252,7 +252,7 @@ def verify_strips(args, scene, loop, dist, rank, world, device):
                 ok &= bool(torch.equal(buf, full[b0:b1, a0:a1]))
         else:
             dist.send(mine, dst=0)
-        if args.replan_frame is not None and i == args.replan_frame and loop.comm is None:
+        if args.replan_frame is not None and i == args.replan_frame:
             # the re-plan while frames run: what a running system has for free -- every rank's last frame time, all-gathered -- scales a cost map inside
             # the ranks' rectangles; the grid is cut again and the cross-frame state follows its pixels
             import numpy as np

@@ -446,6 +446,11 @@ int vhr_comm_start_frame_exchanges(vhr_comm *comm, int32_t history_storage_image
                                    int32_t root, void *gathered_frame);
 /* Raytrace Pass epilogue of the next frame: the context's stream waits for them (no host synchronisation). */
 int vhr_comm_finish_frame_exchanges(vhr_comm *comm);
+/* A re-plan between two frames through the library's own RCCL calls: the communicator and the context take `new_plan` (vhr_tile_plan_make_weighted on the map
+ * every rank holds; same rank, world and image as the plan the communicator was created with), and the three storage images that carry the path's state from frame
+ * to frame travel to the new rectangles (vhr_tile_plan_replan), one grouped batch in the context's stream order.  Collective: every rank, between the same two
+ * frames.  The previous frame's exchanges are finished first; a plan of another rank / world / image is refused before anything is enqueued. */
+int vhr_comm_replan(vhr_comm *comm, const vhr_tile_plan *new_plan, int32_t history_storage_image, int32_t moments_storage_image, int32_t prev_normals_storage_image);
 
 /* Statistics of the last vhr_trace_rays: out[0] = unique rays traced, out[1] = rays the reference would
  * issue (4x duplicate shadow ray, raygen.rgen:38-40), out[2] = covered (non-sky) pixels, out[3] = traversal

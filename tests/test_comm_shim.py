@@ -50,6 +50,25 @@ def test_c_abi_exchanges_on_one_gpu_equal_the_single_context_and_the_torch_route
     _sweep_shim_directories()
 
 
+def test_c_abi_replan_between_frames_on_one_gpu(shim, monkeypatch):
+    """vhr_comm_replan (round 6) at world 4 on one GPU through the stand-in: after verified frame 1 rank 0 is declared twice as slow, every rank cuts the grid again
+    from the same refined map, the communicator and the context take the new plan, the temporal history, the moments history and the previous normals follow their
+    pixels through the library's own plan -> pieces -> pack -> grouped batch -> unpack code -- and verified frames 2-3 on the NEW rectangles, and the frame
+    gathered on rank 0, equal the single context's bit for bit."""
+    args = ["--gpus", "4", "--share-device", "--width", "640", "--height", "360", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
+            "--no-cpu-baseline", "--no-extras", "--verify-frames", "4", "--replan-frame", "1", "--reflections", "--grid", "2x2", "--comm", "c_abi"]
+    monkeypatch.setenv("VHR_RCCL_LIBRARY", shim)
+    monkeypatch.setenv("VHR_RCCL_SHIM_TAG", _TAG)
+    monkeypatch.setenv("VHR_RCCL_SHIM_TIMEOUT_S", "60")
+    monkeypatch.setenv("VHR_BENCH_REPLAN_TIMES", "2,1,1,1")
+    r, line = _bench(args, timeout=600)
+    assert r.returncode == 0 and line and "error" not in line, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "vhr_comm" in line["config"]["exchanges_through"] and line["config"]["strips_vs_single_context"] == "bit-identical"
+    rp = line["config"]["replan"]
+    assert rp["after_frame"] == 1 and rp["rect_before"] != rp["rect_after"]
+    _sweep_shim_directories()
+
+
 def _run_ranks(shim, world, frames, fail, fail_rank, mode="", timeout_s=8):
     port = str(_free_port())
     env = dict(os.environ, VHR_RCCL_LIBRARY=shim, VHR_RCCL_SHIM_TAG=_TAG, VHR_RCCL_SHIM_TIMEOUT_S=str(timeout_s), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -627,6 +627,39 @@ int vhr_comm_start_frame_exchanges(vhr_comm *c, int32_t history_storage_image, i
     return rc;
 }
 
+// A re-plan between two frames: the communicator takes `new_plan` (the same rank, world and image; every rank calls this between the same two frames with
+// plans cut from the same map), the path's cross-frame state -- temporal history, moments history, previous normals -- travels to the new rectangles in one grouped
+// batch on the context's stream (vhr_tile_plan_replan: each pixel from the rank that owned it), and the context computes the new rectangle from the next frame on.
+// The previous frame's exchanges are finished first.  Everything that can be refused is refused before anything is enqueued.
+int vhr_comm_replan(vhr_comm *c, const vhr_tile_plan *new_plan, int32_t history_storage_image, int32_t moments_storage_image, int32_t prev_normals_storage_image) {
+    if (!c || !new_plan) return VHR_ERROR_INVALID_ARGUMENT;
+    vhr_context *ctx = c->ctx;
+    if (c->broken) return c->fail(VHR_ERROR_GRAPH, "vhr_comm: an earlier exchange failed half way; the communicator is unusable");
+    auto storage = [&](int32_t id) -> Image * {
+        return (id >= 0 && uint32_t(id) < vhr_context::kMaxGlobalResources && ctx->storage_images[id].used) ? &ctx->storage_images[id] : nullptr;
+    };
+    Image *imgs[3] = { storage(history_storage_image), storage(moments_storage_image), storage(prev_normals_storage_image) };
+    if (!imgs[0] || !imgs[1] || !imgs[2]) return c->fail(VHR_ERROR_NOT_FOUND, "vhr_comm_replan: no such storage image");
+    vhr_rect_exchange ex[VHR_TILE_MAX_GRID * VHR_TILE_MAX_GRID];
+    const int n = vhr_tile_plan_replan(&c->plan, new_plan, ex, VHR_TILE_MAX_GRID * VHR_TILE_MAX_GRID);
+    if (n < 0) return c->fail(n, "vhr_comm_replan: the new plan is not a plan of this rank, world and image");
+    std::vector<Piece> pieces;
+    for (int k = 0; k < n; ++k)
+        for (Image *im : imgs) {
+            if (ex[k].send.x1 > ex[k].send.x0) pieces.push_back(Piece{ im, ex[k].send, ex[k].peer, true, 0 });
+            if (ex[k].recv.x1 > ex[k].recv.x0) pieces.push_back(Piece{ im, ex[k].recv, ex[k].peer, false, 0 });
+        }
+    HIPC_TRY(c, hipSetDevice(ctx->device));
+    const int frc = vhr_comm_finish_frame_exchanges(c);                 // (the staging buffers are shared with the frame exchanges)
+    if (frc != VHR_OK) return frc;
+    const int rc = run_pieces(c, pieces, ctx->stream);
+    if (rc != VHR_OK) return rc;
+    const int src = vhr_set_tile(ctx, new_plan->col_begin, new_plan->col_end, new_plan->row_begin, new_plan->row_end, new_plan->overlap, new_plan->halo_rows, new_plan->halo_cols);
+    if (src != VHR_OK) return c->fail(src, ctx->error);
+    c->plan = *new_plan;
+    return VHR_OK;
+}
+
 // Before the next frame's svgf.comp (the Raytrace Pass's epilogue): the context's stream waits for the exchanges started after the
 // previous frame's SVGF pass -- also after a start that failed half way (what it did enqueue is drained).  No host synchronisation.
 int vhr_comm_finish_frame_exchanges(vhr_comm *c) {

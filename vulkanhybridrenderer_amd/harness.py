@@ -266,15 +266,19 @@ class HybridFrameLoop:
         """Cut this rank's rectangle again from `tile_cost` (the SAME map on every rank: the ranks' frame times fed back through
         tiling.refine_cost_map, all-gathered by the caller) and carry the path's cross-frame state -- temporal history, moments history, previous normals
         (hybrid_render_path.cpp:247-262) -- to the new rectangles: one grouped batch of point-to-point transfers (tiling.move_state), each pixel from the rank
-        that owned it.  Collective: every rank calls it between the same two frames.  The torch.distributed route only (comm == "torch"); the grid keeps
+        that owned it.  Collective: every rank calls it between the same two frames.  Either route (torch.distributed, or vhr_comm_replan); the grid keeps
         its shape.  Placement only: the frames that follow are the ones the old plan would have produced."""
         if self.world == 1:
             return self.plan
-        if self.comm is not None:
-            raise NotImplementedError("replan: the vhr_comm_* route keeps the plan it was created with (vhr_comm_create_tiled)")
         old = self.plan
         new = tiling.make_tile_plan(self.W, self.H, self.world, self.rank, self.max_motion_rows, self.max_motion_cols, self.atrous_steps,
                                     grid=(old.grid_rows, old.grid_cols), cost=tile_cost)
+        if self.comm is not None:                          # the library's own RCCL calls: vhr_comm_replan moves the state and sets the tile
+            cplan = lib.tile_plan(self.W, self.H, self.world, self.rank, old.grid_rows, old.grid_cols, self.max_motion_rows, self.max_motion_cols, self.atrous_steps, cost=tile_cost)
+            assert (cplan.col_begin, cplan.col_end, cplan.row_begin, cplan.row_end) == new.rect
+            self.comm.replan(cplan, *(int(self.pc[k]) for k in ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")))
+            self.plan, self.tile_cost = new, tile_cost
+            return new
         self.finish_pending_exchange()                     # the last frame's halo exchange and gather have landed
         if self.denoise:
             images = [self._alias(self.ctx.storage_info(int(self.pc[k]))) for k in ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")]

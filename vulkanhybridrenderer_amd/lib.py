@@ -35,7 +35,7 @@ EXPORTS = [
     "vhr_raytraced_last_error",
     "vhr_set_ray_statistics", "vhr_get_ray_statistics", "vhr_get_bvh_statistics", "vhr_get_current_stream", "vhr_get_bvh_builder", "vhr_get_bvh_presplit_level", "vhr_get_bvh_frame", "vhr_get_bvh_form_checks", "vhr_get_bvh_fingerprint", "vhr_get_bvh_tree_fingerprint", "vhr_set_kernel_timing",
     "vhr_get_kernel_time", "vhr_set_option", "vhr_get_option", "vhr_option_count", "vhr_option_info", "vhr_get_traversal_statistics", "vhr_source_fingerprint", "vhr_debug_wave_lifetimes", "vhr_get_reflection_statistics", "vhr_get_binary64_statistics", "vhr_debug_ray_triangle", "vhr_get_traversal_cycles", "vhr_get_drain_statistics", "vhr_get_build_times", "vhr_atrous_overlap", "vhr_atrous_output_extent", "vhr_strip_plan_make",
-    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_tile_plan_replan", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
+    "vhr_strip_plan_exchanges", "vhr_tile_grid_choose", "vhr_tile_plan_make", "vhr_tile_plan_make_weighted", "vhr_get_tile_cost_map", "vhr_tile_plan_exchanges", "vhr_tile_plan_replan", "vhr_comm_replan", "vhr_comm_get_unique_id", "vhr_comm_use_library", "vhr_comm_library", "vhr_comm_create", "vhr_comm_create_tiled", "vhr_comm_destroy", "vhr_comm_last_error", "vhr_comm_exchange_raytraced",
     "vhr_comm_start_frame_exchanges", "vhr_comm_finish_frame_exchanges",
     "vhr_calibration_stream_read",
 ]
@@ -276,6 +276,7 @@ def load():
     L.vhr_comm_exchange_raytraced.argtypes = [vp, C.c_char_p]
     L.vhr_comm_start_frame_exchanges.argtypes = [vp, i32, i32, C.c_char_p, i32, vp]
     L.vhr_comm_finish_frame_exchanges.argtypes = [vp]
+    L.vhr_comm_replan.argtypes = [vp, C.POINTER(TilePlanC), i32, i32, i32]
     L.vhr_calibration_stream_read.argtypes = [vp, i32, u32]
     L.vhr_set_kernel_timing.argtypes = [vp, i32]
     L.vhr_get_kernel_time.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64), i32]
@@ -955,6 +956,10 @@ class Comm:
 
     def finish_frame_exchanges(self):
         self._check(self.ctx.L.vhr_comm_finish_frame_exchanges(self.handle), "vhr_comm_finish_frame_exchanges")
+
+    def replan(self, new_plan, history, moments, prev_normals):
+        """vhr_comm_replan: the communicator and the context take `new_plan` (a TilePlanC), the three cross-frame storage images follow their pixels."""
+        self._check(self.ctx.L.vhr_comm_replan(self.handle, C.byref(new_plan), int(history), int(moments), int(prev_normals)), "vhr_comm_replan")
 
     def destroy(self):
         if self.handle:
