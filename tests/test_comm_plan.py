@@ -165,6 +165,18 @@ def test_comm_tiled_world_size_one_smoke():
             out = g.ctx.download(lib.DENOISED)
             assert np.isfinite(out.view(np.float16).astype(np.float32)).all()
             ref = out if ref is None else ref
+        # vhr_comm_replan: the same plan is a no-op that succeeds; a plan of another world, another image or one the planner would not have made, and a
+        # storage image that does not exist, are refused before anything is enqueued (the communicator stays usable)
+        ids = [int(pc[k]) for k in ("shadow_and_ao_history", "shadow_and_ao_moments_history", "prev_frame_normals_and_object_ids")]
+        comm.replan(plan, *ids)
+        for wrong in (lib.tile_plan(W, H, 2, 0), lib.tile_plan(W + 8, H, 1, 0), bad):
+            with pytest.raises(lib.VhrError):
+                comm.replan(wrong, *ids)
+        with pytest.raises(lib.VhrError):
+            comm.replan(plan, ids[0], ids[1], 4095)
+        comm.replan(plan, *ids)
+        comm.start_frame_exchanges(ids[0], ids[1], lib.DENOISED, 0, None)
+        comm.finish_frame_exchanges()
     finally:
         if comm:
             comm.destroy()
