@@ -496,8 +496,8 @@ __device__ __forceinline__ void pixel_visibility(const RaygenArgs &a, const uint
 // Decision (vi) in the any-hit queue kernel: a pixel one of whose rays met a candidate that contradicts itself is computed again, whole, by the per-pixel
 // kernel's code (binary64 decisions inline) when its tile is done -- a call, so that the queue kernel's loops carry none of this (inlined in its leaf
 // test the binary64 arithmetic cost the kernel 13 registers = a wave per SIMD, 1.3-1.5 % of the frame: profiles/r6_decision_vi_cost.txt).  `a` points at
-// the launch's arguments where they lie in memory (the address of a by-value argument would copy all of it to every lane's scratch).  One pixel in
-// 30 000 on the BASELINE scenes.
+// the launch's arguments where they lie in memory (the address of a by-value argument would copy all of it to every lane's scratch).  At 1080p:
+// none to three pixels of a frame on the BASELINE stand-ins, up to ~70 on sponza_hard_rot (profiles/r6_decision_vi_cost.txt).
 __device__ VHR_REDO_INLINE float2 redo_pixel_visibility(const RaygenArgs *a, const uint32_t x, const uint32_t y) {
     int st[kTraceStack];
     uint32_t overflow = 0;
@@ -1512,7 +1512,7 @@ __device__ __forceinline__ void reflection_pixel(const RaygenArgs &a, const uint
 // none of this: inlined in its leaf test the binary64 arithmetic made the two-bounce kernel spill 45 registers (launch +13 %), a list of the candidates
 // per ray decided by a call at the ray's commit still cost +7 % (profiles/r6_decision_vi_cost.txt).  `a` points at the launch's arguments where they lie
 // in memory (the address of a by-value argument would copy all of it to every lane's scratch: 1.4 KB a lane, and the launch took four times as long for
-// the waves the scratch ring then had room for).  One ray in 10^5 on the BASELINE scenes.  `second`: a second-bounce ray was
+// the waves the scratch ring then had room for).  About one pixel of a 1080p frame on the BASELINE stand-ins, ~70-100 on sponza_hard_rot.  `second`: a second-bounce ray was
 // traced (the launch's ray count).
 struct RedoReflection { f4 payload; uint32_t second; };
 __device__ __attribute__((noinline)) RedoReflection redo_pixel_reflection(const RaygenArgs *a, const uint32_t x, const uint32_t y) {
@@ -1636,8 +1636,8 @@ __device__ __forceinline__ void wave_queue_walk(const DeviceScene &sc, int *stac
                 if (STATS) ++my_tris;
                 const f3 v0 = f3{ ta.x, ta.y, ta.z }, e1 = f3{ ta.w, tb.x, tb.y }, e2 = f3{ tb.z, tb.w, tc.x };
                 if (mt_candidate(ro, rd, v0, e1, e2, tmin, tmax, t, uu, ww)) {
-                    // decision (vi): a candidate that contradicts itself is decided again in binary64.  DEFER (the mirror ray's kernels, where one ray in
-                    // 10^5 has one): not here, where the walk's registers are all alive -- the ray's pixel is flagged and computed again by the per-pixel
+                    // decision (vi): a candidate that contradicts itself is decided again in binary64.  DEFER (the mirror ray's kernels, where about one ray of a
+                    // 1080p frame has one): not here, where the walk's registers are all alive -- the ray's pixel is flagged and computed again by the per-pixel
                     // code when the tile is shaded (redo_pixel_reflection); the walk goes on as if the candidate had missed.  !DEFER (the raytraced path,
                     // whose shadow rays leave the hit point itself: 6 % of its rays have one): inline.
                     if (!solution_consistent(ro, rd, v0, e1, e2, t, uu, ww)) {
